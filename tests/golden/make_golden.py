@@ -1,0 +1,390 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REAL reference (Disty0/sdnq @ /root/reference).
+
+Runs ONLY in the build container (the reference never travels to the GPU box).
+It imports the reference's own Python with a tiny fake ``diffusers`` (the one
+missing dependency), drives its quantizer + eager forward on CPU, and writes
+inputs / module tensors / intermediates / outputs as ``.npz`` fixtures next to
+this file.  The fixtures are DATA only: no reference source is stored.
+
+    SDNQ_USE_TORCH_COMPILE=0   -> pure PyTorch-eager == BASELINE's oracle
+    SDNQ_USE_CONTIGUOUS_MM=0   -> reproduces gfx950's transposed int8 layout
+    SDNQ_ALLOW_FP8_MM=1        -> CPU takes torch._scaled_mm like the GPU does
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+import zlib
+
+os.environ["SDNQ_USE_TORCH_COMPILE"] = "0"
+os.environ["SDNQ_USE_CONTIGUOUS_MM"] = "0"
+os.environ["SDNQ_ALLOW_FP8_MM"] = "1"
+os.environ["SDNQ_USE_OPENVINO_MM"] = "0"
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SRC = "/root/reference/src"
+
+
+def install_fake_diffusers():
+    d = types.ModuleType("diffusers")
+    d.__version__ = "0.40.0"
+    d.__path__ = []
+    q = types.ModuleType("diffusers.quantizers")
+    q.__path__ = []
+    base = types.ModuleType("diffusers.quantizers.base")
+
+    class DiffusersQuantizer:  # noqa: D401
+        pass
+
+    base.DiffusersQuantizer = DiffusersQuantizer
+    qc = types.ModuleType("diffusers.quantizers.quantization_config")
+
+    class QuantizationConfigMixin:
+        @classmethod
+        def from_dict(cls, config_dict, return_unused_kwargs=False, **kwargs):
+            return cls(**config_dict)
+
+    qc.QuantizationConfigMixin = QuantizationConfigMixin
+    auto = types.ModuleType("diffusers.quantizers.auto")
+    auto.AUTO_QUANTIZER_MAPPING = {}
+    auto.AUTO_QUANTIZATION_CONFIG_MAPPING = {}
+    utils = types.ModuleType("diffusers.utils")
+
+    def get_module_from_name(module, tensor_name):
+        if "." in tensor_name:
+            splits = tensor_name.split(".")
+            for split in splits[:-1]:
+                module = getattr(module, split)
+            tensor_name = splits[-1]
+        return module, tensor_name
+
+    utils.get_module_from_name = get_module_from_name
+    for name, mod in {
+        "diffusers": d, "diffusers.quantizers": q, "diffusers.quantizers.base": base,
+        "diffusers.quantizers.quantization_config": qc, "diffusers.quantizers.auto": auto,
+        "diffusers.utils": utils,
+    }.items():
+        sys.modules[name] = mod
+    d.quantizers = q
+    d.utils = utils
+    q.base, q.quantization_config, q.auto = base, qc, auto
+
+
+install_fake_diffusers()
+sys.path.insert(0, REF_SRC)
+import sdnq  # noqa: E402  (the reference)
+from sdnq import SDNQConfig, sdnq_quantize_layer  # noqa: E402
+from sdnq.common import dtype_dict  # noqa: E402
+from sdnq.quant_utils import get_hadamard, rotate_hadamard, quantize_int_mm, quantize_fp_mm  # noqa: E402
+from sdnq.packed_int import pack_int, unpack_int  # noqa: E402
+from sdnq.packed_float import pack_float, unpack_float  # noqa: E402
+
+TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def to_np(t):
+    """Tensor -> (ndarray, dtype_tag); 16-bit floats and fp8 are stored as raw bit patterns."""
+    if t is None:
+        return None, "none"
+    t = t.detach().cpu()
+    if t.dtype == torch.bfloat16:
+        return t.contiguous().view(torch.uint16).numpy().copy(), "bf16"
+    if t.dtype == torch.float16:
+        return t.contiguous().view(torch.uint16).numpy().copy(), "f16"
+    if t.dtype == torch.float8_e4m3fn:
+        return t.contiguous().view(torch.uint8).numpy().copy(), "fp8e4m3"
+    if t.dtype == torch.float8_e5m2:
+        return t.contiguous().view(torch.uint8).numpy().copy(), "fp8e5m2"
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8).numpy().copy(), "bool"
+    if t.dtype == torch.uint16:
+        return t.contiguous().numpy().copy(), "u16"
+    return t.contiguous().numpy().copy(), str(t.dtype).replace("torch.", "")
+
+
+def make_linear(K, N, seed, dtype, bias=True):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(N, K, generator=g) * 0.02
+    cols = torch.randperm(K, generator=g)[: max(1, K // 100)]
+    w[:, cols] *= 8.0
+    lin = torch.nn.Linear(K, N, bias=bias)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        if bias:
+            lin.bias.copy_(torch.randn(N, generator=g) * 0.1)
+    return lin.to(dtype)
+
+
+def make_input(M, K, seed, dtype, lead=None):
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(M, K, generator=g)
+    ch = torch.randperm(K, generator=g)[:2]
+    x[:, ch] *= 20.0
+    if M >= 3:
+        x[2, :] = 0.0  # all-zero activation row edge case
+    x = x.to(dtype)
+    if lead is not None:
+        x = x.reshape(*lead, K)
+    return x
+
+
+def deq_fields(dq):
+    keys = ["weights_dtype", "quantized_matmul_dtype", "hadamard_group_size", "group_size", "svd_rank",
+            "use_quantized_matmul", "re_quantize_for_matmul", "use_hadamard", "use_codebook", "is_packed",
+            "is_unsigned", "is_integer", "is_integer_matmul", "layer_class_name"]
+    d = {k: getattr(dq, k) for k in keys}
+    d["result_dtype"] = str(dq.result_dtype).replace("torch.", "")
+    d["result_shape"] = list(dq.result_shape) if dq.result_shape is not None else None
+    d["quantized_weight_shape"] = list(dq.quantized_weight_shape)
+    d["original_shape"] = list(dq.original_shape)
+    return d
+
+
+CASES = [
+    # name, K, N, Ms, dtype, config kwargs
+    dict(name="int8_rowwise_noqmm_f32", K=256, N=64, Ms=[4, 40], dtype="f32",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=False)),
+    dict(name="int8_rowwise_qmm_bf16", K=512, N=256, Ms=[4, 48, 77], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)),
+    dict(name="int8_rowwise_qmm_f16_nobias", K=256, N=64, Ms=[33], dtype="f16", bias=False,
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)),
+    dict(name="fp8_qmm_bf16", K=512, N=256, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_quantized_matmul=True)),
+    dict(name="int4_had256_qmm_bf16", K=768, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256, use_quantized_matmul=True)),
+    dict(name="uint4_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="uint4", use_quantized_matmul=True)),
+    dict(name="int8_svd32_qmm_bf16", K=512, N=256, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True)),
+    dict(name="int8_svd32_noqmm_bf16", K=256, N=64, Ms=[5], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=False)),
+    dict(name="int6_rowwise_packed_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int6", use_quantized_matmul=True)),
+    dict(name="uint7_rowwise_packed_qmm_bf16", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint7", use_quantized_matmul=True)),
+    dict(name="uint8_int8mm_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_quantized_matmul=True)),
+    dict(name="uint8_uint8mm_qmm_bf16", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", group_size=-1, use_quantized_matmul=True)),
+    dict(name="int8_had256_qmm_bf16", K=512, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_hadamard=True, use_quantized_matmul=True)),
+    dict(name="fp8_had_qmm_bf16", K=512, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_hadamard=True,
+                  use_quantized_matmul=True)),
+    dict(name="fp4_e2m1_fp8mm_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="float4_e2m1fn", use_quantized_matmul=True)),
+    dict(name="int4_svd_had_qmm_bf16", K=512, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="int4", use_svd=True, svd_rank=16, use_hadamard=True, use_quantized_matmul=True)),
+    dict(name="int5_group32_noqmm_bf16", K=128, N=32, Ms=[3], dtype="bf16",
+         cfg=dict(weights_dtype="int5", group_size=32, use_quantized_matmul=False)),
+    dict(name="uint3_noqmm_f16", K=128, N=32, Ms=[3], dtype="f16",
+         cfg=dict(weights_dtype="uint3", use_quantized_matmul=False)),
+    dict(name="int8_had64_k192_qmm_bf16", K=192, N=64, Ms=[40], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_hadamard=True, use_quantized_matmul=True)),
+]
+
+# Every packed storage dtype gets a dequant-only golden (small).
+DEQUANT_DTYPES = (
+    [f"int{b}" for b in (2, 3, 4, 5, 6, 7)] + [f"uint{b}" for b in (1, 2, 3, 4, 5, 6, 7)]
+    + ["int8", "uint8", "float8_e4m3fn", "float8_e5m2"]
+    + ["float2_e1m0fn", "float3_e1m1fn", "float4_e2m1fn", "float4_e3m0fn", "float4_e1m2fn", "float5_e2m2fn",
+       "float6_e3m2fn", "float6_e2m3fn", "float7_e3m3fn", "float7_e4m2fn", "float4_e2m2fnu", "float3_e2m1fnu",
+       "float6_e3m3fnu", "float8_e4m3fn_sdnq", "float8_e3m4fn", "float8_e4m4fnu"]
+    + ["int9", "int10", "int12", "uint11", "uint13", "uint14", "uint15", "float12_e4m7fn", "float16_e5m10fn"]
+)
+
+
+def run_case(case):
+    name = case["name"]
+    dtype = TORCH_DT[case["dtype"]]
+    K, N = case["K"], case["N"]
+    lin = make_linear(K, N, seed=zlib.crc32(name.encode()) % 1000, dtype=dtype, bias=case.get("bias", True))
+    w_float = lin.weight.detach().clone()
+    cfg = SDNQConfig(**case["cfg"])
+    layer = sdnq_quantize_layer(lin, cfg)[0]
+    dq = layer.sdnq_dequantizer
+    out = {}
+    meta = {"name": name, "K": K, "N": N, "dtype": case["dtype"], "cfg": case["cfg"], "deq": deq_fields(dq),
+            "forward_func": layer.forward_func.__name__, "tensors": {}}
+
+    def put(key, t):
+        arr, tag = to_np(t)
+        if arr is not None:
+            out[key] = arr
+        meta["tensors"][key] = {"dtype": tag, "shape": (list(t.shape) if t is not None else None),
+                                "stride": (list(t.stride()) if t is not None else None)}
+
+    put("w_float", w_float)
+    for k in ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias"):
+        put(k, getattr(layer, k, None))
+
+    # full dequantized weight as the module's dequantize() would produce it ([N,K], result dtype)
+    with torch.no_grad():
+        wd = dq(layer.weight, layer.scale, zero_point=layer.zero_point, svd_up=layer.svd_up, svd_down=layer.svd_down,
+                skip_quantized_matmul=dq.use_quantized_matmul)
+        put("w_dequant", wd)
+        wd32 = dq(layer.weight, layer.scale, zero_point=layer.zero_point, svd_up=layer.svd_up, svd_down=layer.svd_down,
+                  skip_quantized_matmul=dq.use_quantized_matmul, dtype=torch.float32, non_hadamard=True)
+        put("w_dequant_f32_nohad", wd32)
+        if dq.use_quantized_matmul and dq.re_quantize_for_matmul:
+            rq = dq.re_quantize_matmul(layer.weight, layer.scale, zero_point=layer.zero_point)
+            put("requant_weight", rq[0])
+            put("requant_scale", rq[1])
+            if len(rq) > 2:
+                put("requant_zero_point", rq[2])
+
+        for i, M in enumerate(case["Ms"]):
+            lead = (2, M // 2) if (M % 2 == 0 and i == len(case["Ms"]) - 1 and M >= 8) else None
+            x = make_input(M, K, seed=i, dtype=dtype, lead=lead)
+            y = layer(x)
+            put(f"x_{M}", x)
+            put(f"y_{M}", y)
+            assert y.dtype == x.dtype
+            # activation-quant intermediates for the qmm branch
+            if dq.use_quantized_matmul and M >= 32:
+                x2 = x.reshape(-1, K)
+                if dq.use_hadamard:
+                    H = get_hadamard(dq.hadamard_group_size, dtype=x.dtype, device=x.device)
+                    x2 = rotate_hadamard(x2, hadamard=H)
+                    put(f"xrot_{M}", x2)
+                if dq.quantized_matmul_dtype in ("int8",):
+                    xq, xs = quantize_int_mm(x2.to(torch.float32), dim=-1)
+                    put(f"xq_{M}", xq)
+                    put(f"xs_{M}", xs)
+                elif dq.quantized_matmul_dtype in ("fp8", "float8_e4m3fn"):
+                    xq, xs = quantize_fp_mm(x2.to(torch.float32), dim=-1)
+                    put(f"xq_{M}", xq)
+                    put(f"xs_{M}", xs)
+    np.savez_compressed(os.path.join(HERE, f"case_{name}.npz"), **out)
+    with open(os.path.join(HERE, f"case_{name}.json"), "w") as f:
+        json.dump(meta, f, indent=1, default=str)
+    print("wrote", name, {k: v.shape for k, v in out.items() if k.startswith("y_")})
+
+
+def run_dequant_dtypes():
+    out, meta = {}, {"dtypes": {}}
+    N, K = 16, 128
+    for wd in DEQUANT_DTYPES:
+        for gs in (-1, 32):
+            lin = make_linear(K, N, seed=7, dtype=torch.float32, bias=False)
+            cfg = SDNQConfig(weights_dtype=wd, group_size=gs, use_quantized_matmul=False)
+            layer = sdnq_quantize_layer(lin, cfg)[0]
+            dq = layer.sdnq_dequantizer
+            key = f"{wd}_g{gs if gs > 0 else 'row'}"
+            with torch.no_grad():
+                w = dq(layer.weight, layer.scale, zero_point=layer.zero_point)
+            ent = {"deq": deq_fields(dq), "tensors": {}}
+            for k, t in (("weight", layer.weight), ("scale", layer.scale), ("zero_point", layer.zero_point), ("out", w)):
+                arr, tag = to_np(t)
+                if arr is not None:
+                    out[f"{key}.{k}"] = arr
+                ent["tensors"][k] = {"dtype": tag, "shape": (list(t.shape) if t is not None else None)}
+            meta["dtypes"][key] = ent
+    np.savez_compressed(os.path.join(HERE, "dequant_dtypes.npz"), **out)
+    with open(os.path.join(HERE, "dequant_dtypes.json"), "w") as f:
+        json.dump(meta, f, indent=1, default=str)
+    print("wrote dequant_dtypes", len(meta["dtypes"]))
+
+
+def run_codecs():
+    """pack/unpack known-answer vectors straight from the reference codecs."""
+    out, meta = {}, {}
+    g = torch.Generator().manual_seed(3)
+    for bits in list(range(1, 8)) + list(range(9, 16)):
+        name = f"uint{bits}"
+        st = dtype_dict[name]["storage_dtype"]
+        n = 16 * 15 * 2
+        vals = torch.randint(0, 2 ** bits, (n,), generator=g, dtype=torch.int32)
+        vals[: 2 ** min(bits, 4)] = torch.arange(2 ** min(bits, 4), dtype=torch.int32)
+        vals[-1] = 2 ** bits - 1
+        v = vals.to(torch.bool if st == torch.bool else st)
+        packed = pack_int(v, name)
+        unpacked = unpack_int(packed, name, v.shape)
+        assert torch.equal(unpacked.to(torch.int32) & (2 ** bits - 1), vals), name
+        out[f"{name}.values"] = vals.numpy().astype(np.int32)
+        out[f"{name}.packed"] = to_np(packed)[0]
+        meta[name] = {"packed_shape": list(packed.shape), "packed_dtype": str(packed.dtype)}
+    # float decode tables: every code of every <=8-bit custom float type
+    for wd, ent in dtype_dict.items():
+        if ent["is_integer"] or not isinstance(ent["target_dtype"], str) or ent["num_bits"] > 8:
+            continue
+        if wd.startswith("float8_e4m3fnuz") or wd.startswith("float8_e5m2fnuz") or wd == "float8_e8m0fnu":
+            continue
+        bits = ent["num_bits"]
+        codes = torch.arange(2 ** bits, dtype=torch.int32)
+        n = codes.numel()
+        reps = (16 * 15 + n - 1) // n * n // n
+        codes = codes.repeat(max(1, 240 // n) if n < 240 else 1)
+        while codes.numel() % 240 != 0 and bits not in (8,):
+            codes = torch.cat([codes, codes[: 240 - codes.numel() % 240]])
+        if bits == 8:
+            packed = codes.to(torch.uint8)
+        else:
+            packed = pack_int(codes.to(dtype_dict[f"uint{bits}"]["storage_dtype"]), f"uint{bits}")
+        dec = unpack_float(packed, wd, codes.shape)
+        out[f"{wd}.codes"] = codes.numpy().astype(np.int32)
+        out[f"{wd}.decoded"] = dec.numpy().astype(np.float32)
+        meta[wd] = {"bits": bits, "exponent": ent["exponent"], "mantissa": ent["mantissa"],
+                    "is_unsigned": ent["is_unsigned"]}
+        # round-trip float -> code through the reference packer on a value sweep
+        sweep = torch.linspace(-1.25, 1.25, 481) * float(min(abs(ent["max"]), 1e6))
+        if ent["is_unsigned"]:
+            sweep = sweep.abs()
+        sweep = sweep.clamp(ent["min"], ent["max"])
+        pk = pack_float(sweep[:480], wd)
+        dec2 = unpack_float(pk, wd, torch.Size([480]))
+        out[f"{wd}.sweep_in"] = sweep[:480].numpy()
+        out[f"{wd}.sweep_packed"] = to_np(pk)[0]
+        out[f"{wd}.sweep_decoded"] = dec2.numpy()
+    np.savez_compressed(os.path.join(HERE, "codecs.npz"), **out)
+    with open(os.path.join(HERE, "codecs.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote codecs", len(meta))
+
+
+def run_hadamard():
+    out = {}
+    for n in (4, 8, 16, 32, 64, 128, 256, 512):
+        H = get_hadamard(n, dtype=torch.float32, device=torch.device("cpu"))
+        out[f"H{n}"] = H.contiguous().numpy()
+    g = torch.Generator().manual_seed(5)
+    for dt in ("bf16", "f32", "f16"):
+        for n in (64, 128, 256):
+            x = (torch.randn(6, 2 * n, generator=g) * 3).to(TORCH_DT[dt])
+            y = rotate_hadamard(x, group_size=n)
+            out[f"x_{dt}_{n}"] = to_np(x)[0]
+            out[f"y_{dt}_{n}"] = to_np(y)[0]
+    np.savez_compressed(os.path.join(HERE, "hadamard.npz"), **out)
+    print("wrote hadamard")
+
+
+def run_dtype_table():
+    table = {}
+    for k, v in dtype_dict.items():
+        table[k] = {kk: (vv if isinstance(vv, (int, float, bool, str)) else str(vv).replace("torch.", ""))
+                    for kk, vv in v.items()}
+    with open(os.path.join(HERE, "dtype_table.json"), "w") as f:
+        json.dump(table, f, indent=0, sort_keys=True)
+    print("wrote dtype_table", len(table))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    only = sys.argv[1:] or None
+    if only is None or "table" in only:
+        run_dtype_table()
+    if only is None or "codecs" in only:
+        run_codecs()
+    if only is None or "hadamard" in only:
+        run_hadamard()
+    if only is None or "dequant" in only:
+        run_dequant_dtypes()
+    for c in CASES:
+        if only is None or "cases" in only or c["name"] in only:
+            run_case(c)
