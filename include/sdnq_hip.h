@@ -1,0 +1,170 @@
+/*
+ * sdnq_hip.h -- C ABI of the MI355X (gfx950 / CDNA4) dequantize-and-matmul hot path.
+ *
+ * The reference (Disty0/sdnq 0.2.5) is pure Python and has NO FFI; this header is the seam a
+ * maintainer would bind (ctypes stub in INTEGRATION.md).  Every entry point replaces one piece
+ * of the reference's per-call chain.  Citations are file:line under /root/reference/src/sdnq/.
+ *
+ * Contract (all entry points):
+ *   - plain pointers + sizes only; device pointers unless stated; no ownership transfer;
+ *   - stream-ordered and non-blocking on `stream` (a hipStream_t passed as void*);
+ *   - no allocation: outputs and workspace are caller-provided;
+ *   - returns SDNQ_OK (0) or a negative SdnqStatus; never throws across the ABI;
+ *   - thread-safe: no mutable global state.
+ *
+ * Memory layouts ("physical" = what is in HBM):
+ *   weight   physical [N][K] with K contiguous (the reference's transposed qmm layout, logical
+ *            [K,N] strides (1,K), quantizer.py:239-244, is the same bytes); packed sub-byte
+ *            formats hold the flattened [N][K] element order in the reference's group codecs
+ *            (packed_int/pack.py) -- byte-identical to the reference state_dict.
+ *   scale / zero_point   float32, one per (row n, group g): [N][G]   (G = K / group_size)
+ *   svd_up   physical [N][R] (R contiguous)     svd_down   physical [R][K] (K contiguous)
+ *   activations x [M][K] row-major with row stride ldx; outputs [M][N] row-major.
+ */
+#ifndef SDNQ_HIP_H
+#define SDNQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDNQ_HIP_ABI_VERSION 1
+
+typedef void* sdnq_stream_t; /* hipStream_t */
+
+typedef enum SdnqStatus {
+    SDNQ_OK = 0,
+    SDNQ_ERR_NULL = -1,        /* required pointer is NULL */
+    SDNQ_ERR_DTYPE = -2,       /* unknown / unsupported dtype code */
+    SDNQ_ERR_SHAPE = -3,       /* bad M/N/K/group (reference needs N,K >= 32 and %16 == 0 for qmm, utils.py:93-98) */
+    SDNQ_ERR_ALIGN = -4,       /* pointer or leading dimension not 16-byte aligned */
+    SDNQ_ERR_UNSUPPORTED = -5, /* valid in the reference but not built yet */
+    SDNQ_ERR_ARCH = -6,        /* device is not gfx950 */
+    SDNQ_ERR_LAUNCH = -7,      /* hipLaunch failed (see hipGetLastError) */
+    SDNQ_ERR_WORKSPACE = -8    /* workspace too small */
+} SdnqStatus;
+
+/* element types of activations / outputs / bias / svd factors */
+typedef enum SdnqFloat { SDNQ_F32 = 0, SDNQ_BF16 = 1, SDNQ_F16 = 2 } SdnqFloat;
+
+/* matmul operand types (dtype_dict rows "int8", "float8_e4m3fn"; common.py:20,65) */
+typedef enum SdnqMM { SDNQ_MM_I8 = 0, SDNQ_MM_FP8 = 1 } SdnqMM;
+
+/* how the quantized weight elements are held in HBM */
+typedef enum SdnqStorage {
+    SDNQ_ST_PACKED_U8 = 0,  /* (u)int1..7, float2..7: reference group codecs in uint8 words (packed_int/unpack.py:233-372) */
+    SDNQ_ST_PACKED_I16 = 1, /* (u)int9..15, float9..15: group codecs in int16 words (packed_int/unpack.py:7-229) */
+    SDNQ_ST_RAW8 = 2,       /* int8 / uint8 / custom float8 codes / native float8_e4m3fn / float8_e5m2 */
+    SDNQ_ST_RAW16 = 3       /* int16 / uint16 / custom float16 codes / native float16 */
+} SdnqStorage;
+
+/* numeric class of the stored code (dtype_dict is_integer / is_unsigned; common.py:16-267) */
+typedef enum SdnqKind {
+    SDNQ_KIND_INT = 0,   /* signed int: stored as value - min (packed) or two's complement (raw) */
+    SDNQ_KIND_UINT = 1,  /* unsigned int, asymmetric (zero_point required) */
+    SDNQ_KIND_FLOAT = 2, /* signed eXmY "fn" float code (packed_float.py:86-132) */
+    SDNQ_KIND_UFLOAT = 3 /* unsigned eXmY "fnu" float code, asymmetric (zero_point required) */
+} SdnqKind;
+
+/* A quantized Linear weight exactly as the reference state_dict holds it. */
+typedef struct SdnqWeight {
+    const void* weight;      /* packed / raw codes, see SdnqStorage */
+    const float* scale;      /* [N][G] */
+    const float* zero_point; /* [N][G] or NULL */
+    const void* svd_up;      /* [N][R] or NULL */
+    const void* svd_down;    /* [R][K] or NULL */
+    int32_t n;               /* output channels N */
+    int32_t k;               /* input channels K */
+    int32_t group_size;      /* elements per scale group along K; == k for row-wise */
+    int32_t svd_rank;        /* R (0 if no SVD) */
+    int32_t svd_dtype;       /* SdnqFloat of svd_up / svd_down */
+    int32_t storage;         /* SdnqStorage */
+    int32_t kind;            /* SdnqKind */
+    int32_t bits;            /* 1..16 */
+    int32_t exponent;        /* float kinds: exponent bits */
+    int32_t mantissa;        /* float kinds: mantissa bits */
+    int32_t native_float;    /* 1: codes are IEEE/OCP native (float8_e4m3fn, float8_e5m2, float16) */
+} SdnqWeight;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int sdnq_hip_version(void);
+const char* sdnq_hip_strerror(int status);
+/* 1 if device `ordinal` is gfx950 (arch gate; the reference parses gcnArchName the same way, sdnext.py:101-105) */
+int sdnq_hip_device_supported(int ordinal);
+
+/* ---- a8/a9: row-wise activation quantization ----------------------------------------------
+ * replaces quantize_int_mm_input (layers/linear/linear_int8.py:15-22 -> quant_utils.py:265-273)
+ * and quantize_fp_mm_input (layers/linear/linear_fp8.py:15-22 -> quant_utils.py:290-299), with the
+ * optional Hadamard rotation of the activation fused in front (linear_int8.py:55-56,
+ * quant_utils.py:194-209).  xs[m] = amax_k|x| / qmax ; xq = cast(clamp(round_half_even(x / xs))).
+ * x: [M][K] of x_dtype, row stride ldx elements. xq: [M][K] int8 or fp8-e4m3fn bytes. xs: [M] f32.
+ * rowsum: optional [M] int32 = sum_k xq (zero-point bias, linear_int8.py:65-69); NULL to skip.
+ * xrot: optional [M][K] of x_dtype receiving the rotated activation (needed by the SVD branch).
+ * hadamard_group: 0 = no rotation, else power of two in [4, 1024] dividing K. */
+int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype,
+                      int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
+                      sdnq_stream_t stream);
+
+/* ---- a15/a16: scaled matmul (the operator seam) --------------------------------------------
+ * replaces int_scaled_mm_func / fp8_scaled_mm_func (kernel_wrappers.py:193-204) and the Triton op
+ * sdnq::scaled_mm (kernels/triton_scaled_mm.py:127-275):
+ *     out[m][n] = cast( fma( f32(sum_k a[m][k]*b[n][k]) * sa[m], sb[n], bias ) )     (bias present)
+ *     out[m][n] = cast( (f32(acc) * sa[m]) * sb[n] )                                 (no bias)
+ * a: [M][K] int8/fp8, b: physical [N][K] int8/fp8 (the reference's b[K,N] strides (1,K)).
+ * bias_ndim 0 (none), 1 ([N]) or 2 ([M][N], row stride ld_bias). int8: int32 accumulate (exact);
+ * fp8: fp32 accumulate. K % 16 == 0. */
+int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
+                       const void* bias, int bias_dtype, int bias_ndim, int64_t ld_bias, void* out,
+                       int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
+
+/* ---- a4/a5/a6: dequantize ---------------------------------------------------------------------
+ * replaces SDNQDequantizer.__call__ -> dequantize_weight (dequantizer.py:135-162, 389-429):
+ * unpack -> f32(w)*scale | fma(f32(w),scale,zp) -> [+ svd_up@svd_down in svd dtype] -> cast ->
+ * [Hadamard rotation in out dtype].  out: [N][K] row-major of out_dtype. */
+int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* out, int out_dtype, sdnq_stream_t stream);
+
+/* ---- a7: re-quantize for matmul ---------------------------------------------------------------
+ * replaces re_quantize_matmul (dequantizer.py:204-239): fp32 dequant (Hadamard NOT undone), then a
+ * per-output-row symmetric quantization to the matmul dtype. wq: physical [N][K]; ws: [N] f32. */
+int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, float* ws, sdnq_stream_t stream);
+
+/* ---- a11: Hadamard rotation -------------------------------------------------------------------
+ * replaces rotate_hadamard (quant_utils.py:194-209): y.view(rows, K/g, g) @ H_g, rounded to dtype.
+ * H_g = kron powers of the reference's H4 (g a power of 4) or Sylvester H2 (other powers of 2),
+ * scaled g^-1/2 (quant_utils.py:145-175).  In-place allowed (y == x). */
+int sdnq_hip_hadamard(const void* x, int dtype, int64_t rows, int64_t k, int64_t ldx, int hadamard_group,
+                      void* y, int64_t ldy, sdnq_stream_t stream);
+
+/* ---- a12: SVD low-rank prologue ---------------------------------------------------------------
+ * t[M][R] = cast_svd_dtype( x[M][K] @ svd_down^T ), the inner torch.mm of
+ * addmm(bias, mm(x, svd_down), svd_up) (linear_int8.py:57-62).  The outer product with svd_up and
+ * the bias add are fused into sdnq_hip_scaled_mm_lowrank's epilogue. */
+int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, const void* svd_down,
+                          int svd_dtype, int rank, void* t, sdnq_stream_t stream);
+
+/* scaled matmul whose bias is  cast_svd( f32(bias[n]) + sum_r t[m][r]*svd_up[n][r] )  [+ zp term]:
+ *   zp_rowsum/zp (both or neither): adds f32(rowsum[m]) * sa[m] * zp[n]  (linear_int8.py:65-69). */
+int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
+                               const void* bias, int bias_dtype, const void* t, const void* svd_up, int svd_dtype,
+                               int rank, const int32_t* zp_rowsum, const float* zp, void* out, int out_dtype,
+                               int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
+
+/* ---- a3: float path  F.linear(x, dequant(W), bias) --------------------------------------------
+ * replaces quantized_linear_forward (layers/linear/forward.py:25-26) and the M<32 branch of the
+ * quantized forwards (linear_int8.py:102-103): out = x @ Wd^T + bias with Wd already dequantized to
+ * the activation dtype ([N][K]), fp32 accumulate, one rounding to the output dtype. */
+int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
+                          int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream);
+
+/* fused skinny variant (M <= 32): streams the quantized weight once, dequantizes in registers to the
+ * activation dtype (same rounding as sdnq_hip_dequant) and accumulates in fp32. No Hadamard/SVD. */
+int sdnq_hip_linear_skinny(const SdnqWeight* w, const void* x, const void* bias, int dtype, void* out,
+                           int64_t m, int64_t ldx, sdnq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDNQ_HIP_H */

@@ -1,0 +1,515 @@
+"""CPU ORACLE of the SDNQ quantized-Linear hot path -- TEST INFRASTRUCTURE ONLY.
+
+A restatement of the reference's algorithm (Disty0/sdnq 0.2.5; citations are file:line under
+/root/reference/src/sdnq/) in numpy + plain C (``sdnq_oracle.c``, compiled on demand with gcc).
+Imported only by ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg as the
+CHECKER; the product path (``sdnq_amd``) never touches it.
+
+Pinning: ``tests/test_oracle_golden.py`` checks this oracle against vectors captured from the imported
+reference (``tests/golden/*.npz`` made by ``tests/golden/make_golden.py``): bit-exact for unpack / dequant /
+activation quantization / int8 matmul, and within the tolerances SURVEY.md 8(c) states for the
+floating-point GEMMs (Hadamard, SVD, fp8, bf16 linear), whose summation order is unspecified in the reference.
+
+Conventions: float tensors are float32 ndarrays holding values representable in the tagged dtype
+("f32" | "bf16" | "f16"); weights/scales are ndarrays in the reference's LOGICAL state_dict layouts.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import platform
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "sdnq_oracle.c")
+_DT = {"f32": 0, "bf16": 1, "f16": 2, "float32": 0, "bfloat16": 1, "float16": 2}
+
+
+# ------------------------------------------------------------------------------------------------
+# build + load the C part
+# ------------------------------------------------------------------------------------------------
+def _cpu_tag() -> str:
+    model = platform.machine()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model += line
+                    break
+                if line.startswith("flags"):
+                    model += line
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1((model + open(_SRC).read()).encode()).hexdigest()[:12]
+
+
+def build_oracle() -> str:
+    out_dir = os.path.join(_HERE, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, f"libsdnq_oracle_{_cpu_tag()}.so")
+    if not os.path.exists(so):
+        tmp = so + f".{os.getpid()}.tmp"
+        cmd = ["gcc", "-O2", "-ftree-vectorize", "-march=native", "-fopenmp", "-ffp-contract=off", "-shared", "-fPIC",
+               "-o", tmp, _SRC, "-lm"]
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, so)
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build_oracle())
+        c = ctypes
+        vp, i32, i64, f32 = c.c_void_p, c.c_int, c.c_int64, c.c_float
+        L.orc_round_bf16.restype = f32
+        L.orc_round_bf16.argtypes = [f32]
+        L.orc_round_f16.restype = f32
+        L.orc_round_f16.argtypes = [f32]
+        L.orc_e4m3fn_to_f32.restype = f32
+        L.orc_e4m3fn_to_f32.argtypes = [c.c_uint8]
+        L.orc_f32_to_e4m3fn.restype = c.c_uint8
+        L.orc_f32_to_e4m3fn.argtypes = [f32]
+        L.orc_decode_exmy.restype = f32
+        L.orc_decode_exmy.argtypes = [c.c_uint32, i32, i32, i32]
+        L.orc_unpack_uint.argtypes = [i32, vp, i64, vp]
+        L.orc_pack_uint.argtypes = [i32, vp, i64, vp]
+        L.orc_dequant_f32.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+        L.orc_svd_add.argtypes = [vp, vp, vp, i64, i64, i64, i32]
+        L.orc_hadamard_matrix.argtypes = [i32, f32, vp]
+        L.orc_hadamard_rotate.argtypes = [vp, i64, i64, i32, f32, i32, vp]
+        L.orc_rowquant_i8.argtypes = [vp, i64, i64, vp, vp, vp]
+        L.orc_rowquant_fp8.argtypes = [vp, i64, i64, vp, vp]
+        L.orc_scaled_mm_i8.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]
+        L.orc_scaled_mm_fp8.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp]
+        L.orc_linear_float.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp]
+        L.orc_lowrank_bias.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp]
+        L.orc_num_threads.restype = i32
+        L.orc_set_num_threads.argtypes = [i32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# ------------------------------------------------------------------------------------------------
+# dtype helpers
+# ------------------------------------------------------------------------------------------------
+def round_dtype(a: np.ndarray, tag: str) -> np.ndarray:
+    """float32 -> nearest value representable in `tag` (RNE), returned as float32."""
+    a = _c(a, np.float32)
+    code = _DT[tag]
+    if code == 0:
+        return a.copy()
+    if code == 1:
+        u = a.view(np.uint32).astype(np.uint64)
+        nan = (u & 0x7fffffff) > 0x7f800000
+        r = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+        r[nan] = 0x7fc00000
+        return r.view(np.float32).reshape(a.shape)
+    return a.astype(np.float16).astype(np.float32)  # numpy float16 conversion is IEEE RNE
+
+
+def from_bits(bits: np.ndarray, tag: str) -> np.ndarray:
+    if tag in ("f32", "float32"):
+        return _c(bits, np.float32)
+    if tag in ("bf16", "bfloat16"):
+        return (bits.astype(np.uint32) << 16).view(np.float32)
+    if tag in ("f16", "float16"):
+        return bits.view(np.float16).astype(np.float32)
+    raise ValueError(tag)
+
+
+def to_bits(a: np.ndarray, tag: str) -> np.ndarray:
+    a = _c(a, np.float32)
+    if tag in ("f32", "float32"):
+        return a
+    if tag in ("bf16", "bfloat16"):
+        return (round_dtype(a, "bf16").view(np.uint32) >> 16).astype(np.uint16)
+    return a.astype(np.float16).view(np.uint16)
+
+
+def e4m3_decode(codes: np.ndarray) -> np.ndarray:
+    L = lib()
+    lut = np.array([L.orc_e4m3fn_to_f32(i) for i in range(256)], dtype=np.float32)
+    return lut[codes.astype(np.uint8)]
+
+
+def e5m2_decode(codes: np.ndarray) -> np.ndarray:
+    return (codes.astype(np.uint16) << 8).view(np.float16).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# a19: dtype table (restated from the format rules; checked against the reference's table fixture)
+# ------------------------------------------------------------------------------------------------
+def dtype_info(name: str) -> dict:
+    import re
+    alias = {"fp8": "float8_e4m3fn", "fp16": "float16", "bf16": "bfloat16", "fp32": "float32", "bool": "uint1", "int1": "uint1",
+             "fp1": "float1_e1m0fnu"}
+    name = alias.get(name, name)
+    m = re.fullmatch(r"(u?)int(\d+)", name)
+    if m:
+        bits, uns = int(m.group(2)), bool(m.group(1))
+        return dict(kind="uint" if uns else "int", bits=bits, packed=bits not in (8, 16, 32), exponent=0, mantissa=0,
+                    native=False, minv=0 if uns else -(1 << (bits - 1)))
+    if name == "float8_e4m3fn":
+        return dict(kind="float", bits=8, packed=False, exponent=4, mantissa=3, native=True)
+    if name == "float8_e5m2":
+        return dict(kind="float", bits=8, packed=False, exponent=5, mantissa=2, native=True)
+    if name == "float16":
+        return dict(kind="float", bits=16, packed=False, exponent=5, mantissa=10, native=True)
+    if name == "bfloat16":
+        return dict(kind="float", bits=16, packed=False, exponent=8, mantissa=7, native=True)
+    m = re.fullmatch(r"float(\d+)_e(\d+)m(\d+)fn(u?)(_sdnq)?", name)
+    if m:
+        bits, e, mm, uns = int(m.group(1)), int(m.group(2)), int(m.group(3)), bool(m.group(4))
+        return dict(kind="ufloat" if uns else "float", bits=bits, packed=True, exponent=e, mantissa=mm, native=False)
+    m = re.fullmatch(r"(u?)fp(\d+)", name)
+    if m:
+        bits, uns = int(m.group(2)), bool(m.group(1))
+        e = {1: 1, 2: 1, 3: 1, 4: 2, 5: 2, 6: 3, 7: 3, 8: 4, 9: 4}.get(bits, 5)
+        return dict(kind="ufloat" if uns else "float", bits=bits, packed=True, exponent=e, mantissa=bits - e - (0 if uns else 1), native=False)
+    raise KeyError(name)
+
+
+# ------------------------------------------------------------------------------------------------
+# a5 / a6: unpack
+# ------------------------------------------------------------------------------------------------
+def unpack_codes(packed: np.ndarray, bits: int, numel: int) -> np.ndarray:
+    """Reference group codecs (packed_int/unpack.py) -> unsigned codes, via the bit-placement tables."""
+    if bits == 8:
+        return packed.reshape(-1).view(np.uint8).astype(np.int32)[:numel]
+    if bits == 16:
+        return packed.reshape(-1).view(np.uint16).astype(np.int32)[:numel]
+    src = np.ascontiguousarray(packed).reshape(-1)
+    if src.dtype in (np.int64, np.bool_):
+        # 1-bit types: the reference packs torch.bool inputs with bitwise ops that promote to int64, so the
+        # state_dict holds one 8-bit word per int64 element (packed_int/pack.py:309-321)
+        src = src.astype(np.uint8)
+    if bits < 8:
+        src = src.view(np.uint8)
+    else:
+        src = src.view(np.uint16)
+    out = np.empty(numel, dtype=np.int32)
+    rc = lib().orc_unpack_uint(bits, _p(src), numel, _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def pack_codes(codes: np.ndarray, bits: int) -> np.ndarray:
+    codes = _c(codes.reshape(-1), np.int32)
+    G = {1: 8, 2: 4, 3: 8, 4: 2, 5: 8, 6: 4, 7: 8, 9: 16, 10: 8, 11: 16, 12: 4, 13: 16, 14: 8, 15: 16}[bits]
+    wb = 8 if bits < 8 else 16
+    nwords = codes.size // G * (G * bits // wb)
+    out = np.zeros(nwords, dtype=np.uint8 if wb == 8 else np.uint16)
+    rc = lib().orc_pack_uint(bits, _p(codes), codes.size, _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def weight_values(weight: np.ndarray, weights_dtype: str, shape) -> np.ndarray:
+    """Stored weight -> numeric values (float32) of logical shape `shape`, before scaling.
+    unpack_int (packed_int/__init__.py:84-88: signed = unsigned code + min) / unpack_float (packed_float.py:86)."""
+    info = dtype_info(weights_dtype)
+    numel = int(np.prod(shape))
+    if info["kind"] in ("int", "uint"):
+        if info["packed"]:
+            codes = unpack_codes(weight, info["bits"], numel)
+            vals = codes + (info["minv"] if info["kind"] == "int" else 0)
+        else:
+            raw = weight.reshape(-1)
+            if info["kind"] == "int":
+                vals = raw.view({8: np.int8, 16: np.int16, 32: np.int32}[info["bits"]]).astype(np.int32)
+            else:
+                vals = raw.view({8: np.uint8, 16: np.uint16}[info["bits"]]).astype(np.int32)
+        return vals.astype(np.float32).reshape(shape)
+    # floats
+    if info["native"]:
+        raw = weight.reshape(-1)
+        if info["bits"] == 8:
+            vals = e4m3_decode(raw.view(np.uint8)) if info["exponent"] == 4 else e5m2_decode(raw.view(np.uint8))
+        else:
+            vals = from_bits(raw.view(np.uint16), "f16" if info["exponent"] == 5 else "bf16")
+        return _c(vals, np.float32).reshape(shape)
+    codes = unpack_codes(weight, info["bits"], numel)
+    L = lib()
+    uns = 1 if info["kind"] == "ufloat" else 0
+    table = np.array([L.orc_decode_exmy(int(c), info["exponent"], info["mantissa"], uns) for c in range(1 << min(info["bits"], 16))],
+                     dtype=np.float32)
+    return table[codes].reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# a11: Hadamard
+# ------------------------------------------------------------------------------------------------
+def hadamard_scale(g: int, tag: str) -> float:
+    """|H_g[0][0]|: H.div_(n**0.5) evaluated in the activation dtype (quant_utils.py:151,163)."""
+    root = np.float64(g) ** 0.5
+    if _DT[tag] == 0:
+        return float(np.float32(1.0) / np.float32(root))
+    one = round_dtype(np.array([1.0], np.float32), tag)[0]
+    r = round_dtype(np.array([root], np.float32), tag)[0]
+    return float(round_dtype(np.array([np.float32(one) / np.float32(r)], np.float32), tag)[0])
+
+
+def get_hadamard_group_size(channel_size: int, group_size: int):
+    """quant_utils.py:212-218."""
+    g = 1
+    while g < min(channel_size, group_size):
+        g *= 2
+    while channel_size % g != 0:
+        g //= 2
+    return g >= 4, g
+
+
+def hadamard_matrix(g: int, tag: str = "f32") -> np.ndarray:
+    H = np.empty((g, g), dtype=np.float32)
+    lib().orc_hadamard_matrix(g, ctypes.c_float(hadamard_scale(g, tag)), _p(H))
+    return H
+
+
+def rotate_hadamard(x: np.ndarray, g: int, tag: str) -> np.ndarray:
+    x2 = _c(x.reshape(-1, x.shape[-1]), np.float32)
+    y = np.empty_like(x2)
+    lib().orc_hadamard_rotate(_p(x2), x2.shape[0], x2.shape[1], g, ctypes.c_float(hadamard_scale(g, tag)), _DT[tag], _p(y))
+    return y.reshape(x.shape)
+
+
+# ------------------------------------------------------------------------------------------------
+# module container + a4 dequantize / a7 re-quantize
+# ------------------------------------------------------------------------------------------------
+class OracleLinear:
+    """An SDNQ-quantized Linear as the reference holds it: logical-layout ndarrays + dequantizer fields."""
+
+    def __init__(self, deq: dict, weight, scale, zero_point=None, svd_up=None, svd_down=None, bias=None, svd_tag="bf16",
+                 bias_tag=None, N=None, K=None):
+        self.deq = deq
+        self.weight, self.scale, self.zero_point = weight, scale, zero_point
+        self.svd_up, self.svd_down, self.bias = svd_up, svd_down, bias  # float32 arrays of dtype-representable values
+        self.svd_tag = svd_tag
+        self.N, self.K = N, K
+        self.result_tag = {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[deq["result_dtype"]]
+        self.bias_tag = bias_tag or self.result_tag
+
+    # -- layout facts -------------------------------------------------------------------------
+    @property
+    def transposed(self):  # quantizer.py:228-244
+        d = self.deq
+        return bool(d["use_quantized_matmul"] and not d["re_quantize_for_matmul"] and not d["is_packed"])
+
+    def _nk_values_scale(self):
+        """numeric values [N,K] (f32), scale [N,G], zp [N,G] in row-major [N][K] order."""
+        d = self.deq
+        N, K = self.N, self.K
+        qshape = d["quantized_weight_shape"]
+        vals = weight_values(self.weight, d["weights_dtype"], qshape)
+        if self.transposed:  # logical [K,N]
+            vals = np.ascontiguousarray(vals.reshape(K, N).T)
+        vals = vals.reshape(N, K)
+        group = d["group_size"] if d["group_size"] > 0 else K
+        G = K // group
+        sc = _c(self.scale, np.float32).reshape(-1)
+        assert sc.size == N * G, (sc.size, N, G)
+        zp = None if self.zero_point is None else _c(self.zero_point, np.float32).reshape(-1)
+        return vals, sc, zp, group
+
+    def dequant_f32_nk(self) -> np.ndarray:
+        """a4 core: W[n][k] = f32(w)*s (dequantizer.py:63) or fma(f32(w), s, zp) (:27)."""
+        vals, sc, zp, group = self._nk_values_scale()
+        out = np.empty((self.N, self.K), dtype=np.float32)
+        lib().orc_dequant_f32(_p(_c(vals, np.float32)), _p(sc), _p(zp), self.N, self.K, group, _p(out))
+        return out
+
+    def svd_nr_rk(self):
+        """svd_up as [N,R], svd_down as [R,K] (the qmm layout stores them transposed, quantizer.py:164-167)."""
+        if self.svd_up is None:
+            return None, None
+        if self.deq["use_quantized_matmul"]:
+            return np.ascontiguousarray(self.svd_up.T), np.ascontiguousarray(self.svd_down.T)
+        return _c(self.svd_up, np.float32), _c(self.svd_down, np.float32)
+
+    def dequantize(self, tag=None, hadamard=True, use_svd=True) -> np.ndarray:
+        """SDNQDequantizer.__call__ -> dequantize_weight (dequantizer.py:389-429, 135-162): [N,K] in `tag`."""
+        tag = tag or self.result_tag
+        W = self.dequant_f32_nk()
+        up, down = self.svd_nr_rk()
+        if up is not None and use_svd:
+            lib().orc_svd_add(_p(W), _p(up), _p(down), self.N, self.K, up.shape[1], _DT[self.svd_tag])
+        W = round_dtype(W, tag)
+        if hadamard and self.deq["use_hadamard"]:
+            W = rotate_hadamard(W, self.deq["hadamard_group_size"], tag)
+        return W
+
+    def re_quantize_matmul(self):
+        """re_quantize_matmul (dequantizer.py:204-239): fp32 dequant (no SVD, Hadamard not undone) -> per-row quant.
+        Returns (wq [N,K] int8 | e4m3 codes uint8, ws [N])."""
+        W = self.dequant_f32_nk()
+        return rowquant(W, self.deq["quantized_matmul_dtype"])[:2]
+
+
+def rowquant(x_f32: np.ndarray, matmul_dtype: str):
+    """quantize_int_mm / quantize_fp_mm on float32 rows (quant_utils.py:265-273, 290-299) -> (q, scale[M], rowsum|None)."""
+    x = _c(x_f32, np.float32)
+    M, K = x.shape
+    s = np.empty(M, dtype=np.float32)
+    if matmul_dtype == "int8":
+        q = np.empty((M, K), dtype=np.int8)
+        rs = np.empty(M, dtype=np.int32)
+        lib().orc_rowquant_i8(_p(x), M, K, _p(q), _p(s), _p(rs))
+        return q, s, rs
+    q = np.empty((M, K), dtype=np.uint8)
+    lib().orc_rowquant_fp8(_p(x), M, K, _p(q), _p(s))
+    return q, s, None
+
+
+def scaled_mm(matmul_dtype: str, a, b_nk, sa, sb, bias, out_tag: str) -> np.ndarray:
+    """int_scaled_mm_torch / fp8_scaled_mm_torch (kernel_wrappers.py:132-144); b_nk is [N,K]; bias None|[N]|[M,N] f32."""
+    M, K = a.shape
+    N = b_nk.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    bias_ld = 0
+    if bias is not None:
+        bias = _c(bias, np.float32)
+        bias_ld = N if bias.ndim == 2 else 0
+    fn = lib().orc_scaled_mm_i8 if matmul_dtype == "int8" else lib().orc_scaled_mm_fp8
+    a = _c(a, np.int8 if matmul_dtype == "int8" else np.uint8)
+    b_nk = _c(b_nk, np.int8 if matmul_dtype == "int8" else np.uint8)
+    fn(_p(a), _p(b_nk), _p(_c(sa, np.float32).reshape(-1)), _p(_c(sb, np.float32).reshape(-1)), _p(bias), bias_ld, M, N, K,
+       _DT[out_tag], _p(out))
+    return out
+
+
+def linear_float(x, w_nk, bias, tag: str) -> np.ndarray:
+    M, K = x.shape
+    N = w_nk.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    lib().orc_linear_float(_p(_c(x, np.float32)), _p(_c(w_nk, np.float32)), _p(None if bias is None else _c(bias, np.float32)),
+                           M, N, K, _DT[tag], _p(out))
+    return out
+
+
+def lowrank_bias(t, up_nr, bias, tag: str) -> np.ndarray:
+    M, R = t.shape
+    N = up_nr.shape[0]
+    out = np.empty((M, N), dtype=np.float32)
+    lib().orc_lowrank_bias(_p(_c(t, np.float32)), _p(_c(up_nr, np.float32)), _p(None if bias is None else _c(bias, np.float32)),
+                           M, N, R, _DT[tag], _p(out))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# a1/a3/a12/a14: the forwards
+# ------------------------------------------------------------------------------------------------
+def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool = False):
+    """SDNQLinear.forward: dispatch of get_forward_func (forward.py:39-57) + the four Linear forwards."""
+    d = mod.deq
+    K, N = mod.K, mod.N
+    lead = x.shape[:-1]
+    x2 = _c(x.reshape(-1, K), np.float32)
+    M = x2.shape[0]
+    inter = {}
+    mmd = d["quantized_matmul_dtype"]
+    if not d["use_quantized_matmul"] or M < 32:
+        # quantized_linear_forward (layers/linear/forward.py:25-26) and the M<32 branch (linear_int8.py:102-103)
+        W = mod.dequantize(mod.result_tag)  # dtype defaults to result_dtype (dequantizer.py:402-403)
+        y = linear_float(x2, W, mod.bias, tag)
+        return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
+
+    if mmd == "uint8":
+        y = _forward_uint8(mod, x2, tag)
+        return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
+    mm = "int8" if mmd == "int8" else "fp8"
+
+    zp = None
+    if d["re_quantize_for_matmul"]:
+        wq, ws = mod.re_quantize_matmul()  # linear_int8.py:104-107
+    else:
+        vals, sc, zpv, group = mod._nk_values_scale()
+        assert group == K, "row-wise only without re-quantization"
+        ws = sc
+        info = dtype_info(d["weights_dtype"])
+        if mm == "int8":
+            if d["is_packed"]:
+                # unpack_int(..., dtype=int8): signed -> values; unsigned -> raw codes viewed as int8 (linear_int8.py:38-44)
+                wq = vals.astype(np.int32).astype(np.uint8).view(np.int8) if info["kind"] == "uint" else vals.astype(np.int8)
+                zp = zpv
+            elif info["kind"] == "uint":  # plain uint8: w ^ 0x80, zp += 128*scale (linear_int8.py:45-50)
+                wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+                zp = (zpv + np.float32(128.0) * sc).astype(np.float32) if zpv is not None else (sc * np.float32(128.0)).astype(np.float32)
+            else:
+                wq = vals.astype(np.int8)
+        else:
+            if d["is_packed"]:  # unpack_float(...).to(float8_e4m3fn) (linear_fp8.py:37)
+                wq = np.array([lib().orc_f32_to_e4m3fn(float(v)) for v in vals.reshape(-1)], dtype=np.uint8).reshape(N, K)
+            else:
+                wq = np.ascontiguousarray(mod.weight.reshape(K, N).T).view(np.uint8) if mod.transposed else mod.weight.reshape(N, K).view(np.uint8)
+    inter["wq"], inter["ws"] = wq, ws
+
+    if d["use_hadamard"]:
+        x2 = rotate_hadamard(x2, d["hadamard_group_size"], tag)  # linear_int8.py:55-56
+        inter["xrot"] = x2
+    bias = mod.bias
+    if mod.svd_up is not None:  # linear_int8.py:57-62
+        up, down = mod.svd_nr_rk()
+        t = linear_float(round_dtype(x2, mod.svd_tag), down, None, mod.svd_tag)
+        b1 = None if bias is None else round_dtype(bias, mod.svd_tag)
+        bias = lowrank_bias(t, up, b1, mod.svd_tag)
+    xq, xs, rowsum = rowquant(x2, mm)  # linear_int8.py:64
+    inter["xq"], inter["xs"] = xq, xs
+    if zp is not None:  # linear_int8.py:65-69
+        zero_bias = (rowsum.astype(np.float32) * xs).astype(np.float32)[:, None] * zp.astype(np.float32)[None, :]
+        zero_bias = zero_bias.astype(np.float32)
+        if bias is not None:
+            zero_bias = (zero_bias + bias.astype(np.float32)).astype(np.float32)
+        bias = zero_bias
+    y = scaled_mm(mm, xq, wq, xs, ws, bias, tag)
+    return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
+
+
+def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
+    """quantized_linear_forward_uint8_matmul (layers/linear/linear_uint8.py:27-131): asymmetric int8 activations."""
+    d = mod.deq
+    K, N = mod.K, mod.N
+    M = x2.shape[0]
+    f = np.float32
+    assert not d["re_quantize_for_matmul"] and not d["is_packed"], "oracle covers plain uint8 weights for the uint8 matmul"
+    vals, sc, zpv, group = mod._nk_values_scale()
+    wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+    zp = (zpv + f(128.0) * sc).astype(f)
+    if d["use_hadamard"]:
+        x2 = rotate_hadamard(x2, d["hadamard_group_size"], tag)
+    bias = mod.bias
+    if mod.svd_up is not None:
+        up, down = mod.svd_nr_rk()
+        t = linear_float(round_dtype(x2, mod.svd_tag), down, None, mod.svd_tag)
+        bias = lowrank_bias(t, up, None if bias is None else round_dtype(bias, mod.svd_tag), mod.svd_tag)
+    # quantize_uint_mm (quant_utils.py:277-286) with matmul_dtype "int8": get_scale_asymmetric (:10-19)
+    xmin, xmax = x2.min(-1, keepdims=True).astype(f), x2.max(-1, keepdims=True).astype(f)
+    xscale = ((xmax - xmin).astype(f) / f(255.0)).astype(f)
+    xzp = (xmin - f(-128.0) * xscale).astype(f)  # zero_point.sub_(scale, alpha=min)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = ((x2 - xzp).astype(f) / xscale).astype(f)
+    q = np.clip(np.rint(q), -128, 127)
+    q = np.where(np.isnan(q), 0, q).astype(np.int8)
+    xs = xscale.reshape(-1)
+    rowsum = q.astype(np.int32).sum(-1)
+    colsum = wq.astype(np.int32).sum(-1)  # sum over K of the weight, per output channel
+    zero_bias = ((rowsum.astype(f) * xs).astype(f)[:, None] * zp[None, :]).astype(f)
+    zero_bias = (zero_bias + ((colsum.astype(f) * sc).astype(f)[None, :] * xzp).astype(f)).astype(f)
+    zero_bias = (zero_bias + f(K) * (xzp * zp[None, :]).astype(f)).astype(f)
+    if bias is not None:
+        zero_bias = (zero_bias + bias.astype(f)).astype(f)
+    return scaled_mm("int8", q, wq, xs, sc, zero_bias, tag)

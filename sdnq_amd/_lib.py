@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI library ``libsdnq_hip.so`` (include/sdnq_hip.h).
+
+The shared object is built in-tree by ``sdnq_amd/csrc/build.sh`` (hipcc --offload-arch=gfx950) so
+that it travels with the source snapshot; nothing here falls back to another implementation: if
+the library is missing or the device is not gfx950 the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdnq_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+# enums of include/sdnq_hip.h
+F32, BF16, F16 = 0, 1, 2
+MM_I8, MM_FP8 = 0, 1
+ST_PACKED_U8, ST_PACKED_I16, ST_RAW8, ST_RAW16 = 0, 1, 2, 3
+KIND_INT, KIND_UINT, KIND_FLOAT, KIND_UFLOAT = 0, 1, 2, 3
+
+EXPORTS = [
+    "sdnq_hip_version", "sdnq_hip_strerror", "sdnq_hip_device_supported", "sdnq_hip_rowquant",
+    "sdnq_hip_scaled_mm", "sdnq_hip_dequant", "sdnq_hip_requant", "sdnq_hip_hadamard",
+    "sdnq_hip_lowrank_down", "sdnq_hip_scaled_mm_lowrank", "sdnq_hip_linear_float", "sdnq_hip_linear_skinny",
+]
+
+
+class SdnqWeight(ctypes.Structure):
+    _fields_ = [
+        ("weight", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("zero_point", ctypes.c_void_p),
+        ("svd_up", ctypes.c_void_p), ("svd_down", ctypes.c_void_p),
+        ("n", ctypes.c_int32), ("k", ctypes.c_int32), ("group_size", ctypes.c_int32), ("svd_rank", ctypes.c_int32),
+        ("svd_dtype", ctypes.c_int32), ("storage", ctypes.c_int32), ("kind", ctypes.c_int32), ("bits", ctypes.c_int32),
+        ("exponent", ctypes.c_int32), ("mantissa", ctypes.c_int32), ("native_float", ctypes.c_int32),
+    ]
+
+
+class SdnqHipError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def sources_newer_than_lib() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    hdr = os.path.join(_HERE, "..", "include", "sdnq_hip.h")
+    files = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))] + [hdr]
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into sdnq_amd/libsdnq_hip.so (no GPU needed)."""
+    if force or sources_newer_than_lib():
+        subprocess.run(["bash", os.path.join(_CSRC, "build.sh"), LIB_PATH], check=True)
+    return LIB_PATH
+
+
+def _declare(lib):
+    c = ctypes
+    vp, i32, i64 = c.c_void_p, c.c_int, c.c_int64
+    lib.sdnq_hip_version.restype = c.c_int
+    lib.sdnq_hip_strerror.restype = c.c_char_p
+    lib.sdnq_hip_strerror.argtypes = [c.c_int]
+    lib.sdnq_hip_device_supported.argtypes = [c.c_int]
+    lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
+    lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
+    lib.sdnq_hip_hadamard.argtypes = [vp, i32, i64, i64, i64, i32, vp, i64, vp]
+    lib.sdnq_hip_lowrank_down.argtypes = [vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
+    lib.sdnq_hip_scaled_mm_lowrank.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_linear_float.argtypes = [vp, vp, vp, i32, vp, i64, i64, i64, i64, vp]
+    lib.sdnq_hip_linear_skinny.argtypes = [c.POINTER(SdnqWeight), vp, vp, i32, vp, i64, i64, vp]
+    for name in EXPORTS:
+        if name not in ("sdnq_hip_strerror",):
+            getattr(lib, name).restype = c.c_int
+
+
+def load():
+    """Load the library (building it first if the sources are newer). Raises if unavailable."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise SdnqHipError(
+                        f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no fallback path.")
+                lib = ctypes.CDLL(LIB_PATH)
+                _declare(lib)
+                _lib = lib
+    return _lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().sdnq_hip_strerror(status).decode()
+        raise SdnqHipError(f"sdnq_hip {what} failed: {msg} (status {status})")

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build the C-ABI shared library for gfx950 (MI355X). hipcc cross-compiles without a GPU.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${1:-$HERE/../libsdnq_hip.so}"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
+OBJ="$HERE/../../build/obj"
+mkdir -p "$OBJ"
+pids=()
+for f in api rowquant gemm dequant; do
+  ( "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" ) &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" "$OBJ"/api.o "$OBJ"/rowquant.o "$OBJ"/gemm.o "$OBJ"/dequant.o
+echo "built $OUT"

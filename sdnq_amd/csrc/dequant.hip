@@ -1,0 +1,272 @@
+// Weight-side kernels for gfx950: dequantize, re-quantize-for-matmul, float linear.
+//
+//   sdnq_hip_dequant   <- SDNQDequantizer.__call__ / dequantize_weight   (dequantizer.py:135-162, 389-429)
+//                         dequantize_symmetric :52-84, dequantize_asymmetric :15-48
+//   sdnq_hip_requant   <- re_quantize_matmul -> re_quantize_int_mm / re_quantize_fp_mm
+//                         (dequantizer.py:204-239, 166-174, 190-201; quantize_int_mm quant_utils.py:265-273)
+//   sdnq_hip_linear_float <- torch.nn.functional.linear on the dequantized weight
+//                         (layers/linear/forward.py:25-26; M<32 branch linear_int8.py:102-103)
+//
+// All three are HBM-streaming kernels: a thread owns 16 consecutive elements of one weight row (a
+// whole number of codec groups for every packed format), so packed reads are contiguous per lane
+// and outputs are 16/32/64-byte lane-contiguous vectors.
+#include "hadamard_dev.h"
+#include "sdnq_dev.h"
+#include "unpack_dev.h"
+
+namespace {
+
+struct DeqParams {
+    const void* w;
+    const float* scale;
+    const float* zp;
+    const void* svd_up;    // [N][R]
+    const void* svd_down;  // [R][K]
+    int64_t N, K;
+    int group_size, G, rank;
+    WeightFmt fmt;
+};
+
+// dequantize 16 elements (row n, columns k0..k0+15) to fp32: f32(w)*s or fma(f32(w), s, zp)
+__device__ __forceinline__ void dequant16(const DeqParams& p, int64_t n, int64_t k0, float (&v)[16]) {
+    load16_values(p.w, n * p.K + k0, p.fmt, v);
+    const float* srow = p.scale + n * p.G;
+    const float* zrow = p.zp ? p.zp + n * p.G : nullptr;
+    if ((p.group_size & 15) == 0) {  // one group covers the whole 16-run (wave-uniform branch)
+        const int g = (int)(k0 / p.group_size);
+        const float s = srow[g];
+        if (zrow) {
+            const float z = zrow[g];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = fmaf(v[j], s, z);  // torch.addcmul == single-rounding fma
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = v[j] * s;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int g = (int)((k0 + j) / p.group_size);
+            v[j] = zrow ? fmaf(v[j], srow[g], zrow[g]) : v[j] * srow[g];
+        }
+    }
+}
+
+template <int OUT_T, int SVD_T>
+__global__ __launch_bounds__(256) void dequant_kernel(const DeqParams p, void* __restrict__ out) {
+    const int64_t units_per_row = p.K / 16;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= p.N * units_per_row) return;
+    const int64_t n = u / units_per_row, k0 = (u % units_per_row) * 16;
+    float v[16];
+    dequant16(p, n, k0, v);
+    if (p.svd_up) {
+        // result.to(svd dtype).addmm_(svd_up, svd_down): one rounding of W, fp32 accumulate, one rounding of the sum
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { v[j] = FT<SVD_T>::round(v[j]); acc[j] = 0.0f; }
+        for (int r = 0; r < p.rank; ++r) {
+            const float up = FT<SVD_T>::load(p.svd_up, n * p.rank + r);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(up, FT<SVD_T>::load(p.svd_down, (int64_t)r * p.K + k0 + j), acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = FT<SVD_T>::round(v[j] + acc[j]);
+    }
+    uint8_t* o = (uint8_t*)out + (n * p.K + k0) * FT<OUT_T>::bytes;
+    if constexpr (OUT_T == SDNQ_F32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(uint4*)(o + 16 * q) = Vec16<SDNQ_F32>::pack(v + 4 * q);
+    } else {
+        *(uint4*)o = Vec16<OUT_T>::pack(v);
+        *(uint4*)(o + 16) = Vec16<OUT_T>::pack(v + 8);
+    }
+}
+
+// one wave per weight row: phase 1 amax of the fp32 dequant, phase 2 quantize (recompute, L2-hot)
+template <int MM>
+__global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    const int64_t npass = (p.K + 1023) / 1024;
+    float amax = 0.0f;
+    for (int64_t ps = 0; ps < npass; ++ps) {
+        const int64_t k0 = ps * 1024 + lane * 16;
+        if (k0 < p.K) {
+            float v[16];
+            dequant16(p, n, k0, v);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) amax = fmaxf(amax, fabsf(v[j]));
+        }
+    }
+    amax = wave_max(amax);
+    const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
+    const float scale = amax / qmax;
+    if (lane == 0) ws[n] = scale;
+    for (int64_t ps = 0; ps < npass; ++ps) {
+        const int64_t k0 = ps * 1024 + lane * 16;
+        if (k0 < p.K) {
+            float v[16];
+            dequant16(p, n, k0, v);
+            u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                u32 byte;
+                if constexpr (MM == SDNQ_MM_I8) {
+                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[j] / scale);
+                    q = fminf(fmaxf(q, -128.0f), 127.0f);
+                    byte = (u32)(int)q & 0xffu;
+                } else {
+                    float q = v[j] / scale;
+                    if (q != q) q = 0.0f;
+                    q = fminf(fmaxf(q, -448.0f), 448.0f);
+                    byte = f32_to_e4m3fn(q);
+                }
+                o[j >> 2] |= byte << (8 * (j & 3));
+            }
+            *(uint4*)(wq + n * p.K + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// out[m][n] = cast( sum_k x[m][k] * w[n][k] + bias[n] ), fp32 accumulate.
+// One wave per output channel n and a chunk of MC activation rows; lanes stride K in 16-byte vectors.
+template <int T_ID, int MC>
+__global__ __launch_bounds__(256) void linear_float_kernel(const void* __restrict__ x, const void* __restrict__ w,
+                                                           const void* __restrict__ bias, void* __restrict__ out, int64_t M,
+                                                           int64_t N, int64_t K, int64_t ldx) {
+    constexpr int VN = Vec16<T_ID>::n;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t m0 = (int64_t)blockIdx.y * MC;
+    if (n >= N) return;
+    float acc[MC];
+#pragma unroll
+    for (int i = 0; i < MC; ++i) acc[i] = 0.0f;
+    const uint8_t* wrow = (const uint8_t*)w + n * K * FT<T_ID>::bytes;
+    for (int64_t k = (int64_t)lane * VN; k < K; k += 64 * VN) {
+        float wv[VN];
+        Vec16<T_ID>::unpack(*(const uint4*)(wrow + k * FT<T_ID>::bytes), wv);
+#pragma unroll
+        for (int i = 0; i < MC; ++i) {
+            const int64_t m = (m0 + i < M) ? m0 + i : M - 1;
+            float xv[VN];
+            Vec16<T_ID>::unpack(*(const uint4*)((const uint8_t*)x + (m * ldx + k) * FT<T_ID>::bytes), xv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) acc[i] = fmaf(xv[e], wv[e], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MC; ++i) {
+        float s = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0 && m0 + i < M) {
+            if (bias) s += FT<T_ID>::load(bias, n);
+            FT<T_ID>::store(out, (m0 + i) * N + n, s);
+        }
+    }
+}
+
+int fill_params(const SdnqWeight* w, DeqParams& p) {
+    if (!w || !w->weight || !w->scale) return SDNQ_ERR_NULL;
+    if (w->n <= 0 || w->k <= 0 || w->group_size <= 0 || (w->k % w->group_size) != 0) return SDNQ_ERR_SHAPE;
+    if ((w->k % 16) != 0) return SDNQ_ERR_SHAPE;
+    if (w->storage < 0 || w->storage > 3 || w->kind < 0 || w->kind > 3) return SDNQ_ERR_DTYPE;
+    if (w->bits < 1 || w->bits > 16) return SDNQ_ERR_DTYPE;
+    if (w->storage == SDNQ_ST_PACKED_U8 && w->bits > 7) return SDNQ_ERR_DTYPE;
+    if (w->storage == SDNQ_ST_PACKED_I16 && (w->bits < 9 || w->bits > 15)) return SDNQ_ERR_DTYPE;
+    if (w->storage == SDNQ_ST_RAW8 && w->bits != 8) return SDNQ_ERR_DTYPE;
+    if (w->storage == SDNQ_ST_RAW16 && w->bits != 16) return SDNQ_ERR_DTYPE;
+    if ((w->kind == SDNQ_KIND_UINT || w->kind == SDNQ_KIND_UFLOAT) && !w->zero_point) return SDNQ_ERR_NULL;
+    if ((w->kind == SDNQ_KIND_FLOAT || w->kind == SDNQ_KIND_UFLOAT) && !w->native_float) {
+        const int sign = (w->kind == SDNQ_KIND_FLOAT) ? 1 : 0;
+        if (w->exponent < 1 || w->exponent > 7 || w->mantissa < 0 || sign + w->exponent + w->mantissa != w->bits) return SDNQ_ERR_DTYPE;
+    }
+    if ((uintptr_t)w->weight % 16) return SDNQ_ERR_ALIGN;
+    if ((w->svd_up == nullptr) != (w->svd_down == nullptr)) return SDNQ_ERR_NULL;
+    if (w->svd_up && (w->svd_rank <= 0 || w->svd_dtype < 0 || w->svd_dtype > 2)) return SDNQ_ERR_SHAPE;
+    p.w = w->weight; p.scale = w->scale; p.zp = w->zero_point; p.svd_up = w->svd_up; p.svd_down = w->svd_down;
+    p.N = w->n; p.K = w->k; p.group_size = w->group_size; p.G = w->k / w->group_size; p.rank = w->svd_rank;
+    p.fmt = WeightFmt{w->storage, w->kind, w->bits, w->exponent, w->mantissa, w->native_float};
+    return SDNQ_OK;
+}
+
+}  // namespace
+
+extern "C" int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* out, int out_dtype, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!out) return SDNQ_ERR_NULL;
+    if (out_dtype < 0 || out_dtype > 2) return SDNQ_ERR_DTYPE;
+    if ((uintptr_t)out % 16) return SDNQ_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t units = p.N * (p.K / 16);
+    dim3 grid((unsigned)((units + 255) / 256)), block(256);
+    const int svd_t = p.svd_up ? w->svd_dtype : out_dtype;
+#define DQ_CASE(O, S) \
+    if (out_dtype == O && svd_t == S) hipLaunchKernelGGL((dequant_kernel<O, S>), grid, block, 0, s, p, out);
+    DQ_CASE(SDNQ_F32, SDNQ_F32)
+    else DQ_CASE(SDNQ_F32, SDNQ_BF16)
+    else DQ_CASE(SDNQ_F32, SDNQ_F16)
+    else DQ_CASE(SDNQ_BF16, SDNQ_BF16)
+    else DQ_CASE(SDNQ_BF16, SDNQ_F32)
+    else DQ_CASE(SDNQ_F16, SDNQ_F16)
+    else DQ_CASE(SDNQ_F16, SDNQ_F32)
+    else return SDNQ_ERR_DTYPE;
+#undef DQ_CASE
+    SDNQ_CHECK_LAUNCH();
+    if (hadamard_group != 0) return sdnq_hip_hadamard(out, out_dtype, p.N, p.K, p.K, hadamard_group, out, p.K, stream);
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, float* ws, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!wq || !ws) return SDNQ_ERR_NULL;
+    if ((uintptr_t)wq % 16) return SDNQ_ERR_ALIGN;
+    p.svd_up = nullptr; p.svd_down = nullptr;  // re_quantize_matmul never receives the SVD factors (linear_int8.py:105)
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
+    if (mm_dtype == SDNQ_MM_I8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws);
+    else if (mm_dtype == SDNQ_MM_FP8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws);
+    else return SDNQ_ERR_DTYPE;
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
+                                     int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {
+    if (!x || !wd || !out) return SDNQ_ERR_NULL;
+    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
+    const int eb = (dtype == SDNQ_F32) ? 4 : 2;
+    if (m <= 0 || n <= 0 || k <= 0 || ldx < k || ((k * eb) % 16) != 0) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)x % 16) || ((uintptr_t)wd % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int MC = 8;
+    dim3 grid((unsigned)((n + 3) / 4), (unsigned)((m + MC - 1) / MC)), block(256);
+    switch (dtype) {
+        case SDNQ_F32: hipLaunchKernelGGL((linear_float_kernel<SDNQ_F32, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx); break;
+        case SDNQ_BF16: hipLaunchKernelGGL((linear_float_kernel<SDNQ_BF16, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx); break;
+        default: hipLaunchKernelGGL((linear_float_kernel<SDNQ_F16, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx); break;
+    }
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, const void* svd_down,
+                                     int svd_dtype, int rank, void* t, sdnq_stream_t stream) {
+    // t = mm(x.to(svd dtype), svd_down): x already lives in the activation dtype; the reference casts x to
+    // svd_down.dtype first (linear_int8.py:60) -- both are the model dtype, so require equality.
+    if (x_dtype != svd_dtype) return SDNQ_ERR_DTYPE;
+    return sdnq_hip_linear_float(x, svd_down, nullptr, x_dtype, t, m, rank, k, ldx, stream);
+}
+
+extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, const void* x, const void* bias, int dtype, void* out, int64_t m,
+                                      int64_t ldx, sdnq_stream_t stream) {
+    (void)w; (void)x; (void)bias; (void)dtype; (void)out; (void)m; (void)ldx; (void)stream;
+    return SDNQ_ERR_UNSUPPORTED;  // fused streaming GEMV lands with the M<32 optimisation pass
+}

@@ -1,0 +1,113 @@
+// In-register fast Hadamard transform over a wave (64 lanes x 8 consecutive elements = 512 per pass).
+//
+// Reference: rotate_hadamard (quant_utils.py:194-209) = x.view(.., K/g, g) @ H_g with
+//   H_g = kron^p(H4) * g^-1/2 when g is a power of 4   (build_hadamard_n4, quant_utils.py:157-165)
+//   H_g = kron^p(H2) * g^-1/2 otherwise (power of 2)   (build_hadamard_n2, quant_utils.py:145-153)
+//   H4 = [[1,1,1,-1],[1,1,-1,1],[1,-1,1,1],[-1,1,1,1]],  H2 = [[1,1],[1,-1]]
+// kron structure => y = apply the 4-point (or 2-point) butterfly along every base-4 (base-2) digit
+// of the in-group index.  For H4: y(i) = S - 2*x(3-i) with S the sum of the four digit partners, and
+// the digit-(3-i) partner is the element with BOTH digit bits flipped.
+// Element index inside the wave pass: idx = lane*8 + e  -> bits 0..2 = e (registers), bits 3..8 = lane.
+#pragma once
+#include "sdnq_dev.h"
+
+// scale constants c(g) = |H_g[0][0]| as the reference materialises them (H.div_(n**0.5) in the
+// activation dtype); powers of 4 are exact powers of two. Values for the Sylvester sizes were read
+// from the reference (tests/golden/hadamard.npz for f32; bf16/f16 are the dtype-rounded values).
+__device__ __forceinline__ float hadamard_scale(int log2g, int dtype) {
+    if ((log2g & 1) == 0) return __uint_as_float((u32)(127 - log2g / 2) << 23);
+    // 1/sqrt(2^L), L odd
+    switch (dtype) {
+        case SDNQ_BF16:
+            switch (log2g) {
+                case 1: return __uint_as_float(0x3f350000u);
+                case 3: return __uint_as_float(0x3eb50000u);
+                case 5: return __uint_as_float(0x3e350000u);
+                case 7: return __uint_as_float(0x3db50000u);
+                default: return __uint_as_float(0x3d350000u);  // 9
+            }
+        case SDNQ_F16:
+            switch (log2g) {
+                case 1: return 0.70703125f;        // 0x39a8
+                case 3: return 0.353515625f;       // 0x35a8
+                case 5: return 0.1767578125f;      // 0x31a8
+                case 7: return 0.08837890625f;     // 0x2da8
+                default: return 0.044189453125f;   // 0x29a8
+            }
+        default:
+            switch (log2g) {
+                case 1: return __uint_as_float(0x3f3504f3u);
+                case 3: return __uint_as_float(0x3eb504f3u);
+                case 5: return __uint_as_float(0x3e3504f3u);
+                case 7: return __uint_as_float(0x3db504f3u);
+                default: return __uint_as_float(0x3d3504f3u);
+            }
+    }
+}
+
+__device__ __forceinline__ void had4_inlane(float& a, float& b, float& c, float& d) {
+    const float s = (a + b) + (c + d);
+    const float na = s - 2.0f * d, nb = s - 2.0f * c, nc = s - 2.0f * b, nd = s - 2.0f * a;
+    a = na; b = nb; c = nc; d = nd;
+}
+
+// v[8]: this lane's 8 consecutive elements. log2g in [2, 9]. Unscaled butterflies, then * scale.
+__device__ __forceinline__ void wave_hadamard(float (&v)[8], int log2g, float scale) {
+    const int lane = threadIdx.x & 63;
+    if ((log2g & 1) == 0) {
+        // ---- kron powers of H4: digits (0,1) (2,3) (4,5) (6,7)
+        had4_inlane(v[0], v[1], v[2], v[3]);
+        had4_inlane(v[4], v[5], v[6], v[7]);
+        if (log2g >= 4) {  // digit (bit2 = register, bit3 = lane bit 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = v[e], b = v[e + 4];
+                const float xa = __shfl_xor(a, 1, 64), xb = __shfl_xor(b, 1, 64);
+                const float s = (a + b) + (xa + xb);
+                // partner with both bits flipped: for register e -> other lane's e+4, for e+4 -> other lane's e
+                v[e] = s - 2.0f * xb;
+                v[e + 4] = s - 2.0f * xa;
+            }
+        }
+#pragma unroll
+        for (int d = 6; d <= 8; d += 2) {  // digits made of lane bits (1,2) then (3,4)
+            if (log2g >= d) {
+                const int ma = 1 << (d - 5), mb = 1 << (d - 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p1 = __shfl_xor(v[e], ma, 64), p2 = __shfl_xor(v[e], mb, 64), p3 = __shfl_xor(v[e], ma | mb, 64);
+                    const float s = (v[e] + p1) + (p2 + p3);
+                    v[e] = s - 2.0f * p3;
+                }
+            }
+        }
+    } else {
+        // ---- Sylvester: single-bit butterflies on bits 0..log2g-1
+#pragma unroll
+        for (int bit = 0; bit < 3; ++bit) {
+            const int st = 1 << bit;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if ((e & st) == 0) {
+                    const float a = v[e], b = v[e + st];
+                    v[e] = a + b;
+                    v[e + st] = a - b;
+                }
+            }
+        }
+#pragma unroll
+        for (int bit = 3; bit < 9; ++bit) {
+            if (log2g > bit) {
+                const int m = 1 << (bit - 3);
+                const bool hi = (lane & m) != 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float p = __shfl_xor(v[e], m, 64);
+                    v[e] = hi ? (p - v[e]) : (v[e] + p);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= scale;
+}

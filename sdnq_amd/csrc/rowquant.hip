@@ -1,0 +1,216 @@
+// Row-wise activation quantization (+ fused Hadamard rotation) for gfx950.
+//
+// Reference chain replaced (per call, several eager/Inductor kernels there; ONE launch here):
+//   rotate_hadamard(x)                          quant_utils.py:194-209   (linear_int8.py:55-56)
+//   x.flatten(0,-2).to(float32)                 linear_int8.py:16-18
+//   scale = amax(|x|, -1) / 127   (or / 448)    quant_utils.py:23-24, 268 / 293
+//   q = clamp(round(x / scale), -128, 127).to(int8)                       quant_utils.py:269-272
+//   q = clamp(nan_to_num(x / scale), -448, 448).to(float8_e4m3fn)         quant_utils.py:298
+//   rowsum = sum(q, -1, dtype=int32)            linear_int8.py:66
+//
+// HBM-bound: reads 2 B (bf16) and writes 1 B per element + 4 B per row.
+// Layout: one wave (64 lanes) per activation row, 8 consecutive elements per lane per pass, so
+// every global access is a 16-byte (bf16/f16) or 2x16-byte (f32) lane-contiguous vector and a
+// 256/512-wide Hadamard group lives inside one pass (cross-lane butterflies via DPP/bpermute).
+// Two phases over the row: (1) amax, (2) quantize; the second read hits L2.
+#include "hadamard_dev.h"
+#include "sdnq_dev.h"
+
+namespace {
+
+template <int T_ID>
+__device__ __forceinline__ void load8(const void* row, int64_t idx, bool ok, float (&v)[8]) {
+    if constexpr (T_ID == SDNQ_F32) {
+        if (ok) {
+            const uint4 a = *(const uint4*)((const float*)row + idx);
+            const uint4 b = *(const uint4*)((const float*)row + idx + 4);
+            Vec16<SDNQ_F32>::unpack(a, v);
+            Vec16<SDNQ_F32>::unpack(b, v + 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        }
+    } else {
+        if (ok) {
+            const uint4 a = *(const uint4*)((const uint16_t*)row + idx);
+            Vec16<T_ID>::unpack(a, v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+        }
+    }
+}
+
+template <int T_ID>
+__device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[8]) {
+    if constexpr (T_ID == SDNQ_F32) {
+        *(uint4*)((float*)row + idx) = Vec16<SDNQ_F32>::pack(v);
+        *(uint4*)((float*)row + idx + 4) = Vec16<SDNQ_F32>::pack(v + 4);
+    } else {
+        *(uint4*)((uint16_t*)row + idx) = Vec16<T_ID>::pack(v);
+    }
+}
+
+// T_ID: activation dtype; MM: SdnqMM; HAD: rotate first
+template <int T_ID, int MM, bool HAD>
+__global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
+                                                       int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
+                                                       int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;  // whole wave exits together (wave-uniform)
+    const void* row = (const char*)x + m * ldx * FT<T_ID>::bytes;
+    const float hscale = HAD ? hadamard_scale(log2g, T_ID) : 1.0f;
+    const int64_t npass = (K + 511) / 512;
+
+    // ---- phase 1: row amax (after rotation + rounding to the activation dtype) ------------------
+    float amax = 0.0f;
+    for (int64_t p = 0; p < npass; ++p) {
+        const int64_t idx = p * 512 + lane * 8;
+        float v[8];
+        load8<T_ID>(row, idx, idx < K, v);
+        if constexpr (HAD) {
+            wave_hadamard(v, log2g, hscale);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    }
+    amax = wave_max(amax);
+    const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
+    const float scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
+    if (lane == 0) xs[m] = scale;
+
+    // ---- phase 2: quantize ---------------------------------------------------------------------
+    int isum = 0;
+    uint8_t* qrow = xq + m * K;
+    for (int64_t p = 0; p < npass; ++p) {
+        const int64_t idx = p * 512 + lane * 8;
+        const bool ok = idx < K;
+        float v[8];
+        load8<T_ID>(row, idx, ok, v);
+        if constexpr (HAD) {
+            wave_hadamard(v, log2g, hscale);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+            if (xrot != nullptr && ok) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v);
+        }
+        u32 w0 = 0, w1 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            u32 byte;
+            if constexpr (MM == SDNQ_MM_I8) {
+                // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
+                float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[e] / scale);
+                q = fminf(fmaxf(q, -128.0f), 127.0f);
+                const int qi = (int)q;
+                isum += qi;
+                byte = (u32)qi & 0xffu;
+            } else {
+                float q = v[e] / scale;
+                if (q != q) q = 0.0f;  // nan_to_num; +-inf fall to the clamp
+                q = fminf(fmaxf(q, -448.0f), 448.0f);
+                byte = f32_to_e4m3fn(q);
+            }
+            if (e < 4) w0 |= byte << (8 * e);
+            else w1 |= byte << (8 * (e - 4));
+        }
+        if (ok) *(uint2*)(qrow + idx) = make_uint2(w0, w1);
+    }
+    if (rowsum != nullptr) {
+        isum = wave_sum_i32(isum);
+        if (lane == 0) rowsum[m] = isum;
+    }
+}
+
+// standalone rotation: y = rotate(x), rounded to dtype
+template <int T_ID>
+__global__ __launch_bounds__(256) void hadamard_kernel(const void* __restrict__ x, int64_t rows, int64_t K, int64_t ldx,
+                                                       int log2g, void* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const void* row = (const char*)x + r * ldx * FT<T_ID>::bytes;
+    void* orow = (char*)y + r * ldy * FT<T_ID>::bytes;
+    const float hscale = hadamard_scale(log2g, T_ID);
+    const int64_t npass = (K + 511) / 512;
+    for (int64_t p = 0; p < npass; ++p) {
+        const int64_t idx = p * 512 + lane * 8;
+        const bool ok = idx < K;
+        float v[8];
+        load8<T_ID>(row, idx, ok, v);
+        wave_hadamard(v, log2g, hscale);
+        if (ok) store8<T_ID>(orow, idx, v);
+    }
+}
+
+int ilog2(int64_t v) {
+    int l = 0;
+    while ((1LL << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype,
+                                 int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
+                                 sdnq_stream_t stream) {
+    if (!x || !xq || !xs) return SDNQ_ERR_NULL;
+    if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
+    if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
+    if (x_dtype < 0 || x_dtype > 2) return SDNQ_ERR_DTYPE;
+    const int eb = (x_dtype == SDNQ_F32) ? 4 : 2;
+    if (((uintptr_t)x % 16) || ((ldx * eb) % 16) || ((uintptr_t)xq % 8)) return SDNQ_ERR_ALIGN;
+    int log2g = 0;
+    if (hadamard_group != 0) {
+        log2g = ilog2(hadamard_group);
+        if ((1 << log2g) != hadamard_group || hadamard_group < 4 || hadamard_group > 512 || (k % hadamard_group) != 0)
+            return SDNQ_ERR_SHAPE;
+        if (hadamard_group < 8 && false) return SDNQ_ERR_UNSUPPORTED;
+        if (xrot && ((uintptr_t)xrot % 16)) return SDNQ_ERR_ALIGN;
+    }
+    if (rowsum && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+#define RQ_LAUNCH(T, MMV, H) \
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot)
+#define RQ_DISPATCH_H(T, MMV)              \
+    do {                                   \
+        if (log2g) RQ_LAUNCH(T, MMV, true); \
+        else RQ_LAUNCH(T, MMV, false);      \
+    } while (0)
+#define RQ_DISPATCH_MM(T)                                         \
+    do {                                                          \
+        if (mm_dtype == SDNQ_MM_I8) RQ_DISPATCH_H(T, SDNQ_MM_I8); \
+        else RQ_DISPATCH_H(T, SDNQ_MM_FP8);                       \
+    } while (0)
+    switch (x_dtype) {
+        case SDNQ_F32: RQ_DISPATCH_MM(SDNQ_F32); break;
+        case SDNQ_BF16: RQ_DISPATCH_MM(SDNQ_BF16); break;
+        default: RQ_DISPATCH_MM(SDNQ_F16); break;
+    }
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_hadamard(const void* x, int dtype, int64_t rows, int64_t k, int64_t ldx, int hadamard_group,
+                                 void* y, int64_t ldy, sdnq_stream_t stream) {
+    if (!x || !y) return SDNQ_ERR_NULL;
+    if (rows <= 0 || k <= 0 || (k % 8) != 0 || ldx < k || ldy < k) return SDNQ_ERR_SHAPE;
+    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
+    const int log2g = ilog2(hadamard_group);
+    if ((1 << log2g) != hadamard_group || hadamard_group < 4 || hadamard_group > 512 || (k % hadamard_group) != 0)
+        return SDNQ_ERR_SHAPE;
+    const int eb = (dtype == SDNQ_F32) ? 4 : 2;
+    if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((ldx * eb) % 16) || ((ldy * eb) % 16)) return SDNQ_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    switch (dtype) {
+        case SDNQ_F32: hipLaunchKernelGGL((hadamard_kernel<SDNQ_F32>), grid, block, 0, s, x, rows, k, ldx, log2g, y, ldy); break;
+        case SDNQ_BF16: hipLaunchKernelGGL((hadamard_kernel<SDNQ_BF16>), grid, block, 0, s, x, rows, k, ldx, log2g, y, ldy); break;
+        default: hipLaunchKernelGGL((hadamard_kernel<SDNQ_F16>), grid, block, 0, s, x, rows, k, ldx, log2g, y, ldy); break;
+    }
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}

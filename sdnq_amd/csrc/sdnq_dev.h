@@ -1,0 +1,151 @@
+// Device-side helpers shared by the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdnq_hip.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef short v8s __attribute__((ext_vector_type(8)));
+typedef unsigned int u32;
+
+#define SDNQ_WAVE 64
+
+// ---- float format conversions -----------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((u32)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {  // RNE, v_cvt_pk_bf16_f32 on gfx950
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+// element type traits: T_ID is SdnqFloat
+template <int T_ID> struct FT;
+template <> struct FT<SDNQ_F32> {
+    typedef float store_t;
+    static constexpr int bytes = 4;
+    static __device__ __forceinline__ float load(const void* p, int64_t i) { return ((const float*)p)[i]; }
+    static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <> struct FT<SDNQ_BF16> {
+    typedef uint16_t store_t;
+    static constexpr int bytes = 2;
+    static __device__ __forceinline__ float load(const void* p, int64_t i) { return bf16_bits_to_f32(((const uint16_t*)p)[i]); }
+    static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = f32_to_bf16_bits(v); }
+    static __device__ __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+};
+template <> struct FT<SDNQ_F16> {
+    typedef uint16_t store_t;
+    static constexpr int bytes = 2;
+    static __device__ __forceinline__ float load(const void* p, int64_t i) { return f16_bits_to_f32(((const uint16_t*)p)[i]); }
+    static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = f32_to_f16_bits(v); }
+    static __device__ __forceinline__ float round(float v) { return f16_bits_to_f32(f32_to_f16_bits(v)); }
+};
+
+// 16-byte vector of elements -> 8 (16-bit) or 4 (f32) floats
+template <int T_ID> struct Vec16;
+template <> struct Vec16<SDNQ_F32> {
+    static constexpr int n = 4;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct Vec16<SDNQ_BF16> {
+    static constexpr int n = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        u32 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (u32)f32_to_bf16_bits(f[2 * i]) | ((u32)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Vec16<SDNQ_F16> {
+    static constexpr int n = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = f16_bits_to_f32((uint16_t)(w[i] & 0xffffu));
+            f[2 * i + 1] = f16_bits_to_f32((uint16_t)(w[i] >> 16));
+        }
+    }
+    static __device__ __forceinline__ uint4 pack(const float* f) {
+        u32 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (u32)f32_to_f16_bits(f[2 * i]) | ((u32)f32_to_f16_bits(f[2 * i + 1]) << 16);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ---- fp8 e4m3fn (OCP) -------------------------------------------------------------------------
+// float -> e4m3fn, round-to-nearest-even, input already clamped to [-448, 448] (quant_utils.py:298),
+// so no overflow handling is needed; matches torch's .to(torch.float8_e4m3fn) on that range.
+__device__ __forceinline__ uint8_t f32_to_e4m3fn(float f) {
+    u32 u = __float_as_uint(f);
+    const u32 sign = (u >> 24) & 0x80u;
+    u &= 0x7fffffffu;
+    if (u >= 0x43f00000u) return (uint8_t)(sign | 0x7f);  // >= 480 or NaN -> NaN (torch does not saturate)
+    u32 r;
+    if (u < 0x3c800000u) {  // |f| < 2^-6: e4m3 subnormal, quantum 2^-9 (x512 is exact, rint is RNE)
+        r = (u32)__builtin_rintf(__uint_as_float(u) * 512.0f);
+    } else {
+        u += 0x7ffffu + ((u >> 20) & 1u);  // RNE at bit 20; a mantissa carry bumps the exponent
+        r = (u >> 20) - (120u << 3);       // rebias 127 -> 7
+    }
+    return (uint8_t)(sign | r);
+}
+__device__ __forceinline__ float e4m3fn_to_f32(uint8_t b) {
+    const u32 sign = ((u32)b & 0x80u) << 24;
+    const u32 e = (b >> 3) & 0xfu, m = b & 7u;
+    float v;
+    if (e == 0) v = (float)m * 0.001953125f;                      // m * 2^-9
+    else if (e == 15 && m == 7) v = __uint_as_float(0x7fc00000u);  // NaN
+    else v = __uint_as_float(((e + 120u) << 23) | (m << 20));
+    return __uint_as_float(__float_as_uint(v) | sign);
+}
+__device__ __forceinline__ float e5m2_to_f32(uint8_t b) {  // == fp16 with the low byte zero
+    return f16_bits_to_f32((uint16_t)((u32)b << 8));
+}
+
+// ---- reductions -------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Host-side launch helpers implemented per translation unit.
+#define SDNQ_CHECK_LAUNCH()                              \
+    do {                                                 \
+        if (hipGetLastError() != hipSuccess) return SDNQ_ERR_LAUNCH; \
+    } while (0)

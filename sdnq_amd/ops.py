@@ -1,0 +1,253 @@
+"""Tensor-level wrappers over the C ABI (``include/sdnq_hip.h``).
+
+PyTorch is only plumbing here: it owns device memory and the current HIP stream; every arithmetic
+step runs in the hand-written gfx950 kernels of ``libsdnq_hip.so``.  All functions raise
+``SdnqHipError`` on a non-zero status -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F16, F32, MM_FP8, MM_I8, SdnqWeight, check
+from .common import dtype_dict
+
+_FLOAT_CODE = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+_MM_TORCH = {MM_I8: torch.int8, MM_FP8: torch.float8_e4m3fn}
+
+
+def float_code(dt: torch.dtype) -> int:
+    try:
+        return _FLOAT_CODE[dt]
+    except KeyError:
+        raise _lib.SdnqHipError(f"unsupported float dtype {dt}") from None
+
+
+def mm_code(matmul_dtype: str) -> int:
+    if matmul_dtype == "int8":
+        return MM_I8
+    if matmul_dtype in ("fp8", "float8_e4m3fn"):
+        return MM_FP8
+    raise _lib.SdnqHipError(f"unsupported quantized_matmul_dtype {matmul_dtype!r}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.SdnqHipError("sdnq_amd kernels need tensors on a gfx950 device (got a CPU tensor); "
+                                    "there is no CPU fallback in the product path")
+
+
+# ---------------------------------------------------------------------------------------------
+# quantized weight descriptor
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class QuantWeight:
+    """A quantized Linear weight in the physical layout the kernels read ([N][K], scales [N][G])."""
+    desc: SdnqWeight
+    n: int
+    k: int
+    group_size: int
+    keep: tuple  # tensors kept alive for the raw pointers in `desc`
+
+
+def _storage_kind(weights_dtype: str):
+    ent = dtype_dict[weights_dtype]
+    bits = ent["num_bits"]
+    native = 0
+    if ent["is_integer"]:
+        kind = _lib.KIND_UINT if ent["is_unsigned"] else _lib.KIND_INT
+        if ent["is_packed"]:
+            storage = _lib.ST_PACKED_U8 if bits < 8 else _lib.ST_PACKED_I16
+        elif bits == 8:
+            storage = _lib.ST_RAW8
+        elif bits == 16:
+            storage = _lib.ST_RAW16
+        else:
+            raise _lib.SdnqHipError(f"weights_dtype {weights_dtype} is not a storage format of the matmul path")
+    else:
+        kind = _lib.KIND_UFLOAT if ent["is_unsigned"] else _lib.KIND_FLOAT
+        if ent["is_packed"]:
+            storage = _lib.ST_RAW8 if bits == 8 else (_lib.ST_RAW16 if bits == 16 else (_lib.ST_PACKED_U8 if bits < 8 else _lib.ST_PACKED_I16))
+        else:
+            native = 1
+            if bits == 8:
+                storage = _lib.ST_RAW8
+            elif bits == 16:
+                storage = _lib.ST_RAW16
+            else:
+                raise _lib.SdnqHipError(f"weights_dtype {weights_dtype} is not a storage format of the matmul path")
+    return storage, kind, bits, ent["exponent"], ent["mantissa"], native
+
+
+def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Tensor, zero_point, svd_up, svd_down,
+                      n: int, k: int, group_size: int, transposed: bool) -> QuantWeight:
+    """Canonicalise module tensors (reference layouts) into the kernels' physical layout.
+
+    transposed=False: weight is packed bytes / [N,K] / [N,G,g] (element order [N][K]); svd_up [N,R], svd_down [R,K].
+    transposed=True : the qmm layout the reference's quantizer produces when use_quantized_matmul and not
+                      re_quantize_for_matmul and not packed (quantizer.py:228-244): weight logical [K,N] with
+                      strides (1,K) -- the same bytes as physical [N][K]; a *contiguous* [K,N] (as stored in
+                      safetensors) is re-laid out once, like prepare_weight_for_matmul (quant_utils.py:240-249);
+                      scale [1,N]; svd_up [R,N], svd_down [K,R] (quantizer.py:164-167).
+    """
+    _require_cuda(weight, scale)
+    storage, kind, bits, ebits, mbits, native = _storage_kind(weights_dtype)
+    if transposed:
+        if tuple(weight.shape) != (k, n):
+            raise _lib.SdnqHipError(f"transposed weight must be [K,N]=({k},{n}), got {tuple(weight.shape)}")
+        w_phys = weight.t()
+        if not w_phys.is_contiguous():
+            w_phys = w_phys.contiguous()
+    else:
+        w_phys = weight if weight.is_contiguous() else weight.contiguous()
+    if scale.dtype != torch.float32:
+        raise _lib.SdnqHipError("scale must be float32 (dequantize_fp32=True, the reference default)")
+    g = k // group_size
+    sc = scale.contiguous().view(-1)
+    if sc.numel() != n * g:
+        raise _lib.SdnqHipError(f"scale has {sc.numel()} elements, expected N*G = {n * g}")
+    zp = None
+    if zero_point is not None:
+        zp = zero_point.to(torch.float32).contiguous().view(-1)
+        if zp.numel() != n * g:
+            raise _lib.SdnqHipError("zero_point size mismatch")
+    up = down = None
+    rank, svd_dt = 0, 0
+    if svd_up is not None:
+        if transposed:  # [R,N] , [K,R]
+            up = svd_up.t().contiguous()
+            down = svd_down.t().contiguous()
+        else:  # [N,R] , [R,K]
+            up = svd_up.contiguous()
+            down = svd_down.contiguous()
+        rank = up.shape[1]
+        svd_dt = float_code(up.dtype)
+    d = SdnqWeight(weight=_ptr(w_phys), scale=_ptr(sc), zero_point=_ptr(zp), svd_up=_ptr(up), svd_down=_ptr(down),
+                   n=n, k=k, group_size=group_size, svd_rank=rank, svd_dtype=svd_dt, storage=storage, kind=kind,
+                   bits=bits, exponent=ebits, mantissa=mbits, native_float=native)
+    return QuantWeight(desc=d, n=n, k=k, group_size=group_size, keep=(w_phys, sc, zp, up, down))
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels
+# ---------------------------------------------------------------------------------------------
+def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: bool = False, want_xrot: bool = False):
+    """Row-quantize activations [M,K] -> (xq [M,K] int8|fp8, xs [M,1] f32, rowsum [M] i32|None, xrot|None)."""
+    _require_cuda(x2d)
+    assert x2d.ndim == 2 and x2d.stride(1) == 1
+    m, k = x2d.shape
+    xq = torch.empty((m, k), device=x2d.device, dtype=_MM_TORCH[mm])
+    xs = torch.empty((m, 1), device=x2d.device, dtype=torch.float32)
+    rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
+    xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if (want_xrot and hadamard_group) else None
+    check(_lib.load().sdnq_hip_rowquant(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), mm, hadamard_group,
+                                        xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _stream(x2d)), "rowquant")
+    return xq, xs, rowsum, xrot
+
+
+def scaled_mm(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype):
+    """out[M,N] = cast(fma(f32(a @ b_phys^T) * sa, sb, bias)); b_phys is physical [N,K]."""
+    _require_cuda(a, b_phys, sa, sb, bias)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    out = torch.empty((m, n), device=a.device, dtype=out_dtype)
+    bias_ndim, ld_bias, bias_dt = 0, 0, 0
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_ndim = bias.ndim
+        ld_bias = bias.shape[-1]
+        bias_dt = float_code(bias.dtype)
+    check(_lib.load().sdnq_hip_scaled_mm(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                         bias_dt, bias_ndim, ld_bias, out.data_ptr(), float_code(out_dtype), m, n, k,
+                                         _stream(a)), "scaled_mm")
+    return out
+
+
+def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, zp, out_dtype: torch.dtype):
+    _require_cuda(a, b_phys)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    out = torch.empty((m, n), device=a.device, dtype=out_dtype)
+    rank = 0 if t is None else t.shape[1]
+    svd_dt = 0 if t is None else float_code(t.dtype)
+    bias_dt = 0
+    if bias is not None:
+        if t is not None and bias.dtype != t.dtype:
+            bias = bias.to(t.dtype)  # bias.to(dtype=svd_down.dtype), linear_int8.py:60
+        bias = bias.contiguous()
+        bias_dt = float_code(bias.dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_lowrank(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                                 bias_dt, _ptr(t), _ptr(svd_up_phys), svd_dt, rank, _ptr(rowsum), _ptr(zp),
+                                                 out.data_ptr(), float_code(out_dtype), m, n, k, _stream(a)), "scaled_mm_lowrank")
+    return out
+
+
+def dequant(qw: QuantWeight, out_dtype: torch.dtype, hadamard_group: int = 0, use_svd: bool = True) -> torch.Tensor:
+    dev = qw.keep[0].device
+    out = torch.empty((qw.n, qw.k), device=dev, dtype=out_dtype)
+    d = qw.desc
+    if not use_svd and d.svd_up:
+        d = SdnqWeight.from_buffer_copy(bytes(d))
+        d.svd_up = None
+        d.svd_down = None
+        d.svd_rank = 0
+    check(_lib.load().sdnq_hip_dequant(ctypes.byref(d), hadamard_group, out.data_ptr(), float_code(out_dtype),
+                                       torch.cuda.current_stream(dev).cuda_stream), "dequant")
+    return out
+
+
+def requant(qw: QuantWeight, mm: int):
+    dev = qw.keep[0].device
+    wq = torch.empty((qw.n, qw.k), device=dev, dtype=_MM_TORCH[mm])
+    ws = torch.empty((qw.n,), device=dev, dtype=torch.float32)
+    check(_lib.load().sdnq_hip_requant(ctypes.byref(qw.desc), mm, wq.data_ptr(), ws.data_ptr(),
+                                       torch.cuda.current_stream(dev).cuda_stream), "requant")
+    return wq, ws
+
+
+def hadamard(x: torch.Tensor, group: int) -> torch.Tensor:
+    _require_cuda(x)
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], x2.shape[1]), device=x.device, dtype=x.dtype)
+    check(_lib.load().sdnq_hip_hadamard(x2.data_ptr(), float_code(x.dtype), x2.shape[0], x2.shape[1], x2.stride(0), group,
+                                        y.data_ptr(), y.stride(0), _stream(x)), "hadamard")
+    return y.view(shape)
+
+
+def linear_float(x2d: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
+    """x2d [M,K] @ w[N,K]^T + bias, all in one float dtype, fp32 accumulate."""
+    _require_cuda(x2d, w, bias)
+    m, k = x2d.shape
+    n = w.shape[0]
+    assert w.is_contiguous() and x2d.stride(1) == 1 and w.dtype == x2d.dtype
+    if bias is not None and bias.dtype != x2d.dtype:
+        bias = bias.to(x2d.dtype)
+    out = torch.empty((m, n), device=x2d.device, dtype=x2d.dtype)
+    check(_lib.load().sdnq_hip_linear_float(x2d.data_ptr(), w.data_ptr(), _ptr(bias), float_code(x2d.dtype), out.data_ptr(),
+                                            m, n, k, x2d.stride(0), _stream(x2d)), "linear_float")
+    return out
+
+
+def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor:
+    """t[M,R] = cast(x2d @ svd_down_phys^T); svd_down_phys is physical [R,K]."""
+    m, k = x2d.shape
+    r = svd_down_phys.shape[0]
+    t = torch.empty((m, r), device=x2d.device, dtype=svd_down_phys.dtype)
+    check(_lib.load().sdnq_hip_lowrank_down(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), svd_down_phys.data_ptr(),
+                                            float_code(svd_down_phys.dtype), r, t.data_ptr(), _stream(x2d)), "lowrank_down")
+    return t

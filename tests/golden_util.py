@@ -1,0 +1,78 @@
+"""Loading of the golden fixtures captured from the reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TAGS = {"bf16": "bf16", "f16": "f16", "float32": "f32"}
+
+
+def case_names():
+    return sorted(f[5:-5] for f in os.listdir(GOLD) if f.startswith("case_") and f.endswith(".json"))
+
+
+class Case:
+    def __init__(self, name):
+        self.name = name
+        self.meta = json.load(open(os.path.join(GOLD, f"case_{name}.json")))
+        self.z = np.load(os.path.join(GOLD, f"case_{name}.npz"))
+        self.deq = self.meta["deq"]
+        self.N, self.K = self.meta["N"], self.meta["K"]
+        self.tag = self.meta["dtype"]  # bf16 | f16 | f32
+
+    def info(self, key):
+        return self.meta["tensors"].get(key)
+
+    def has(self, key):
+        i = self.info(key)
+        return i is not None and i["dtype"] != "none"
+
+    def raw(self, key):
+        return self.z[key] if self.has(key) else None
+
+    def f32(self, key):
+        """float tensor -> float32 values (bf16/f16 bit patterns decoded)."""
+        from oracle import oracle as O
+        if not self.has(key):
+            return None
+        tag = self.info(key)["dtype"]
+        arr = self.z[key]
+        if tag in ("bf16", "f16"):
+            return O.from_bits(arr, tag)
+        return arr.astype(np.float32)
+
+    def tensor_tag(self, key):
+        return TAGS.get(self.info(key)["dtype"], self.info(key)["dtype"])
+
+    def ms(self):
+        return sorted(int(k[2:]) for k in self.meta["tensors"] if k.startswith("x_"))
+
+    def oracle_module(self):
+        from oracle import oracle as O
+        svd_tag = self.tensor_tag("svd_up") if self.has("svd_up") else "bf16"
+        return O.OracleLinear(self.deq, self.raw("weight"), self.raw("scale"), self.raw("zero_point"), self.f32("svd_up"),
+                              self.f32("svd_down"), self.f32("bias"), svd_tag=svd_tag,
+                              bias_tag=self.tensor_tag("bias") if self.has("bias") else None, N=self.N, K=self.K)
+
+    # ---- torch views for the product path -------------------------------------------------------
+    def torch_tensor(self, key, device=None):
+        import torch
+        if not self.has(key):
+            return None
+        info = self.info(key)
+        t = torch.from_numpy(np.ascontiguousarray(self.z[key]))
+        tag = info["dtype"]
+        view = {"bf16": torch.bfloat16, "f16": torch.float16, "fp8e4m3": torch.float8_e4m3fn, "fp8e5m2": torch.float8_e5m2,
+                "bool": torch.bool}.get(tag)
+        if view is not None:
+            t = t.view(view)
+        st = info.get("stride")
+        if st is not None and t.ndim == 2 and st == [1, t.shape[0]] and t.shape[0] != 1:
+            t = t.t().contiguous().t()  # restore the reference's transposed (1, K) strides
+        if device is not None:
+            if st is not None and t.ndim == 2 and st == [1, t.shape[0]] and t.shape[0] != 1:
+                t = t.t().contiguous().to(device).t()
+            else:
+                t = t.to(device)
+        return t
