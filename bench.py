@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Headline benchmark: quantized-matmul GOP/s + SDXL-UNet Linear step latency, int8 w8a8, bs=1, on N MI355X.
+
+A "step" is ONE pass of the hot path over every quantized Linear of one SDXL-UNet denoising step
+(BASELINE.json configs[1]: weights_dtype=int8, group_size=-1, use_quantized_matmul=True, bf16 activations):
+722 int8 GEMM layers (M >= 32: fused row-quantize + MFMA scaled-mm) + 19 M=1 embedding layers (dequant +
+float GEMM branch), synthetic weights (randn*0.02, quantized by this package) and synthetic bf16 activations,
+all resident in HBM before the timed region.  Attention/conv/norm are NOT part of the step (the reference
+only replaces Linear layers by default; quant_conv=False).  The step is replayed from a hipGraph so the
+number measures the GPU, not the Python launch loop (the reference's own harness uses torch.compile).
+
+    value       = algorithmic ops per step (reference formula 2*M*K*N + M*N*[bias]) * steps / time, whole job
+    ms_per_step = SDXL-UNet Linear step latency;  tokens/s = 16384 latent tokens / step latency
+    roofline    = the int8 MFMA scaled-mm kernel alone: algorithmic ops of all its launches in one step divided by
+                  their summed duration, measured with HIP events on the launch stream, vs the dense int8 MFMA peak
+    cpu_baseline= the CPU oracle (plain C + OpenMP restatement of the reference's eager path) on a bounded sample of
+                  the same layer list, on this box's host cores (rank 0, N=1 only)
+
+N > 1 (driver launches one rank per GPU via torch.distributed.run): default = one independent latent per GPU
+(replicas, weak scaling, no data-path collective).  ``--tp`` column-shards every Linear across the ranks and
+all-gathers the outputs over RCCL/xGMI (strong scaling; see DESIGN.md for why that is link/latency-bound at bs=1).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+INT8_MFMA_PEAK_TOPS = 5033.0  # dense: 1024 MAC/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz x 2 (MI355X_MICROARCH.md: i8 = 2x bf16 rate)
+FP8_MFMA_PEAK_TFLOPS = 5033.0
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8"])
+    p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--layers-scale", type=float, default=1.0, help="debug: fraction of each layer's repeat count")
+    return p.parse_args()
+
+
+def workload_config(name: str):
+    from sdnq_amd import shapes
+    if name == "sdxl_int8":
+        return shapes.sdxl_unet_linears(), dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), "int8", 16384
+    if name == "sdxl_fp8":
+        return shapes.sdxl_unet_linears(), dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1,
+                                                use_quantized_matmul=True), "fp8", 16384
+    if name == "flux_int4_had":
+        return shapes.flux_dev_linears(), dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256,
+                                               use_quantized_matmul=True), "int8", 4608
+    if name == "flux_int8_svd":
+        return shapes.flux_dev_linears(), dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
+                                               use_quantized_matmul=True), "int8", 4608
+    if name == "linear_int8":  # the reference's own micro-benchmark shape (scripts/benchmark_sdnq_inference_matmul.py)
+        return [("bench.linear", 16384, 4096, 8192, True, 1)], dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), "int8", 16384
+    raise ValueError(name)
+
+
+def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0):
+    """-> list of (name, module, x, M, K, N, bias). One module per layer instance (distinct weights, like a real UNet);
+    one activation buffer per shape class."""
+    import sdnq_amd
+    g = torch.Generator(device=device).manual_seed(seed)
+    layers = []
+    for (name, m, k, n, has_bias, repeat) in shape_list:
+        repeat = max(1, int(round(repeat * scale)))
+        x = torch.randn(m, k, device=device, dtype=torch.bfloat16, generator=g)
+        for r in range(repeat):
+            n_local = n
+            lin = torch.nn.Linear(k, n_local, bias=has_bias, device=device, dtype=torch.bfloat16)
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(n_local, k, device=device, generator=g) * 0.02)
+                if has_bias:
+                    lin.bias.copy_(torch.randn(n_local, device=device, generator=g) * 0.1)
+            cfg = sdnq_amd.SDNQConfig(**cfg_kwargs)
+            if tp_world > 1:
+                from sdnq_amd.parallel import column_shard_linear
+                mod = column_shard_linear(lin, cfg, tp_rank, tp_world)
+            else:
+                mod, _ = sdnq_amd.sdnq_quantize_layer(lin, cfg)
+            layers.append((name, mod, x, m, k, n, has_bias))
+    return layers
+
+
+def run_step(layers):
+    out = None
+    for (_, mod, x, *_rest) in layers:
+        out = mod(x)
+    return out
+
+
+def time_gemm_kernel(layers, mm_name, device):
+    """Dominant-kernel roofline: every M>=32 layer's scaled-mm launch alone, back to back on one stream, HIP events."""
+    from sdnq_amd import linear as L
+    from sdnq_amd import ops
+    mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
+    calls, total_ops = [], 0
+    for (_, mod, x, m, k, n, has_bias) in layers:
+        if m < 32 or not hasattr(mod, "sdnq_dequantizer"):
+            continue
+        dq = mod.sdnq_dequantizer
+        if dq.svd_rank and getattr(mod, "svd_up", None) is not None:
+            continue
+        st = L._state(mod)
+        wq, ws, zp = L._prepare_mm_weights(mod, st, mm)
+        xq, xs, _, _ = ops.rowquant(x, mm, dq.hadamard_group_size if dq.use_hadamard else 0)
+        calls.append((xq, wq, xs, ws, mod.bias))
+        total_ops += 2 * m * k * n + (m * n if has_bias else 0)
+    if not calls:
+        return None
+
+    def launch_all():
+        for (xq, wq, xs, ws, bias) in calls:
+            ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
+    launch_all()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(device=device)
+    reps = 5
+    with torch.cuda.stream(s):
+        graph = torch.cuda.CUDAGraph()
+        launch_all()
+        s.synchronize()
+        with torch.cuda.graph(graph, stream=s):
+            launch_all()
+        graph.replay()
+        s.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(s)
+        s.synchronize()
+    dur_s = e0.elapsed_time(e1) / 1e3 / reps
+    return {"launches": len(calls), "ops": total_ops, "seconds": dur_s}
+
+
+def cpu_baseline(shape_list, mm_name, budget_s):
+    """The oracle (a C + OpenMP port of the reference's CPU-eager semantics) timed on a bounded sample of the layer list."""
+    import numpy as np
+    from oracle import oracle as O
+    L = O.lib()
+    cores = L.orc_num_threads()
+    rng = np.random.default_rng(0)
+    done_ops, t_total, sample = 0, 0.0, []
+    # one instance per distinct GEMM shape, smallest first, until the time budget is used
+    seen = sorted({(m, k, n, b) for (_, m, k, n, b, _r) in shape_list if m >= 32}, key=lambda s: s[0] * s[1] * s[2])
+    for (m, k, n, b) in seen:
+        x = O.round_dtype(rng.standard_normal((m, k), dtype=np.float32), "bf16")
+        w = rng.integers(-127, 128, size=(n, k), dtype=np.int8)
+        ws = (rng.random(n, dtype=np.float32) * 0.01 + 1e-4).astype(np.float32)
+        bias = O.round_dtype(rng.standard_normal(n, dtype=np.float32), "bf16") if b else None
+        t0 = time.perf_counter()
+        xq, xs, _ = O.rowquant(x, "int8" if mm_name == "int8" else "fp8")
+        if mm_name == "int8":
+            O.scaled_mm("int8", xq, w, xs, ws, bias, "bf16")
+        else:
+            O.scaled_mm("fp8", xq, w.view(np.uint8) & 0x7e, xs, ws, bias, "bf16")
+        dt = time.perf_counter() - t0
+        t_total += dt
+        done_ops += 2 * m * k * n + (m * n if b else 0)
+        sample.append(f"{m}x{k}x{n}")
+        if t_total > budget_s:
+            break
+    return {"value": round(done_ops / t_total / 1e9, 2), "unit": "GOP/s", "cores": cores, "kind": "port",
+            "sample": "row-quantize + int8 scaled-mm, one instance of SDXL GEMM shapes " + ",".join(sample) + f" ({t_total:.1f}s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from sdnq_amd import _lib, shapes
+    if not _lib.load().sdnq_hip_device_supported(local_rank):
+        raise SystemExit("device is not gfx950: the HIP kernels of this repo target MI355X only")
+
+    shape_list, cfg_kwargs, mm_name, tokens = workload_config(args.workload)
+    tp = args.tp and distributed
+    layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
+                          tp_world=world if tp else 1, seed=0 if tp else rank)
+    ops_per_step = sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in layers)
+
+    # eager warm-up (builds the per-module weight caches), then capture the whole step
+    for _ in range(2):
+        run_step(layers)
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph and not tp:
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(side):
+            run_step(layers)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                run_step(layers)
+        torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            run_step(layers)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    replicas = 1 if tp or not distributed else world
+    total_ops = ops_per_step * args.steps * replicas
+    value = total_ops / elapsed / 1e9  # GOP/s, whole job
+
+    result = {
+        "metric": "quantized-matmul GOP/s (SDXL UNet int8 Linear step, bs=1)" if args.workload == "sdxl_int8"
+        else f"quantized-matmul GOP/s ({args.workload})",
+        "value": round(value, 1), "unit": "GOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
+        "vs_baseline": None, "dtype": "i8" if mm_name == "int8" else "fp8", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {len(layers)} quantized Linear layers of one denoising step, bs=1 "
+                               f"({sum(1 for l in layers if l[3] >= 32)} w8a8 GEMMs + {sum(1 for l in layers if l[3] < 32)} M=1 layers)",
+                   "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
+                   "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16",
+                   "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
+        "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
+        "step_latency_ms": round(ms_per_step, 4),
+    }
+
+    if rank == 0:
+        try:
+            gk = time_gemm_kernel(layers, mm_name, device)
+        except Exception as e:  # noqa: BLE001
+            gk, result["roofline_error"] = None, repr(e)
+        if gk:
+            ach = gk["ops"] / gk["seconds"] / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s" if mm_name == "int8" else "TFLOP/s",
+                                  "frac": round(ach / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
+                                  "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(shape_list, mm_name, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline_error"] = repr(e)
+        print(json.dumps(result))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

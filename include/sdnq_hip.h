@@ -131,6 +131,16 @@ int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* out, int out
  * per-output-row symmetric quantization to the matmul dtype. wq: physical [N][K]; ws: [N] f32. */
 int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, float* ws, sdnq_stream_t stream);
 
+/* ---- a12/a13 (weight half): matmul operand WITHOUT re-quantization ----------------------------
+ * replaces the per-call unpack in get_int8_matmul_inputs / get_fp8_matmul_inputs
+ * (layers/linear/linear_int8.py:38-50, linear_fp8.py:36-38) for row-wise weights whose codes already fit
+ * the matmul dtype:
+ *   int8 mm: packed signed -> value; packed unsigned -> raw code (caller keeps zero_point);
+ *            raw uint8 -> code ^ 0x80 (caller adds 128*scale to the zero point); raw int8 -> copy
+ *   fp8  mm: packed custom float -> e4m3fn(decoded value); native float8_e4m3fn -> copy
+ * wq: physical [N][K] bytes. Scales are untouched (row-wise, already [N]). */
+int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, sdnq_stream_t stream);
+
 /* ---- a11: Hadamard rotation -------------------------------------------------------------------
  * replaces rotate_hadamard (quant_utils.py:194-209): y.view(rows, K/g, g) @ H_g, rounded to dtype.
  * H_g = kron powers of the reference's H4 (g a power of 4) or Sylvester H2 (other powers of 2),

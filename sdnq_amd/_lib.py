@@ -23,7 +23,7 @@ KIND_INT, KIND_UINT, KIND_FLOAT, KIND_UFLOAT = 0, 1, 2, 3
 
 EXPORTS = [
     "sdnq_hip_version", "sdnq_hip_strerror", "sdnq_hip_device_supported", "sdnq_hip_rowquant",
-    "sdnq_hip_scaled_mm", "sdnq_hip_dequant", "sdnq_hip_requant", "sdnq_hip_hadamard",
+    "sdnq_hip_scaled_mm", "sdnq_hip_dequant", "sdnq_hip_requant", "sdnq_hip_unpack_mm", "sdnq_hip_hadamard",
     "sdnq_hip_lowrank_down", "sdnq_hip_scaled_mm_lowrank", "sdnq_hip_linear_float", "sdnq_hip_linear_skinny",
 ]
 
@@ -73,6 +73,7 @@ def _declare(lib):
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
     lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
+    lib.sdnq_hip_unpack_mm.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp]
     lib.sdnq_hip_hadamard.argtypes = [vp, i32, i64, i64, i64, i32, vp, i64, vp]
     lib.sdnq_hip_lowrank_down.argtypes = [vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
     lib.sdnq_hip_scaled_mm_lowrank.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, i32, i64, i64, i64, vp]

@@ -130,6 +130,30 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
     }
 }
 
+// matmul operand straight from the stored codes (no scaling): see sdnq_hip_unpack_mm in the header
+template <int MM>
+__global__ __launch_bounds__(256) void unpack_mm_kernel(const DeqParams p, uint8_t* __restrict__ wq) {
+    const int64_t units = p.N * p.K / 16;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    float v[16];
+    load16_values(p.w, u * 16, p.fmt, v);
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        u32 byte;
+        if constexpr (MM == SDNQ_MM_I8) {
+            int iv = (int)v[j];  // exact: |v| < 256
+            if (p.fmt.kind == SDNQ_KIND_UINT && p.fmt.storage == SDNQ_ST_RAW8) iv ^= 0x80;  // uint8 -> int8 (linear_int8.py:46)
+            byte = (u32)iv & 0xffu;
+        } else {
+            byte = f32_to_e4m3fn(v[j]);
+        }
+        o[j >> 2] |= byte << (8 * (j & 3));
+    }
+    *(uint4*)(wq + u * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // out[m][n] = cast( sum_k x[m][k] * w[n][k] + bias[n] ), fp32 accumulate.
 // One wave per output channel n and a chunk of MC activation rows; lanes stride K in 16-byte vectors.
 template <int T_ID, int MC>
@@ -234,6 +258,28 @@ extern "C" int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, flo
     if (mm_dtype == SDNQ_MM_I8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws);
     else if (mm_dtype == SDNQ_MM_FP8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws);
     else return SDNQ_ERR_DTYPE;
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!wq) return SDNQ_ERR_NULL;
+    if ((uintptr_t)wq % 16) return SDNQ_ERR_ALIGN;
+    if (mm_dtype == SDNQ_MM_I8) {
+        if ((p.fmt.kind != SDNQ_KIND_INT && p.fmt.kind != SDNQ_KIND_UINT) || p.fmt.bits > 8) return SDNQ_ERR_DTYPE;
+    } else if (mm_dtype == SDNQ_MM_FP8) {
+        if (p.fmt.kind != SDNQ_KIND_FLOAT || p.fmt.bits > 8) return SDNQ_ERR_DTYPE;
+    } else {
+        return SDNQ_ERR_DTYPE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t units = p.N * p.K / 16;
+    dim3 grid((unsigned)((units + 255) / 256)), block(256);
+    if (mm_dtype == SDNQ_MM_I8) hipLaunchKernelGGL((unpack_mm_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq);
+    else hipLaunchKernelGGL((unpack_mm_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }

@@ -1,0 +1,25 @@
+"""Forward-function dispatch: same predicate tree as the reference's ``get_forward_func``
+(forward.py:6-57, Linear branch :39-57), re-pointed at the HIP-backed forwards."""
+from __future__ import annotations
+
+from collections.abc import Callable
+
+from .common import conv_transpose_types, conv_types, dtype_dict, embedding_types
+
+
+def get_forward_func(layer_class_name: str, quantized_matmul_dtype: str, use_quantized_matmul: bool) -> Callable:
+    if layer_class_name in embedding_types or layer_class_name in conv_types or layer_class_name in conv_transpose_types:
+        raise NotImplementedError(
+            f"{layer_class_name}: only Linear layers are on the MI355X hot path (quant_conv / quant_embedding are off by "
+            "default in the reference, quantizer.py:952-953)")
+    from . import linear
+    if use_quantized_matmul:
+        ent = dtype_dict[quantized_matmul_dtype]
+        if ent["is_integer"]:
+            if ent["is_unsigned"]:
+                return linear.quantized_linear_forward_uint8_matmul
+            return linear.quantized_linear_forward_int8_matmul
+        if ent["num_bits"] == 8:
+            return linear.quantized_linear_forward_fp8_matmul
+        return linear.quantized_linear_forward_fp16_matmul
+    return linear.quantized_linear_forward

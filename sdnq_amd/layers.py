@@ -1,0 +1,62 @@
+"""Module wrappers of the drop-in boundary.
+
+Same surface as the reference's ``layers/__init__.py`` (SDNQLayer :6-33, SDNQLinear :36-37,
+get_sdnq_wrapper_class :72-93): the wrapper adopts the original layer's ``__dict__`` (so it shares
+``_parameters``), remembers ``original_class`` and routes ``forward`` through ``self.forward_func(self, x)``
+-- the seam this build plugs its HIP forwards into.  Attributes ``weight, scale, zero_point, svd_up,
+svd_down, bias, sdnq_dequantizer`` keep the reference names and state_dict layout.
+"""
+from __future__ import annotations
+
+from collections.abc import Callable
+
+import torch
+
+
+class SDNQLayer(torch.nn.Module):
+    def __init__(self, original_layer: torch.nn.Module, forward_func: Callable):
+        torch.nn.Module.__init__(self)
+        skip = {"forward", "forward_func", "original_class", "state_dict", "load_state_dict"}
+        for key, value in original_layer.__dict__.items():
+            if key not in skip:
+                setattr(self, key, value)
+        self.original_class = original_layer.__class__
+        self.forward_func = forward_func
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.sdnq_dequantizer.result_dtype if hasattr(self, "sdnq_dequantizer") else self.weight.dtype
+
+    def dequantize(self):
+        """Back to the original float layer (reference layers/__init__.py:19-27)."""
+        if hasattr(self, "sdnq_dequantizer"):
+            dq = self.sdnq_dequantizer
+            w = dq(self.weight, self.scale, zero_point=self.zero_point, svd_up=self.svd_up, svd_down=self.svd_down,
+                   skip_quantized_matmul=dq.use_quantized_matmul)
+            self.weight = torch.nn.Parameter(w, requires_grad=True)
+            del self.sdnq_dequantizer, self.scale, self.zero_point, self.svd_up, self.svd_down
+            self.__dict__.pop("_sdnq_hip_state", None)
+        self.__class__ = self.original_class
+        del self.original_class, self.forward_func
+        return self
+
+    def forward(self, *args, **kwargs) -> torch.Tensor:
+        return self.forward_func(self, *args, **kwargs)
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(original_class={self.original_class} forward_func={self.forward_func} "
+                f"sdnq_dequantizer={getattr(self, 'sdnq_dequantizer', None)})")
+
+
+class SDNQLinear(SDNQLayer, torch.nn.Linear):
+    original_class: torch.nn.Linear
+
+
+torch.serialization.add_safe_globals([SDNQLayer, SDNQLinear])
+
+
+def get_sdnq_wrapper_class(original_layer: torch.nn.Module, forward_func: Callable) -> SDNQLayer:
+    if original_layer.__class__.__name__ == "Linear":
+        return SDNQLinear(original_layer, forward_func)
+    # conv / embedding wrappers are outside the hot path this build covers
+    return SDNQLayer(original_layer, forward_func)

@@ -1,0 +1,157 @@
+"""The Linear forwards of the drop-in boundary: ``forward_func(self: SDNQLinear, input) -> Tensor``.
+
+One function per reference forward (same names, same control flow, same numerics contract):
+
+    quantized_linear_forward               layers/linear/forward.py:25-26
+    quantized_linear_forward_int8_matmul   layers/linear/linear_int8.py:101-125  (+ :26-97)
+    quantized_linear_forward_fp8_matmul    layers/linear/linear_fp8.py:82-104    (+ :26-78)
+    quantized_linear_forward_uint8_matmul  layers/linear/linear_uint8.py:106-131
+
+Where the reference runs unpack / scale / Hadamard / SVD / row-quant / zero-point as a chain of eager or
+Inductor kernels and then a Triton GEMM, this build issues at most three HIP launches per call:
+``rowquant`` (Hadamard + amax + quantize [+ rowsum] fused), [``lowrank_down`` for SVD], and the MFMA
+``scaled_mm`` whose epilogue applies scales, bias, the low-rank term and the zero-point term.
+
+Weight-side work that depends only on static tensors (re-quantization of group-wise / packed weights to
+int8/fp8, unpacking of 6/7-bit rows, SVD factor layout) is done ONCE and cached on the module -- the
+reference redoes it every forward (dequantizer.py:204-239) but the result is identical because the
+inputs never change.  ``SDNQ_HIP_CACHE_WEIGHTS=0`` restores the per-call behaviour.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import ops
+from .common import dtype_dict
+
+CACHE_WEIGHTS = os.environ.get("SDNQ_HIP_CACHE_WEIGHTS", "1").lower() not in {"0", "false", "no"}
+
+
+class _State:
+    """Per-module cache of kernel-ready tensors, keyed on the identity of the module's parameters."""
+    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "svd_up", "svd_down", "wd", "bias")
+
+
+def _key(mod):
+    def k(t):
+        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+    return (k(mod.weight), k(mod.scale), k(getattr(mod, "zero_point", None)), k(getattr(mod, "svd_up", None)),
+            k(getattr(mod, "svd_down", None)))
+
+
+def _state(mod) -> _State:
+    st = mod.__dict__.get("_sdnq_hip_state")
+    key = _key(mod)
+    if st is None or st.key != key:
+        dq = mod.sdnq_dequantizer
+        st = _State()
+        st.key = key
+        st.qw = dq.quant_weight(mod.weight, mod.scale, getattr(mod, "zero_point", None), getattr(mod, "svd_up", None),
+                                getattr(mod, "svd_down", None))
+        st.mm = None
+        st.mm_weight = st.mm_scale = st.mm_zp = None
+        st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
+        st.wd = None
+        mod.__dict__["_sdnq_hip_state"] = st
+    return st
+
+
+def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
+    """F.linear(input, dequant(W), bias): dequantize to [N,K] in the result dtype (Hadamard un-rotated, SVD added),
+    then a float GEMM with fp32 accumulation."""
+    dq = mod.sdnq_dequantizer
+    k, n = dq.in_features, dq.out_features
+    if input.dtype != dq.result_dtype:
+        raise RuntimeError(f"expected input dtype {dq.result_dtype} (the layer's result_dtype) but got {input.dtype}")
+    wd = st.wd
+    if wd is None:
+        wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)
+        if CACHE_WEIGHTS and os.environ.get("SDNQ_HIP_CACHE_DEQUANT", "0") == "1":
+            st.wd = wd
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    y = ops.linear_float(x2, wd, mod.bias)
+    return y.view(*input.shape[:-1], n)
+
+
+@torch.no_grad()
+def quantized_linear_forward(self, input: torch.Tensor) -> torch.Tensor:
+    return _float_forward(self, input, _state(self))
+
+
+def _prepare_mm_weights(mod, st: _State, mm: int):
+    """Weight operand of the quantized matmul: (wq [N,K], ws [N], zp [N] | None)."""
+    dq = mod.sdnq_dequantizer
+    if st.mm == mm and st.mm_weight is not None:
+        return st.mm_weight, st.mm_scale, st.mm_zp
+    zp = None
+    if dq.re_quantize_for_matmul:
+        wq, ws = ops.requant(st.qw, mm)  # linear_int8.py:104-107; zero_point folded, none afterwards
+    else:
+        ws = st.qw.keep[1]  # row-wise scale [N]
+        ent = dtype_dict[dq.weights_dtype]
+        plain = (not ent["is_packed"]) and ((mm == ops.MM_I8 and dq.weights_dtype == "int8")
+                                            or (mm == ops.MM_FP8 and ent["torch_dtype"] == torch.float8_e4m3fn))
+        if plain:
+            wq = st.qw.keep[0]  # already the physical [N,K] operand
+            if wq.dtype == torch.uint8:
+                wq = wq.view(torch.int8)
+        else:
+            wq = ops.unpack_mm(st.qw, mm)  # linear_int8.py:38-50 / linear_fp8.py:36-38
+        if mm == ops.MM_I8 and ent["is_unsigned"]:
+            zp = st.qw.keep[2]
+            if not ent["is_packed"]:  # plain uint8: zero_point += 128 * scale (linear_int8.py:47-50)
+                zp = torch.add(zp, ws, alpha=128) if zp is not None else ws * 128
+    if CACHE_WEIGHTS:
+        st.mm, st.mm_weight, st.mm_scale, st.mm_zp = mm, wq, ws, zp
+    return wq, ws, zp
+
+
+def _quantized_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
+    dq = self.sdnq_dequantizer
+    st = _state(self)
+    k, n = dq.in_features, dq.out_features
+    m = input.numel() // input.shape[-1]
+    if m < 32:  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
+        return _float_forward(self, input, st)
+    wq, ws, zp = _prepare_mm_weights(self, st, mm)
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+        x2 = x2.contiguous()
+    had = dq.hadamard_group_size if dq.use_hadamard else 0
+    has_svd = st.svd_up is not None
+    xq, xs, rowsum, xrot = ops.rowquant(x2, mm, had, want_rowsum=zp is not None, want_xrot=has_svd)
+    bias = self.bias
+    if has_svd or zp is not None:
+        t = None
+        if has_svd:  # mm(x, svd_down) of addmm(bias, mm(x, svd_down), svd_up), linear_int8.py:57-62
+            t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down)
+        y = ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, st.svd_up, rowsum, zp, input.dtype)
+    else:
+        y = ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype)
+    return y.view(*input.shape[:-1], n)
+
+
+@torch.no_grad()
+def quantized_linear_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    return _quantized_matmul_forward(self, input, ops.MM_I8)
+
+
+@torch.no_grad()
+def quantized_linear_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    return _quantized_matmul_forward(self, input, ops.MM_FP8)
+
+
+@torch.no_grad()
+def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    # asymmetric-activation int8 matmul (linear_uint8.py): not in any BASELINE config; scheduled last
+    raise NotImplementedError("quantized_matmul_dtype='uint8' (asymmetric activations) is not built yet; "
+                              "use quantized_matmul_dtype='int8' for uint8 weights")
+
+
+@torch.no_grad()
+def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    raise NotImplementedError("quantized_matmul_dtype='float16' is outside the MI355X hot path (SURVEY 8a note)")

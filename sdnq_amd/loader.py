@@ -1,0 +1,93 @@
+"""Re-pointing already-built SDNQ models at the MI355X kernels.
+
+``accelerate(model)`` is the least-assumption drop-in (SURVEY 8b ii): it walks a model that the *reference*
+package built or loaded, finds modules carrying ``sdnq_dequantizer`` (the reference's own idiom, loader.py:204,239)
+and replaces ``forward_func`` exactly like the reference's ``apply_sdnq_options_to_module`` does (loader.py:301).
+Nothing else about the module changes: parameters, names and state_dict layout stay the reference's.
+
+``apply_sdnq_options_to_model`` mirrors the reference entry point of the same name (loader.py:315) for the
+options that matter on this path: toggling ``use_quantized_matmul`` and choosing the matmul dtype.
+"""
+from __future__ import annotations
+
+import torch
+
+from .dequantizer import SDNQDequantizer
+from .forward import get_forward_func
+from .quantizer import check_quantized_matmul_is_allowed
+
+_DQ_FIELDS = ("result_dtype", "result_shape", "original_shape", "original_stride", "quantized_weight_shape", "weights_dtype",
+              "quantized_matmul_dtype", "hadamard_group_size", "group_size", "svd_rank", "svd_steps", "codebook_steps",
+              "use_quantized_matmul", "re_quantize_for_matmul", "use_stochastic_rounding", "use_hadamard", "use_codebook",
+              "layer_class_name")
+
+
+def adopt_dequantizer(dq) -> SDNQDequantizer:
+    """Any object with the reference dataclass' fields (dequantizer.py:282-303) -> this package's record."""
+    if isinstance(dq, SDNQDequantizer):
+        return dq
+    return SDNQDequantizer(**{f: getattr(dq, f) for f in _DQ_FIELDS})
+
+
+def is_hot_path_linear(module: torch.nn.Module) -> bool:
+    dq = getattr(module, "sdnq_dequantizer", None)
+    return dq is not None and getattr(dq, "layer_class_name", None) in ("Linear", "SDNQLinear") and not getattr(dq, "use_codebook", False)
+
+
+@torch.no_grad()
+def accelerate(model: torch.nn.Module) -> int:
+    """Route every quantized Linear of ``model`` through the HIP forwards. Returns the number of re-pointed modules."""
+    count = 0
+    for module in model.modules():
+        if is_hot_path_linear(module):
+            dq = adopt_dequantizer(module.sdnq_dequantizer)
+            module.sdnq_dequantizer = dq
+            module.forward_func = get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul)
+            module.__dict__.pop("_sdnq_hip_state", None)
+            count += 1
+    return count
+
+
+@torch.no_grad()
+def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
+                                use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):
+    if dequantize_fp32 is False:
+        raise NotImplementedError("dequantize_fp32=False is not supported by the HIP kernels (scales stay float32)")
+    for module in model.modules():
+        if not is_hot_path_linear(module):
+            continue
+        dq = adopt_dequantizer(module.sdnq_dequantizer)
+        module.sdnq_dequantizer = dq
+        if dtype is not None:
+            dq.result_dtype = dtype
+            for name in ("svd_up", "svd_down", "bias"):
+                t = getattr(module, name, None)
+                if t is not None and t.dtype != dtype:
+                    setattr(module, name, torch.nn.Parameter(t.to(dtype), requires_grad=False))
+        if use_quantized_matmul is not None and use_quantized_matmul != dq.use_quantized_matmul:
+            n, k = dq.out_features, dq.in_features
+            want = check_quantized_matmul_is_allowed(use_quantized_matmul, n, k)
+            if want != dq.use_quantized_matmul:
+                _relayout(module, dq, want)
+        if quantized_matmul_dtype is not None:
+            dq.quantized_matmul_dtype = quantized_matmul_dtype
+        module.forward_func = get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul)
+        module.__dict__.pop("_sdnq_hip_state", None)
+    return model
+
+
+def _relayout(module, dq: SDNQDequantizer, want_qmm: bool):
+    """Switch a layer between the plain and the transposed (direct-matmul) layouts (reference loader.py:262-300)."""
+    was_transposed = dq.weight_is_transposed
+    dq.use_quantized_matmul = want_qmm
+    now_transposed = dq.weight_is_transposed
+    P = lambda t: torch.nn.Parameter(t, requires_grad=False)  # noqa: E731
+    if was_transposed != now_transposed:
+        module.weight = P(module.weight.t())  # same bytes, other logical view
+        module.scale = P(module.scale.t().contiguous())
+        if getattr(module, "zero_point", None) is not None:
+            module.zero_point = P(module.zero_point.t().contiguous())
+        dq.quantized_weight_shape = module.weight.shape
+    if getattr(module, "svd_up", None) is not None:  # SVD factors follow use_quantized_matmul (quantizer.py:164-167)
+        module.svd_up = P(module.svd_up.t())
+        module.svd_down = P(module.svd_down.t())

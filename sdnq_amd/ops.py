@@ -92,7 +92,7 @@ def _storage_kind(weights_dtype: str):
 
 
 def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Tensor, zero_point, svd_up, svd_down,
-                      n: int, k: int, group_size: int, transposed: bool) -> QuantWeight:
+                      n: int, k: int, group_size: int, transposed: bool, svd_transposed: bool | None = None) -> QuantWeight:
     """Canonicalise module tensors (reference layouts) into the kernels' physical layout.
 
     transposed=False: weight is packed bytes / [N,K] / [N,G,g] (element order [N][K]); svd_up [N,R], svd_down [R,K].
@@ -100,8 +100,12 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
                       re_quantize_for_matmul and not packed (quantizer.py:228-244): weight logical [K,N] with
                       strides (1,K) -- the same bytes as physical [N][K]; a *contiguous* [K,N] (as stored in
                       safetensors) is re-laid out once, like prepare_weight_for_matmul (quant_utils.py:240-249);
-                      scale [1,N]; svd_up [R,N], svd_down [K,R] (quantizer.py:164-167).
+                      scale [1,N].
+    svd_transposed  : svd_up [R,N], svd_down [K,R] -- the quantizer transposes the SVD factors whenever
+                      use_quantized_matmul is on, independent of the weight layout (quantizer.py:164-167).
     """
+    if svd_transposed is None:
+        svd_transposed = transposed
     _require_cuda(weight, scale)
     storage, kind, bits, ebits, mbits, native = _storage_kind(weights_dtype)
     if transposed:
@@ -112,6 +116,10 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
             w_phys = w_phys.contiguous()
     else:
         w_phys = weight if weight.is_contiguous() else weight.contiguous()
+        if w_phys.dtype in (torch.int64, torch.bool):
+            # 1-bit types: the reference's pack_uint1 on a bool tensor promotes to int64 words holding 8 bits each
+            # (packed_int/pack.py:309-321); the kernels read uint8 words
+            w_phys = w_phys.to(torch.uint8)
     if scale.dtype != torch.float32:
         raise _lib.SdnqHipError("scale must be float32 (dequantize_fp32=True, the reference default)")
     g = k // group_size
@@ -126,7 +134,7 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
     up = down = None
     rank, svd_dt = 0, 0
     if svd_up is not None:
-        if transposed:  # [R,N] , [K,R]
+        if svd_transposed:  # [R,N] , [K,R]
             up = svd_up.t().contiguous()
             down = svd_down.t().contiguous()
         else:  # [N,R] , [R,K]
@@ -215,6 +223,15 @@ def requant(qw: QuantWeight, mm: int):
     check(_lib.load().sdnq_hip_requant(ctypes.byref(qw.desc), mm, wq.data_ptr(), ws.data_ptr(),
                                        torch.cuda.current_stream(dev).cuda_stream), "requant")
     return wq, ws
+
+
+def unpack_mm(qw: QuantWeight, mm: int) -> torch.Tensor:
+    """Stored codes -> matmul operand [N,K] without re-quantization (linear_int8.py:38-50, linear_fp8.py:36-38)."""
+    dev = qw.keep[0].device
+    wq = torch.empty((qw.n, qw.k), device=dev, dtype=_MM_TORCH[mm])
+    check(_lib.load().sdnq_hip_unpack_mm(ctypes.byref(qw.desc), mm, wq.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+          "unpack_mm")
+    return wq
 
 
 def hadamard(x: torch.Tensor, group: int) -> torch.Tensor:

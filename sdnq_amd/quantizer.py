@@ -1,0 +1,274 @@
+"""Config + load-time quantization of float Linear layers into the SDNQ state_dict layout.
+
+API names are the reference's (quantizer.py: SDNQConfig :846, sdnq_quantize_layer_weight :66,
+sdnq_quantize_layer :423, apply_sdnq_to_module :477, QuantizationMethod :60) so host code switches with an
+import change; the module/tensor layout produced is byte-compatible with reference checkpoints
+(SURVEY App. C), which tests/test_quantizer.py checks against the golden fixtures.  Only what feeds the Linear
+hot path is implemented: no HF/diffusers quantizer plugin, no dynamic dtype search, no codebook, no
+stochastic rounding, no conv/embedding (SURVEY 2, rows 12-16 marked out of scope).
+"""
+from __future__ import annotations
+
+from enum import Enum
+
+import torch
+
+from . import packed
+from .common import dtype_dict, linear_types, sdnq_version
+from .dequantizer import SDNQDequantizer
+from .forward import get_forward_func
+from .layers import get_sdnq_wrapper_class
+from .quant_utils import apply_hadamard, apply_svdquant, quantize_weight
+
+
+class QuantizationMethod(str, Enum):
+    SDNQ = "sdnq"
+    SDNQ_TRAINING = "sdnq_training"
+
+
+def get_quantized_matmul_dtype(weights_dtype: str, quantized_matmul_dtype: str | None = None) -> str:
+    """Default matmul dtype per weight dtype (reference utils.py:203-214)."""
+    if quantized_matmul_dtype is not None:
+        return quantized_matmul_dtype
+    ent = dtype_dict[weights_dtype]
+    if ent["is_integer"]:
+        return "uint8" if weights_dtype == "uint8" else "int8"
+    return "float8_e4m3fn" if ent["num_bits"] < 16 else "float16"
+
+
+def check_quantized_matmul_is_allowed(use_quantized_matmul: bool, output_channel_size: int, channel_size: int) -> bool:
+    """reference utils.py:93-98."""
+    return bool(use_quantized_matmul and output_channel_size >= 32 and channel_size >= 32
+                and output_channel_size % 16 == 0 and channel_size % 16 == 0)
+
+
+class SDNQConfig:
+    """Quantization options; keyword names and defaults of the reference's SDNQConfig (quantizer.py:938-973)."""
+
+    def __init__(self, weights_dtype: str = "int8", quantized_matmul_dtype: str | None = None, hadamard_group_size: int = 256,
+                 group_size: int = 0, svd_rank: int = 32, svd_steps: int = 8, codebook_steps: int = 24,
+                 dynamic_loss_threshold: float | None = None, use_svd: bool = False, use_hadamard: bool = False,
+                 use_codebook: bool = False, use_grad_ckpt: bool = True, quant_conv: bool = False, quant_embedding: bool = False,
+                 use_quantized_matmul: bool = False, use_quantized_matmul_conv: bool = False,
+                 use_static_quantization: bool = True, use_dynamic_quantization: bool = False,
+                 use_stochastic_rounding: bool = False, dequantize_fp32: bool = True, non_blocking: bool = False,
+                 add_skip_keys: bool = True, minimum_allowed_numel: int = 16384, minimum_allowed_channel_size: int = 32,
+                 modules_to_not_convert=None, modules_to_not_use_matmul=None, modules_dtype_dict=None,
+                 modules_quant_config=None, quantization_device=None, return_device=None, sdnq_version: str | None = None,
+                 is_training: bool = False, **kwargs):
+        if weights_dtype not in dtype_dict:
+            raise ValueError(f"SDNQ only support weight dtypes in {sorted(dtype_dict)} but found {weights_dtype}")
+        if quantized_matmul_dtype is not None and quantized_matmul_dtype not in {"int8", "uint8", "fp8", "fp16", "float8_e4m3fn", "float16"}:
+            raise ValueError(f"unsupported quantized_matmul_dtype {quantized_matmul_dtype}")
+        for name in ("use_codebook", "use_dynamic_quantization", "use_stochastic_rounding", "quant_conv", "quant_embedding",
+                     "is_training"):
+            if locals()[name]:
+                raise NotImplementedError(f"SDNQConfig({name}=True) is outside the MI355X Linear hot path")
+        self.weights_dtype = weights_dtype
+        self.quantized_matmul_dtype = quantized_matmul_dtype
+        self.hadamard_group_size = hadamard_group_size
+        self.group_size = group_size
+        self.svd_rank = svd_rank
+        self.svd_steps = svd_steps
+        self.codebook_steps = codebook_steps
+        self.dynamic_loss_threshold = dynamic_loss_threshold
+        self.use_svd = use_svd
+        self.use_hadamard = use_hadamard
+        self.use_codebook = use_codebook
+        self.use_grad_ckpt = use_grad_ckpt
+        self.quant_conv = quant_conv
+        self.quant_embedding = quant_embedding
+        self.use_quantized_matmul = use_quantized_matmul
+        self.use_quantized_matmul_conv = use_quantized_matmul_conv
+        self.use_static_quantization = use_static_quantization
+        self.use_dynamic_quantization = use_dynamic_quantization
+        self.use_stochastic_rounding = use_stochastic_rounding
+        self.dequantize_fp32 = dequantize_fp32
+        self.non_blocking = non_blocking
+        self.add_skip_keys = add_skip_keys
+        self.minimum_allowed_numel = minimum_allowed_numel
+        self.minimum_allowed_channel_size = minimum_allowed_channel_size
+        self.modules_to_not_convert = list(modules_to_not_convert or [])
+        self.modules_to_not_use_matmul = list(modules_to_not_use_matmul or [])
+        self.modules_dtype_dict = dict(modules_dtype_dict or {})
+        self.modules_quant_config = dict(modules_quant_config or {})
+        self.quantization_device = quantization_device
+        self.return_device = return_device
+        self.sdnq_version = globals()["sdnq_version"] if sdnq_version is None else sdnq_version
+        self.is_training = is_training
+        self.is_integer = dtype_dict[weights_dtype]["is_integer"]
+        self.is_unsigned = dtype_dict[weights_dtype]["is_unsigned"]
+        self.quant_method = QuantizationMethod.SDNQ
+
+    def to_dict(self) -> dict:
+        d = {k: v for k, v in self.__dict__.items()}
+        d["quant_method"] = self.quant_method.value
+        for k in ("quantization_device", "return_device"):
+            d[k] = None if d[k] is None else str(d[k])
+        return d
+
+    @classmethod
+    def from_dict(cls, config_dict: dict, **kwargs):
+        cfg = dict(config_dict)
+        for k in ("quant_method", "is_integer", "is_unsigned"):
+            cfg.pop(k, None)
+        cfg.update(kwargs)
+        return cls(**cfg)
+
+
+def _needs_requant(weights_dtype: str, matmul_dtype: str) -> bool:
+    """Whether stored codes cannot be fed to the matmul as they are (reference quantizer.py:101-116)."""
+    w, m = dtype_dict[weights_dtype], dtype_dict[matmul_dtype]
+    if w["num_bits"] > m["num_bits"] or w["is_integer"] != m["is_integer"]:
+        return True
+    if w["is_unsigned"] and not m["is_integer"]:
+        return True
+    if w["is_packed"] and not w["is_integer"] and not m["is_integer"]:
+        return w["num_bits"] >= m["num_bits"] or w["max"] > m["max"]
+    return False
+
+
+def _pick_group_size(group_size: int, channel_size: int, weights_dtype: str, is_linear: bool, has_svd: bool,
+                     direct_matmul: bool) -> tuple[int, int]:
+    """-> (group_size or -1, num_groups). Policy of reference quantizer.py:173-201."""
+    if group_size == 0:
+        if direct_matmul and dtype_dict[weights_dtype]["num_bits"] >= 6:
+            return -1, 1
+        p = 1 + dtype_dict[weights_dtype]["num_bits"] + (1 if is_linear else 0) + (1 if has_svd else 0)
+        group_size = 2 ** p
+    if group_size <= 0 or group_size >= channel_size:
+        return -1, 1
+    groups = channel_size // group_size
+    while groups * group_size != channel_size:  # shrink the group count until it divides the channel size
+        groups -= 1
+        if groups <= 1:
+            return -1, 1
+        group_size = channel_size // groups
+    return (int(group_size), int(groups)) if groups > 1 else (-1, 1)
+
+
+@torch.no_grad()
+def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Linear", weights_dtype: str = "int8",
+                               quantized_matmul_dtype: str | None = None, group_size: int = 0, hadamard_group_size: int = 256,
+                               svd_rank: int = 32, svd_steps: int = 8, use_svd: bool = False, use_hadamard: bool = False,
+                               use_quantized_matmul: bool = False, dequantize_fp32: bool = True,
+                               torch_dtype: torch.dtype | None = None, **_unused):
+    """Float [N,K] weight -> (SDNQDequantizer, {"weight","scale","zero_point","svd_up","svd_down"}).
+
+    Order of operations as in the reference (quantizer.py:158-253): Hadamard -> SVD split -> grouping ->
+    quantize -> (transpose for direct matmul) -> pack.
+    """
+    if layer_class_name not in linear_types:
+        raise NotImplementedError(f"{layer_class_name}: only Linear layers are on the MI355X hot path")
+    if not dequantize_fp32:
+        raise NotImplementedError("dequantize_fp32=False (low-precision scales) is not supported by the HIP kernels")
+    weight = weight.detach()
+    original_shape, original_stride = weight.shape, weight.stride()
+    torch_dtype = weight.dtype if torch_dtype is None else torch_dtype
+    n, k = weight.shape
+    mm_dtype = get_quantized_matmul_dtype(weights_dtype, quantized_matmul_dtype)
+    use_qmm = check_quantized_matmul_is_allowed(use_quantized_matmul, n, k)
+    requant = _needs_requant(weights_dtype, mm_dtype)
+    ent = dtype_dict[weights_dtype]
+
+    if use_hadamard:
+        weight, use_hadamard, hadamard_group_size = apply_hadamard(weight, hadamard_group_size)
+    svd_up = svd_down = None
+    if use_svd:
+        weight, svd_up, svd_down = apply_svdquant(weight, rank=svd_rank, steps=svd_steps, dtype=torch_dtype)
+        if use_qmm:  # the matmul branch consumes x @ svd_down then @ svd_up: store both transposed (:164-167)
+            svd_up, svd_down = svd_up.t(), svd_down.t()
+
+    group_size, groups = _pick_group_size(group_size, k, weights_dtype, True, svd_up is not None,
+                                          direct_matmul=use_qmm and not requant)
+    result_shape = None
+    if groups > 1:
+        result_shape = weight.shape
+        weight = weight.unflatten(-1, (groups, group_size))
+    requant = requant or groups > 1
+    transpose = use_qmm and not requant and not ent["is_packed"]
+
+    q, scale, zero_point = quantize_weight(weight, -1, weights_dtype)
+    if transpose:  # logical [K,N] with strides (1,K): the bytes stay [N][K] (prepare_weight_for_matmul on gfx950)
+        q = q.t()
+        scale = scale.t().contiguous()
+        zero_point = None if zero_point is None else zero_point.t().contiguous()
+    quantized_weight_shape = q.shape
+    if ent["is_packed"]:
+        q = packed.pack_int(q, weights_dtype) if ent["is_integer"] else packed.pack_float(q, weights_dtype)
+    else:
+        q = q.to(ent["torch_dtype"])
+
+    dq = SDNQDequantizer(result_dtype=torch_dtype, result_shape=result_shape, original_shape=original_shape,
+                         original_stride=original_stride, quantized_weight_shape=quantized_weight_shape,
+                         weights_dtype=weights_dtype, quantized_matmul_dtype=mm_dtype, hadamard_group_size=hadamard_group_size,
+                         group_size=group_size, svd_rank=svd_rank, svd_steps=svd_steps, codebook_steps=24,
+                         use_quantized_matmul=use_qmm, re_quantize_for_matmul=requant, use_stochastic_rounding=False,
+                         use_hadamard=bool(use_hadamard), use_codebook=False, layer_class_name=layer_class_name)
+    return dq, {"weight": q, "scale": scale, "zero_point": zero_point, "svd_up": svd_up, "svd_down": svd_down}
+
+
+def _quant_kwargs(cfg: SDNQConfig, torch_dtype, param_name: str) -> dict:
+    kw = dict(weights_dtype=cfg.weights_dtype, quantized_matmul_dtype=cfg.quantized_matmul_dtype, group_size=cfg.group_size,
+              hadamard_group_size=cfg.hadamard_group_size, svd_rank=cfg.svd_rank, svd_steps=cfg.svd_steps,
+              use_svd=cfg.use_svd, use_hadamard=cfg.use_hadamard, use_quantized_matmul=cfg.use_quantized_matmul,
+              dequantize_fp32=cfg.dequantize_fp32, torch_dtype=torch_dtype)
+    for dt, names in cfg.modules_dtype_dict.items():
+        if any(nm and nm in param_name for nm in names):
+            kw["weights_dtype"] = dt
+    if any(nm and nm in param_name for nm in cfg.modules_to_not_use_matmul):
+        kw["use_quantized_matmul"] = False
+    return kw
+
+
+@torch.no_grad()
+def sdnq_quantize_layer(layer: torch.nn.Module, quantization_config: SDNQConfig, torch_dtype: torch.dtype | None = None,
+                        param_name: str = "", quant_kwargs: dict | None = None):
+    """Quantize one Linear IN PLACE (the wrapper shares the layer's parameters) -> (SDNQLinear, config)."""
+    if torch_dtype is None:
+        torch_dtype = layer.weight.dtype
+    name = layer.__class__.__name__
+    if name not in linear_types:
+        quantization_config.modules_to_not_convert.append(param_name)
+        return layer, quantization_config
+    kw = quant_kwargs or _quant_kwargs(quantization_config, torch_dtype, param_name)
+    layer.weight.requires_grad_(False)
+    dev = layer.weight.device if quantization_config.return_device is None else quantization_config.return_device
+    w = layer.weight if quantization_config.quantization_device is None else layer.weight.to(quantization_config.quantization_device)
+    dq, tensors = sdnq_quantize_layer_weight(w, layer_class_name=name, **kw)
+    layer.sdnq_dequantizer = dq
+    layer = get_sdnq_wrapper_class(layer, get_forward_func(name, dq.quantized_matmul_dtype, dq.use_quantized_matmul))
+    for key, value in tensors.items():
+        setattr(layer, key, None if value is None else torch.nn.Parameter(value.to(dev), requires_grad=False))
+    if kw["use_quantized_matmul"] and not dq.use_quantized_matmul and param_name not in quantization_config.modules_to_not_use_matmul:
+        quantization_config.modules_to_not_use_matmul.append(param_name)
+    return layer, quantization_config
+
+
+@torch.no_grad()
+def apply_sdnq_to_module(model: torch.nn.Module, quantization_config: SDNQConfig, torch_dtype: torch.dtype | None = None,
+                         full_param_name: str = ""):
+    """Recursively replace eligible nn.Linear children by SDNQLinear (reference quantizer.py:477-495)."""
+    for child_name, child in list(model.named_children()):
+        pname = f"{full_param_name}.{child_name}" if full_param_name else child_name
+        if child.__class__.__name__ == "Linear" and child.weight is not None:
+            wname = pname + ".weight"
+            skip = any(s and s in wname for s in quantization_config.modules_to_not_convert)
+            big = (child.weight.shape[-1] >= quantization_config.minimum_allowed_channel_size
+                   and child.weight.numel() >= quantization_config.minimum_allowed_numel)
+            if not skip and big and child.weight.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
+                child, quantization_config = sdnq_quantize_layer(child, quantization_config, torch_dtype=torch_dtype, param_name=wname)
+                setattr(model, child_name, child)
+            else:
+                quantization_config.modules_to_not_convert.append(wname)
+        else:
+            apply_sdnq_to_module(child, quantization_config, torch_dtype=torch_dtype, full_param_name=pname)
+    return model, quantization_config
+
+
+def sdnq_post_load_quant(model: torch.nn.Module, weights_dtype: str = "int8", torch_dtype: torch.dtype | None = None, **kwargs):
+    cfg = SDNQConfig(weights_dtype=weights_dtype, **kwargs)
+    model, cfg = apply_sdnq_to_module(model, cfg, torch_dtype=torch_dtype)
+    model.quantization_config = cfg
+    model.quantization_method = QuantizationMethod.SDNQ
+    return model

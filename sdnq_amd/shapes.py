@@ -1,0 +1,66 @@
+"""Linear shape lists of the synthetic "model step" workloads (from the public model configs,
+not from the reference, which ships no model code).
+
+Each entry: (name, M tokens, K in_features, N out_features, has_bias, repeat).
+``M`` is the number of activation rows the layer sees in ONE denoising step at batch size 1.
+"""
+from __future__ import annotations
+
+
+def sdxl_unet_linears(latent: int = 128, text_tokens: int = 77):
+    """SDXL-base UNet, bs=1, latent x latent (128 -> 1024^2 px). 11 Transformer2D modules:
+    C=640 @ (latent/2)^2 tokens: 5 modules x 2 layers; C=1280 @ (latent/4)^2 tokens: 6 modules x 10 layers."""
+    out = []
+    for c, tokens, modules, layers in ((640, (latent // 2) ** 2, 5, 2), (1280, (latent // 4) ** 2, 6, 10)):
+        nl = modules * layers
+        out += [
+            (f"c{c}.attn1.to_qkv", tokens, c, c, False, 3 * nl),
+            (f"c{c}.attn1.to_out", tokens, c, c, True, nl),
+            (f"c{c}.attn2.to_q", tokens, c, c, False, nl),
+            (f"c{c}.attn2.to_kv", text_tokens, 2048, c, False, 2 * nl),
+            (f"c{c}.attn2.to_out", tokens, c, c, True, nl),
+            (f"c{c}.ff.proj_geglu", tokens, c, 8 * c, True, nl),
+            (f"c{c}.ff.out", tokens, 4 * c, c, True, nl),
+            (f"c{c}.proj_in_out", tokens, c, c, True, 2 * modules),
+        ]
+    # M = 1 layers (time / added-condition embeddings): take the M < 32 dequant + float GEMM branch
+    out += [
+        ("resnet.time_emb_proj.320", 1, 1280, 320, True, 5),
+        ("resnet.time_emb_proj.640", 1, 1280, 640, True, 5),
+        ("resnet.time_emb_proj.1280", 1, 1280, 1280, True, 7),
+        ("add_embedding.linear_1", 1, 2816, 1280, True, 1),
+        ("add_embedding.linear_2", 1, 1280, 1280, True, 1),
+    ]
+    return out
+
+
+def flux_dev_linears(img_tokens: int = 4096, txt_tokens: int = 512, d: int = 3072):
+    """FLUX.1-dev transformer, 1024^2 px: 19 double blocks + 38 single blocks."""
+    t_all = img_tokens + txt_tokens
+    out = []
+    for stream, tokens in (("img", img_tokens), ("txt", txt_tokens)):
+        out += [
+            (f"double.{stream}.qkv", tokens, d, d, True, 3 * 19),
+            (f"double.{stream}.out", tokens, d, d, True, 19),
+            (f"double.{stream}.ff.proj", tokens, d, 4 * d, True, 19),
+            (f"double.{stream}.ff.out", tokens, 4 * d, d, True, 19),
+            (f"double.{stream}.adaln", 1, d, 6 * d, True, 19),
+        ]
+    out += [
+        ("single.qkv", t_all, d, d, True, 3 * 38),
+        ("single.proj_mlp", t_all, d, 4 * d, True, 38),
+        ("single.proj_out", t_all, 5 * d, d, True, 38),
+        ("single.adaln", 1, d, 3 * d, True, 37),
+    ]
+    return out
+
+
+def ops_of(shapes, min_m: int = 0) -> int:
+    """Algorithmic ops with the reference's formula 2*M*K*N + M*N*[bias] (scripts/benchmark_sdnq_inference_matmul.py:41-42)."""
+    return sum(r * (2 * m * k * n + (m * n if b else 0)) for (_, m, k, n, b, r) in shapes if m >= min_m)
+
+
+def bytes_of(shapes, weight_bits: float = 8.0, act_bytes: int = 2) -> dict:
+    w = sum(r * (n * k * weight_bits / 8 + 4 * n + (act_bytes * n if b else 0)) for (_, m, k, n, b, r) in shapes)
+    a = sum(r * (act_bytes * m * k + act_bytes * m * n) for (_, m, k, n, b, r) in shapes)
+    return {"weights": w, "activations": a}

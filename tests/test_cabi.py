@@ -1,0 +1,57 @@
+"""The C-ABI shared library loads (no GPU needed) and exports every symbol include/sdnq_hip.h declares."""
+import ctypes
+import os
+import re
+
+from sdnq_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "sdnq_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdnq_hip_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 13
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/sdnq_hip.h but not exported"
+    assert set(syms) == set(_lib.EXPORTS), (set(syms) ^ set(_lib.EXPORTS))
+
+
+def test_version_and_strerror():
+    lib = _lib.load()
+    assert lib.sdnq_hip_version() == 1
+    assert lib.sdnq_hip_strerror(0) == b"ok"
+    for code in range(-8, 0):
+        msg = lib.sdnq_hip_strerror(code)
+        assert msg and msg != b"unknown status"
+    assert lib.sdnq_hip_strerror(-99) == b"unknown status"
+
+
+def test_argument_validation_without_gpu():
+    """Validation runs before any launch, so error codes are observable on a CPU-only box."""
+    lib = _lib.load()
+    assert lib.sdnq_hip_rowquant(None, 1, 4, 64, 64, 0, 0, None, None, None, None, None) == -1          # NULL
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(buf)
+    p += (-p) % 16
+    assert lib.sdnq_hip_rowquant(p, 7, 4, 64, 64, 0, 0, p, p, None, None, None) == -2                  # dtype
+    assert lib.sdnq_hip_rowquant(p, 1, 4, 60, 60, 0, 0, p, p, None, None, None) == -3                  # K % 8
+    assert lib.sdnq_hip_rowquant(p + 2, 1, 4, 64, 64, 0, 0, p, p, None, None, None) == -4              # alignment
+    assert lib.sdnq_hip_rowquant(p, 1, 4, 64, 64, 0, 48, p, p, None, None, None) == -3                 # Hadamard group not pow2
+    assert lib.sdnq_hip_scaled_mm(0, p, p, p, p, None, 0, 0, 0, p, 1, 32, 32, 24, None) == -3          # K % 16
+    assert lib.sdnq_hip_scaled_mm(5, p, p, p, p, None, 0, 0, 0, p, 1, 32, 32, 32, None) == -2          # mm dtype
+    w = _lib.SdnqWeight(weight=p, scale=p, zero_point=None, svd_up=None, svd_down=None, n=16, k=64, group_size=48, svd_rank=0,
+                        svd_dtype=0, storage=0, kind=0, bits=4, exponent=0, mantissa=0, native_float=0)
+    assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -3                                   # K % group
+    w.group_size = 64
+    w.kind = 1
+    assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -1                                   # uint without zero_point
+    w.kind, w.bits, w.storage = 0, 9, 0
+    assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -2                                   # 9 bits in uint8 words

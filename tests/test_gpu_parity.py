@@ -1,0 +1,292 @@
+"""GPU parity tests (run on the MI355X box with ``-m gpu``): the HIP path, called through the C ABI, against
+(1) the golden vectors captured from the reference and (2) the CPU oracle on seeded inputs.
+
+Tolerances (written here):
+  * unpack / dequant (fp32 path) / re-quant / activation quantization / int8 matmul: BIT-EXACT;
+  * asymmetric dequant: fma == CPU addcmul -> bit-exact as well;
+  * SVD dequant (addmm in bf16): <= 1 bf16 ulp;
+  * Hadamard in bf16/f16: <= 1 ulp of the dtype on rare elements (summation order), f32: ~1e-6 relative;
+  * fp8 matmul / bf16 float GEMM: fp32 accumulation-order noise, then ONE rounding to the output dtype:
+    |err| <= 2 ulp(out dtype) of the output's magnitude scale, rel-L2 <= 2e-3 (bf16) / 1e-5 (f32).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.golden_util import GOLD, Case, case_names
+from tests.modules_util import TORCH_DT, module_from_case, to_f32_numpy
+
+pytestmark = pytest.mark.gpu
+
+from sdnq_amd import ops  # noqa: E402
+
+
+def bits_of(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().contiguous().cpu()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy()
+    if t.dtype in (torch.float8_e4m3fn, torch.int8):
+        return t.view(torch.uint8).numpy()
+    return t.numpy()
+
+
+def assert_close_float(got: np.ndarray, ref: np.ndarray, tag: str, what, hadamard=False, f32_lim=2e-6):
+    scale = float(np.abs(ref).max()) or 1.0
+    err = float(np.abs(got - ref).max()) / scale
+    lim = {"bf16": 2 * 2.0 ** -8, "f16": 2 * 2.0 ** -11, "f32": f32_lim}[tag] * (2.0 if hadamard else 1.0)
+    assert err <= lim, (what, "max err / scale", err, lim)
+    l2 = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) or 1.0))
+    assert l2 <= {"bf16": 2e-3, "f16": 5e-4, "f32": 1e-5}[tag], (what, "rel l2", l2)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", case_names())
+def test_module_forward_vs_golden_and_oracle(name, gpu_device):
+    c = Case(name)
+    d = c.deq
+    if d["quantized_matmul_dtype"] == "uint8" and d["use_quantized_matmul"]:
+        pytest.skip("uint8 (asymmetric-activation) matmul is not built yet")
+    mod = module_from_case(c, gpu_device)
+    omod = c.oracle_module()
+    for M in c.ms():
+        x = c.torch_tensor(f"x_{M}", device=gpu_device)
+        y = mod(x)
+        assert y.dtype == x.dtype and tuple(y.shape) == tuple(c.info(f"y_{M}")["shape"])
+        got = to_f32_numpy(y)
+        ref = c.f32(f"y_{M}")
+        orc = O.forward(omod, c.f32(f"x_{M}"), c.tag)
+        qmm = d["use_quantized_matmul"] and M >= 32
+        exact = qmm and d["quantized_matmul_dtype"] == "int8" and not d["use_hadamard"] and not c.has("svd_up")
+        if exact:
+            assert np.array_equal(got, ref), (name, M, "vs golden", int((got != ref).sum()))
+            assert np.array_equal(got, orc), (name, M, "vs oracle")
+        else:
+            assert_close_float(got, ref, c.tag, (name, M, "golden"), hadamard=d["use_hadamard"])
+            assert_close_float(got, orc, c.tag, (name, M, "oracle"), hadamard=d["use_hadamard"])
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_dequant_and_requant_vs_golden(name, gpu_device):
+    c = Case(name)
+    mod = module_from_case(c, gpu_device)
+    dq = mod.sdnq_dequantizer
+    # fp32, Hadamard not undone: the tensor re_quantize_matmul starts from
+    w32 = dq(mod.weight, mod.scale, zero_point=mod.zero_point, svd_up=mod.svd_up, svd_down=mod.svd_down,
+             skip_quantized_matmul=dq.use_quantized_matmul, dtype=torch.float32, non_hadamard=True)
+    ref32 = c.f32("w_dequant_f32_nohad").reshape(c.N, c.K)
+    got32 = to_f32_numpy(w32).reshape(c.N, c.K)
+    if c.has("svd_up"):
+        assert np.all(np.abs(got32 - ref32) <= np.maximum(np.abs(ref32), 1e-30) * 2.0 ** -7), name
+        assert np.mean(got32 != ref32) < 1e-3, name
+    else:
+        assert np.array_equal(got32, ref32), (name, int((got32 != ref32).sum()))
+    # result dtype, as SDNQLayer.dequantize() produces it
+    w = dq(mod.weight, mod.scale, zero_point=mod.zero_point, svd_up=mod.svd_up, svd_down=mod.svd_down,
+           skip_quantized_matmul=dq.use_quantized_matmul)
+    ref = c.f32("w_dequant").reshape(c.N, c.K)
+    got = to_f32_numpy(w).reshape(c.N, c.K)
+    if dq.use_hadamard or c.has("svd_up"):
+        assert np.all(np.abs(got - ref) <= 2 * np.maximum(np.abs(ref), 1e-30) * 2.0 ** -7 + 1e-6), name
+    else:
+        assert np.array_equal(got, ref), name
+    if c.has("requant_weight"):
+        wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, zero_point=mod.zero_point)
+        assert tuple(wq.shape) == (c.K, c.N) and wq.stride() == (1, c.K)
+        rw = c.raw("requant_weight").reshape(c.K, c.N)
+        assert np.array_equal(bits_of(wq.contiguous()), rw.view(np.uint8)), name
+        assert np.array_equal(ws.cpu().numpy().reshape(-1), c.raw("requant_scale").reshape(-1)), name
+
+
+def test_dequant_every_storage_dtype_bit_exact(gpu_device):
+    z = np.load(os.path.join(GOLD, "dequant_dtypes.npz"))
+    meta = json.load(open(os.path.join(GOLD, "dequant_dtypes.json")))["dtypes"]
+    from tests.modules_util import dequantizer_from_fields
+    n_checked = 0
+    for key, ent in meta.items():
+        dq = dequantizer_from_fields(ent["deq"])
+        wt = torch.from_numpy(z[f"{key}.weight"])
+        tag = ent["tensors"]["weight"]["dtype"]
+        view = {"fp8e4m3": torch.float8_e4m3fn, "fp8e5m2": torch.float8_e5m2, "f16": torch.float16, "bf16": torch.bfloat16}.get(tag)
+        if view is not None:
+            wt = wt.view(view)
+        sc = torch.from_numpy(z[f"{key}.scale"]).to(gpu_device)
+        zp = torch.from_numpy(z[f"{key}.zero_point"]).to(gpu_device) if ent["tensors"]["zero_point"]["dtype"] != "none" else None
+        out = dq(wt.to(gpu_device), sc, zero_point=zp, dtype=torch.float32)
+        ref = z[f"{key}.out"].reshape(16, 128)
+        assert np.array_equal(out.cpu().numpy().reshape(16, 128), ref), key
+        n_checked += 1
+    assert n_checked >= 80
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(48, 256, 512), (77, 640, 2048), (333, 80, 48), (1000, 336, 144), (4096, 640, 640),
+                                   (129, 1280, 1280), (64, 64, 64), (32, 32, 32), (257, 2576, 656)])
+@pytest.mark.parametrize("out_dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_scaled_mm_int8_bit_exact_vs_oracle(shape, out_dt, gpu_device):
+    m, n, k = shape
+    if out_dt != torch.bfloat16 and m > 400:
+        pytest.skip("large shapes once, in bf16")
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8, generator=g)
+    b = torch.randint(-128, 128, (n, k), dtype=torch.int8, generator=g)
+    sa = torch.rand(m, generator=g) * 0.02 + 1e-4
+    sb = torch.rand(n, generator=g) * 0.02 + 1e-4
+    tag = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}[out_dt]
+    for bias_mode in ("none", "1d", "2d"):
+        bias = None if bias_mode == "none" else (torch.randn(n, generator=g) if bias_mode == "1d" else torch.randn(m, n, generator=g))
+        bias_t = None if bias is None else bias.to(out_dt if bias_mode == "1d" else torch.float32)
+        out = ops.scaled_mm(ops.MM_I8, a.to(gpu_device), b.to(gpu_device), sa.to(gpu_device), sb.to(gpu_device),
+                            None if bias_t is None else bias_t.to(gpu_device), out_dt)
+        ref = O.scaled_mm("int8", a.numpy(), b.numpy(), sa.numpy(), sb.numpy(),
+                          None if bias_t is None else bias_t.float().numpy(), tag)
+        got = to_f32_numpy(out)
+        assert np.array_equal(got, ref), (shape, out_dt, bias_mode, int((got != ref).sum()))
+
+
+@pytest.mark.parametrize("shape", [(48, 256, 512), (100, 64, 192), (256, 128, 1280), (77, 1280, 2048), (513, 336, 208)])
+def test_scaled_mm_fp8_vs_oracle(shape, gpu_device):
+    m, n, k = shape
+    g = torch.Generator().manual_seed(11 + m)
+    a = (torch.randn(m, k, generator=g) * 60).clamp(-448, 448).to(torch.float8_e4m3fn)
+    b = (torch.randn(n, k, generator=g) * 60).clamp(-448, 448).to(torch.float8_e4m3fn)
+    sa = torch.rand(m, generator=g) * 0.02 + 1e-4
+    sb = torch.rand(n, generator=g) * 0.02 + 1e-4
+    bias = torch.randn(n, generator=g).to(torch.bfloat16)
+    for out_dt, tag in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+        out = ops.scaled_mm(ops.MM_FP8, a.to(gpu_device), b.to(gpu_device), sa.to(gpu_device), sb.to(gpu_device),
+                            bias.to(gpu_device), out_dt)
+        ref = O.scaled_mm("fp8", a.view(torch.uint8).numpy(), b.view(torch.uint8).numpy(), sa.numpy(), sb.numpy(),
+                          bias.float().numpy(), tag)
+        # fp32 output exposes the accumulator: the K=64 block-scaled fp8 MFMA sums its 64 products at reduced internal
+        # width before the fp32 accumulate, so allow 1e-4 of the output scale there (bf16 output: 2 ulp as usual)
+        assert_close_float(to_f32_numpy(out), ref, tag, (shape, tag), f32_lim=1e-4)
+
+
+@pytest.mark.parametrize("m,k", [(100, 640), (33, 1280), (7, 5120), (64, 48), (40, 15360), (4096, 640)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_rowquant_bit_exact_vs_oracle(m, k, dt, gpu_device):
+    if dt != torch.bfloat16 and m * k > 300000:
+        pytest.skip("large once")
+    g = torch.Generator().manual_seed(k + m)
+    x = torch.randn(m, k, generator=g) * 3
+    x[:, 5 % k] *= 20
+    x[min(3, m - 1)] = 0  # all-zero row: scale 0 -> q 0
+    x = x.to(dt)
+    xf = x.float().numpy()
+    for mm, name in ((ops.MM_I8, "int8"), (ops.MM_FP8, "fp8")):
+        xq, xs, rs, _ = ops.rowquant(x.to(gpu_device), mm, want_rowsum=(mm == ops.MM_I8))
+        q, s, rowsum = O.rowquant(xf, name)
+        assert np.array_equal(bits_of(xq), q.view(np.uint8)), (m, k, dt, name)
+        assert np.array_equal(xs.cpu().numpy().reshape(-1), s), (m, k, dt, name)
+        if rowsum is not None:
+            assert np.array_equal(rs.cpu().numpy(), rowsum)
+
+
+@pytest.mark.parametrize("g_size", [4, 8, 16, 32, 64, 128, 256, 512])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+def test_hadamard_vs_oracle(g_size, dt, gpu_device):
+    tag = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}[dt]
+    k = g_size * 3 if g_size >= 8 else 24
+    gen = torch.Generator().manual_seed(g_size)
+    x = (torch.randn(37, k, generator=gen) * 2).to(dt)
+    y = ops.hadamard(x.to(gpu_device), g_size)
+    ref = O.rotate_hadamard(x.float().numpy(), g_size, tag)
+    got = to_f32_numpy(y)
+    ulp = {"bf16": 2.0 ** -8, "f16": 2.0 ** -11, "f32": 2.0 ** -21}[tag]
+    assert np.all(np.abs(got - ref) <= 2 * ulp * np.maximum(np.abs(ref), np.abs(ref).max() * (1.0 if tag == "f32" else 0.0) + 1e-3)), (g_size, tag)
+    if tag != "f32":
+        assert np.mean(got != ref) < 0.02, (g_size, tag, float(np.mean(got != ref)))
+    # involution: H is symmetric orthonormal, rotating twice returns the input (to rounding)
+    if g_size in (4, 16, 64, 256) and tag == "f32":
+        back = to_f32_numpy(ops.hadamard(y, g_size))
+        assert np.allclose(back, x.float().numpy(), rtol=0, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes
+# ------------------------------------------------------------------------------------------------
+def test_int8_matmul_properties_at_sdxl_size(gpu_device):
+    m, n, k = 4096, 5120, 640
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8, generator=g).to(gpu_device)
+    b = torch.randint(-128, 128, (n, k), dtype=torch.int8, generator=g).to(gpu_device)
+    sa = (torch.rand(m, generator=g) * 0.02 + 1e-4).to(gpu_device)
+    sb = (torch.rand(n, generator=g) * 0.02 + 1e-4).to(gpu_device)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16).to(gpu_device)
+    full = ops.scaled_mm(ops.MM_I8, a, b, sa, sb, bias, torch.bfloat16)
+    # (1) K-permutation invariance: int32 accumulation is exact
+    perm = torch.randperm(k, generator=g).to(gpu_device)
+    p = ops.scaled_mm(ops.MM_I8, a[:, perm].contiguous(), b[:, perm].contiguous(), sa, sb, bias, torch.bfloat16)
+    assert torch.equal(full, p)
+    # (2) row/column slices of the big problem equal the small problems (tile independence)
+    rows = ops.scaled_mm(ops.MM_I8, a[1000:1077].contiguous(), b, sa[1000:1077].contiguous(), sb, bias, torch.bfloat16)
+    assert torch.equal(full[1000:1077], rows)
+    cols = ops.scaled_mm(ops.MM_I8, a, b[640:1280].contiguous(), sa, sb[640:1280].contiguous(), bias[640:1280].contiguous(), torch.bfloat16)
+    assert torch.equal(full[:, 640:1280], cols)
+    # (3) a sampled block against the oracle
+    ref = O.scaled_mm("int8", a[:64].cpu().numpy(), b[:256].cpu().numpy(), sa[:64].cpu().numpy(), sb[:256].cpu().numpy(),
+                      bias[:256].float().cpu().numpy(), "bf16")
+    assert np.array_equal(to_f32_numpy(full[:64, :256]), ref)
+    # (4) power-of-two scaling of sa is exact
+    dbl = ops.scaled_mm(ops.MM_I8, a, b, sa * 2, sb, None, torch.float32)
+    base = ops.scaled_mm(ops.MM_I8, a, b, sa, sb, None, torch.float32)
+    assert torch.equal(dbl, base * 2)
+
+
+def test_cfg1_4096_dequant_roundtrip_and_linear(gpu_device):
+    """BASELINE configs[0]: 4096x4096 int8 row-wise, qmm off, fp32: dequant == q*scale exactly; linear vs oracle on a slab."""
+    import sdnq_amd
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4096, 4096, bias=True)
+    w_float = lin.weight.detach().clone()
+    layer, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=False))
+    layer = layer.to(gpu_device)
+    dq = layer.sdnq_dequantizer
+    wd = dq(layer.weight, layer.scale)
+    assert torch.equal(wd.cpu(), layer.weight.cpu().float() * layer.scale.cpu())
+    assert (wd.cpu() - w_float).abs().max() <= layer.scale.cpu().max() * 0.5 + 1e-12  # quantization error bound
+    x = torch.randn(8, 4096)
+    y = layer(x.to(gpu_device))
+    ref = O.linear_float(x.numpy(), wd.cpu().numpy(), layer.bias.cpu().numpy(), "f32")
+    assert_close_float(to_f32_numpy(y), ref, "f32", "cfg1 linear")
+
+
+def test_operator_seam_and_errors(gpu_device):
+    """int_scaled_mm_func keeps the reference's signature: b is the logical [K,N] operand in either memory layout."""
+    from sdnq_amd import int_scaled_mm_func
+    from sdnq_amd._lib import SdnqHipError
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 96, 64, 128
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8, generator=g).to(gpu_device)
+    w = torch.randint(-128, 128, (n, k), dtype=torch.int8, generator=g).to(gpu_device)
+    sa = (torch.rand(m, 1, generator=g) * 0.01 + 1e-3).to(gpu_device)
+    sb = (torch.rand(1, n, generator=g) * 0.01 + 1e-3).to(gpu_device)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16).to(gpu_device)
+    y1 = int_scaled_mm_func(a, w.t(), sa, sb, bias=bias, out_dtype=torch.bfloat16)               # strides (1,K), gfx950 layout
+    y2 = int_scaled_mm_func(a, w.t().contiguous(), sa, sb, bias=bias, out_dtype=torch.bfloat16)  # row-major [K,N]
+    assert torch.equal(y1, y2)
+    ref = O.scaled_mm("int8", a.cpu().numpy(), w.cpu().numpy(), sa.cpu().numpy(), sb.cpu().numpy(), bias.float().cpu().numpy(), "bf16")
+    assert np.array_equal(to_f32_numpy(y1), ref)
+    with pytest.raises(SdnqHipError):
+        int_scaled_mm_func(a.cpu(), w.t().cpu(), sa.cpu(), sb.cpu())  # no CPU fallback in the product path
+    with pytest.raises(SdnqHipError):  # K % 16 != 0 is rejected by the C ABI (SDNQ_ERR_SHAPE)
+        ops.scaled_mm(ops.MM_I8, a[:, :100].contiguous(), w[:, :100].contiguous(), sa.view(-1), sb.view(-1), None, torch.bfloat16)
+
+
+def test_accelerate_repoints_a_foreign_module(gpu_device):
+    """accelerate(): a module built elsewhere (any object graph with the reference's attributes) gets the HIP forward."""
+    import types
+    import sdnq_amd
+    c = Case("int8_rowwise_qmm_bf16")
+    mod = module_from_case(c, gpu_device)
+    foreign = types.SimpleNamespace(**{f: getattr(mod.sdnq_dequantizer, f) for f in sdnq_amd.loader._DQ_FIELDS})
+    mod.sdnq_dequantizer = foreign
+    mod.forward_func = lambda self, x: (_ for _ in ()).throw(RuntimeError("reference forward should have been replaced"))
+    holder = torch.nn.Sequential(mod)
+    assert sdnq_amd.accelerate(holder) == 1
+    x = c.torch_tensor("x_48", device=gpu_device)
+    assert np.array_equal(to_f32_numpy(holder(x)), c.f32("y_48"))
