@@ -12,7 +12,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdnq_hip.so")
+LIB_PATH = os.environ.get("SDNQ_HIP_LIB") or os.path.join(_HERE, "libsdnq_hip.so")  # override: development builds only
 _CSRC = os.path.join(_HERE, "csrc")
 
 # enums of include/sdnq_hip.h

@@ -8,21 +8,43 @@
 //     K-contiguous vector per lane -- no transposes anywhere;
 //   * int8 -> v_mfma_i32_32x32x32_i8 (exact int32 accumulate, so any K order is bit-identical);
 //     fp8  -> v_mfma_scale_f32_32x32x64_f8f6f4 with neutral E8M0 scales (the only full-rate fp8 MFMA);
+//   * HBM -> LDS goes through global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip) into an NS-deep ring of
+//     stages; each stage is BK = 128 bytes of K for BM + BN rows.  The wave only waits with a COUNTED
+//     s_waitcnt vmcnt(n) for the stage it is about to read, so NS-2 stages stay in flight across the single
+//     raw s_barrier per K-step (a __syncthreads() would drain the DMA queue);
+//   * LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row >> 1) & 7: conflict-free
+//     ds_read_b128 for the 32-row MFMA fragment pattern.  LDS-DMA writes lane-linearly, so the swizzle is
+//     applied to the per-lane SOURCE address (and again on the read);
 //   * MFMA computes the TRANSPOSED tile (A-operand = weight rows n, B-operand = activation rows m):
 //     a lane then owns ONE activation row m and 16 output channels in runs of 4, so the epilogue
 //     packs 4 results per 8-byte LDS store and the tile leaves the CU as full 16-byte row segments;
-//   * LDS tile rows are 128 B (BK = 128 bytes of K) with the 16-byte chunk index XOR-swizzled by
-//     (row >> 1) & 7: conflict-free ds_read_b128 for the 32-row fragment pattern;
 //   * epilogue: fma(f32(acc) * sa[m], sb[n], bias) -- single-rounding FMA like tl.fma
-//     (triton_scaled_mm.py:225) and CPU addcmul; int32 -> f32 conversion is RNE above 2^24.
+//     (triton_scaled_mm.py:225) and CPU addcmul; int32 -> f32 conversion is RNE above 2^24;
 //   * optional fused low-rank (SVD) bias: bias2d[m][n] = cast_svd(f32(bias[n]) + sum_r t[m][r] * up[n][r])
 //     (linear_int8.py:57-62) and zero-point term f32(rowsum[m]) * sa[m] * zp[n] (linear_int8.py:65-69)
-//     are produced in the epilogue instead of materialising an [M][N] bias in HBM.
+//     are produced in the epilogue instead of materialising an [M][N] bias in HBM;
+//   * block -> tile map is XCD-aware: the 8 XCDs (private L2s) each walk a contiguous range of tiles.
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+
 #include "sdnq_dev.h"
 
 namespace {
 
 constexpr int BKB = 128;  // bytes of K per LDS stage row
+
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};  // source of K-tail chunks for the LDS-DMA
+
+#ifdef SDNQ_TRACE  // development build only: per-workgroup phase timestamps (shader clock), read back by tools/trace_gemm.py
+__device__ unsigned long long g_trace[4096 * 8];
+#define TRACE(slot)                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define TRACE(slot) do { } while (0)
+#endif
 
 struct GemmParams {
     const uint8_t* a;   // [M][K]
@@ -38,6 +60,7 @@ struct GemmParams {
     int64_t M, N, K;
     int64_t ld_bias;
     int bias_ndim;
+    int bias_dtype;  // SdnqFloat of bias (and of lr_t / lr_up, which share the svd dtype)
     int rank;
     int tiles_m, tiles_n;
 };
@@ -67,26 +90,63 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * BKB + ((c ^ ((
 
 template <int T_ID> __device__ __forceinline__ float ldf(const void* p, int64_t i) { return FT<T_ID>::load(p, i); }
 
-// BM x BN block tile, WM x WN wave tile (multiples of 32), 256 threads.
-template <int MM, int OUT_T, int BIAS_T, int BM, int BN, int WM, int WN, bool LOWRANK>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-    typedef MmaTraits<MM> MT;
-    constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_CHUNKS = BM * 8 / 256, B_CHUNKS = BN * 8 / 256;  // 16-byte chunks per thread per stage
-    constexpr int OUT_B = FT<OUT_T>::bytes;
-    constexpr int STAGE_ROW = BN * OUT_B + 16;  // epilogue staging row stride (bytes)
-    constexpr int MAIN_BYTES = 2 * (BM + BN) * BKB;
-    constexpr int EPI_BYTES = BM * STAGE_ROW;
-    constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_BYTES];
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// f(integral_constant<N-1>), ..., f(integral_constant<0>): a compile-time unrolled countdown
+template <int N, typename F> __device__ __forceinline__ void static_for_down(F&& f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, N - 1>{});
+        static_for_down<N - 1>(f);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+enum { EPI_NONE = 0, EPI_BIAS1D = 1, EPI_BIAS2D = 2, EPI_LOWRANK = 3 };
+
+__device__ __forceinline__ float ldf_rt(const void* p, int64_t i, int dt) {
+    return dt == SDNQ_F32 ? ((const float*)p)[i] : (dt == SDNQ_BF16 ? bf16_bits_to_f32(((const uint16_t*)p)[i]) : f16_bits_to_f32(((const uint16_t*)p)[i]));
+}
+__device__ __forceinline__ float round_rt(float v, int dt) {
+    return dt == SDNQ_F32 ? v : (dt == SDNQ_BF16 ? FT<SDNQ_BF16>::round(v) : FT<SDNQ_F16>::round(v));
+}
+
+// BM x BN block tile, WM x WN wave tile (multiples of 32), NW = (BM/WM)*(BN/WN) waves, NS LDS stages.
+// EPI selects the epilogue at compile time.
+//
+// Code-size discipline: on this machine straight-line code that a wave executes ONCE runs at instruction-fetch
+// speed (cold I-cache: ~600 cycles per ~100 instructions were measured in the unrolled pipeline-drain copies of an
+// earlier version), and diffusion-size GEMMs only run 5-40 K-steps, so everything outside the K loop is kept
+// compact: the DMA prologue and the epilogue are runtime loops, and the K loop has ONE body for fill, steady state
+// and drain (stages past the end of K are issued as zero-fill DMAs, which keeps the counted vmcnt a constant).
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
+    typedef MmaTraits<MM> MT;
+    constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN, NW = WAVES_M * WAVES_N, NT = NW * 64;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PIECES = BM / 8 / NW, B_PIECES = BN / 8 / NW, PPW = A_PIECES + B_PIECES;  // 1-KiB DMA pieces per wave per stage
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly into 8-row DMA pieces");
+    static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
+    constexpr int STAGE_BYTES = (BM + BN) * BKB;
+    constexpr int OUT_B = FT<OUT_T>::bytes;
+    constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [BM][ACC_ROW]
+    constexpr int MAIN_BYTES = NS * STAGE_BYTES, EPI_BYTES = BM * ACC_ROW;
+    constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
+    float* s_bias = s_sb + BN;              // [BN] 1-D bias as f32
+    float* s_zp = s_bias + BN;              // [BN] zero points (EPI_LOWRANK)
+
+    TRACE(0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware tile order: consecutive ids on one XCD walk the n-tiles of one m-strip, so the strip of
-    // A (the larger operand at diffusion shapes) stays in that XCD's L2. Block b runs on XCD b % 8.
+    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous range of tiles that walks the
+    // n-tiles of one m-strip first, so a strip of A is fetched into one XCD's L2 once.
     const int nwg = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
     {
@@ -95,29 +155,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int64_t K = p.K;
+    const int K = (int)p.K;
 
-    // global->LDS staging assignment: chunk id = i*256 + tid -> row = id/8, chunk = id%8
-    const uint8_t* ga[A_CHUNKS];
-    const uint8_t* gb[B_CHUNKS];
-    int la[A_CHUNKS], lb[B_CHUNKS];
-    const int ck = tid & 7;
+    // ---- LDS-DMA assignment: piece = 8 tile rows x 128 B; lane l -> row l/8, physical chunk l%8 ----------------
+    // wave w owns A pieces w, w+NW, ... and B pieces w, w+NW, ...; the source chunk is the swizzle-inverse of the
+    // physical chunk so that LDS stays lane-linear (base + lane*16) as the DMA requires.
+    const uint8_t* src[PPW];
+    const int r8 = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < A_CHUNKS; ++i) {
-        const int r = (i * 256 + tid) >> 3;
-        int64_t gm = m0 + r;
-        if (gm >= p.M) gm = p.M - 1;  // clamp: rows past M are computed on valid memory and never stored
-        ga[i] = p.a + gm * K + ck * 16;
-        la[i] = lds_off(r, ck);
+    for (int i = 0; i < PPW; ++i) {
+        const bool isA = i < A_PIECES;
+        const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+        const int r = piece * 8 + r8;
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t g = (isA ? m0 : n0) + r;
+        const int64_t lim = isA ? p.M : p.N;
+        if (g >= lim) g = lim - 1;  // clamp: rows past the edge are computed on valid memory and never stored
+        src[i] = (isA ? p.a : p.b) + g * (int64_t)K + c * 16;
     }
+    // logical K offset (bytes) of this lane's chunk: the swizzle only depends on (piece*8 + r8) >> 1, and piece*8 is a
+    // multiple of 8, so the chunk is the same for every piece of an operand up to the parity of piece*4 -- NW is even,
+    // hence (piece*8 >> 1) & 7 alternates with `piece & 1`; it is recomputed (2 VALU) instead of stored.
+    auto kofs = [&](int i) {
+        const bool isA = i < A_PIECES;
+        const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+        return (((lane & 7) ^ (((piece * 8 + r8) >> 1) & 7)) << 4);
+    };
+    int slot_i = 0;  // ring slot the next issued stage goes to
+    auto issue = [&](int kt) {
+        const int k0 = kt * BKB;
+        uint8_t* stage = lds + slot_i * STAGE_BYTES;
+        slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
 #pragma unroll
-    for (int i = 0; i < B_CHUNKS; ++i) {
-        const int r = (i * 256 + tid) >> 3;
-        int64_t gn = n0 + r;
-        if (gn >= p.N) gn = p.N - 1;
-        gb[i] = p.b + gn * K + ck * 16;
-        lb[i] = BM * BKB + lds_off(r, ck);
-    }
+        for (int i = 0; i < PPW; ++i) {
+            const bool isA = i < A_PIECES;
+            const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+            uint8_t* dst = stage + (isA ? 0 : BM * BKB) + piece * 1024;
+            // chunks past K (K % 16 == 0) and whole stages past the end of K come from a 16-byte zero constant
+            const uint8_t* s = (k0 + kofs(i) < K) ? src[i] + k0 : (const uint8_t*)&g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
+        }
+    };
 
     typename MT::acc_t acc[TN][TM];  // [n-subtile][m-subtile]; MFMA A-operand = weights (n), B-operand = activations (m)
 #pragma unroll
@@ -125,191 +203,238 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) MT::zero(acc[i][j]);
 
-    const int nk = (int)((K + BKB - 1) / BKB);
-    uint4 ra[A_CHUNKS], rb[B_CHUNKS];
-    auto gload = [&](int kt) {
-        const int64_t k0 = (int64_t)kt * BKB;
-        const bool ok = (k0 + ck * 16) < K;  // K % 16 == 0, so a chunk is fully in or fully out
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) ra[i] = ok ? *(const uint4*)(ga[i] + k0) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) rb[i] = ok ? *(const uint4*)(gb[i] + k0) : make_uint4(0, 0, 0, 0);
-    };
-    auto lstore = [&](int buf) {
-        uint8_t* base = lds + buf * (BM + BN) * BKB;
-#pragma unroll
-        for (int i = 0; i < A_CHUNKS; ++i) *(uint4*)(base + la[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) *(uint4*)(base + lb[i]) = rb[i];
-    };
+    const int nk = (K + BKB - 1) / BKB;
+    constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed
+#pragma nounroll
+    for (int s = 0; s < AHEAD; ++s) issue(s);
+    TRACE(1);
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    // per-output-channel epilogue vectors -> LDS once per workgroup (after the DMA prologue so its load latency hides
+    // under it; visible after the first barrier of the K loop)
+    for (int i = tid; i < BN; i += NT) {
+        int64_t gn = n0 + i;
+        if (gn >= p.N) gn = p.N - 1;
+        s_sb[i] = p.sb[gn];
+        if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = p.bias ? ldf_rt(p.bias, gn, p.bias_dtype) : 0.0f;
+        if constexpr (EPI == EPI_LOWRANK) s_zp[i] = p.zp ? p.zp[gn] : 0.0f;
+    }
 
     const int frow = lane & 31, fgrp = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const uint8_t* sA = lds + buf * (BM + BN) * BKB;
+    int slot_c = 0;  // ring slot being consumed
+    auto compute = [&]() {
+        const uint8_t* sA = lds + slot_c * STAGE_BYTES;
         const uint8_t* sB = sA + BM * BKB;
+        slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+        constexpr int KS = BKB / MT::KB;
+        if constexpr (MM == SDNQ_MM_I8) {
+            // all fragment reads of the stage are issued before the first MFMA, so LDS latency overlaps the matrix pipe
+            v4i fa[KS][TM], fb[KS][TN];
 #pragma unroll
-        for (int ks = 0; ks < BKB / MT::KB; ++ks) {
-            if constexpr (MM == SDNQ_MM_I8) {
-                v4i fa[TM], fb[TN];
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fa[j] = *(const v4i*)(sA + lds_off(wm * WM + j * 32 + frow, ks * 2 + fgrp));
+                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off(wm * WM + j * 32 + frow, ks * 2 + fgrp));
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[i] = *(const v4i*)(sB + lds_off(wn * WN + i * 32 + frow, ks * 2 + fgrp));
+                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off(wn * WN + i * 32 + frow, ks * 2 + fgrp));
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[i], fa[j], acc[i][j], 0, 0, 0);
-            } else {
-                v8i fa[TM], fb[TN];
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+        } else {
+            v8i fa[KS][TM], fb[KS][TN];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     const int r = wm * WM + j * 32 + frow;
                     const v4i lo = *(const v4i*)(sA + lds_off(r, ks * 4 + fgrp * 2));
                     const v4i hi = *(const v4i*)(sA + lds_off(r, ks * 4 + fgrp * 2 + 1));
-                    fa[j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fa[ks][j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     const int r = wn * WN + i * 32 + frow;
                     const v4i lo = *(const v4i*)(sB + lds_off(r, ks * 4 + fgrp * 2));
                     const v4i hi = *(const v4i*)(sB + lds_off(r, ks * 4 + fgrp * 2 + 1));
-                    fb[i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fb[ks][i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[i], fa[j], acc[i][j], 0, 0, 0,
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0,
                                                                                     0x7f7f7f7f, 0, 0x7f7f7f7f);
-            }
         }
-        if (kt + 1 < nk) lstore(buf ^ 1);
-        __syncthreads();
+    };
+
+    // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the single
+    // raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs of stage kt.
+#pragma nounroll
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt<(AHEAD - 1) * PPW>();
+        __builtin_amdgcn_s_barrier();
+        if (kt == 0) TRACE(2);
+        issue(kt + AHEAD);
+        compute();
     }
+    TRACE(3);
+    wait_vmcnt<0>();  // the trailing zero-fill DMAs target ring slots the epilogue is about to reuse
+    __syncthreads();
+    TRACE(4);
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    // acc[i][j][reg]: n = n0 + wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = m0 + wm*WM + j*32 + (lane&31)
-    uint8_t* stage = lds;  // [BM][STAGE_ROW]; main-loop buffers are dead (last iteration ended with a barrier)
+    // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
+    //     acc[i][j][reg]: n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = wm*WM + j*32 + (lane&31)
+    uint8_t* stage = lds;
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int ml = wm * WM + j * 32 + frow;
-        int64_t gm = m0 + ml;
-        if (gm >= p.M) gm = p.M - 1;
-        const float sa = p.sa[gm];
-        float zsum = 0.0f;
-        if constexpr (LOWRANK) {
-            if (p.zp_rowsum) zsum = (float)p.zp_rowsum[gm] * sa;  // .to(f32).mul_(input_scale), linear_int8.py:66
-        }
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int nl = wn * WN + i * 32 + e + 8 * q + 4 * fgrp;
-                    int64_t gn = n0 + nl;
-                    if (gn >= p.N) gn = p.N - 1;
-                    const float v = MT::tof(acc[i][j], q * 4 + e) * sa;
-                    const float sb = p.sb[gn];
-                    if constexpr (LOWRANK) {
-                        // bias2d = cast_svd(f32(bias[n]) + sum_r t[m][r]*up[n][r]); then + zp term; f32 into the fma
-                        float bv = 0.0f;
-                        bool has = false;
-                        if (p.lr_t) {
-                            float s = 0.0f;
-                            for (int r = 0; r < p.rank; ++r)
-                                s = fmaf(ldf<BIAS_T>(p.lr_t, gm * p.rank + r), ldf<BIAS_T>(p.lr_up, gn * p.rank + r), s);
-                            if (p.bias) s += ldf<BIAS_T>(p.bias, gn);
-                            bv = FT<BIAS_T>::round(s);
-                            has = true;
-                        } else if (p.bias) {
-                            bv = ldf<BIAS_T>(p.bias, gn);
-                            has = true;
-                        }
-                        if (p.zp) {
-                            const float zb = zsum * p.zp[gn];
-                            bv = has ? zb + bv : zb;  // zero_bias.add_(bias), linear_int8.py:67-68
-                            has = true;
-                        }
-                        o[e] = has ? fmaf(v, sb, bv) : v * sb;
-                    } else {
-                        if (p.bias_ndim == 1) o[e] = fmaf(v, sb, ldf<BIAS_T>(p.bias, gn));
-                        else if (p.bias_ndim == 2) o[e] = fmaf(v, sb, ldf<BIAS_T>(p.bias, gm * p.ld_bias + gn));
-                        else o[e] = v * sb;
-                    }
-                }
+                const int ml = wm * WM + j * 32 + frow;
                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
-                uint8_t* dst = stage + ml * STAGE_ROW + nl0 * OUT_B;
-                if constexpr (OUT_T == SDNQ_F32) {
-                    *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
-                } else if constexpr (OUT_T == SDNQ_BF16) {
-                    *(uint2*)dst = make_uint2((u32)f32_to_bf16_bits(o[0]) | ((u32)f32_to_bf16_bits(o[1]) << 16),
-                                              (u32)f32_to_bf16_bits(o[2]) | ((u32)f32_to_bf16_bits(o[3]) << 16));
+                if constexpr (MM == SDNQ_MM_I8)
+                    *(v4i*)(stage + ml * ACC_ROW + nl0 * 4) = (v4i){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                else
+                    *(v4f*)(stage + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            }
+    __syncthreads();
+    TRACE(5);
+    // (2) one compact loop: 8 consecutive channels of one row per thread -> scale, bias, cast, 16/32-byte store
+    constexpr int G8 = BN / 8;
+#pragma nounroll
+    for (int v = tid; v < BM * G8; v += NT) {
+        const int r = v / G8, c8 = (v % G8) * 8;
+        const int64_t gm = m0 + r, gn0 = n0 + c8;
+        if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a group of 8 never straddles N
+        const float sa = p.sa[gm];
+        float zsum = 0.0f;
+        if constexpr (EPI == EPI_LOWRANK) {
+            if (p.zp_rowsum) zsum = (float)p.zp_rowsum[gm] * sa;  // .to(f32).mul_(input_scale), linear_int8.py:66
+        }
+        float o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float a4[4];
+            if constexpr (MM == SDNQ_MM_I8) {
+                const v4i t = *(const v4i*)(stage + r * ACC_ROW + (c8 + 4 * h) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[e] = (float)t[e];  // int32 -> f32 (RNE above 2^24)
+            } else {
+                const v4f t = *(const v4f*)(stage + r * ACC_ROW + (c8 + 4 * h) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a4[e] = t[e];
+            }
+            const v4f sb4 = *(const v4f*)(s_sb + c8 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float vv = a4[e] * sa;
+                float res;
+                if constexpr (EPI == EPI_NONE) {
+                    res = vv * sb4[e];
+                } else if constexpr (EPI == EPI_BIAS1D) {
+                    res = fmaf(vv, sb4[e], s_bias[c8 + 4 * h + e]);
+                } else if constexpr (EPI == EPI_BIAS2D) {
+                    res = fmaf(vv, sb4[e], ldf_rt(p.bias, gm * p.ld_bias + gn0 + 4 * h + e, p.bias_dtype));
                 } else {
-                    *(uint2*)dst = make_uint2((u32)f32_to_f16_bits(o[0]) | ((u32)f32_to_f16_bits(o[1]) << 16),
-                                              (u32)f32_to_f16_bits(o[2]) | ((u32)f32_to_f16_bits(o[3]) << 16));
+                    // bias2d = cast_svd(f32(bias[n]) + sum_r t[m][r]*up[n][r]) (linear_int8.py:57-62), then the zero-point
+                    // term f32(rowsum)*sa*zp[n] + bias2d (linear_int8.py:65-69), all f32 into the single-rounding fma
+                    const int cn = c8 + 4 * h + e;
+                    float bv = s_bias[cn];
+                    bool has = p.bias != nullptr;
+                    if (p.lr_t) {
+                        float sacc = 0.0f;
+                        for (int rr = 0; rr < p.rank; ++rr)
+                            sacc = fmaf(ldf_rt(p.lr_t, gm * p.rank + rr, p.bias_dtype), ldf_rt(p.lr_up, (n0 + cn) * p.rank + rr, p.bias_dtype), sacc);
+                        bv = round_rt(has ? sacc + bv : sacc, p.bias_dtype);
+                        has = true;
+                    }
+                    if (p.zp) {
+                        const float zb = zsum * s_zp[cn];
+                        bv = has ? zb + bv : zb;
+                        has = true;
+                    }
+                    res = has ? fmaf(vv, sb4[e], bv) : vv * sb4[e];
                 }
+                o[4 * h + e] = res;
             }
         }
-    }
-    __syncthreads();
-    // coalesced tile store: 16-byte vectors along n
-    constexpr int VEC_PER_ROW = BN * OUT_B / 16;
-    constexpr int ELEMS_PER_VEC = 16 / OUT_B;
-    for (int v = tid; v < BM * VEC_PER_ROW; v += 256) {
-        const int r = v / VEC_PER_ROW, c = v % VEC_PER_ROW;
-        const int64_t gm = m0 + r, gn = n0 + (int64_t)c * ELEMS_PER_VEC;
-        if (gm < p.M && gn < p.N) {  // N % 16 == 0 (utils.py:96-97) so a 16-byte vector never straddles N
-            const uint4 val = *(const uint4*)(stage + r * STAGE_ROW + c * 16);
-            *(uint4*)((uint8_t*)p.out + (gm * p.N + gn) * OUT_B) = val;
+        uint8_t* dst = (uint8_t*)p.out + (gm * p.N + gn0) * OUT_B;
+        if constexpr (OUT_T == SDNQ_F32) {
+            *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
+            *(uint4*)(dst + 16) = Vec16<SDNQ_F32>::pack(o + 4);
+        } else {
+            *(uint4*)dst = Vec16<OUT_T>::pack(o);
         }
     }
+    TRACE(6);
 }
 
-template <int MM, int OUT_T, int BIAS_T, bool LOWRANK>
-int launch_tiles(const GemmParams& p0, hipStream_t s) {
-    GemmParams p = p0;
-    // tile choice: fill >= ~1 wave of CUs (256) when the problem allows it
-    const int64_t t128 = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const int64_t t64x128 = ((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (t128 >= 256 || t64x128 < 64) {
-        p.tiles_m = (int)((p.M + 127) / 128);
-        p.tiles_n = (int)((p.N + 127) / 128);
-        hipLaunchKernelGGL((gemm_kernel<MM, OUT_T, BIAS_T, 128, 128, 64, 64, LOWRANK>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
-    } else if (t64x128 >= 256 || ((p.M + 63) / 64) * ((p.N + 63) / 64) < 64) {
-        p.tiles_m = (int)((p.M + 63) / 64);
-        p.tiles_n = (int)((p.N + 127) / 128);
-        hipLaunchKernelGGL((gemm_kernel<MM, OUT_T, BIAS_T, 64, 128, 32, 64, LOWRANK>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
-    } else {
-        p.tiles_m = (int)((p.M + 63) / 64);
-        p.tiles_n = (int)((p.N + 63) / 64);
-        hipLaunchKernelGGL((gemm_kernel<MM, OUT_T, BIAS_T, 64, 64, 32, 32, LOWRANK>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS>
+int launch_one(GemmParams p, hipStream_t s) {
+    constexpr int NW = (BM / WM) * (BN / WN);
+    constexpr int MAIN = NS * (BM + BN) * BKB;
+    constexpr int EPIB = BM * (BN * 4 + 16);
+    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 3 * BN * 4;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS>;
+    static std::atomic<bool> attr_set{false};
+    if (LDS_BYTES > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return SDNQ_ERR_LAUNCH;
+        attr_set.store(true, std::memory_order_release);
     }
+    p.tiles_m = (int)((p.M + BM - 1) / BM);
+    p.tiles_n = (int)((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), LDS_BYTES, s, p);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }
 
-template <int MM, bool LOWRANK>
-int dispatch_types(const GemmParams& p, int out_dtype, int bias_dtype, hipStream_t s) {
-#define GEMM_CASE(O, B) \
-    if (out_dtype == O && bias_dtype == B) return launch_tiles<MM, O, B, LOWRANK>(p, s);
-    GEMM_CASE(SDNQ_BF16, SDNQ_BF16)
-    GEMM_CASE(SDNQ_BF16, SDNQ_F32)
-    GEMM_CASE(SDNQ_F16, SDNQ_F16)
-    GEMM_CASE(SDNQ_F16, SDNQ_F32)
-    GEMM_CASE(SDNQ_F32, SDNQ_F32)
-    GEMM_CASE(SDNQ_F32, SDNQ_BF16)
-    GEMM_CASE(SDNQ_F32, SDNQ_F16)
-#undef GEMM_CASE
-    return SDNQ_ERR_DTYPE;
+// Tile choice. The chip has 256 CUs and the LDS-DMA latency is ~1 us, so what matters for diffusion-size GEMMs
+// (1-30 GOP, a few hundred tiles) is (a) enough workgroups to touch every CU and (b) as many bytes in flight per CU
+// as the 160 KB LDS allows: every configuration uses a ring deep enough to fill most of the LDS of its CU.
+template <int MM, int OUT_T, int EPI>
+int launch_tiles(const GemmParams& p, hipStream_t s) {
+    auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    static const int force = [] { const char* e = getenv("SDNQ_HIP_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
+    if (force == 0) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 64, 4>(p, s);
+    if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 64, 6>(p, s);
+    if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 8>(p, s);
+    if (force == 3) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);  // 8 waves: two per SIMD
+    if (force == 4) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 6>(p, s);   // 8 waves
+    // measured on MI355X (tools/bench_gemm.py): two waves per SIMD (8-wave workgroups) beat one for every shape;
+    // 128x128 once it yields >= ~120 workgroups, 64x128 for mid-size problems, 64x64 for the few-row GEMMs (M = 77)
+    if (tiles(128, 128) >= 120) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);
+    if (tiles(64, 128) >= 40) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 6>(p, s);
+    return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 8>(p, s);
+}
+
+template <int MM, int EPI>
+int dispatch_out(const GemmParams& p, int out_dtype, hipStream_t s) {
+    switch (out_dtype) {
+        case SDNQ_BF16: return launch_tiles<MM, SDNQ_BF16, EPI>(p, s);
+        case SDNQ_F16: return launch_tiles<MM, SDNQ_F16, EPI>(p, s);
+        case SDNQ_F32: return launch_tiles<MM, SDNQ_F32, EPI>(p, s);
+        default: return SDNQ_ERR_DTYPE;
+    }
+}
+
+template <int MM>
+int dispatch_epi(const GemmParams& p, int epi, int out_dtype, hipStream_t s) {
+    switch (epi) {
+        case EPI_NONE: return dispatch_out<MM, EPI_NONE>(p, out_dtype, s);
+        case EPI_BIAS1D: return dispatch_out<MM, EPI_BIAS1D>(p, out_dtype, s);
+        case EPI_BIAS2D: return dispatch_out<MM, EPI_BIAS2D>(p, out_dtype, s);
+        default: return dispatch_out<MM, EPI_LOWRANK>(p, out_dtype, s);
+    }
 }
 
 int check_common(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, void* out, int out_dtype,
@@ -324,6 +449,15 @@ int check_common(int mm_dtype, const void* a, const void* b, const float* sa, co
 
 }  // namespace
 
+#ifdef SDNQ_TRACE
+extern "C" int sdnq_hip_debug_trace(unsigned long long* host, int n_words) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n_words) != hipSuccess) return -7;
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_trace)) != hipSuccess) return -7;
+    return hipMemset(dptr, 0, sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -7;
+}
+#endif
+
 extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
                                   const void* bias, int bias_dtype, int bias_ndim, int64_t ld_bias, void* out,
                                   int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
@@ -331,16 +465,15 @@ extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, co
     if (st != SDNQ_OK) return st;
     if (bias_ndim < 0 || bias_ndim > 2) return SDNQ_ERR_SHAPE;
     if (bias_ndim != 0 && !bias) return SDNQ_ERR_NULL;
-    if (bias_ndim == 0) { bias = nullptr; bias_dtype = (out_dtype == SDNQ_F16) ? SDNQ_F16 : (out_dtype == SDNQ_BF16 ? SDNQ_BF16 : SDNQ_F32); }
+    if (bias_ndim == 0) { bias = nullptr; bias_dtype = out_dtype; }
     if (bias_dtype < 0 || bias_dtype > 2) return SDNQ_ERR_DTYPE;
     if (bias_ndim == 2 && ld_bias < n) return SDNQ_ERR_SHAPE;
-    if ((n % 16) != 0 && out_dtype != SDNQ_F32) return SDNQ_ERR_SHAPE;
     GemmParams p{};
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
-    p.M = m; p.N = n; p.K = k; p.ld_bias = ld_bias; p.bias_ndim = bias_ndim;
+    p.M = m; p.N = n; p.K = k; p.ld_bias = ld_bias; p.bias_ndim = bias_ndim; p.bias_dtype = bias_dtype;
     hipStream_t s = (hipStream_t)stream;
-    if (mm_dtype == SDNQ_MM_I8) return dispatch_types<SDNQ_MM_I8, false>(p, out_dtype, bias_dtype, s);
-    return dispatch_types<SDNQ_MM_FP8, false>(p, out_dtype, bias_dtype, s);
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, bias_ndim, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, bias_ndim, out_dtype, s);
 }
 
 extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
@@ -352,7 +485,6 @@ extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const voi
     if ((t == nullptr) != (svd_up == nullptr)) return SDNQ_ERR_NULL;
     if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
     if (t && (rank <= 0 || rank > 1024)) return SDNQ_ERR_SHAPE;
-    if ((n % 16) != 0 && out_dtype != SDNQ_F32) return SDNQ_ERR_SHAPE;
     // the [M][N] bias of the reference lives in the svd dtype (addmm in svd_down.dtype, linear_int8.py:60);
     // a 1-D bias is cast to it first, so bias/t/up share one element type here.
     int bt = t ? svd_dtype : (bias ? bias_dtype : out_dtype);
@@ -361,8 +493,8 @@ extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const voi
     GemmParams p{};
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
     p.lr_t = t; p.lr_up = svd_up; p.rank = rank; p.zp_rowsum = zp_rowsum; p.zp = zp;
-    p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0;
+    p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bt;
     hipStream_t s = (hipStream_t)stream;
-    if (mm_dtype == SDNQ_MM_I8) return dispatch_types<SDNQ_MM_I8, true>(p, out_dtype, bt, s);
-    return dispatch_types<SDNQ_MM_FP8, true>(p, out_dtype, bt, s);
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, EPI_LOWRANK, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, EPI_LOWRANK, out_dtype, s);
 }

@@ -51,8 +51,35 @@ __device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[
     }
 }
 
-// T_ID: activation dtype; MM: SdnqMM; HAD: rotate first
-template <int T_ID, int MM, bool HAD>
+template <int MM>
+__device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& isum) {
+    u32 w0 = 0, w1 = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        u32 byte;
+        if constexpr (MM == SDNQ_MM_I8) {
+            // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
+            float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[e] / scale);
+            q = fminf(fmaxf(q, -128.0f), 127.0f);
+            const int qi = (int)q;
+            isum += qi;
+            byte = (u32)qi & 0xffu;
+        } else {
+            float q = v[e] / scale;
+            if (q != q) q = 0.0f;  // nan_to_num; +-inf fall to the clamp
+            q = fminf(fmaxf(q, -448.0f), 448.0f);
+            byte = f32_to_e4m3fn(q);
+        }
+        if (e < 4) w0 |= byte << (8 * e);
+        else w1 |= byte << (8 * (e - 4));
+    }
+    return make_uint2(w0, w1);
+}
+
+// T_ID: activation dtype; MM: SdnqMM; HAD: rotate first; NP: 512-element passes of the row held in registers
+// (K <= NP*512: the row is read from HBM exactly once, all loads in flight together); NP == 0: two-phase fallback
+// for very long rows (second read is L2-hot).
+template <int T_ID, int MM, bool HAD, int NP>
 __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
                                                        int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
                                                        int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
@@ -61,62 +88,77 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
     if (m >= M) return;  // whole wave exits together (wave-uniform)
     const void* row = (const char*)x + m * ldx * FT<T_ID>::bytes;
     const float hscale = HAD ? hadamard_scale(log2g, T_ID) : 1.0f;
-    const int64_t npass = (K + 511) / 512;
-
-    // ---- phase 1: row amax (after rotation + rounding to the activation dtype) ------------------
-    float amax = 0.0f;
-    for (int64_t p = 0; p < npass; ++p) {
-        const int64_t idx = p * 512 + lane * 8;
-        float v[8];
-        load8<T_ID>(row, idx, idx < K, v);
-        if constexpr (HAD) {
-            wave_hadamard(v, log2g, hscale);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
-    }
-    amax = wave_max(amax);
     const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
-    const float scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
-    if (lane == 0) xs[m] = scale;
-
-    // ---- phase 2: quantize ---------------------------------------------------------------------
-    int isum = 0;
     uint8_t* qrow = xq + m * K;
-    for (int64_t p = 0; p < npass; ++p) {
-        const int64_t idx = p * 512 + lane * 8;
-        const bool ok = idx < K;
-        float v[8];
-        load8<T_ID>(row, idx, ok, v);
-        if constexpr (HAD) {
-            wave_hadamard(v, log2g, hscale);
+    int isum = 0;
+
+    if constexpr (NP > 0) {
+        float v[NP][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
-            if (xrot != nullptr && ok) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v);
+        for (int p = 0; p < NP; ++p) {
+            const int64_t idx = (int64_t)p * 512 + lane * 8;
+            load8<T_ID>(row, idx, idx < K, v[p]);
         }
-        u32 w0 = 0, w1 = 0;
+        float amax = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            u32 byte;
-            if constexpr (MM == SDNQ_MM_I8) {
-                // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
-                float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[e] / scale);
-                q = fminf(fmaxf(q, -128.0f), 127.0f);
-                const int qi = (int)q;
-                isum += qi;
-                byte = (u32)qi & 0xffu;
-            } else {
-                float q = v[e] / scale;
-                if (q != q) q = 0.0f;  // nan_to_num; +-inf fall to the clamp
-                q = fminf(fmaxf(q, -448.0f), 448.0f);
-                byte = f32_to_e4m3fn(q);
+        for (int p = 0; p < NP; ++p) {
+            if constexpr (HAD) {
+                if ((int64_t)p * 512 < K) {  // wave-uniform
+                    wave_hadamard(v[p], log2g, hscale);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[p][e] = FT<T_ID>::round(v[p][e]);
+                }
             }
-            if (e < 4) w0 |= byte << (8 * e);
-            else w1 |= byte << (8 * (e - 4));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[p][e]));
         }
-        if (ok) *(uint2*)(qrow + idx) = make_uint2(w0, w1);
+        amax = wave_max(amax);
+        const float scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
+        if (lane == 0) xs[m] = scale;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int64_t idx = (int64_t)p * 512 + lane * 8;
+            if (idx < K) {
+                if constexpr (HAD) {
+                    if (xrot != nullptr) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v[p]);
+                }
+                *(uint2*)(qrow + idx) = quant8<MM>(v[p], scale, isum);
+            }
+        }
+    } else {
+        const int64_t npass = (K + 511) / 512;
+        // ---- phase 1: row amax (after rotation + rounding to the activation dtype)
+        float amax = 0.0f;
+        for (int64_t p = 0; p < npass; ++p) {
+            const int64_t idx = p * 512 + lane * 8;
+            float v[8];
+            load8<T_ID>(row, idx, idx < K, v);
+            if constexpr (HAD) {
+                wave_hadamard(v, log2g, hscale);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+        }
+        amax = wave_max(amax);
+        const float scale = amax / qmax;
+        if (lane == 0) xs[m] = scale;
+        // ---- phase 2: quantize
+        for (int64_t p = 0; p < npass; ++p) {
+            const int64_t idx = p * 512 + lane * 8;
+            const bool ok = idx < K;
+            float v[8];
+            load8<T_ID>(row, idx, ok, v);
+            if constexpr (HAD) {
+                wave_hadamard(v, log2g, hscale);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+                if (xrot != nullptr && ok) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v);
+            }
+            const uint2 w = quant8<MM>(v, scale, isum);
+            if (ok) *(uint2*)(qrow + idx) = w;
+        }
     }
     if (rowsum != nullptr) {
         isum = wave_sum_i32(isum);
@@ -173,12 +215,21 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     if (rowsum && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((m + 3) / 4)), block(256);
-#define RQ_LAUNCH(T, MMV, H) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot)
-#define RQ_DISPATCH_H(T, MMV)              \
-    do {                                   \
-        if (log2g) RQ_LAUNCH(T, MMV, true); \
-        else RQ_LAUNCH(T, MMV, false);      \
+    const int np = (int)((k + 511) / 512);
+#define RQ_LAUNCH(T, MMV, H, NPV) \
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot)
+#define RQ_DISPATCH_NP(T, MMV, H)               \
+    do {                                        \
+        if (np <= 2) RQ_LAUNCH(T, MMV, H, 2);   \
+        else if (np <= 3) RQ_LAUNCH(T, MMV, H, 3); \
+        else if (np <= 5) RQ_LAUNCH(T, MMV, H, 5); \
+        else if (np <= 10) RQ_LAUNCH(T, MMV, H, 10); \
+        else RQ_LAUNCH(T, MMV, H, 0);            \
+    } while (0)
+#define RQ_DISPATCH_H(T, MMV)                      \
+    do {                                           \
+        if (log2g) RQ_DISPATCH_NP(T, MMV, true);    \
+        else RQ_DISPATCH_NP(T, MMV, false);         \
     } while (0)
 #define RQ_DISPATCH_MM(T)                                         \
     do {                                                          \

@@ -53,9 +53,9 @@ class ColumnShardedLinear(torch.nn.Module):
         y2 = y_local.reshape(-1, y_local.shape[-1]).contiguous()
         m = y2.shape[0]
         if self.even:
-            gathered = torch.empty((self.world, m, y2.shape[1]), device=y2.device, dtype=y2.dtype)
+            gathered = torch.empty((self.world * m, y2.shape[1]), device=y2.device, dtype=y2.dtype)  # rank-major concat
             dist.all_gather_into_tensor(gathered, y2, group=self.group)
-            out = gathered.permute(1, 0, 2).reshape(m, self.n_total)
+            out = gathered.view(self.world, m, y2.shape[1]).permute(1, 0, 2).reshape(m, self.n_total)
         else:
             parts = [torch.empty((m, b - a), device=y2.device, dtype=y2.dtype) for a, b in self.bounds]
             dist.all_gather(parts, y2, group=self.group)

@@ -1,0 +1,68 @@
+"""Load-time quantizer (host side): layouts and values vs the reference-built goldens."""
+import numpy as np
+import pytest
+import torch
+
+import sdnq_amd
+from sdnq_amd import quantizer
+from tests.golden_util import Case
+from tests.modules_util import TORCH_DT
+
+# cases whose quantization is deterministic given the float weight (no randomized SVD, no float GEMM before rounding)
+EXACT = ["int8_rowwise_noqmm_f32", "int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "fp8_qmm_bf16", "uint4_qmm_bf16",
+         "int6_rowwise_packed_qmm_bf16", "uint7_rowwise_packed_qmm_bf16", "uint8_int8mm_qmm_bf16", "uint8_uint8mm_qmm_bf16",
+         "fp4_e2m1_fp8mm_qmm_bf16", "int5_group32_noqmm_bf16", "uint3_noqmm_f16"]
+
+
+@pytest.mark.parametrize("name", EXACT)
+def test_quantizer_reproduces_reference_state_dict(name):
+    c = Case(name)
+    w = c.torch_tensor("w_float")
+    dq, tensors = quantizer.sdnq_quantize_layer_weight(w, layer_class_name="Linear", **c.meta["cfg"])
+    d = c.deq
+    for f in ("weights_dtype", "group_size", "use_quantized_matmul", "re_quantize_for_matmul", "use_hadamard", "is_packed"):
+        assert getattr(dq, f) == d[f], (name, f, getattr(dq, f), d[f])
+    assert dq.quantized_matmul_dtype in (d["quantized_matmul_dtype"], {"fp8": "float8_e4m3fn"}.get(d["quantized_matmul_dtype"]))
+    assert list(dq.quantized_weight_shape) == d["quantized_weight_shape"]
+    for key in ("weight", "scale", "zero_point"):
+        ref = c.torch_tensor(key)
+        mine = tensors[key]
+        assert (ref is None) == (mine is None), (name, key)
+        if ref is None:
+            continue
+        assert tuple(mine.shape) == tuple(ref.shape), (name, key, mine.shape, ref.shape)
+        if key == "weight" and mine.ndim == 2 and dq.weight_is_transposed:
+            assert mine.stride() == (1, mine.shape[0])
+        a = mine.contiguous().view(torch.uint8) if mine.dtype in (torch.float8_e4m3fn, torch.int8) else mine.contiguous()
+        b = ref.contiguous().view(torch.uint8) if ref.dtype in (torch.float8_e4m3fn, torch.int8) else ref.contiguous()
+        assert torch.equal(a.to(b.dtype) if a.dtype != b.dtype else a, b), (name, key)
+
+
+def test_hadamard_and_svd_configs_have_the_reference_layout():
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(512, 64).to(torch.bfloat16)
+    layer, cfg = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int4", use_svd=True, svd_rank=16, use_hadamard=True,
+                                                                       use_quantized_matmul=True))
+    dq = layer.sdnq_dequantizer
+    assert dq.re_quantize_for_matmul and dq.use_hadamard and dq.hadamard_group_size == 256 and dq.group_size == 128
+    assert layer.weight.dtype == torch.uint8 and layer.weight.numel() == 64 * 512 // 2
+    assert tuple(layer.scale.shape) == (64, 4, 1) and layer.zero_point is None
+    assert tuple(layer.svd_up.shape) == (16, 64) and tuple(layer.svd_down.shape) == (512, 16)   # transposed for qmm
+    assert layer.forward_func is sdnq_amd.linear.quantized_linear_forward_int8_matmul
+    small = torch.nn.Linear(40, 24)
+    l2, cfg2 = sdnq_amd.sdnq_quantize_layer(small, sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True), param_name="small.weight")
+    assert not l2.sdnq_dequantizer.use_quantized_matmul and "small.weight" in cfg2.modules_to_not_use_matmul  # utils.py:93-98
+
+
+def test_apply_to_module_and_config_roundtrip():
+    model = torch.nn.Sequential(torch.nn.Linear(256, 256), torch.nn.ReLU(), torch.nn.Linear(256, 64), torch.nn.Linear(8, 8))
+    cfg = sdnq_amd.SDNQConfig(weights_dtype="uint4", use_quantized_matmul=True, minimum_allowed_numel=1024)
+    model, cfg = sdnq_amd.apply_sdnq_to_module(model, cfg)
+    assert isinstance(model[0], sdnq_amd.SDNQLinear) and isinstance(model[2], sdnq_amd.SDNQLinear)
+    assert not isinstance(model[3], sdnq_amd.SDNQLinear) and "3.weight" in cfg.modules_to_not_convert
+    keys = set(model.state_dict().keys())
+    assert {"0.weight", "0.scale", "0.zero_point", "0.bias"} <= keys
+    cfg2 = sdnq_amd.SDNQConfig.from_dict(cfg.to_dict())
+    assert cfg2.weights_dtype == "uint4" and cfg2.use_quantized_matmul and cfg2.to_dict()["quant_method"] == "sdnq"
+    with pytest.raises(NotImplementedError):
+        sdnq_amd.SDNQConfig(use_codebook=True)
