@@ -103,10 +103,13 @@ int sdnq_hip_device_supported(int ordinal);
  * x: [M][K] of x_dtype, row stride ldx elements. xq: [M][K] int8 or fp8-e4m3fn bytes. xs: [M] f32.
  * rowsum: optional [M] int32 = sum_k xq (zero-point bias, linear_int8.py:65-69); NULL to skip.
  * xrot: optional [M][K] of x_dtype receiving the rotated activation (needed by the SVD branch).
- * hadamard_group: 0 = no rotation, else power of two in [4, 1024] dividing K. */
+ * hadamard_group: 0 = no rotation, else power of two in [4, 512] dividing K.
+ * prefetch / prefetch_bytes: optional software prefetch (may be NULL / 0): extra workgroups of the same launch read
+ * this range (the weight operand of the matmul that follows) so that it is resident in the last-level cache when
+ * the GEMM starts; pure hint, no effect on results. */
 int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype,
                       int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
-                      sdnq_stream_t stream);
+                      const void* prefetch, int64_t prefetch_bytes, sdnq_stream_t stream);
 
 /* ---- a15/a16: scaled matmul (the operator seam) --------------------------------------------
  * replaces int_scaled_mm_func / fp8_scaled_mm_func (kernel_wrappers.py:193-204) and the Triton op

@@ -63,6 +63,8 @@ struct GemmParams {
     int bias_dtype;  // SdnqFloat of bias (and of lr_t / lr_up, which share the svd dtype)
     int rank;
     int tiles_m, tiles_n;
+    int group_m;  // m-strips per rasterization group
+    int swz;      // LDS chunk swizzle mask (7; 0 only for experiments)
 };
 
 template <int MM> struct MmaTraits;
@@ -86,7 +88,7 @@ template <> struct MmaTraits<SDNQ_MM_FP8> {
 };
 
 // LDS byte offset of 16-byte chunk c (0..7) of tile row r; rows are 128 B, chunk XOR-swizzled.
-__device__ __forceinline__ int lds_off(int r, int c) { return r * BKB + ((c ^ ((r >> 1) & 7)) << 4); }
+__device__ __forceinline__ int lds_off(int r, int c, int swz = 7) { return r * BKB + ((c ^ ((r >> 1) & swz)) << 4); }
 
 template <int T_ID> __device__ __forceinline__ float ldf(const void* p, int64_t i) { return FT<T_ID>::load(p, i); }
 
@@ -98,6 +100,13 @@ template <int N, typename F> __device__ __forceinline__ void static_for_down(F&&
     if constexpr (N > 0) {
         f(std::integral_constant<int, N - 1>{});
         static_for_down<N - 1>(f);
+    }
+}
+
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for_up(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_up<N, I + 1>(f);
     }
 }
 
@@ -122,7 +131,14 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
 // earlier version), and diffusion-size GEMMs only run 5-40 K-steps, so everything outside the K loop is kept
 // compact: the DMA prologue and the epilogue are runtime loops, and the K loop has ONE body for fill, steady state
 // and drain (stages past the end of K are issued as zero-fill DMAs, which keeps the counted vmcnt a constant).
-template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS>
+// LD selects how HBM/L2 -> LDS is done:
+//   LD_DMA : global_load_lds_dwordx4 into an NS-deep LDS ring (no VGPR round trip, but ~100+ issue cycles per 1-KiB
+//            piece and ~1 us latency: bytes in flight are bounded by the LDS ring);
+//   LD_REG : global_load_dwordx4 into an NS-deep ring of VGPRs, then ds_write_b128 into a 2-buffer LDS: cheap to
+//            issue, in-flight bytes live in the (much larger) register file, the compiler counts vmcnt itself.
+enum { LD_DMA = 0, LD_REG = 1 };
+
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
     typedef MmaTraits<MM> MT;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN, NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -131,9 +147,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly into 8-row DMA pieces");
     static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
     constexpr int STAGE_BYTES = (BM + BN) * BKB;
+    constexpr int LDS_STAGES = LD == LD_DMA ? NS : 2;
     constexpr int OUT_B = FT<OUT_T>::bytes;
     constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [BM][ACC_ROW]
-    constexpr int MAIN_BYTES = NS * STAGE_BYTES, EPI_BYTES = BM * ACC_ROW;
+    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES, EPI_BYTES = BM * ACC_ROW;
     constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
@@ -145,15 +162,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous range of tiles that walks the
-    // n-tiles of one m-strip first, so a strip of A is fetched into one XCD's L2 once.
+    // L2-aware tile order. (1) block b runs on XCD b % 8 (private 4 MiB L2 each): give every XCD a CONTIGUOUS range of
+    // the tile sequence. (2) the sequence itself is grouped: GROUP_M m-strips are walked together, m fastest, so the
+    // ~32 workgroups resident on one XCD at a time cover a near-square GROUP_M x (32/GROUP_M) patch of tiles and
+    // share both their A strips and their B slabs in that L2 (a 1 x 32 row of tiles would re-fetch every B slab from
+    // MALL/HBM for each m-strip: measured 51% of wave cycles parked on vmcnt/barrier at 16384 x 8192 x 4096).
     const int nwg = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
-    const int tile_m = bid / p.tiles_n, tile_n = bid % p.tiles_n;
+    int tile_m, tile_n;
+    {
+        const int per_group = p.group_m * p.tiles_n;
+        const int gid = bid / per_group, first_m = gid * p.group_m;
+        const int gsz = (p.tiles_m - first_m) < p.group_m ? (p.tiles_m - first_m) : p.group_m;
+        const int in_g = bid - gid * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    }
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const int K = (int)p.K;
 
@@ -167,7 +195,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const bool isA = i < A_PIECES;
         const int piece = (isA ? i : i - A_PIECES) * NW + wave;
         const int r = piece * 8 + r8;
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int c = (lane & 7) ^ ((r >> 1) & p.swz);
         int64_t g = (isA ? m0 : n0) + r;
         const int64_t lim = isA ? p.M : p.N;
         if (g >= lim) g = lim - 1;  // clamp: rows past the edge are computed on valid memory and never stored
@@ -179,7 +207,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     auto kofs = [&](int i) {
         const bool isA = i < A_PIECES;
         const int piece = (isA ? i : i - A_PIECES) * NW + wave;
-        return (((lane & 7) ^ (((piece * 8 + r8) >> 1) & 7)) << 4);
+        return (((lane & 7) ^ (((piece * 8 + r8) >> 1) & p.swz)) << 4);
     };
     int slot_i = 0;  // ring slot the next issued stage goes to
     auto issue = [&](int kt) {
@@ -204,9 +232,31 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         for (int j = 0; j < TM; ++j) MT::zero(acc[i][j]);
 
     const int nk = (K + BKB - 1) / BKB;
-    constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed
+    constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed (LD_DMA)
+    uint4 R[LD == LD_REG ? NS : 1][PPW];  // LD_REG: register ring of in-flight stages
+    auto gload = [&](auto dc, int kt) {  // stage kt -> R[d]
+        constexpr int d = decltype(dc)::value;
+        const int k0 = kt * BKB;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            R[d][i] = (k0 + kofs(i) < K) ? *(const uint4*)(src[i] + k0) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto lwrite = [&](auto dc, int buf) {  // R[d] -> LDS buffer `buf`, same lane-linear image the DMA produces
+        constexpr int d = decltype(dc)::value;
+        uint8_t* stage = lds + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const bool isA = i < A_PIECES;
+            const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+            *(uint4*)(stage + (isA ? 0 : BM * BKB) + piece * 1024 + lane * 16) = R[d][i];
+        }
+    };
+    if constexpr (LD == LD_DMA) {
 #pragma nounroll
-    for (int s = 0; s < AHEAD; ++s) issue(s);
+        for (int s = 0; s < AHEAD; ++s) issue(s);
+    } else {
+        static_for_up<NS>([&](auto dc) { gload(dc, decltype(dc)::value); });
+    }
     TRACE(1);
 
     // per-output-channel epilogue vectors -> LDS once per workgroup (after the DMA prologue so its load latency hides
@@ -232,9 +282,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off(wm * WM + j * 32 + frow, ks * 2 + fgrp));
+                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off(wm * WM + j * 32 + frow, ks * 2 + fgrp, p.swz));
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off(wn * WN + i * 32 + frow, ks * 2 + fgrp));
+                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off(wn * WN + i * 32 + frow, ks * 2 + fgrp, p.swz));
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -273,15 +323,33 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
     };
 
-    // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the single
-    // raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs of stage kt.
+    if constexpr (LD == LD_DMA) {
+        // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
+        // single raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs.
 #pragma nounroll
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt<(AHEAD - 1) * PPW>();
-        __builtin_amdgcn_s_barrier();
-        if (kt == 0) TRACE(2);
-        issue(kt + AHEAD);
-        compute();
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt<(AHEAD - 1) * PPW>();
+            __builtin_amdgcn_s_barrier();
+            if (kt == 0) TRACE(2);
+            issue(kt + AHEAD);
+            compute();
+        }
+    } else {
+        // register ring: stage kt sits in R[kt % NS]; write it to LDS buffer kt & 1, immediately re-issue the same
+        // registers for stage kt + NS, one barrier, MFMAs. The loop is unrolled NS times so R is statically indexed.
+#pragma nounroll
+        for (int kt0 = 0; kt0 < nk; kt0 += NS) {
+            static_for_up<NS>([&](auto dc) {
+                const int kt = kt0 + decltype(dc)::value;
+                if (kt < nk) {  // workgroup-uniform
+                    lwrite(dc, kt & 1);
+                    gload(dc, kt + NS);
+                    __syncthreads();
+                    slot_c = kt & 1;
+                    compute();
+                }
+            });
+        }
     }
     TRACE(3);
     wait_vmcnt<0>();  // the trailing zero-fill DMAs target ring slots the epilogue is about to reuse
@@ -377,14 +445,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     TRACE(6);
 }
 
-template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS>
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA>
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int MAIN = NS * (BM + BN) * BKB;
+    constexpr int MAIN = (LD == LD_DMA ? NS : 2) * (BM + BN) * BKB;
     constexpr int EPIB = BM * (BN * 4 + 16);
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 3 * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS>;
+    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD>;
     static std::atomic<bool> attr_set{false};
     if (LDS_BYTES > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
@@ -393,6 +461,15 @@ int launch_one(GemmParams p, hipStream_t s) {
     }
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = (int)((p.N + BN - 1) / BN);
+    {
+        static const int gm_env = [] { const char* e = getenv("SDNQ_HIP_GROUP_M"); return e ? atoi(e) : 0; }();  // tuning aid
+        // near-square patch of ~32 concurrent tiles per XCD: rows*BM ~ cols*BN
+        int gm = gm_env > 0 ? gm_env : (BM >= BN ? 6 : 8);
+        if (gm > p.tiles_m) gm = p.tiles_m;
+        p.group_m = gm;
+        static const int swz_env = [] { const char* e = getenv("SDNQ_HIP_SWZ"); return e ? atoi(e) : 7; }();
+        p.swz = swz_env;
+    }
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), LDS_BYTES, s, p);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
@@ -410,11 +487,21 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 8>(p, s);
     if (force == 3) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);  // 8 waves: two per SIMD
     if (force == 4) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 6>(p, s);   // 8 waves
-    // measured on MI355X (tools/bench_gemm.py): two waves per SIMD (8-wave workgroups) beat one for every shape;
-    // 128x128 once it yields >= ~120 workgroups, 64x128 for mid-size problems, 64x64 for the few-row GEMMs (M = 77)
-    if (tiles(128, 128) >= 120) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);
-    if (tiles(64, 128) >= 40) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 6>(p, s);
-    return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 8>(p, s);
+    if (force == 5) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4, LD_REG>(p, s);
+    if (force == 6) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 4, LD_REG>(p, s);
+    if (force == 7) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_REG>(p, s);
+    if (force == 8) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 6, LD_REG>(p, s);
+    if (force == 9) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 8, LD_REG>(p, s);
+    if (force == 10) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);    // 64 KB LDS: two workgroups per CU
+    if (force == 11) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);   // 72 KB LDS: two per CU
+    if (force == 12) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_REG>(p, s);
+    // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt): every kernel launch starts with cold
+    // L2s (data comes from MALL/HBM at ~2 us loaded latency), so for diffusion-size GEMMs what pays is two waves per
+    // SIMD (8-wave workgroups) and TWO co-resident workgroups per CU (<= 80 KB LDS each): 64x128 tiles with a 3-deep
+    // ring. Very large problems amortise a deeper ring on 128x128 tiles; few-row GEMMs (M = 77) take 64x64 tiles.
+    if (tiles(128, 128) >= 2048) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);
+    if (p.M > 128) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);
+    return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);
 }
 
 template <int MM, int EPI>

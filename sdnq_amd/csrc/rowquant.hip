@@ -82,7 +82,21 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& i
 template <int T_ID, int MM, bool HAD, int NP>
 __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
                                                        int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
-                                                       int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
+                                                       int32_t* __restrict__ rowsum, void* __restrict__ xrot,
+                                                       const uint4* __restrict__ pf, int64_t pf_vecs, int row_blocks) {
+    if ((int)blockIdx.x >= row_blocks) {
+        // software prefetch of the following GEMM's weight operand: these extra workgroups just stream it once so it
+        // sits in the last-level cache (MALL) / L2 when the GEMM's LDS-DMA asks for it. 8 loads in flight per lane.
+        const int64_t base = ((int64_t)blockIdx.x - row_blocks) * (256 * 8) + threadIdx.x;
+        u32 acc = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = base + (int64_t)u * 256;
+            if (i < pf_vecs) { const uint4 v = pf[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+        }
+        if (acc == 0x9e3779b9u && pf_vecs < 0) xs[0] = 0.0f;  // never true: keeps the loads alive
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;  // whole wave exits together (wave-uniform)
@@ -197,7 +211,7 @@ int ilog2(int64_t v) {
 
 extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype,
                                  int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
-                                 sdnq_stream_t stream) {
+                                 const void* prefetch, int64_t prefetch_bytes, sdnq_stream_t stream) {
     if (!x || !xq || !xs) return SDNQ_ERR_NULL;
     if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
     if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
@@ -214,10 +228,18 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     }
     if (rowsum && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    const int row_blocks = (int)((m + 3) / 4);
+    const uint4* pf = (const uint4*)prefetch;
+    int64_t pf_vecs = 0;
+    if (prefetch && prefetch_bytes > 0 && ((uintptr_t)prefetch % 16) == 0) {
+        const int64_t cap = (int64_t)32 << 20;  // at most 32 MiB: beyond that the prefetch outlives this kernel
+        pf_vecs = (prefetch_bytes < cap ? prefetch_bytes : cap) / 16;
+    }
+    const int pf_blocks = (int)((pf_vecs + 256 * 8 - 1) / (256 * 8));
+    dim3 grid((unsigned)(row_blocks + pf_blocks)), block(256);
     const int np = (int)((k + 511) / 512);
 #define RQ_LAUNCH(T, MMV, H, NPV) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot)
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks)
 #define RQ_DISPATCH_NP(T, MMV, H)               \
     do {                                        \
         if (np <= 2) RQ_LAUNCH(T, MMV, H, 2);   \

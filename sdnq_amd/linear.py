@@ -27,6 +27,7 @@ from . import ops
 from .common import dtype_dict
 
 CACHE_WEIGHTS = os.environ.get("SDNQ_HIP_CACHE_WEIGHTS", "1").lower() not in {"0", "false", "no"}
+PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "1").lower() not in {"0", "false", "no"}
 
 
 class _State:
@@ -123,7 +124,8 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tenso
         x2 = x2.contiguous()
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
-    xq, xs, rowsum, xrot = ops.rowquant(x2, mm, had, want_rowsum=zp is not None, want_xrot=has_svd)
+    xq, xs, rowsum, xrot = ops.rowquant(x2, mm, had, want_rowsum=zp is not None, want_xrot=has_svd,
+                                        prefetch=wq if PREFETCH_WEIGHTS else None)
     bias = self.bias
     if has_svd or zp is not None:
         t = None

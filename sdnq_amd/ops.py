@@ -151,8 +151,10 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
 # ---------------------------------------------------------------------------------------------
 # kernels
 # ---------------------------------------------------------------------------------------------
-def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: bool = False, want_xrot: bool = False):
-    """Row-quantize activations [M,K] -> (xq [M,K] int8|fp8, xs [M,1] f32, rowsum [M] i32|None, xrot|None)."""
+def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: bool = False, want_xrot: bool = False,
+             prefetch: torch.Tensor | None = None):
+    """Row-quantize activations [M,K] -> (xq [M,K] int8|fp8, xs [M,1] f32, rowsum [M] i32|None, xrot|None).
+    `prefetch`: tensor (the weight operand of the following matmul) to pull into the last-level cache meanwhile."""
     _require_cuda(x2d)
     assert x2d.ndim == 2 and x2d.stride(1) == 1
     m, k = x2d.shape
@@ -161,7 +163,9 @@ def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: b
     rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
     xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if (want_xrot and hadamard_group) else None
     check(_lib.load().sdnq_hip_rowquant(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), mm, hadamard_group,
-                                        xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _stream(x2d)), "rowquant")
+                                        xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _ptr(prefetch),
+                                        0 if prefetch is None else prefetch.numel() * prefetch.element_size(), _stream(x2d)),
+          "rowquant")
     return xq, xs, rowsum, xrot
 
 
