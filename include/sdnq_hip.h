@@ -106,10 +106,13 @@ int sdnq_hip_device_supported(int ordinal);
  * hadamard_group: 0 = no rotation, else power of two in [4, 512] dividing K.
  * prefetch / prefetch_bytes: optional software prefetch (may be NULL / 0): extra workgroups of the same launch read
  * this range (the weight operand of the matmul that follows) so that it is resident in the last-level cache when
- * the GEMM starts; pure hint, no effect on results. */
+ * the GEMM starts; pure hint, no effect on results.
+ * xzp: NULL for the symmetric quantization above; non-NULL ([M] f32) selects the ASYMMETRIC int8 quantization of the
+ * uint8 matmul (quantize_uint_mm_input, layers/linear/linear_uint8.py:15-23 -> quant_utils.py:277-286):
+ * xs = (max - min) / 255, xzp = min + 128 * xs, xq = clamp(round_half_even((x - xzp) / xs), -128, 127). */
 int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype,
                       int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
-                      const void* prefetch, int64_t prefetch_bytes, sdnq_stream_t stream);
+                      const void* prefetch, int64_t prefetch_bytes, float* xzp, sdnq_stream_t stream);
 
 /* ---- a15/a16: scaled matmul (the operator seam) --------------------------------------------
  * replaces int_scaled_mm_func / fp8_scaled_mm_func (kernel_wrappers.py:193-204) and the Triton op
@@ -158,11 +161,14 @@ int sdnq_hip_hadamard(const void* x, int dtype, int64_t rows, int64_t k, int64_t
 int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, const void* svd_down,
                           int svd_dtype, int rank, void* t, sdnq_stream_t stream);
 
-/* scaled matmul whose bias is  cast_svd( f32(bias[n]) + sum_r t[m][r]*svd_up[n][r] )  [+ zp term]:
- *   zp_rowsum/zp (both or neither): adds f32(rowsum[m]) * sa[m] * zp[n]  (linear_int8.py:65-69). */
+/* scaled matmul whose bias is  cast_svd( f32(bias[n]) + sum_r t[m][r]*svd_up[n][r] )  [+ zero-point terms]:
+ *   zp_rowsum/zp (both or neither): adds f32(rowsum[m]) * sa[m] * zp[n]  (linear_int8.py:65-69);
+ *   a_zp/w_colsum_scaled (both or neither; the uint8 matmul, linear_uint8.py:61-66): adds
+ *       w_colsum_scaled[n] * a_zp[m]  +  K * (a_zp[m] * zp[n])      with w_colsum_scaled[n] = f32(sum_k b[n][k]) * sb[n]. */
 int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
                                const void* bias, int bias_dtype, const void* t, const void* svd_up, int svd_dtype,
-                               int rank, const int32_t* zp_rowsum, const float* zp, void* out, int out_dtype,
+                               int rank, const int32_t* zp_rowsum, const float* zp, const float* a_zp,
+                               const float* w_colsum_scaled, void* out, int out_dtype,
                                int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
 /* ---- a3: float path  F.linear(x, dequant(W), bias) --------------------------------------------

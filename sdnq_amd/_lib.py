@@ -69,14 +69,14 @@ def _declare(lib):
     lib.sdnq_hip_strerror.restype = c.c_char_p
     lib.sdnq_hip_strerror.argtypes = [c.c_int]
     lib.sdnq_hip_device_supported.argtypes = [c.c_int]
-    lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp]
+    lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
     lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
     lib.sdnq_hip_unpack_mm.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp]
     lib.sdnq_hip_hadamard.argtypes = [vp, i32, i64, i64, i64, i32, vp, i64, vp]
     lib.sdnq_hip_lowrank_down.argtypes = [vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
-    lib.sdnq_hip_scaled_mm_lowrank.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_scaled_mm_lowrank.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_linear_float.argtypes = [vp, vp, vp, i32, vp, i64, i64, i64, i64, vp]
     lib.sdnq_hip_linear_skinny.argtypes = [c.POINTER(SdnqWeight), vp, vp, i32, vp, i64, i64, vp]
     for name in EXPORTS:

@@ -57,6 +57,8 @@ struct GemmParams {
     const void* lr_up;  // [N][R]
     const int32_t* zp_rowsum;  // [M] or null
     const float* zp;           // [N] or null
+    const float* a_zp;         // [M] activation zero point (uint8 matmul) or null
+    const float* wcs;          // [N] f32(colsum(b)) * sb (uint8 matmul) or null
     int64_t M, N, K;
     int64_t ld_bias;
     int bias_ndim;
@@ -150,12 +152,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int LDS_STAGES = LD == LD_DMA ? NS : 2;
     constexpr int OUT_B = FT<OUT_T>::bytes;
     constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [BM][ACC_ROW]
-    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES, EPI_BYTES = BM * ACC_ROW;
+    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES, EPI_BYTES = BM * ACC_ROW * (EPI == EPI_LOWRANK ? 2 : 1);
     constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
     float* s_bias = s_sb + BN;              // [BN] 1-D bias as f32
     float* s_zp = s_bias + BN;              // [BN] zero points (EPI_LOWRANK)
+    float* s_wcs = s_zp + BN;               // [BN] scaled weight column sums (EPI_LOWRANK, uint8 matmul)
 
     TRACE(0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         if (gn >= p.N) gn = p.N - 1;
         s_sb[i] = p.sb[gn];
         if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = p.bias ? ldf_rt(p.bias, gn, p.bias_dtype) : 0.0f;
-        if constexpr (EPI == EPI_LOWRANK) s_zp[i] = p.zp ? p.zp[gn] : 0.0f;
+        if constexpr (EPI == EPI_LOWRANK) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
     }
 
     const int frow = lane & 31, fgrp = lane >> 5;
@@ -356,6 +359,47 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     __syncthreads();
     TRACE(4);
 
+    // ---- low-rank (SVD) term on the matrix cores: lr[n][m] = sum_r up[n][r] * t[m][r] -----------------------------
+    // same 32x32 MFMA shape as the main product, so every lane gets the low-rank value of exactly the outputs it owns;
+    // operands are 16-byte rows of t [M][R] / svd_up [N][R] straight from global (R/16 MFMAs per sub-tile).
+    v16f lr[TN][TM];
+    bool lr_mfma = false;
+    if constexpr (EPI == EPI_LOWRANK) {
+        lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
+        if (lr_mfma) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) lr[i][j][e] = 0.0f;
+            for (int kr = 0; kr < p.rank; kr += 16) {
+                uint4 fu[TN], ft[TM];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    int64_t gn = n0 + wn * WN + i * 32 + (lane & 31);
+                    if (gn >= p.N) gn = p.N - 1;
+                    fu[i] = *(const uint4*)((const uint16_t*)p.lr_up + gn * p.rank + kr + (lane >> 5) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    int64_t gm = m0 + wm * WM + j * 32 + (lane & 31);
+                    if (gm >= p.M) gm = p.M - 1;
+                    ft[j] = *(const uint4*)((const uint16_t*)p.lr_t + gm * p.rank + kr + (lane >> 5) * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        if (p.bias_dtype == SDNQ_BF16)
+                            lr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fu[i]), __builtin_bit_cast(v8bf, ft[j]), lr[i][j], 0, 0, 0);
+                        else
+                            lr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fu[i]), __builtin_bit_cast(v8h, ft[j]), lr[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
     // ---- epilogue ---------------------------------------------------------------------------------
     // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
     //     acc[i][j][reg]: n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = wm*WM + j*32 + (lane&31)
@@ -372,6 +416,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     *(v4i*)(stage + ml * ACC_ROW + nl0 * 4) = (v4i){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 else
                     *(v4f*)(stage + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if constexpr (EPI == EPI_LOWRANK) {
+                    if (lr_mfma)
+                        *(v4f*)(stage + BM * ACC_ROW + ml * ACC_ROW + nl0 * 4) = (v4f){lr[i][j][4 * q], lr[i][j][4 * q + 1], lr[i][j][4 * q + 2], lr[i][j][4 * q + 3]};
+                }
             }
     __syncthreads();
     TRACE(5);
@@ -383,9 +431,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int64_t gm = m0 + r, gn0 = n0 + c8;
         if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a group of 8 never straddles N
         const float sa = p.sa[gm];
-        float zsum = 0.0f;
+        float zsum = 0.0f, azp = 0.0f;
         if constexpr (EPI == EPI_LOWRANK) {
             if (p.zp_rowsum) zsum = (float)p.zp_rowsum[gm] * sa;  // .to(f32).mul_(input_scale), linear_int8.py:66
+            if (p.a_zp) azp = p.a_zp[gm];
         }
         float o[8];
 #pragma unroll
@@ -418,17 +467,27 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     float bv = s_bias[cn];
                     bool has = p.bias != nullptr;
                     if (p.lr_t) {
-                        float sacc = 0.0f;
-                        for (int rr = 0; rr < p.rank; ++rr)
-                            sacc = fmaf(ldf_rt(p.lr_t, gm * p.rank + rr, p.bias_dtype), ldf_rt(p.lr_up, (n0 + cn) * p.rank + rr, p.bias_dtype), sacc);
+                        float sacc;
+                        if (lr_mfma) {
+                            sacc = *(const float*)(stage + BM * ACC_ROW + r * ACC_ROW + cn * 4);
+                        } else {  // f32 factors or a rank that is not a multiple of 16: plain fma chain
+                            sacc = 0.0f;
+                            for (int rr = 0; rr < p.rank; ++rr)
+                                sacc = fmaf(ldf_rt(p.lr_t, gm * p.rank + rr, p.bias_dtype), ldf_rt(p.lr_up, (n0 + cn) * p.rank + rr, p.bias_dtype), sacc);
+                        }
                         bv = round_rt(has ? sacc + bv : sacc, p.bias_dtype);
                         has = true;
                     }
-                    if (p.zp) {
-                        const float zb = zsum * s_zp[cn];
-                        bv = has ? zb + bv : zb;
-                        has = true;
+                    float zb = 0.0f;
+                    bool hasz = false;
+                    if (p.zp) { zb = zsum * s_zp[cn]; hasz = true; }
+                    if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
+                        const float t2 = s_wcs[cn] * azp;
+                        zb = hasz ? zb + t2 : t2;
+                        if (p.zp) zb = fmaf(azp * s_zp[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
+                        hasz = true;
                     }
+                    if (hasz) { bv = has ? zb + bv : zb; has = true; }
                     res = has ? fmaf(vv, sb4[e], bv) : vv * sb4[e];
                 }
                 o[4 * h + e] = res;
@@ -449,8 +508,8 @@ template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, in
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int MAIN = (LD == LD_DMA ? NS : 2) * (BM + BN) * BKB;
-    constexpr int EPIB = BM * (BN * 4 + 16);
-    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 3 * BN * 4;
+    constexpr int EPIB = BM * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1);
+    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 4 * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD>;
     static std::atomic<bool> attr_set{false};
@@ -482,19 +541,10 @@ template <int MM, int OUT_T, int EPI>
 int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     static const int force = [] { const char* e = getenv("SDNQ_HIP_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
-    if (force == 0) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 64, 4>(p, s);
-    if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 64, 6>(p, s);
-    if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 8>(p, s);
-    if (force == 3) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);  // 8 waves: two per SIMD
-    if (force == 4) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 6>(p, s);   // 8 waves
-    if (force == 5) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4, LD_REG>(p, s);
-    if (force == 6) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 4, LD_REG>(p, s);
-    if (force == 7) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_REG>(p, s);
-    if (force == 8) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 6, LD_REG>(p, s);
-    if (force == 9) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 8, LD_REG>(p, s);
-    if (force == 10) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);    // 64 KB LDS: two workgroups per CU
-    if (force == 11) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);   // 72 KB LDS: two per CU
-    if (force == 12) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_REG>(p, s);
+    if (force == 0) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);
+    if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);
+    if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);
+    if (force == 3) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 4, LD_REG>(p, s);  // register-ring loader (A/B aid)
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt): every kernel launch starts with cold
     // L2s (data comes from MALL/HBM at ~2 us loaded latency), so for diffusion-size GEMMs what pays is two waves per
     // SIMD (8-wave workgroups) and TWO co-resident workgroups per CU (<= 80 KB LDS each): 64x128 tiles with a 3-deep
@@ -565,12 +615,14 @@ extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, co
 
 extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
                                           const void* bias, int bias_dtype, const void* t, const void* svd_up,
-                                          int svd_dtype, int rank, const int32_t* zp_rowsum, const float* zp, void* out,
-                                          int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+                                          int svd_dtype, int rank, const int32_t* zp_rowsum, const float* zp, const float* a_zp,
+                                          const float* w_colsum_scaled, void* out, int out_dtype, int64_t m, int64_t n, int64_t k,
+                                          sdnq_stream_t stream) {
     int st = check_common(mm_dtype, a, b, sa, sb, out, out_dtype, m, n, k);
     if (st != SDNQ_OK) return st;
     if ((t == nullptr) != (svd_up == nullptr)) return SDNQ_ERR_NULL;
     if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
+    if ((a_zp == nullptr) != (w_colsum_scaled == nullptr)) return SDNQ_ERR_NULL;
     if (t && (rank <= 0 || rank > 1024)) return SDNQ_ERR_SHAPE;
     // the [M][N] bias of the reference lives in the svd dtype (addmm in svd_down.dtype, linear_int8.py:60);
     // a 1-D bias is cast to it first, so bias/t/up share one element type here.
@@ -579,7 +631,7 @@ extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const voi
     if (bt < 0 || bt > 2) return SDNQ_ERR_DTYPE;
     GemmParams p{};
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
-    p.lr_t = t; p.lr_up = svd_up; p.rank = rank; p.zp_rowsum = zp_rowsum; p.zp = zp;
+    p.lr_t = t; p.lr_up = svd_up; p.rank = rank; p.zp_rowsum = zp_rowsum; p.zp = zp; p.a_zp = a_zp; p.wcs = w_colsum_scaled;
     p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bt;
     hipStream_t s = (hipStream_t)stream;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, EPI_LOWRANK, out_dtype, s);

@@ -52,14 +52,16 @@ __device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[
 }
 
 template <int MM>
-__device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& isum) {
+__device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& isum, float zp = 0.0f, bool asym = false) {
     u32 w0 = 0, w1 = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         u32 byte;
         if constexpr (MM == SDNQ_MM_I8) {
             // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
-            float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[e] / scale);
+            // asymmetric (quantize_uint_mm, quant_utils.py:277-286): (x - zero_point) / scale
+            const float xv = asym ? v[e] - zp : v[e];
+            float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(xv / scale);
             q = fminf(fmaxf(q, -128.0f), 127.0f);
             const int qi = (int)q;
             isum += qi;
@@ -83,7 +85,8 @@ template <int T_ID, int MM, bool HAD, int NP>
 __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
                                                        int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
                                                        int32_t* __restrict__ rowsum, void* __restrict__ xrot,
-                                                       const uint4* __restrict__ pf, int64_t pf_vecs, int row_blocks) {
+                                                       const uint4* __restrict__ pf, int64_t pf_vecs, int row_blocks,
+                                                       float* __restrict__ xzp) {
     if ((int)blockIdx.x >= row_blocks) {
         // software prefetch of the following GEMM's weight operand: these extra workgroups just stream it once so it
         // sits in the last-level cache (MALL) / L2 when the GEMM's LDS-DMA asks for it. 8 loads in flight per lane.
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
             const int64_t idx = (int64_t)p * 512 + lane * 8;
             load8<T_ID>(row, idx, idx < K, v[p]);
         }
-        float amax = 0.0f;
+        const bool asym = xzp != nullptr;  // asymmetric int8 activations of the uint8 matmul (linear_uint8.py:15-23)
+        float amax = 0.0f, vmin = 3.4e38f, vmax = -3.4e38f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if constexpr (HAD) {
@@ -123,11 +127,24 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                     for (int e = 0; e < 8; ++e) v[p][e] = FT<T_ID>::round(v[p][e]);
                 }
             }
+            const bool in = (int64_t)p * 512 + lane * 8 < K;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[p][e]));
+            for (int e = 0; e < 8; ++e) {
+                amax = fmaxf(amax, fabsf(v[p][e]));
+                if (in) { vmin = fminf(vmin, v[p][e]); vmax = fmaxf(vmax, v[p][e]); }
+            }
         }
-        amax = wave_max(amax);
-        const float scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
+        float scale, zpv = 0.0f;
+        if (asym) {
+            vmin = wave_min(vmin);
+            vmax = wave_max(vmax);
+            scale = (vmax - vmin) / 255.0f;          // get_scale_asymmetric, quant_utils.py:10-19 with the int8 range
+            zpv = fmaf(128.0f, scale, vmin);         // zero_point.sub_(scale, alpha=-128); 128*scale is exact
+            if (lane == 0) xzp[m] = zpv;
+        } else {
+            amax = wave_max(amax);
+            scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
+        }
         if (lane == 0) xs[m] = scale;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 if constexpr (HAD) {
                     if (xrot != nullptr) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v[p]);
                 }
-                *(uint2*)(qrow + idx) = quant8<MM>(v[p], scale, isum);
+                *(uint2*)(qrow + idx) = quant8<MM>(v[p], scale, isum, zpv, asym);
             }
         }
     } else {
@@ -211,8 +228,9 @@ int ilog2(int64_t v) {
 
 extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype,
                                  int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
-                                 const void* prefetch, int64_t prefetch_bytes, sdnq_stream_t stream) {
+                                 const void* prefetch, int64_t prefetch_bytes, float* xzp, sdnq_stream_t stream) {
     if (!x || !xq || !xs) return SDNQ_ERR_NULL;
+    if (xzp && (mm_dtype != SDNQ_MM_I8 || k > 5120)) return SDNQ_ERR_UNSUPPORTED;  // asymmetric: int8 only, register-resident rows
     if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
     if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
     if (x_dtype < 0 || x_dtype > 2) return SDNQ_ERR_DTYPE;
@@ -239,7 +257,7 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     dim3 grid((unsigned)(row_blocks + pf_blocks)), block(256);
     const int np = (int)((k + 511) / 512);
 #define RQ_LAUNCH(T, MMV, H, NPV) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks)
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
 #define RQ_DISPATCH_NP(T, MMV, H)               \
     do {                                        \
         if (np <= 2) RQ_LAUNCH(T, MMV, H, 2);   \

@@ -32,7 +32,7 @@ PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "1").lower() not 
 
 class _State:
     """Per-module cache of kernel-ready tensors, keyed on the identity of the module's parameters."""
-    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "svd_up", "svd_down", "wd", "bias")
+    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "wd", "bias")
 
 
 def _key(mod):
@@ -52,7 +52,7 @@ def _state(mod) -> _State:
         st.qw = dq.quant_weight(mod.weight, mod.scale, getattr(mod, "zero_point", None), getattr(mod, "svd_up", None),
                                 getattr(mod, "svd_down", None))
         st.mm = None
-        st.mm_weight = st.mm_scale = st.mm_zp = None
+        st.mm_weight = st.mm_scale = st.mm_zp = st.mm_wcs = None
         st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
         st.wd = None
         mod.__dict__["_sdnq_hip_state"] = st
@@ -149,9 +149,34 @@ def quantized_linear_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tens
 
 @torch.no_grad()
 def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
-    # asymmetric-activation int8 matmul (linear_uint8.py): not in any BASELINE config; scheduled last
-    raise NotImplementedError("quantized_matmul_dtype='uint8' (asymmetric activations) is not built yet; "
-                              "use quantized_matmul_dtype='int8' for uint8 weights")
+    """Asymmetric-activation int8 matmul (layers/linear/linear_uint8.py:106-131): activations get a per-row zero point,
+    the three cross terms of (x - xzp)(w - wzp) are added in the GEMM epilogue instead of a materialised [M,N] bias."""
+    dq = self.sdnq_dequantizer
+    st = _state(self)
+    k, n = dq.in_features, dq.out_features
+    m = input.numel() // input.shape[-1]
+    if m < 32:
+        return _float_forward(self, input, st)
+    if dq.re_quantize_for_matmul:
+        raise NotImplementedError("uint8 matmul with re-quantized (group-wise / sub-byte) weights needs the asymmetric weight "
+                                  "re-quantizer (dequantizer.py:178-187), which is not built; use quantized_matmul_dtype='int8'")
+    wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8)
+    wcs = st.mm_wcs
+    if wcs is None:  # f32(sum_k wq[n][k]) * ws[n]: static per layer (linear_uint8.py:63 computes it every call)
+        wcs = wq.to(torch.int32).sum(dim=1).to(torch.float32).mul_(ws)
+        if CACHE_WEIGHTS:
+            st.mm_wcs = wcs
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+        x2 = x2.contiguous()
+    had = dq.hadamard_group_size if dq.use_hadamard else 0
+    has_svd = st.svd_up is not None
+    xq, xs, rowsum, xrot, xzp = ops.rowquant(x2, ops.MM_I8, had, want_rowsum=zp is not None, want_xrot=has_svd,
+                                             prefetch=wq if PREFETCH_WEIGHTS else None, asymmetric=True)
+    t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
+    y = ops.scaled_mm_lowrank(ops.MM_I8, xq, wq, xs, ws, self.bias, t, st.svd_up, rowsum, zp, input.dtype, a_zp=xzp,
+                              w_colsum_scaled=wcs)
+    return y.view(*input.shape[:-1], n)
 
 
 @torch.no_grad()

@@ -152,9 +152,10 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
 # kernels
 # ---------------------------------------------------------------------------------------------
 def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: bool = False, want_xrot: bool = False,
-             prefetch: torch.Tensor | None = None):
+             prefetch: torch.Tensor | None = None, asymmetric: bool = False):
     """Row-quantize activations [M,K] -> (xq [M,K] int8|fp8, xs [M,1] f32, rowsum [M] i32|None, xrot|None).
-    `prefetch`: tensor (the weight operand of the following matmul) to pull into the last-level cache meanwhile."""
+    `prefetch`: tensor (the weight operand of the following matmul) to pull into the last-level cache meanwhile.
+    `asymmetric`: int8 activations with a zero point (uint8 matmul); returns a 5th value xzp [M] f32."""
     _require_cuda(x2d)
     assert x2d.ndim == 2 and x2d.stride(1) == 1
     m, k = x2d.shape
@@ -162,10 +163,13 @@ def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: b
     xs = torch.empty((m, 1), device=x2d.device, dtype=torch.float32)
     rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
     xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if (want_xrot and hadamard_group) else None
+    xzp = torch.empty((m,), device=x2d.device, dtype=torch.float32) if asymmetric else None
     check(_lib.load().sdnq_hip_rowquant(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), mm, hadamard_group,
                                         xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _ptr(prefetch),
-                                        0 if prefetch is None else prefetch.numel() * prefetch.element_size(), _stream(x2d)),
-          "rowquant")
+                                        0 if prefetch is None else prefetch.numel() * prefetch.element_size(), _ptr(xzp),
+                                        _stream(x2d)), "rowquant")
+    if asymmetric:
+        return xq, xs, rowsum, xrot, xzp
     return xq, xs, rowsum, xrot
 
 
@@ -187,7 +191,8 @@ def scaled_mm(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, 
     return out
 
 
-def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, zp, out_dtype: torch.dtype):
+def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, zp, out_dtype: torch.dtype, a_zp=None,
+                      w_colsum_scaled=None):
     _require_cuda(a, b_phys)
     m, k = a.shape
     n = b_phys.shape[0]
@@ -202,7 +207,7 @@ def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, 
         bias_dt = float_code(bias.dtype)
     check(_lib.load().sdnq_hip_scaled_mm_lowrank(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
                                                  bias_dt, _ptr(t), _ptr(svd_up_phys), svd_dt, rank, _ptr(rowsum), _ptr(zp),
-                                                 out.data_ptr(), float_code(out_dtype), m, n, k, _stream(a)), "scaled_mm_lowrank")
+                                                 _ptr(a_zp), _ptr(w_colsum_scaled), out.data_ptr(), float_code(out_dtype), m, n, k, _stream(a)), "scaled_mm_lowrank")
     return out
 
 

@@ -56,10 +56,14 @@ class ColumnShardedLinear(torch.nn.Module):
             gathered = torch.empty((self.world * m, y2.shape[1]), device=y2.device, dtype=y2.dtype)  # rank-major concat
             dist.all_gather_into_tensor(gathered, y2, group=self.group)
             out = gathered.view(self.world, m, y2.shape[1]).permute(1, 0, 2).reshape(m, self.n_total)
-        else:
-            parts = [torch.empty((m, b - a), device=y2.device, dtype=y2.dtype) for a, b in self.bounds]
-            dist.all_gather(parts, y2, group=self.group)
-            out = torch.cat(parts, dim=-1)
+        else:  # uneven shards: pad every slab to the widest one (collectives want equal messages), gather, trim
+            wmax = max(b - a for a, b in self.bounds)
+            padded = torch.zeros((m, wmax), device=y2.device, dtype=y2.dtype)
+            padded[:, : y2.shape[1]] = y2
+            gathered = torch.empty((self.world * m, wmax), device=y2.device, dtype=y2.dtype)
+            dist.all_gather_into_tensor(gathered, padded, group=self.group)
+            g3 = gathered.view(self.world, m, wmax)
+            out = torch.cat([g3[r, :, : b - a] for r, (a, b) in enumerate(self.bounds)], dim=-1)
         return out.view(*lead, self.n_total)
 
 

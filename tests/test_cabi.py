@@ -37,14 +37,14 @@ def test_version_and_strerror():
 def test_argument_validation_without_gpu():
     """Validation runs before any launch, so error codes are observable on a CPU-only box."""
     lib = _lib.load()
-    assert lib.sdnq_hip_rowquant(None, 1, 4, 64, 64, 0, 0, None, None, None, None, None, 0, None) == -1          # NULL
+    assert lib.sdnq_hip_rowquant(None, 1, 4, 64, 64, 0, 0, None, None, None, None, None, 0, None, None) == -1          # NULL
     buf = ctypes.create_string_buffer(4096)
     p = ctypes.addressof(buf)
     p += (-p) % 16
-    assert lib.sdnq_hip_rowquant(p, 7, 4, 64, 64, 0, 0, p, p, None, None, None, 0, None) == -2                  # dtype
-    assert lib.sdnq_hip_rowquant(p, 1, 4, 60, 60, 0, 0, p, p, None, None, None, 0, None) == -3                  # K % 8
-    assert lib.sdnq_hip_rowquant(p + 2, 1, 4, 64, 64, 0, 0, p, p, None, None, None, 0, None) == -4              # alignment
-    assert lib.sdnq_hip_rowquant(p, 1, 4, 64, 64, 0, 48, p, p, None, None, None, 0, None) == -3                 # Hadamard group not pow2
+    assert lib.sdnq_hip_rowquant(p, 7, 4, 64, 64, 0, 0, p, p, None, None, None, 0, None, None) == -2                  # dtype
+    assert lib.sdnq_hip_rowquant(p, 1, 4, 60, 60, 0, 0, p, p, None, None, None, 0, None, None) == -3                  # K % 8
+    assert lib.sdnq_hip_rowquant(p + 2, 1, 4, 64, 64, 0, 0, p, p, None, None, None, 0, None, None) == -4              # alignment
+    assert lib.sdnq_hip_rowquant(p, 1, 4, 64, 64, 0, 48, p, p, None, None, None, 0, None, None) == -3                 # Hadamard group not pow2
     assert lib.sdnq_hip_scaled_mm(0, p, p, p, p, None, 0, 0, 0, p, 1, 32, 32, 24, None) == -3          # K % 16
     assert lib.sdnq_hip_scaled_mm(5, p, p, p, p, None, 0, 0, 0, p, 1, 32, 32, 32, None) == -2          # mm dtype
     w = _lib.SdnqWeight(weight=p, scale=p, zero_point=None, svd_up=None, svd_down=None, n=16, k=64, group_size=48, svd_rank=0,

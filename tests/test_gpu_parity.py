@@ -48,8 +48,6 @@ def assert_close_float(got: np.ndarray, ref: np.ndarray, tag: str, what, hadamar
 def test_module_forward_vs_golden_and_oracle(name, gpu_device):
     c = Case(name)
     d = c.deq
-    if d["quantized_matmul_dtype"] == "uint8" and d["use_quantized_matmul"]:
-        pytest.skip("uint8 (asymmetric-activation) matmul is not built yet")
     mod = module_from_case(c, gpu_device)
     omod = c.oracle_module()
     for M in c.ms():
@@ -60,7 +58,7 @@ def test_module_forward_vs_golden_and_oracle(name, gpu_device):
         ref = c.f32(f"y_{M}")
         orc = O.forward(omod, c.f32(f"x_{M}"), c.tag)
         qmm = d["use_quantized_matmul"] and M >= 32
-        exact = qmm and d["quantized_matmul_dtype"] == "int8" and not d["use_hadamard"] and not c.has("svd_up")
+        exact = qmm and d["quantized_matmul_dtype"] in ("int8", "uint8") and not d["use_hadamard"] and not c.has("svd_up")
         if exact:
             assert np.array_equal(got, ref), (name, M, "vs golden", int((got != ref).sum()))
             assert np.array_equal(got, orc), (name, M, "vs oracle")
