@@ -32,7 +32,7 @@
 
 namespace {
 
-constexpr int BKB = 128;  // bytes of K per LDS stage row
+constexpr int BKB = 128;  // default bytes of K per LDS stage row (a full 128-byte line per row)
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};  // source of K-tail chunks for the LDS-DMA
 
@@ -90,7 +90,13 @@ template <> struct MmaTraits<SDNQ_MM_FP8> {
 };
 
 // LDS byte offset of 16-byte chunk c (0..7) of tile row r; rows are 128 B, chunk XOR-swizzled.
-__device__ __forceinline__ int lds_off(int r, int c, int swz = 7) { return r * BKB + ((c ^ ((r >> 1) & swz)) << 4); }
+// LDS byte offset of 16-byte chunk c of tile row r, XOR-swizzled so that the 16 lanes of a ds_read_b128 group (16
+// distinct rows, same logical chunk) land on 16 distinct 16-byte slots of the 256-byte bank row:
+//   128-byte rows (8 chunks, 2 rows per bank row): chunk ^= (r >> 1) & 7;   64-byte rows (4 chunks, 4 rows): chunk ^= (r >> 2) & 3
+template <int BK> __device__ __forceinline__ int lds_off(int r, int c, int swz) {
+    if constexpr (BK == 128) return r * 128 + ((c ^ ((r >> 1) & swz)) << 4);
+    else return r * 64 + ((c ^ ((r >> 2) & (swz & 3))) << 4);
+}
 
 template <int T_ID> __device__ __forceinline__ float ldf(const void* p, int64_t i) { return FT<T_ID>::load(p, i); }
 
@@ -140,19 +146,23 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
 //            issue, in-flight bytes live in the (much larger) register file, the compiler counts vmcnt itself.
 enum { LD_DMA = 0, LD_REG = 1 };
 
-template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD>
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
     typedef MmaTraits<MM> MT;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN, NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_PIECES = BM / 8 / NW, B_PIECES = BN / 8 / NW, PPW = A_PIECES + B_PIECES;  // 1-KiB DMA pieces per wave per stage
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly into 8-row DMA pieces");
+    constexpr int RPP = 1024 / BK;   // tile rows per 1-KiB DMA piece (8 for 128-byte rows, 16 for 64-byte rows)
+    constexpr int LPR = BK / 16;     // lanes (16-byte chunks) per row
+    constexpr int A_PIECES = BM / RPP / NW, B_PIECES = BN / RPP / NW, PPW = A_PIECES + B_PIECES;  // DMA pieces per wave per stage
+    static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split evenly into DMA pieces");
+    static_assert(BK == 64 || BK == 128, "stage rows are 64 or 128 bytes");
     static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
-    constexpr int STAGE_BYTES = (BM + BN) * BKB;
+    constexpr int STAGE_BYTES = (BM + BN) * BK;
     constexpr int LDS_STAGES = LD == LD_DMA ? NS : 2;
     constexpr int OUT_B = FT<OUT_T>::bytes;
-    constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [BM][ACC_ROW]
-    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES, EPI_BYTES = BM * ACC_ROW * (EPI == EPI_LOWRANK ? 2 : 1);
+    constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [CH][ACC_ROW]
+    constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // the tile leaves in ECH chunks of CH rows (LDS budget)
+    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES, EPI_BYTES = CH * ACC_ROW * (EPI == EPI_LOWRANK ? 2 : 1);
     constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
@@ -192,13 +202,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // wave w owns A pieces w, w+NW, ... and B pieces w, w+NW, ...; the source chunk is the swizzle-inverse of the
     // physical chunk so that LDS stays lane-linear (base + lane*16) as the DMA requires.
     const uint8_t* src[PPW];
-    const int r8 = lane >> 3;
+    const int r8 = lane / LPR;  // row of this lane inside a DMA piece
+    auto chunk_of = [&](int r) { return BK == 128 ? ((lane & 7) ^ ((r >> 1) & p.swz)) : ((lane & 3) ^ ((r >> 2) & (p.swz & 3))); };
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const bool isA = i < A_PIECES;
         const int piece = (isA ? i : i - A_PIECES) * NW + wave;
-        const int r = piece * 8 + r8;
-        const int c = (lane & 7) ^ ((r >> 1) & p.swz);
+        const int r = piece * RPP + r8;
+        const int c = chunk_of(r);
         int64_t g = (isA ? m0 : n0) + r;
         const int64_t lim = isA ? p.M : p.N;
         if (g >= lim) g = lim - 1;  // clamp: rows past the edge are computed on valid memory and never stored
@@ -210,18 +221,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     auto kofs = [&](int i) {
         const bool isA = i < A_PIECES;
         const int piece = (isA ? i : i - A_PIECES) * NW + wave;
-        return (((lane & 7) ^ (((piece * 8 + r8) >> 1) & p.swz)) << 4);
+        return chunk_of(piece * RPP + r8) << 4;
     };
     int slot_i = 0;  // ring slot the next issued stage goes to
     auto issue = [&](int kt) {
-        const int k0 = kt * BKB;
+        const int k0 = kt * BK;
         uint8_t* stage = lds + slot_i * STAGE_BYTES;
         slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const bool isA = i < A_PIECES;
             const int piece = (isA ? i : i - A_PIECES) * NW + wave;
-            uint8_t* dst = stage + (isA ? 0 : BM * BKB) + piece * 1024;
+            uint8_t* dst = stage + (isA ? 0 : BM * BK) + piece * 1024;
             // chunks past K (K % 16 == 0) and whole stages past the end of K come from a 16-byte zero constant
             const uint8_t* s = (k0 + kofs(i) < K) ? src[i] + k0 : (const uint8_t*)&g_zero16;
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
@@ -234,12 +245,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
         for (int j = 0; j < TM; ++j) MT::zero(acc[i][j]);
 
-    const int nk = (K + BKB - 1) / BKB;
+    const int nk = (K + BK - 1) / BK;
     constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed (LD_DMA)
     uint4 R[LD == LD_REG ? NS : 1][PPW];  // LD_REG: register ring of in-flight stages
     auto gload = [&](auto dc, int kt) {  // stage kt -> R[d]
         constexpr int d = decltype(dc)::value;
-        const int k0 = kt * BKB;
+        const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             R[d][i] = (k0 + kofs(i) < K) ? *(const uint4*)(src[i] + k0) : make_uint4(0u, 0u, 0u, 0u);
@@ -251,7 +262,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         for (int i = 0; i < PPW; ++i) {
             const bool isA = i < A_PIECES;
             const int piece = (isA ? i : i - A_PIECES) * NW + wave;
-            *(uint4*)(stage + (isA ? 0 : BM * BKB) + piece * 1024 + lane * 16) = R[d][i];
+            *(uint4*)(stage + (isA ? 0 : BM * BK) + piece * 1024 + lane * 16) = R[d][i];
         }
     };
     if constexpr (LD == LD_DMA) {
@@ -276,18 +287,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     int slot_c = 0;  // ring slot being consumed
     auto compute = [&]() {
         const uint8_t* sA = lds + slot_c * STAGE_BYTES;
-        const uint8_t* sB = sA + BM * BKB;
+        const uint8_t* sB = sA + BM * BK;
         slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
-        constexpr int KS = BKB / MT::KB;
+        constexpr int KS = BK / MT::KB;
+        static_assert(KS >= 1, "stage row shorter than one MFMA K step");
         if constexpr (MM == SDNQ_MM_I8) {
             // all fragment reads of the stage are issued before the first MFMA, so LDS latency overlaps the matrix pipe
             v4i fa[KS][TM], fb[KS][TN];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off(wm * WM + j * 32 + frow, ks * 2 + fgrp, p.swz));
+                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off<BK>(wm * WM + j * 32 + frow, ks * 2 + fgrp, p.swz));
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off(wn * WN + i * 32 + frow, ks * 2 + fgrp, p.swz));
+                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off<BK>(wn * WN + i * 32 + frow, ks * 2 + fgrp, p.swz));
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
@@ -303,15 +315,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
                     const int r = wm * WM + j * 32 + frow;
-                    const v4i lo = *(const v4i*)(sA + lds_off(r, ks * 4 + fgrp * 2));
-                    const v4i hi = *(const v4i*)(sA + lds_off(r, ks * 4 + fgrp * 2 + 1));
+                    const v4i lo = *(const v4i*)(sA + lds_off<BK>(r, ks * 4 + fgrp * 2, p.swz));
+                    const v4i hi = *(const v4i*)(sA + lds_off<BK>(r, ks * 4 + fgrp * 2 + 1, p.swz));
                     fa[ks][j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     const int r = wn * WN + i * 32 + frow;
-                    const v4i lo = *(const v4i*)(sB + lds_off(r, ks * 4 + fgrp * 2));
-                    const v4i hi = *(const v4i*)(sB + lds_off(r, ks * 4 + fgrp * 2 + 1));
+                    const v4i lo = *(const v4i*)(sB + lds_off<BK>(r, ks * 4 + fgrp * 2, p.swz));
+                    const v4i hi = *(const v4i*)(sB + lds_off<BK>(r, ks * 4 + fgrp * 2 + 1, p.swz));
                     fb[ks][i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
             }
@@ -404,13 +416,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
     //     acc[i][j][reg]: n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = wm*WM + j*32 + (lane&31)
     uint8_t* stage = lds;
+    static_for_up<ECH>([&](auto chc) {
+    constexpr int ch = decltype(chc)::value;
+    if (ch > 0) __syncthreads();  // previous chunk fully stored before its staging area is overwritten
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int ml = wm * WM + j * 32 + frow;
+                if (ECH > 1 && (wm * WM + j * 32) / CH != ch) continue;  // wave-uniform: this 32-row block is in another chunk
+                const int ml = wm * WM + j * 32 + frow - ch * CH;
                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
                 if constexpr (MM == SDNQ_MM_I8)
                     *(v4i*)(stage + ml * ACC_ROW + nl0 * 4) = (v4i){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
@@ -418,7 +434,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     *(v4f*)(stage + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 if constexpr (EPI == EPI_LOWRANK) {
                     if (lr_mfma)
-                        *(v4f*)(stage + BM * ACC_ROW + ml * ACC_ROW + nl0 * 4) = (v4f){lr[i][j][4 * q], lr[i][j][4 * q + 1], lr[i][j][4 * q + 2], lr[i][j][4 * q + 3]};
+                        *(v4f*)(stage + CH * ACC_ROW + ml * ACC_ROW + nl0 * 4) = (v4f){lr[i][j][4 * q], lr[i][j][4 * q + 1], lr[i][j][4 * q + 2], lr[i][j][4 * q + 3]};
                 }
             }
     __syncthreads();
@@ -426,9 +442,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // (2) one compact loop: 8 consecutive channels of one row per thread -> scale, bias, cast, 16/32-byte store
     constexpr int G8 = BN / 8;
 #pragma nounroll
-    for (int v = tid; v < BM * G8; v += NT) {
-        const int r = v / G8, c8 = (v % G8) * 8;
-        const int64_t gm = m0 + r, gn0 = n0 + c8;
+    for (int v = tid; v < CH * G8; v += NT) {
+        const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
+        const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c8;
         if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a group of 8 never straddles N
         const float sa = p.sa[gm];
         float zsum = 0.0f, azp = 0.0f;
@@ -469,7 +485,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     if (p.lr_t) {
                         float sacc;
                         if (lr_mfma) {
-                            sacc = *(const float*)(stage + BM * ACC_ROW + r * ACC_ROW + cn * 4);
+                            sacc = *(const float*)(stage + CH * ACC_ROW + r * ACC_ROW + cn * 4);
                         } else {  // f32 factors or a rank that is not a multiple of 16: plain fma chain
                             sacc = 0.0f;
                             for (int rr = 0; rr < p.rank; ++rr)
@@ -501,17 +517,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             *(uint4*)dst = Vec16<OUT_T>::pack(o);
         }
     }
+    });
     TRACE(6);
 }
 
-template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA>
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB>
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int MAIN = (LD == LD_DMA ? NS : 2) * (BM + BN) * BKB;
-    constexpr int EPIB = BM * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1);
+    constexpr int MAIN = (LD == LD_DMA ? NS : 2) * (BM + BN) * BK;
+    constexpr int EPIB = (BM > 128 ? 64 : BM) * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1);
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 4 * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD>;
+    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK>;
     static std::atomic<bool> attr_set{false};
     if (LDS_BYTES > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
@@ -541,15 +558,17 @@ template <int MM, int OUT_T, int EPI>
 int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     static const int force = [] { const char* e = getenv("SDNQ_HIP_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
-    if (force == 0) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);
+    if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_DMA, 64>(p, s);
     if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);
     if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);
-    if (force == 3) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 4, LD_REG>(p, s);  // register-ring loader (A/B aid)
-    // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt): every kernel launch starts with cold
-    // L2s (data comes from MALL/HBM at ~2 us loaded latency), so for diffusion-size GEMMs what pays is two waves per
-    // SIMD (8-wave workgroups) and TWO co-resident workgroups per CU (<= 80 KB LDS each): 64x128 tiles with a 3-deep
-    // ring. Very large problems amortise a deeper ring on 128x128 tiles; few-row GEMMs (M = 77) take 64x64 tiles.
-    if (tiles(128, 128) >= 2048) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4>(p, s);
+    // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt). Every kernel launch starts with cold
+    // L2s (data comes from MALL/HBM at ~2 us loaded latency) and the L2->LDS fill rate per CU is ~30 B/clk, so:
+    //  * large problems: 256x256 tiles (8 waves of 128x64, 64-byte K stages, 4-deep ring) -- twice the MACs per byte
+    //    staged through LDS of a 128x128 tile: 2.0-2.1 POP/s at 8192^3 / 16384x8192x4096 vs 1.4-1.5;
+    //  * diffusion-size GEMMs (1-30 GOP): 64x128 tiles, two waves per SIMD and TWO co-resident workgroups per CU
+    //    (3-deep ring, 72 KB LDS each);
+    //  * few-row GEMMs (M <= 128, e.g. the 77-token text projections): 64x64 tiles.
+    if (tiles(256, 256) >= 200) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_DMA, 64>(p, s);
     if (p.M > 128) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);
     return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);
 }
