@@ -193,6 +193,63 @@ __global__ __launch_bounds__(256) void linear_float_kernel(const void* __restric
     }
 }
 
+// t[M][R] = cast( x[M][K] . down[R][K]^T ) on the matrix cores (bf16 / f16): the inner torch.mm of the SVD branch
+// (linear_int8.py:60).  One workgroup = 32 activation rows; its 8 waves split K, each accumulating a 32(n) x 32(m)
+// tile with v_mfma_f32_32x32x16 (A-operand = svd_down rows, B-operand = activation rows, both K-contiguous 16-byte
+// lane vectors), partial tiles are summed through LDS.  HBM-bound on x: 2*M*K bytes.
+template <bool IS_BF16>
+__global__ __launch_bounds__(512) void lowrank_down_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ down,
+                                                           uint16_t* __restrict__ t, int64_t M, int64_t K, int64_t ldx, int R) {
+    __shared__ float part[8][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * 32;
+    int64_t gm = m0 + (lane & 31);
+    if (gm >= M) gm = M - 1;
+    const uint16_t* xrow = x + gm * ldx + (lane >> 5) * 8;
+    const int n_tiles = (R + 31) / 32;
+    const int64_t kw = ((K / 16 + 7) / 8) * 16;  // K range of one wave, multiple of 16
+    const int64_t kbeg = wave * kw, kend = (kbeg + kw < K) ? kbeg + kw : K;
+    for (int nt = 0; nt < n_tiles; ++nt) {
+        const int gn = nt * 32 + (lane & 31);
+        const bool nok = gn < R;
+        const uint16_t* drow = down + (int64_t)(nok ? gn : 0) * K + (lane >> 5) * 8;
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+        for (int64_t k = kbeg; k < kend; k += 64) {
+            uint4 fx[4], fd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = k + u * 16 < kend;
+                fx[u] = ok ? *(const uint4*)(xrow + k + u * 16) : make_uint4(0, 0, 0, 0);
+                fd[u] = (ok && nok) ? *(const uint4*)(drow + k + u * 16) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if constexpr (IS_BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fd[u]), __builtin_bit_cast(v8bf, fx[u]), acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fd[u]), __builtin_bit_cast(v8h, fx[u]), acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();  // previous n-tile's partials consumed
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
+        __syncthreads();
+        // acc[e] of lane l: n = (e&3) + 8*(e>>2) + 4*(l>>5), m = l&31.  1024 outputs, 512 threads: 2 each.
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int idx = tid + o * 512;
+            const int e = idx >> 6, l = idx & 63;
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += part[w][e][l];
+            const int n = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
+            const int64_t m = m0 + (l & 31);
+            if (m < M && n < R) t[m * R + n] = IS_BF16 ? f32_to_bf16_bits(sum) : f32_to_f16_bits(sum);
+        }
+    }
+}
+
 int fill_params(const SdnqWeight* w, DeqParams& p) {
     if (!w || !w->weight || !w->scale) return SDNQ_ERR_NULL;
     if (w->n <= 0 || w->k <= 0 || w->group_size <= 0 || (w->k % w->group_size) != 0) return SDNQ_ERR_SHAPE;
@@ -308,6 +365,17 @@ extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int6
     // t = mm(x.to(svd dtype), svd_down): x already lives in the activation dtype; the reference casts x to
     // svd_down.dtype first (linear_int8.py:60) -- both are the model dtype, so require equality.
     if (x_dtype != svd_dtype) return SDNQ_ERR_DTYPE;
+    if (x_dtype != SDNQ_F32 && (k % 16) == 0 && rank > 0 && x && svd_down && t && ((uintptr_t)x % 16) == 0 &&
+        ((uintptr_t)svd_down % 16) == 0 && ((ldx * 2) % 16) == 0) {
+        hipStream_t s = (hipStream_t)stream;
+        dim3 grid((unsigned)((m + 31) / 32)), block(512);
+        if (x_dtype == SDNQ_BF16)
+            hipLaunchKernelGGL((lowrank_down_kernel<true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)svd_down, (uint16_t*)t, m, k, ldx, rank);
+        else
+            hipLaunchKernelGGL((lowrank_down_kernel<false>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)svd_down, (uint16_t*)t, m, k, ldx, rank);
+        SDNQ_CHECK_LAUNCH();
+        return SDNQ_OK;
+    }
     return sdnq_hip_linear_float(x, svd_down, nullptr, x_dtype, t, m, rank, k, ldx, stream);
 }
 

@@ -441,6 +441,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     TRACE(5);
     // (2) one compact loop: 8 consecutive channels of one row per thread -> scale, bias, cast, 16/32-byte store
     constexpr int G8 = BN / 8;
+    const bool has_bias = p.bias != nullptr;
+    const bool lr_fast = EPI == EPI_LOWRANK && lr_mfma && p.bias_dtype == SDNQ_BF16 && p.zp == nullptr && p.a_zp == nullptr;
 #pragma nounroll
     for (int v = tid; v < CH * G8; v += NT) {
         const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
@@ -466,6 +468,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 for (int e = 0; e < 4; ++e) a4[e] = t[e];
             }
             const v4f sb4 = *(const v4f*)(s_sb + c8 + 4 * h);
+            v4f lr4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (EPI == EPI_LOWRANK) {
+                if (lr_mfma) lr4 = *(const v4f*)(stage + CH * ACC_ROW + r * ACC_ROW + (c8 + 4 * h) * 4);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float vv = a4[e] * sa;
@@ -480,31 +486,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     // bias2d = cast_svd(f32(bias[n]) + sum_r t[m][r]*up[n][r]) (linear_int8.py:57-62), then the zero-point
                     // term f32(rowsum)*sa*zp[n] + bias2d (linear_int8.py:65-69), all f32 into the single-rounding fma
                     const int cn = c8 + 4 * h + e;
-                    float bv = s_bias[cn];
-                    bool has = p.bias != nullptr;
-                    if (p.lr_t) {
-                        float sacc;
-                        if (lr_mfma) {
-                            sacc = *(const float*)(stage + CH * ACC_ROW + r * ACC_ROW + cn * 4);
-                        } else {  // f32 factors or a rank that is not a multiple of 16: plain fma chain
-                            sacc = 0.0f;
-                            for (int rr = 0; rr < p.rank; ++rr)
-                                sacc = fmaf(ldf_rt(p.lr_t, gm * p.rank + rr, p.bias_dtype), ldf_rt(p.lr_up, (n0 + cn) * p.rank + rr, p.bias_dtype), sacc);
+                    if (lr_fast) {  // SVD only (cfg5): staged MFMA low-rank value, bf16 bias2d, no zero-point terms
+                        const float sacc = lr4[e];
+                        res = fmaf(vv, sb4[e], FT<SDNQ_BF16>::round(has_bias ? sacc + s_bias[cn] : sacc));
+                    } else {
+                        float bv = s_bias[cn];
+                        bool has = has_bias;
+                        if (p.lr_t) {
+                            float sacc;
+                            if (lr_mfma) {
+                                sacc = lr4[e];
+                            } else {  // f32 factors or a rank that is not a multiple of 16: plain fma chain
+                                sacc = 0.0f;
+                                for (int rr = 0; rr < p.rank; ++rr)
+                                    sacc = fmaf(ldf_rt(p.lr_t, gm * p.rank + rr, p.bias_dtype), ldf_rt(p.lr_up, (n0 + cn) * p.rank + rr, p.bias_dtype), sacc);
+                            }
+                            bv = round_rt(has ? sacc + bv : sacc, p.bias_dtype);
+                            has = true;
                         }
-                        bv = round_rt(has ? sacc + bv : sacc, p.bias_dtype);
-                        has = true;
+                        float zb = 0.0f;
+                        bool hasz = false;
+                        if (p.zp) { zb = zsum * s_zp[cn]; hasz = true; }
+                        if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
+                            const float t2 = s_wcs[cn] * azp;
+                            zb = hasz ? zb + t2 : t2;
+                            if (p.zp) zb = fmaf(azp * s_zp[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
+                            hasz = true;
+                        }
+                        if (hasz) { bv = has ? zb + bv : zb; has = true; }
+                        res = has ? fmaf(vv, sb4[e], bv) : vv * sb4[e];
                     }
-                    float zb = 0.0f;
-                    bool hasz = false;
-                    if (p.zp) { zb = zsum * s_zp[cn]; hasz = true; }
-                    if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
-                        const float t2 = s_wcs[cn] * azp;
-                        zb = hasz ? zb + t2 : t2;
-                        if (p.zp) zb = fmaf(azp * s_zp[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
-                        hasz = true;
-                    }
-                    if (hasz) { bv = has ? zb + bv : zb; has = true; }
-                    res = has ? fmaf(vv, sb4[e], bv) : vv * sb4[e];
                 }
                 o[4 * h + e] = res;
             }
