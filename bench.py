@@ -55,48 +55,68 @@ def parse():
 def workload_config(name: str):
     from sdnq_amd import shapes
     if name == "sdxl_int8":
-        return shapes.sdxl_unet_linears(), dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), "int8", 16384
+        return shapes.sdxl_unet_layer_sequence(), dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), "int8", 16384
     if name == "sdxl_fp8":
-        return shapes.sdxl_unet_linears(), dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1,
+        return shapes.sdxl_unet_layer_sequence(), dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1,
                                                 use_quantized_matmul=True), "fp8", 16384
     if name == "flux_int4_had":
-        return shapes.flux_dev_linears(), dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256,
+        return shapes.flux_dev_layer_sequence(), dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256,
                                                use_quantized_matmul=True), "int8", 4608
     if name == "flux_int8_svd":
-        return shapes.flux_dev_linears(), dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
+        return shapes.flux_dev_layer_sequence(), dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
                                                use_quantized_matmul=True), "int8", 4608
     if name == "linear_int8":  # the reference's own micro-benchmark shape (scripts/benchmark_sdnq_inference_matmul.py)
         return [("bench.linear", 16384, 4096, 8192, True, 1)], dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), "int8", 16384
     raise ValueError(name)
 
 
+def expand_layers(shape_list, scale=1.0):
+    """-> execution-ordered [(name, M, K, N, bias, input_key)].  Aggregated lists (name, M, K, N, bias, repeat) are expanded
+    with one distinct activation tensor per layer instance."""
+    seq = []
+    for i, e in enumerate(shape_list):
+        if isinstance(e[5], str):
+            seq.append(e)
+        else:
+            for r in range(max(1, int(round(e[5] * scale)))):
+                seq.append((e[0], e[1], e[2], e[3], e[4], f"{e[0]}#{r}"))
+    if scale != 1.0 and shape_list and isinstance(shape_list[0][5], str):
+        seq = seq[: max(1, int(round(len(seq) * scale)))]
+    return seq
+
+
 def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0):
-    """-> list of (name, module, x, M, K, N, bias). One module per layer instance (distinct weights, like a real UNet);
-    one activation buffer per shape class."""
+    """-> list of (name, module, x, M, K, N, bias). One module per layer instance (distinct weights, like a real UNet /
+    DiT); one activation tensor per distinct input_key: layers that consume the same tensor in the real model (q/k/v
+    projections, every cross-attention k/v) get the SAME tensor object here, all others get their own."""
     import sdnq_amd
     g = torch.Generator(device=device).manual_seed(seed)
-    layers = []
-    for (name, m, k, n, has_bias, repeat) in shape_list:
-        repeat = max(1, int(round(repeat * scale)))
-        x = torch.randn(m, k, device=device, dtype=torch.bfloat16, generator=g)
-        for r in range(repeat):
-            n_local = n
-            lin = torch.nn.Linear(k, n_local, bias=has_bias, device=device, dtype=torch.bfloat16)
-            with torch.no_grad():
-                lin.weight.copy_(torch.randn(n_local, k, device=device, generator=g) * 0.02)
-                if has_bias:
-                    lin.bias.copy_(torch.randn(n_local, device=device, generator=g) * 0.1)
-            cfg = sdnq_amd.SDNQConfig(**cfg_kwargs)
-            if tp_world > 1:
-                from sdnq_amd.parallel import column_shard_linear
-                mod = column_shard_linear(lin, cfg, tp_rank, tp_world)
-            else:
-                mod, _ = sdnq_amd.sdnq_quantize_layer(lin, cfg)
-            layers.append((name, mod, x, m, k, n, has_bias))
+    layers, inputs = [], {}
+    for (name, m, k, n, has_bias, key) in expand_layers(shape_list, scale):
+        if key not in inputs:
+            inputs[key] = torch.randn(m, k, device=device, dtype=torch.bfloat16, generator=g)
+        x = inputs[key]
+        assert x.shape == (m, k), (name, key, x.shape, m, k)
+        lin = torch.nn.Linear(k, n, bias=has_bias, device=device, dtype=torch.bfloat16)
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(n, k, device=device, generator=g) * 0.02)
+            if has_bias:
+                lin.bias.copy_(torch.randn(n, device=device, generator=g) * 0.1)
+        cfg = sdnq_amd.SDNQConfig(**cfg_kwargs)
+        if tp_world > 1:
+            from sdnq_amd.parallel import column_shard_linear
+            mod = column_shard_linear(lin, cfg, tp_rank, tp_world)
+        else:
+            mod, _ = sdnq_amd.sdnq_quantize_layer(lin, cfg)
+        layers.append((name, mod, x, m, k, n, has_bias))
     return layers
 
 
 def run_step(layers):
+    """One pass over every layer.  The activation-quantization cache is emptied first: within a step a tensor consumed by
+    several layers is quantized once (sdnq_amd/linear.py:_ActivationCache), but nothing is carried across steps."""
+    from sdnq_amd import linear as L
+    L.clear_activation_cache()
     out = None
     for (_, mod, x, *_rest) in layers:
         out = mod(x)
@@ -108,7 +128,7 @@ def time_gemm_kernel(layers, mm_name, device):
     from sdnq_amd import linear as L
     from sdnq_amd import ops
     mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
-    calls, total_ops = [], 0
+    calls, total_ops, total_bytes = [], 0, 0
     for (_, mod, x, m, k, n, has_bias) in layers:
         if m < 32 or not hasattr(mod, "sdnq_dequantizer"):
             continue
@@ -120,6 +140,7 @@ def time_gemm_kernel(layers, mm_name, device):
         xq, xs, _, _ = ops.rowquant(x, mm, dq.hadamard_group_size if dq.use_hadamard else 0)
         calls.append((xq, wq, xs, ws, mod.bias))
         total_ops += 2 * m * k * n + (m * n if has_bias else 0)
+        total_bytes += m * k + n * k + 2 * m * n + 4 * (m + n) + (2 * n if has_bias else 0)  # xq + Wq + y(bf16) + xs + ws + bias
     if not calls:
         return None
 
@@ -145,7 +166,7 @@ def time_gemm_kernel(layers, mm_name, device):
         e1.record(s)
         s.synchronize()
     dur_s = e0.elapsed_time(e1) / 1e3 / reps
-    return {"launches": len(calls), "ops": total_ops, "seconds": dur_s}
+    return {"launches": len(calls), "ops": total_ops, "bytes": total_bytes, "seconds": dur_s}
 
 
 def cpu_baseline(shape_list, mm_name, budget_s):
@@ -157,7 +178,7 @@ def cpu_baseline(shape_list, mm_name, budget_s):
     rng = np.random.default_rng(0)
     done_ops, t_total, sample = 0, 0.0, []
     # distinct GEMM shapes of the step, weighted like the step (layer counts), cycled until the time budget is used
-    seen = sorted({(m, k, n, b) for (_, m, k, n, b, _r) in shape_list if m >= 32}, key=lambda s: s[0] * s[1] * s[2])
+    seen = sorted({(e[1], e[2], e[3], e[4]) for e in shape_list if e[1] >= 32}, key=lambda s: s[0] * s[1] * s[2])
     data = {}
     for (m, k, n, b) in seen:
         x = O.round_dtype(rng.standard_normal((m, k), dtype=np.float32), "bf16")
@@ -200,6 +221,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from sdnq_amd import _lib, shapes
+    from sdnq_amd import linear as L
     if not _lib.load().sdnq_hip_device_supported(local_rank):
         raise SystemExit("device is not gfx950: the HIP kernels of this repo target MI355X only")
 
@@ -264,6 +286,8 @@ def main():
                                f"({sum(1 for l in layers if l[3] >= 32)} w8a8 GEMMs + {sum(1 for l in layers if l[3] < 32)} M=1 layers)",
                    "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
                    "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16",
+                   "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
+                   "requantized_weight_cache": L.CACHE_WEIGHTS,
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
         "step_latency_ms": round(ms_per_step, 4),
@@ -274,10 +298,19 @@ def main():
             gk = time_gemm_kernel(layers, mm_name, device)
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
+        if args.workload == "sdxl_int8" and os.path.exists(pmc):
+            # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            # (tools/pmc_shapes.py + tools/pmc_traffic.py; counters cannot be read inside this process)
+            with open(pmc) as f:
+                traffic = round(json.load(f)["_all_gemm_kernel"]["hbm_bytes_per_launch"])
+            traffic_src = "profiles/r01_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)"
         if gk:
             ach = gk["ops"] / gk["seconds"] / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s" if mm_name == "int8" else "TFLOP/s",
-                                  "frac": round(ach / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
+                                  "frac": round(ach / INT8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                                  "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
                                   "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3)}
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -178,10 +178,26 @@ int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const
 int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
                           int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream);
 
-/* fused skinny variant (M <= 32): streams the quantized weight once, dequantizes in registers to the
- * activation dtype (same rounding as sdnq_hip_dequant) and accumulates in fp32. No Hadamard/SVD. */
-int sdnq_hip_linear_skinny(const SdnqWeight* w, const void* x, const void* bias, int dtype, void* out,
+/* fused skinny variant (M <= 64, meant for the M < 32 branch): streams the quantized weight ONCE, dequantizes in
+ * registers to the activation dtype (same arithmetic and rounding as sdnq_hip_dequant) and accumulates in fp32.
+ * No SVD (SDNQ_ERR_UNSUPPORTED if w->svd_up is set).  hadamard_group != 0: the stored weight is rotated; each rounded
+ * 16-element run is un-rotated in registers and rounded again (dequantizer.py:82-87 order), so x is passed as is. */
+int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, const void* x, const void* bias, int dtype, void* out,
                            int64_t m, int64_t ldx, sdnq_stream_t stream);
+
+/* ---- 8(f) rank 1: load-time weight quantizer + packers ------------------------------------------
+ * replaces quantize_weight (quant_utils.py:28-56: get_scale_symmetric :23-24, get_scale_asymmetric :10-19) followed by
+ * pack_int (packed_int/__init__.py:77-80 + packed_int/pack.py) or pack_float (packed_float.py:27-82) for one float
+ * weight src [N][K] (row stride ld_src elements, dtype src_dtype = SdnqFloat), grouped along K by w->group_size.
+ * `w` describes the OUTPUT: w->weight (codes in w->storage / kind / bits / exponent / mantissa, element order [N][K] --
+ * the same bytes the reference stores, including its transposed [K,N]-strides-(1,K) matmul layout), w->scale [N][G] f32,
+ * w->zero_point [N][G] f32 (unsigned kinds; NULL otherwise).  svd_* fields are ignored (the caller subtracts the
+ * low-rank term first, as apply_svdquant does, quant_utils.py:124-141).  qmin / qmax = dtype_dict[...]["min"/"max"]
+ * (common.py:16-267).  Symmetric: s = amax|w| / qmax, q = w / s.  Asymmetric: s = (max - min) / (qmax - qmin),
+ * zp = min, q = (w - zp) / s.  Integers: round-half-even, clamp, stored as value - qmin when packed.  Floats:
+ * nan_to_num, clamp, then the native conversion (fp8 e4m3fn / e5m2, fp16, bf16) or the reference's eXmY encoder. */
+int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, const SdnqWeight* w, float qmin,
+                             float qmax, sdnq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -193,6 +193,71 @@ __global__ __launch_bounds__(256) void linear_float_kernel(const void* __restric
     }
 }
 
+// Fused skinny linear (M < 32): out[m][n] = cast( sum_k x[m][k] * round_T(dequant(W)[n][k]) + bias[n] ).
+// Streams the QUANTIZED weight exactly once (bits/8 bytes per element instead of writing and re-reading a 2-byte
+// dequantized copy): one wave per output channel, a lane decodes 16 consecutive elements per pass with the same
+// arithmetic as sdnq_hip_dequant (f32(w)*s | fma, one rounding to the activation dtype T -- the reference rounds the
+// dequantized weight to result_dtype before F.linear, dequantizer.py:82-83), fp32 accumulate, wave reduction.
+// MROWS activation rows per launch column (grid.y walks M); x slices are re-read per channel from L1/L2.
+// log2had != 0: the stored weight is Hadamard-rotated; the rounded dequantized run is un-rotated in registers (FWHT across
+// the wave, 1024 elements per pass, groups never straddle a pass) and rounded to T again, exactly the order of the
+// reference (dequantize -> .to(result_dtype) -> rotate_hadamard in result_dtype, dequantizer.py:82-87).
+template <int T_ID, int MROWS>
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const DeqParams p, const void* __restrict__ x, const void* __restrict__ bias,
+                                                            void* __restrict__ out, int64_t M, int64_t ldx, int log2had) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t m0 = (int64_t)blockIdx.y * MROWS;
+    if (n >= p.N) return;
+    float acc[MROWS];
+#pragma unroll
+    for (int i = 0; i < MROWS; ++i) acc[i] = 0.0f;
+    const float hscale = log2had ? hadamard_scale(log2had, T_ID) : 1.0f;
+    for (int64_t kb = 0; kb < p.K; kb += 1024) {  // wave-uniform trip count: the FWHT shuffles need every lane
+        const int64_t k0 = kb + (int64_t)lane * 16;
+        const bool live = k0 < p.K;
+        float w[16];
+        if (live) {
+            dequant16(p, n, k0, w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = FT<T_ID>::round(w[j]);
+        if (log2had) {
+            wave_hadamard16(w, log2had, hscale);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = FT<T_ID>::round(w[j]);
+        }
+        if (!live) continue;
+#pragma unroll
+        for (int i = 0; i < MROWS; ++i) {
+            const int64_t m = (m0 + i < M) ? m0 + i : M - 1;
+            float xv[16];
+            if constexpr (T_ID == SDNQ_F32) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Vec16<SDNQ_F32>::unpack(*(const uint4*)((const float*)x + m * ldx + k0 + 4 * q), xv + 4 * q);
+            } else {
+                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + m * ldx + k0), xv);
+                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + m * ldx + k0 + 8), xv + 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i] = fmaf(xv[j], w[j], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MROWS; ++i) {
+        float sum = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0 && m0 + i < M) {
+            if (bias) sum += FT<T_ID>::load(bias, n);
+            FT<T_ID>::store(out, (m0 + i) * p.N + n, sum);
+        }
+    }
+}
+
 // t[M][R] = cast( x[M][K] . down[R][K]^T ) on the matrix cores (bf16 / f16): the inner torch.mm of the SVD branch
 // (linear_int8.py:60).  One workgroup = 32 activation rows; its 8 waves split K, each accumulating a 32(n) x 32(m)
 // tile with v_mfma_f32_32x32x16 (A-operand = svd_down rows, B-operand = activation rows, both K-contiguous 16-byte
@@ -379,8 +444,40 @@ extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int6
     return sdnq_hip_linear_float(x, svd_down, nullptr, x_dtype, t, m, rank, k, ldx, stream);
 }
 
-extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, const void* x, const void* bias, int dtype, void* out, int64_t m,
-                                      int64_t ldx, sdnq_stream_t stream) {
-    (void)w; (void)x; (void)bias; (void)dtype; (void)out; (void)m; (void)ldx; (void)stream;
-    return SDNQ_ERR_UNSUPPORTED;  // fused streaming GEMV lands with the M<32 optimisation pass
+extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, const void* x, const void* bias, int dtype, void* out,
+                                      int64_t m, int64_t ldx, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!x || !out) return SDNQ_ERR_NULL;
+    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
+    if (m <= 0 || m > 64 || ldx < p.K) return SDNQ_ERR_SHAPE;
+    if (w->svd_up) return SDNQ_ERR_UNSUPPORTED;  // the SVD term needs the dequantize-then-GEMM path
+    int log2had = 0;
+    if (hadamard_group != 0) {
+        if (hadamard_group < 4 || hadamard_group > 512 || (hadamard_group & (hadamard_group - 1)) || (p.K % hadamard_group)) return SDNQ_ERR_SHAPE;
+        while ((1 << log2had) < hadamard_group) ++log2had;
+    }
+    const int eb = (dtype == SDNQ_F32) ? 4 : 2;
+    if (((uintptr_t)x % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+#define SK_LAUNCH(T, MR)                                                                                      \
+    hipLaunchKernelGGL((linear_skinny_kernel<T, MR>), dim3((unsigned)((p.N + 3) / 4), (unsigned)((m + MR - 1) / MR)), \
+                       dim3(256), 0, s, p, x, bias, out, m, ldx, log2had)
+#define SK_DISPATCH(T)                 \
+    do {                               \
+        if (m == 1) SK_LAUNCH(T, 1);   \
+        else if (m <= 2) SK_LAUNCH(T, 2); \
+        else if (m <= 4) SK_LAUNCH(T, 4); \
+        else SK_LAUNCH(T, 8);          \
+    } while (0)
+    switch (dtype) {
+        case SDNQ_F32: SK_DISPATCH(SDNQ_F32); break;
+        case SDNQ_BF16: SK_DISPATCH(SDNQ_BF16); break;
+        default: SK_DISPATCH(SDNQ_F16); break;
+    }
+#undef SK_DISPATCH
+#undef SK_LAUNCH
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
 }

@@ -111,3 +111,58 @@ __device__ __forceinline__ void wave_hadamard(float (&v)[8], int log2g, float sc
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= scale;
 }
+
+// Same transform for a lane that owns 16 consecutive elements (idx = lane*16 + e: bits 0..3 = registers, bits 4..8 =
+// lane bits 0..4), used where the unit of work is a 16-element codec run (fused skinny linear on Hadamard layers).
+__device__ __forceinline__ void wave_hadamard16(float (&v)[16], int log2g, float scale) {
+    const int lane = threadIdx.x & 63;
+    if ((log2g & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) had4_inlane(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);  // digit (0,1)
+        if (log2g >= 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) had4_inlane(v[e], v[e + 4], v[e + 8], v[e + 12]);             // digit (2,3)
+        }
+#pragma unroll
+        for (int d = 6; d <= 8; d += 2) {  // digits (4,5) = lane bits (0,1), (6,7) = lane bits (2,3)
+            if (log2g >= d) {
+                const int ma = 1 << (d - 6), mb = 1 << (d - 5);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p1 = __shfl_xor(v[e], ma, 64), p2 = __shfl_xor(v[e], mb, 64), p3 = __shfl_xor(v[e], ma | mb, 64);
+                    const float s = (v[e] + p1) + (p2 + p3);
+                    v[e] = s - 2.0f * p3;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int bit = 0; bit < 4; ++bit) {
+            const int st = 1 << bit;
+            if (log2g > bit) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if ((e & st) == 0) {
+                        const float a = v[e], b = v[e + st];
+                        v[e] = a + b;
+                        v[e + st] = a - b;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int bit = 4; bit < 9; ++bit) {
+            if (log2g > bit) {
+                const int m = 1 << (bit - 4);
+                const bool hi = (lane & m) != 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = __shfl_xor(v[e], m, 64);
+                    v[e] = hi ? (p - v[e]) : (v[e] + p);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] *= scale;
+}

@@ -11,7 +11,7 @@
 #include "sdnq_dev.h"
 
 // 8 elements from `bits` (1..7) bytes
-__device__ __forceinline__ void unpack8_u8(const uint8_t* __restrict__ p, int bits, u32 (&e)[8]) {
+__host__ __device__ __forceinline__ void unpack8_u8(const uint8_t* __restrict__ p, int bits, u32 (&e)[8]) {
     switch (bits) {
         case 1: {
             const u32 w = p[0];
@@ -67,7 +67,7 @@ __device__ __forceinline__ void unpack8_u8(const uint8_t* __restrict__ p, int bi
 }
 
 // 16 elements from `bits` (9..15) 16-bit words
-__device__ __forceinline__ void unpack16_i16(const uint16_t* __restrict__ p, int bits, u32 (&e)[16]) {
+__host__ __device__ __forceinline__ void unpack16_i16(const uint16_t* __restrict__ p, int bits, u32 (&e)[16]) {
     switch (bits) {
         case 9: {
             const u32 w8 = p[8];

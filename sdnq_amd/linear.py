@@ -28,6 +28,63 @@ from .common import dtype_dict
 
 CACHE_WEIGHTS = os.environ.get("SDNQ_HIP_CACHE_WEIGHTS", "1").lower() not in {"0", "false", "no"}
 PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "1").lower() not in {"0", "false", "no"}
+FUSED_SKINNY = os.environ.get("SDNQ_HIP_FUSED_SKINNY", "1").lower() not in {"0", "false", "no"}
+CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
+
+
+class _ActivationCache:
+    """Quantized activations keyed on the identity of the input tensor.
+
+    In a transformer block several Linear layers consume the SAME tensor object (attn.to_q / to_k / to_v all get
+    `hidden_states`; every cross-attention to_k / to_v gets the same `encoder_hidden_states`).  The reference
+    re-quantizes it for each of them (linear_int8.py:64); the result is identical every time, so this build keeps the
+    last few (xq, xs, ...) tuples and reuses them when the very same tensor object (unchanged `_version`) comes back
+    with the same quantization parameters.  Entries hold a strong reference to their input, so its storage cannot be
+    recycled for a different tensor while the entry is alive.
+    """
+
+    def __init__(self, size: int):
+        self.size = size
+        self.entries = []  # most recent last: (tensor, version, params, result)
+
+    def get(self, t: torch.Tensor, params):
+        for i in range(len(self.entries) - 1, -1, -1):
+            e = self.entries[i]
+            if e[0] is t and e[1] == t._version and e[2] == params:
+                self.entries.append(self.entries.pop(i))
+                return e[3]
+        return None
+
+    def put(self, t: torch.Tensor, params, result):
+        self.entries.append((t, t._version, params, result))
+        if len(self.entries) > self.size:
+            self.entries.pop(0)
+
+    def clear(self):
+        self.entries.clear()
+
+
+_act_cache = _ActivationCache(CACHE_ACTIVATIONS)
+
+
+def clear_activation_cache():
+    _act_cache.clear()
+
+
+def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum: bool, want_xrot: bool, prefetch, asymmetric=False):
+    params = (mm, had, want_rowsum, want_xrot, asymmetric)
+    if CACHE_ACTIVATIONS > 0:
+        hit = _act_cache.get(input, params)
+        if hit is not None:
+            return hit
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+        x2 = x2.contiguous()
+    res = ops.rowquant(x2, mm, had, want_rowsum=want_rowsum, want_xrot=want_xrot, prefetch=prefetch, asymmetric=asymmetric)
+    res = (x2,) + tuple(res)
+    if CACHE_ACTIVATIONS > 0:
+        _act_cache.put(input, params, res)
+    return res
 
 
 class _State:
@@ -66,6 +123,14 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
     k, n = dq.in_features, dq.out_features
     if input.dtype != dq.result_dtype:
         raise RuntimeError(f"expected input dtype {dq.result_dtype} (the layer's result_dtype) but got {input.dtype}")
+    m = input.numel() // input.shape[-1]
+    if FUSED_SKINNY and m <= 32 and st.svd_up is None and k % 16 == 0:
+        # few rows (time/AdaLN embeddings, the M < 32 branch): stream the quantized weight once instead of writing and
+        # re-reading a dequantized copy; on Hadamard layers the kernel un-rotates each weight run in registers.
+        x2 = input.reshape(-1, k)
+        if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+            x2 = x2.contiguous()
+        return ops.linear_skinny(st.qw, x2, mod.bias, dq.hadamard_group_size if dq.use_hadamard else 0).view(*input.shape[:-1], n)
     wd = st.wd
     if wd is None:
         wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)
@@ -119,13 +184,9 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tenso
     if m < 32:  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
         return _float_forward(self, input, st)
     wq, ws, zp = _prepare_mm_weights(self, st, mm)
-    x2 = input.reshape(-1, k)
-    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
-        x2 = x2.contiguous()
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
-    xq, xs, rowsum, xrot = ops.rowquant(x2, mm, had, want_rowsum=zp is not None, want_xrot=has_svd,
-                                        prefetch=wq if PREFETCH_WEIGHTS else None)
+    x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, wq if PREFETCH_WEIGHTS else None)
     bias = self.bias
     if has_svd or zp is not None:
         t = None
@@ -166,13 +227,10 @@ def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Te
         wcs = wq.to(torch.int32).sum(dim=1).to(torch.float32).mul_(ws)
         if CACHE_WEIGHTS:
             st.mm_wcs = wcs
-    x2 = input.reshape(-1, k)
-    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
-        x2 = x2.contiguous()
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
-    xq, xs, rowsum, xrot, xzp = ops.rowquant(x2, ops.MM_I8, had, want_rowsum=zp is not None, want_xrot=has_svd,
-                                             prefetch=wq if PREFETCH_WEIGHTS else None, asymmetric=True)
+    x2, xq, xs, rowsum, xrot, xzp = _rowquant_cached(input, k, ops.MM_I8, had, zp is not None, has_svd,
+                                                     wq if PREFETCH_WEIGHTS else None, asymmetric=True)
     t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
     y = ops.scaled_mm_lowrank(ops.MM_I8, xq, wq, xs, ws, self.bias, t, st.svd_up, rowsum, zp, input.dtype, a_zp=xzp,
                               w_colsum_scaled=wcs)

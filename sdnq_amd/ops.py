@@ -269,6 +269,20 @@ def linear_float(x2d: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
     return out
 
 
+def linear_skinny(qw: QuantWeight, x2d: torch.Tensor, bias, hadamard_group: int = 0) -> torch.Tensor:
+    """Fused dequant (+ Hadamard un-rotation of the weight in registers) + float linear for M < 32 rows: streams the
+    quantized weight once (no SVD)."""
+    _require_cuda(x2d, bias)
+    m, k = x2d.shape
+    assert k == qw.k and x2d.stride(1) == 1
+    if bias is not None and bias.dtype != x2d.dtype:
+        bias = bias.to(x2d.dtype)
+    out = torch.empty((m, qw.n), device=x2d.device, dtype=x2d.dtype)
+    check(_lib.load().sdnq_hip_linear_skinny(ctypes.byref(qw.desc), hadamard_group, x2d.data_ptr(), _ptr(bias), float_code(x2d.dtype), out.data_ptr(), m,
+                                             x2d.stride(0), _stream(x2d)), "linear_skinny")
+    return out
+
+
 def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor:
     """t[M,R] = cast(x2d @ svd_down_phys^T); svd_down_phys is physical [R,K]."""
     m, k = x2d.shape
@@ -277,3 +291,44 @@ def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor
     check(_lib.load().sdnq_hip_lowrank_down(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), svd_down_phys.data_ptr(),
                                             float_code(svd_down_phys.dtype), r, t.data_ptr(), _stream(x2d)), "lowrank_down")
     return t
+
+
+def quantize_weight(weight2d: torch.Tensor, weights_dtype: str, group_size: int):
+    """Float [N,K] weight -> (codes, scale [N,G] f32, zero_point [N,G] f32 | None) with the codes in the reference's storage
+    (packed words shaped like the reference's packers return them, or [N,K] raw int8/uint8/int16/fp8/fp16...).
+    HIP replacement of quantize_weight + pack_int / pack_float (quant_utils.py:28-56, packed_int/__init__.py:77-80,
+    packed_float.py:27-82); `group_size` == K for row-wise."""
+    from .common import dtype_dict
+    from . import packed as _packed
+    _require_cuda(weight2d)
+    if weight2d.dtype not in _FLOAT_CODE:
+        raise _lib.SdnqHipError(f"quantize_weight: unsupported source dtype {weight2d.dtype}")
+    w = weight2d if weight2d.stride(1) == 1 else weight2d.contiguous()
+    n, k = w.shape
+    ent = dtype_dict[weights_dtype]
+    storage, kind, bits, ebits, mbits, native = _storage_kind(weights_dtype)
+    g = k // group_size
+    dev = w.device
+    if storage == _lib.ST_PACKED_U8:
+        raw = torch.empty((n * k // 8 * bits,), device=dev, dtype=torch.uint8)
+    elif storage == _lib.ST_PACKED_I16:
+        raw = torch.empty((n * k // 16 * bits,), device=dev, dtype=torch.int16)
+    elif storage == _lib.ST_RAW8:
+        raw = torch.empty((n, k), device=dev, dtype=torch.uint8)
+    else:
+        raw = torch.empty((n, k), device=dev, dtype=torch.int16)
+    scale = torch.empty((n, g), device=dev, dtype=torch.float32)
+    zp = torch.empty((n, g), device=dev, dtype=torch.float32) if ent["is_unsigned"] else None
+    d = SdnqWeight(weight=raw.data_ptr(), scale=scale.data_ptr(), zero_point=_ptr(zp), svd_up=None, svd_down=None, n=n, k=k,
+                   group_size=group_size, svd_rank=0, svd_dtype=0, storage=storage, kind=kind, bits=bits, exponent=ebits,
+                   mantissa=mbits, native_float=native)
+    check(_lib.load().sdnq_hip_quantize_weight(w.data_ptr(), float_code(w.dtype), w.stride(0), ctypes.byref(d), float(ent["min"]),
+                                               float(ent["max"]), _stream(w)), "quantize_weight")
+    if ent["is_packed"] and bits not in (8, 16):
+        _g, words, _wb = _packed._GEOM[bits]
+        codes = raw if words == 1 else raw.view(-1, words)
+    elif ent["is_packed"]:  # custom float8 / float16 codes (pack_float returns uint8 / uint16)
+        codes = raw.view(torch.uint16) if bits == 16 else raw
+    else:
+        codes = raw.view(ent["torch_dtype"]) if ent["torch_dtype"].itemsize == raw.element_size() else raw
+    return codes, scale, zp

@@ -70,6 +70,21 @@ def _placement(bits: int):
     return [(e, b) + _place(bits, e, b) for e in range(g) for b in range(bits)]
 
 
+@functools.lru_cache(maxsize=None)
+def _base_elements(bits: int):
+    """[(word, element)] for the elements a word holds at shift 0.  The reference ORs those in UNMASKED
+    (packed_int/pack.py, e.g. :115 `packed[:, :8] | (packed[:, 8:] << 11)`), so a code that does not fit in `bits` bits --
+    uint9..15 have max = 2**bits in the dtype table (common.py), and the largest element of every asymmetric group
+    quantizes to exactly that -- leaks its high bits into the word.  Reproduced for byte-identical checkpoints."""
+    g, w, _ = _GEOM[bits]
+    out = []
+    for e in range(g):
+        places = [_place(bits, e, b) for b in range(bits)]
+        if all(p == (places[0][0], b) for b, p in enumerate(places)):
+            out.append((places[0][0], e))
+    return out
+
+
 def pack_uint(codes: torch.Tensor, bits: int) -> torch.Tensor:
     """Unsigned codes (any int dtype, numel % group == 0) -> packed words, [numel/G, W] (1-D for 1/2/4 bits)."""
     g, w, wb = _GEOM[bits]
@@ -77,6 +92,8 @@ def pack_uint(codes: torch.Tensor, bits: int) -> torch.Tensor:
     out = torch.zeros((c.shape[0], w), dtype=torch.int32, device=codes.device)
     for e, b, word, pos in _placement(bits):
         out[:, word] |= ((c[:, e] >> b) & 1) << pos
+    for word, e in _base_elements(bits):
+        out[:, word] |= c[:, e] & (((1 << wb) - 1) & ~((1 << bits) - 1))
     if wb == 8:
         out = out.to(torch.uint8)
     else:

@@ -9,6 +9,8 @@ stochastic rounding, no conv/embedding (SURVEY 2, rows 12-16 marked out of scope
 """
 from __future__ import annotations
 
+import os
+
 from enum import Enum
 
 import torch
@@ -116,6 +118,10 @@ class SDNQConfig:
         return cls(**cfg)
 
 
+USE_HIP_QUANTIZER = os.environ.get("SDNQ_HIP_QUANTIZER", "1").lower() not in {"0", "false", "no"}
+_HIP_QUANTIZER_SKIP = {"int1", "uint1", "bool", "float8_e8m0fnu", "float8_e4m3fnuz", "float8_e5m2fnuz"}
+
+
 def _needs_requant(weights_dtype: str, matmul_dtype: str) -> bool:
     """Whether stored codes cannot be fed to the matmul as they are (reference quantizer.py:101-116)."""
     w, m = dtype_dict[weights_dtype], dtype_dict[matmul_dtype]
@@ -188,16 +194,38 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
     requant = requant or groups > 1
     transpose = use_qmm and not requant and not ent["is_packed"]
 
-    q, scale, zero_point = quantize_weight(weight, -1, weights_dtype)
-    if transpose:  # logical [K,N] with strides (1,K): the bytes stay [N][K] (prepare_weight_for_matmul on gfx950)
-        q = q.t()
-        scale = scale.t().contiguous()
-        zero_point = None if zero_point is None else zero_point.t().contiguous()
-    quantized_weight_shape = q.shape
-    if ent["is_packed"]:
-        q = packed.pack_int(q, weights_dtype) if ent["is_integer"] else packed.pack_float(q, weights_dtype)
+    if weight.is_cuda and USE_HIP_QUANTIZER and weight.dtype in (torch.float32, torch.bfloat16, torch.float16) and k % 16 == 0 \
+            and (ent["is_packed"] or ent["num_bits"] in (8, 16)) and weights_dtype not in _HIP_QUANTIZER_SKIP:
+        # GPU tensors: one HIP launch pair does scale/zero-point, quantize and pack (csrc/quantize.hip); the element order
+        # [N][K] is the same for the plain, grouped and transposed layouts, only the logical views differ
+        from . import ops
+        w2d = weight.reshape(n, k)
+        q, scale, zero_point = ops.quantize_weight(w2d, weights_dtype, group_size if groups > 1 else k)
+        if groups > 1:
+            scale = scale.view(n, groups, 1)
+            zero_point = None if zero_point is None else zero_point.view(n, groups, 1)
+            quantized_weight_shape = torch.Size((n, groups, group_size))
+        elif transpose:
+            scale = scale.view(1, n)
+            zero_point = None if zero_point is None else zero_point.view(1, n)
+            quantized_weight_shape = torch.Size((k, n))
+        else:
+            quantized_weight_shape = torch.Size((n, k))
+        if not ent["is_packed"]:
+            q = q.view(n, groups, group_size) if groups > 1 else (q.t() if transpose else q)
+        elif ent["num_bits"] in (8, 16):  # custom float8 / float16 codes keep the tensor shape (pack_float :75-80)
+            q = q.view(quantized_weight_shape)
     else:
-        q = q.to(ent["torch_dtype"])
+        q, scale, zero_point = quantize_weight(weight, -1, weights_dtype)
+        if transpose:  # logical [K,N] with strides (1,K): the bytes stay [N][K] (prepare_weight_for_matmul on gfx950)
+            q = q.t()
+            scale = scale.t().contiguous()
+            zero_point = None if zero_point is None else zero_point.t().contiguous()
+        quantized_weight_shape = q.shape
+        if ent["is_packed"]:
+            q = packed.pack_int(q, weights_dtype) if ent["is_integer"] else packed.pack_float(q, weights_dtype)
+        else:
+            q = q.to(ent["torch_dtype"])
 
     dq = SDNQDequantizer(result_dtype=torch_dtype, result_shape=result_shape, original_shape=original_shape,
                          original_stride=original_stride, quantized_weight_shape=quantized_weight_shape,

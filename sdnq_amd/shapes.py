@@ -34,6 +34,33 @@ def sdxl_unet_linears(latent: int = 128, text_tokens: int = 77):
     return out
 
 
+def sdxl_unet_layer_sequence(latent: int = 128, text_tokens: int = 77):
+    """The same Linear layers as `sdxl_unet_linears`, in execution order, each with the identity of the activation tensor
+    it consumes: (name, M, K, N, has_bias, input_key).  Layers with the same input_key read the SAME tensor object in
+    diffusers' attention processors (to_q / to_k / to_v of self-attention share `hidden_states`; every cross-attention
+    to_k / to_v reads the one `encoder_hidden_states`), which is what an activation-quantization cache can exploit."""
+    seq = []
+    lid = 0
+    for c, tokens, modules, layers in ((640, (latent // 2) ** 2, 5, 2), (1280, (latent // 4) ** 2, 6, 10)):
+        for mod in range(modules):
+            seq.append((f"c{c}.proj_in", tokens, c, c, True, f"m{c}.{mod}.in"))
+            for _ in range(layers):
+                L = f"L{lid}"
+                lid += 1
+                seq += [
+                    (f"c{c}.attn1.to_q", tokens, c, c, False, L + ".h1"), (f"c{c}.attn1.to_k", tokens, c, c, False, L + ".h1"),
+                    (f"c{c}.attn1.to_v", tokens, c, c, False, L + ".h1"), (f"c{c}.attn1.to_out", tokens, c, c, True, L + ".a1"),
+                    (f"c{c}.attn2.to_q", tokens, c, c, False, L + ".h2"), (f"c{c}.attn2.to_k", text_tokens, 2048, c, False, "text"),
+                    (f"c{c}.attn2.to_v", text_tokens, 2048, c, False, "text"), (f"c{c}.attn2.to_out", tokens, c, c, True, L + ".a2"),
+                    (f"c{c}.ff.proj_geglu", tokens, c, 8 * c, True, L + ".h3"), (f"c{c}.ff.out", tokens, 4 * c, c, True, L + ".g"),
+                ]
+            seq.append((f"c{c}.proj_out", tokens, c, c, True, f"m{c}.{mod}.out"))
+    for i, (k, n, rep) in enumerate(((1280, 320, 5), (1280, 640, 5), (1280, 1280, 7))):
+        seq += [(f"resnet.time_emb_proj.{n}", 1, k, n, True, "temb")] * rep
+    seq += [("add_embedding.linear_1", 1, 2816, 1280, True, "add_in"), ("add_embedding.linear_2", 1, 1280, 1280, True, "add_mid")]
+    return seq
+
+
 def flux_dev_linears(img_tokens: int = 4096, txt_tokens: int = 512, d: int = 3072):
     """FLUX.1-dev transformer, 1024^2 px: 19 double blocks + 38 single blocks."""
     t_all = img_tokens + txt_tokens
@@ -53,6 +80,36 @@ def flux_dev_linears(img_tokens: int = 4096, txt_tokens: int = 512, d: int = 307
         ("single.adaln", 1, d, 3 * d, True, 37),
     ]
     return out
+
+
+def flux_dev_layer_sequence(img_tokens: int = 4096, txt_tokens: int = 512, d: int = 3072):
+    """`flux_dev_linears` in execution order with activation identity (see `sdxl_unet_layer_sequence`): in the double
+    blocks q/k/v of each stream read one normed tensor, in the single blocks q/k/v/proj_mlp read one normed tensor, and
+    every adaLN modulation layer reads the one conditioning vector."""
+    t_all = img_tokens + txt_tokens
+    seq = []
+    for i in range(19):
+        for stream, tokens in (("img", img_tokens), ("txt", txt_tokens)):
+            p = f"D{i}.{stream}"
+            seq.append((f"double.{stream}.adaln", 1, d, 6 * d, True, "vec"))
+            seq += [(f"double.{stream}.qkv", tokens, d, d, True, p + ".n1")] * 3
+        for stream, tokens in (("img", img_tokens), ("txt", txt_tokens)):
+            p = f"D{i}.{stream}"
+            seq += [
+                (f"double.{stream}.out", tokens, d, d, True, p + ".a"),
+                (f"double.{stream}.ff.proj", tokens, d, 4 * d, True, p + ".n2"),
+                (f"double.{stream}.ff.out", tokens, 4 * d, d, True, p + ".g"),
+            ]
+    for i in range(38):
+        if i < 37:
+            seq.append(("single.adaln", 1, d, 3 * d, True, "vec"))
+        seq += [("single.qkv", t_all, d, d, True, f"S{i}.n")] * 3
+        seq += [("single.proj_mlp", t_all, d, 4 * d, True, f"S{i}.n"), ("single.proj_out", t_all, 5 * d, d, True, f"S{i}.cat")]
+    return seq
+
+
+def ops_of_sequence(seq, min_m: int = 0) -> int:
+    return sum(2 * m * k * n + (m * n if b else 0) for (_, m, k, n, b, _key) in seq if m >= min_m)
 
 
 def ops_of(shapes, min_m: int = 0) -> int:

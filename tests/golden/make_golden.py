@@ -270,6 +270,7 @@ def run_case(case):
 def run_dequant_dtypes():
     out, meta = {}, {"dtypes": {}}
     N, K = 16, 128
+    out["w_float"] = make_linear(K, N, seed=7, dtype=torch.float32, bias=False).weight.detach().numpy().copy()  # input of every entry
     for wd in DEQUANT_DTYPES:
         for gs in (-1, 32):
             lin = make_linear(K, N, seed=7, dtype=torch.float32, bias=False)

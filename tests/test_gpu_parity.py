@@ -288,3 +288,123 @@ def test_accelerate_repoints_a_foreign_module(gpu_device):
     assert sdnq_amd.accelerate(holder) == 1
     x = c.torch_tensor("x_48", device=gpu_device)
     assert np.array_equal(to_f32_numpy(holder(x)), c.f32("y_48"))
+
+
+@pytest.mark.parametrize("wdt,gs", [("int8", -1), ("int4", 32), ("uint4", 64), ("int6", 32), ("uint2", 16), ("int3", 32), ("fp8", -1),
+                                    ("float6_e3m2fn", 32), ("uint7", 128), ("int5", -1)])
+@pytest.mark.parametrize("m", [1, 5, 32])
+def test_fused_skinny_matches_dequant_then_linear(wdt, gs, m, gpu_device):
+    """M <= 32: the fused unpack+scale+GEMV kernel equals dequantize -> float linear (dequantizer.py:204 + F.linear)."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(11)
+    k, n = 384, 200
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin.to(gpu_device), sdnq_amd.SDNQConfig(weights_dtype=wdt, group_size=gs, use_quantized_matmul=False))
+    x = torch.randn(m, k, device=gpu_device, dtype=torch.bfloat16)
+    try:
+        L.FUSED_SKINNY = True
+        y_fused = mod(x)
+        L.FUSED_SKINNY = False
+        y_plain = mod(x)
+    finally:
+        L.FUSED_SKINNY = True
+    wd = mod.sdnq_dequantizer(mod.weight, mod.scale, mod.zero_point, None, None)
+    ref = O.linear_float(to_f32_numpy(x), to_f32_numpy(wd), to_f32_numpy(mod.bias), "bf16")
+    assert_close_float(to_f32_numpy(y_fused), ref, "bf16", (wdt, gs, m, "fused vs oracle"))
+    assert_close_float(to_f32_numpy(y_plain), ref, "bf16", (wdt, gs, m, "plain vs oracle"))
+
+
+def test_activation_cache_is_transparent(gpu_device):
+    """q/k/v-style sharing: three layers fed the same tensor object give bit-identical results with and without the
+    activation-quantization cache; an in-place update of the tensor invalidates its entry."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(5)
+    k, n, m = 640, 320, 96
+    mods = []
+    for i in range(3):
+        lin = torch.nn.Linear(k, n, bias=i == 2).to(torch.bfloat16).to(gpu_device)
+        mods.append(sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True))[0])
+    x = torch.randn(m, k, device=gpu_device, dtype=torch.bfloat16)
+    old = L.CACHE_ACTIVATIONS
+    try:
+        L.CACHE_ACTIVATIONS = 0
+        ref = [mo(x).clone() for mo in mods]
+        L.CACHE_ACTIVATIONS = 12
+        L.clear_activation_cache()
+        got = [mo(x).clone() for mo in mods]
+        assert len(L._act_cache.entries) == 1
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        x.mul_(2.0)
+        L.CACHE_ACTIVATIONS = 0
+        ref2 = mods[0](x).clone()
+        L.CACHE_ACTIVATIONS = 12
+        assert torch.equal(mods[0](x), ref2) and not torch.equal(ref2, ref[0])
+    finally:
+        L.CACHE_ACTIVATIONS = old
+        L.clear_activation_cache()
+
+
+def _golden_dtype_entries():
+    with open(os.path.join(GOLD, "dequant_dtypes.json")) as f:
+        return sorted(json.load(f)["dtypes"].keys())
+
+
+def _bytes_of(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().contiguous().cpu()
+    if t.dtype in (torch.int64, torch.bool):  # reference's 1-bit packer promotes to int64 words of 8 bits each
+        t = t.to(torch.uint8)
+    return t.view(torch.uint8).numpy().reshape(-1)
+
+
+@pytest.mark.parametrize("key", _golden_dtype_entries())
+def test_hip_quantizer_reproduces_reference_weights(key, gpu_device):
+    """8(f) rank 1: sdnq_hip_quantize_weight on the fixture's float weight == the reference quantizer's packed bytes,
+    scales and zero points, for every storage dtype x {row-wise, group 32} captured in tests/golden/dequant_dtypes.*."""
+    import sdnq_amd
+    from sdnq_amd import quantizer as Q
+    z = np.load(os.path.join(GOLD, "dequant_dtypes.npz"))
+    with open(os.path.join(GOLD, "dequant_dtypes.json")) as f:
+        ent = json.load(f)["dtypes"][key]
+    wd, gs = ent["deq"]["weights_dtype"], ent["deq"]["group_size"]
+    if wd in Q._HIP_QUANTIZER_SKIP:
+        pytest.skip(f"{wd}: host-side packer only")
+    w = torch.from_numpy(z["w_float"]).to(gpu_device)
+    assert Q.USE_HIP_QUANTIZER
+    dq, tensors = Q.sdnq_quantize_layer_weight(w, weights_dtype=wd, group_size=gs, use_quantized_matmul=False)
+    assert list(dq.quantized_weight_shape) == ent["deq"]["quantized_weight_shape"]
+    assert list(tensors["weight"].shape) == ent["tensors"]["weight"]["shape"], (key, tensors["weight"].shape)
+    assert np.array_equal(_bytes_of(tensors["weight"]), z[f"{key}.weight"].reshape(-1).view(np.uint8) if z[f"{key}.weight"].dtype != np.int64
+                          else z[f"{key}.weight"].astype(np.uint8)), (key, "codes")
+    assert np.array_equal(tensors["scale"].cpu().numpy().view(np.uint32), z[f"{key}.scale"].view(np.uint32)), (key, "scale")
+    if f"{key}.zero_point" in z:
+        assert np.array_equal(tensors["zero_point"].cpu().numpy().view(np.uint32), z[f"{key}.zero_point"].view(np.uint32)), (key, "zp")
+    else:
+        assert tensors["zero_point"] is None
+
+
+@pytest.mark.parametrize("wd,gs,dt", [("int4", 64, torch.bfloat16), ("uint4", 0, torch.bfloat16), ("int8", -1, torch.bfloat16),
+                                      ("fp8", -1, torch.float16), ("int6", -1, torch.float32), ("uint3", 48, torch.bfloat16),
+                                      ("float6_e3m2fn", 32, torch.bfloat16), ("int12", 32, torch.float32), ("uint5", 0, torch.float16)])
+@pytest.mark.parametrize("qmm", [False, True])
+def test_hip_quantizer_equals_host_quantizer(wd, gs, dt, qmm, gpu_device):
+    """Same module tensors (bit for bit, same shapes / strides) from the HIP quantizer on a GPU weight and the host-side
+    torch implementation on the CPU copy, through every layout branch (grouped, transposed-for-matmul, packed)."""
+    from sdnq_amd import quantizer as Q
+    g = torch.Generator().manual_seed(21)
+    w = (torch.randn(208, 384, generator=g) * 0.02).to(dt)
+    w[:, 5] *= 9
+    kw = dict(weights_dtype=wd, group_size=gs, use_quantized_matmul=qmm)
+    dq_c, t_c = Q.sdnq_quantize_layer_weight(w, **kw)
+    dq_g, t_g = Q.sdnq_quantize_layer_weight(w.to(gpu_device), **kw)
+    assert dq_c == dq_g
+    for key in ("weight", "scale", "zero_point"):
+        a, b = t_c[key], t_g[key]
+        assert (a is None) == (b is None), key
+        if a is None:
+            continue
+        strides = lambda t: tuple(st for st, sz in zip(t.stride(), t.shape) if sz > 1)  # noqa: E731  (size-1 dims carry no layout)
+        assert a.shape == b.shape and strides(a) == strides(b) and a.dtype == b.dtype, (key, a.shape, b.shape, a.stride(), b.stride(), a.dtype, b.dtype)
+        assert np.array_equal(_bytes_of(a), _bytes_of(b)), (wd, gs, key)

@@ -66,3 +66,33 @@ def test_apply_to_module_and_config_roundtrip():
     assert cfg2.weights_dtype == "uint4" and cfg2.use_quantized_matmul and cfg2.to_dict()["quant_method"] == "sdnq"
     with pytest.raises(NotImplementedError):
         sdnq_amd.SDNQConfig(use_codebook=True)
+
+
+def _dtype_entries():
+    import json
+    import os
+    from tests.golden_util import GOLD
+    with open(os.path.join(GOLD, "dequant_dtypes.json")) as f:
+        return json.load(f)["dtypes"]
+
+
+@pytest.mark.parametrize("key", sorted(_dtype_entries().keys()))
+def test_host_quantizer_reproduces_every_storage_dtype(key):
+    """All 84 dtype x group fixtures: codes (incl. the reference's unmasked-overflow quirk of uint9..15), scales, zero points."""
+    import os
+    from tests.golden_util import GOLD
+    ent = _dtype_entries()[key]
+    z = np.load(os.path.join(GOLD, "dequant_dtypes.npz"))
+    dq, t = quantizer.sdnq_quantize_layer_weight(torch.from_numpy(z["w_float"]), weights_dtype=ent["deq"]["weights_dtype"],
+                                                 group_size=ent["deq"]["group_size"], use_quantized_matmul=False)
+    a = t["weight"].contiguous()
+    a = (a.to(torch.uint8) if a.dtype in (torch.int64, torch.bool) else a).view(torch.uint8).numpy().reshape(-1)
+    b = z[key + ".weight"]
+    b = b.astype(np.uint8) if b.dtype == np.int64 else b.reshape(-1).view(np.uint8)
+    assert a.shape == b.shape and np.array_equal(a, b), (key, "codes")
+    assert list(t["weight"].shape) == ent["tensors"]["weight"]["shape"]
+    assert np.array_equal(t["scale"].numpy().view(np.uint32), z[key + ".scale"].view(np.uint32)), (key, "scale")
+    if key + ".zero_point" in z:
+        assert np.array_equal(t["zero_point"].numpy().view(np.uint32), z[key + ".zero_point"].view(np.uint32)), (key, "zero_point")
+    else:
+        assert t["zero_point"] is None
