@@ -406,6 +406,9 @@ extern "C" int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, s
     return SDNQ_OK;
 }
 
+int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,
+                    int64_t ldx, hipStream_t s);  // gemm.hip
+
 extern "C" int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
                                      int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {
     if (!x || !wd || !out) return SDNQ_ERR_NULL;
@@ -414,6 +417,8 @@ extern "C" int sdnq_hip_linear_float(const void* x, const void* wd, const void* 
     if (m <= 0 || n <= 0 || k <= 0 || ldx < k || ((k * eb) % 16) != 0) return SDNQ_ERR_SHAPE;
     if (((uintptr_t)x % 16) || ((uintptr_t)wd % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    // more than a few rows: the MFMA GEMM of gemm.hip (bf16 / f16 / f32 matrix cores); its stores are 8 channels wide
+    if (m > 32 && (n % 8) == 0 && ((uintptr_t)out % 16) == 0) return sdnq_float_gemm(x, wd, bias, dtype, out, m, n, k, ldx, s);
     constexpr int MC = 8;
     dim3 grid((unsigned)((n + 3) / 4), (unsigned)((m + MC - 1) / MC)), block(256);
     switch (dtype) {

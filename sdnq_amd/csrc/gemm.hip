@@ -59,7 +59,8 @@ struct GemmParams {
     const float* zp;           // [N] or null
     const float* a_zp;         // [M] activation zero point (uint8 matmul) or null
     const float* wcs;          // [N] f32(colsum(b)) * sb (uint8 matmul) or null
-    int64_t M, N, K;
+    int64_t M, N, K;   // K in BYTES of one operand row (== elements for int8 / fp8)
+    int64_t lda, ldb;  // operand row strides in bytes (0: K)
     int64_t ld_bias;
     int bias_ndim;
     int bias_dtype;  // SdnqFloat of bias (and of lr_t / lr_up, which share the svd dtype)
@@ -88,6 +89,25 @@ template <> struct MmaTraits<SDNQ_MM_FP8> {
     }
     static __device__ __forceinline__ float tof(const acc_t& c, int i) { return c[i]; }
 };
+
+// Plain float GEMMs (the dequantize-then-F.linear branch at M > 32, layers/linear/forward.py:25-26): same tiles, same LDS
+// image, K counted in BYTES.  32 bytes of a K row feed one v_mfma_f32_32x32x16_{bf16,f16} (8 elements per lane) or four
+// v_mfma_f32_32x32x2_f32 (lane holds 4 consecutive floats; MFMA r consumes float r of both operands, so lanes < 32 cover
+// k = 0..3 and lanes >= 32 cover k = 4..7 of the segment).  No scales: out = cast(acc + bias).
+enum { MM_BF16 = 2, MM_F16 = 3, MM_F32 = 4 };
+template <int MM> struct FloatMma {
+    typedef v16f acc_t;
+    static constexpr int KB = 32;
+    static __device__ __forceinline__ void zero(acc_t& c) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c[i] = 0.0f;
+    }
+    static __device__ __forceinline__ float tof(const acc_t& c, int i) { return c[i]; }
+};
+template <> struct MmaTraits<MM_BF16> : FloatMma<MM_BF16> {};
+template <> struct MmaTraits<MM_F16> : FloatMma<MM_F16> {};
+template <> struct MmaTraits<MM_F32> : FloatMma<MM_F32> {};
+template <int MM> constexpr bool is_float_mm = (MM >= MM_BF16);
 
 // LDS byte offset of 16-byte chunk c (0..7) of tile row r; rows are 128 B, chunk XOR-swizzled.
 // LDS byte offset of 16-byte chunk c of tile row r, XOR-swizzled so that the 16 lanes of a ds_read_b128 group (16
@@ -213,7 +233,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         int64_t g = (isA ? m0 : n0) + r;
         const int64_t lim = isA ? p.M : p.N;
         if (g >= lim) g = lim - 1;  // clamp: rows past the edge are computed on valid memory and never stored
-        src[i] = (isA ? p.a : p.b) + g * (int64_t)K + c * 16;
+        src[i] = (isA ? p.a + g * p.lda : p.b + g * p.ldb) + c * 16;
     }
     // logical K offset (bytes) of this lane's chunk: the swizzle only depends on (piece*8 + r8) >> 1, and piece*8 is a
     // multiple of 8, so the chunk is the same for every piece of an operand up to the parity of piece*4 -- NW is even,
@@ -278,7 +298,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int i = tid; i < BN; i += NT) {
         int64_t gn = n0 + i;
         if (gn >= p.N) gn = p.N - 1;
-        s_sb[i] = p.sb[gn];
+        if constexpr (!is_float_mm<MM>) s_sb[i] = p.sb[gn];
         if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = p.bias ? ldf_rt(p.bias, gn, p.bias_dtype) : 0.0f;
         if constexpr (EPI == EPI_LOWRANK) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
     }
@@ -308,6 +328,31 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                     for (int j = 0; j < TM; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
+        } else if constexpr (is_float_mm<MM>) {
+            v4i fa[KS][TM], fb[KS][TN];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off<BK>(wm * WM + j * 32 + frow, ks * 2 + fgrp, p.swz));
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off<BK>(wn * WN + i * 32 + frow, ks * 2 + fgrp, p.swz));
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        if constexpr (MM == MM_BF16) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fb[ks][i]), __builtin_bit_cast(v8bf, fa[ks][j]), acc[i][j], 0, 0, 0);
+                        } else if constexpr (MM == MM_F16) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fb[ks][i]), __builtin_bit_cast(v8h, fa[ks][j]), acc[i][j], 0, 0, 0);
+                        } else {
+                            const v4f wb = __builtin_bit_cast(v4f, fb[ks][i]), xa = __builtin_bit_cast(v4f, fa[ks][j]);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[r], xa[r], acc[i][j], 0, 0, 0);
+                        }
+                    }
         } else {
             v8i fa[KS][TM], fb[KS][TN];
 #pragma unroll
@@ -448,7 +493,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
         const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c8;
         if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a group of 8 never straddles N
-        const float sa = p.sa[gm];
+        const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
         float zsum = 0.0f, azp = 0.0f;
         if constexpr (EPI == EPI_LOWRANK) {
             if (p.zp_rowsum) zsum = (float)p.zp_rowsum[gm] * sa;  // .to(f32).mul_(input_scale), linear_int8.py:66
@@ -466,6 +511,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 const v4f t = *(const v4f*)(stage + r * ACC_ROW + (c8 + 4 * h) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a4[e] = t[e];
+            }
+            if constexpr (is_float_mm<MM>) {  // F.linear: f32 accumulate, bias added in f32, one rounding
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * h + e] = (EPI == EPI_BIAS1D) ? a4[e] + s_bias[c8 + 4 * h + e] : a4[e];
+                continue;
             }
             const v4f sb4 = *(const v4f*)(s_sb + c8 + 4 * h);
             v4f lr4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -546,6 +596,8 @@ int launch_one(GemmParams p, hipStream_t s) {
             return SDNQ_ERR_LAUNCH;
         attr_set.store(true, std::memory_order_release);
     }
+    if (p.lda == 0) p.lda = p.K;
+    if (p.ldb == 0) p.ldb = p.K;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = (int)((p.N + BN - 1) / BN);
     {
@@ -624,6 +676,20 @@ extern "C" int sdnq_hip_debug_trace(unsigned long long* host, int n_words) {
     return hipMemset(dptr, 0, sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -7;
 }
 #endif
+
+// internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`
+int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,
+                    int64_t ldx, hipStream_t s) {
+    const int eb = (dtype == SDNQ_F32) ? 4 : 2;
+    GemmParams p{};
+    p.a = (const uint8_t*)x; p.b = (const uint8_t*)w; p.bias = bias; p.out = out;
+    p.M = m; p.N = n; p.K = k * eb; p.lda = ldx * eb; p.ldb = k * eb; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = dtype;
+#define FG(MMV, T) (bias ? launch_tiles<MMV, T, EPI_BIAS1D>(p, s) : launch_tiles<MMV, T, EPI_NONE>(p, s))
+    if (dtype == SDNQ_BF16) return FG(MM_BF16, SDNQ_BF16);
+    if (dtype == SDNQ_F16) return FG(MM_F16, SDNQ_F16);
+    return FG(MM_F32, SDNQ_F32);
+#undef FG
+}
 
 extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
                                   const void* bias, int bias_dtype, int bias_ndim, int64_t ld_bias, void* out,

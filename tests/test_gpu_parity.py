@@ -408,3 +408,24 @@ def test_hip_quantizer_equals_host_quantizer(wd, gs, dt, qmm, gpu_device):
         strides = lambda t: tuple(st for st, sz in zip(t.stride(), t.shape) if sz > 1)  # noqa: E731  (size-1 dims carry no layout)
         assert a.shape == b.shape and strides(a) == strides(b) and a.dtype == b.dtype, (key, a.shape, b.shape, a.stride(), b.stride(), a.dtype, b.dtype)
         assert np.array_equal(_bytes_of(a), _bytes_of(b)), (wd, gs, key)
+
+
+@pytest.mark.parametrize("shape", [(48, 256, 512), (333, 80, 48), (1000, 336, 144), (2048, 640, 1280), (77, 2048, 640)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_float_gemm_vs_oracle(shape, dt, with_bias, gpu_device):
+    """M > 32 rows of the dequantize-then-F.linear branch run on the bf16 / f16 / f32 matrix cores (gemm.hip float
+    variants); compared with the oracle's fp32-accumulate linear on the same operands."""
+    m, k, n = shape
+    g = torch.Generator().manual_seed(m * 7 + k)
+    x = torch.randn(m, k, generator=g).to(dt)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dt)
+    b = torch.randn(n, generator=g).to(dt) if with_bias else None
+    y = ops.linear_float(x.to(gpu_device), w.to(gpu_device), None if b is None else b.to(gpu_device))
+    tag = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}[dt]
+    ref = O.linear_float(to_f32_numpy(x), to_f32_numpy(w), None if b is None else to_f32_numpy(b), tag)
+    assert y.dtype == dt and tuple(y.shape) == (m, n)
+    assert_close_float(to_f32_numpy(y), ref, tag, (shape, tag, with_bias))
+    if m >= 64:  # row-slab consistency: the GEMM path is independent of which rows share a tile
+        y2 = ops.linear_float(x[5:70].contiguous().to(gpu_device), w.to(gpu_device), None if b is None else b.to(gpu_device))
+        assert torch.equal(y2, y[5:70])
