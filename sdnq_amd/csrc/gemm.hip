@@ -151,6 +151,38 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
     return dt == SDNQ_F32 ? v : (dt == SDNQ_BF16 ? FT<SDNQ_BF16>::round(v) : FT<SDNQ_F16>::round(v));
 }
 
+// One MFMA operand fragment (the K-contiguous bytes of tile row `r` this lane feeds to K sub-step `ks`) and the MFMA on it.
+template <int MM> struct FragOps {
+    typedef v4i frag_t;
+    template <int BK> static __device__ __forceinline__ frag_t load(const uint8_t* s, int r, int ks, int fgrp, int swz) {
+        return *(const v4i*)(s + lds_off<BK>(r, ks * 2 + fgrp, swz));
+    }
+    static __device__ __forceinline__ void mma(typename MmaTraits<MM>::acc_t& c, const frag_t& w, const frag_t& x) {
+        if constexpr (MM == SDNQ_MM_I8) {
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, x, c, 0, 0, 0);
+        } else if constexpr (MM == MM_BF16) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, x), c, 0, 0, 0);
+        } else if constexpr (MM == MM_F16) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, x), c, 0, 0, 0);
+        } else {
+            const v4f wf = __builtin_bit_cast(v4f, w), xf = __builtin_bit_cast(v4f, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[r], xf[r], c, 0, 0, 0);
+        }
+    }
+};
+template <> struct FragOps<SDNQ_MM_FP8> {
+    typedef v8i frag_t;
+    template <int BK> static __device__ __forceinline__ frag_t load(const uint8_t* s, int r, int ks, int fgrp, int swz) {
+        const v4i lo = *(const v4i*)(s + lds_off<BK>(r, ks * 4 + fgrp * 2, swz));
+        const v4i hi = *(const v4i*)(s + lds_off<BK>(r, ks * 4 + fgrp * 2 + 1, swz));
+        return (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+    static __device__ __forceinline__ void mma(v16f& c, const frag_t& w, const frag_t& x) {
+        c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+};
+
 // BM x BN block tile, WM x WN wave tile (multiples of 32), NW = (BM/WM)*(BN/WN) waves, NS LDS stages.
 // EPI selects the epilogue at compile time.
 //
@@ -164,7 +196,11 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
 //            piece and ~1 us latency: bytes in flight are bounded by the LDS ring);
 //   LD_REG : global_load_dwordx4 into an NS-deep ring of VGPRs, then ds_write_b128 into a 2-buffer LDS: cheap to
 //            issue, in-flight bytes live in the (much larger) register file, the compiler counts vmcnt itself.
-enum { LD_DMA = 0, LD_REG = 1 };
+//   LD_PIPE: the LD_DMA ring, plus software pipelining of the LDS->register fragment reads: while the MFMAs of K sub-step
+//            ks run, the fragments of sub-step ks+1 (or of the next stage, right after the barrier) are already being
+//            read into the other of two fragment sets, so neither the LDS latency nor the two waves of a SIMD reading
+//            LDS in lock-step after every barrier leave the matrix pipe idle.
+enum { LD_DMA = 0, LD_REG = 1, LD_PIPE = 2 };
 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
@@ -178,7 +214,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     static_assert(BK == 64 || BK == 128, "stage rows are 64 or 128 bytes");
     static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
     constexpr int STAGE_BYTES = (BM + BN) * BK;
-    constexpr int LDS_STAGES = LD == LD_DMA ? NS : 2;
+    constexpr int LDS_STAGES = LD != LD_REG ? NS : 2;
     constexpr int OUT_B = FT<OUT_T>::bytes;
     constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [CH][ACC_ROW]
     constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // the tile leaves in ECH chunks of CH rows (LDS budget)
@@ -285,7 +321,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             *(uint4*)(stage + (isA ? 0 : BM * BK) + piece * 1024 + lane * 16) = R[d][i];
         }
     };
-    if constexpr (LD == LD_DMA) {
+    if constexpr (LD != LD_REG) {
 #pragma nounroll
         for (int s = 0; s < AHEAD; ++s) issue(s);
     } else {
@@ -383,7 +419,54 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
     };
 
-    if constexpr (LD == LD_DMA) {
+    if constexpr (LD == LD_PIPE) {
+        typedef typename FragOps<MM>::frag_t frag_t;
+        constexpr int KS = BK / MT::KB;
+        constexpr int U = (KS & 1) ? 2 : 1;  // stages per loop trip, so that the fragment-set parity is static
+        frag_t fa[2][TM], fb[2][TN];
+        auto load_set = [&](int slot, auto ksc, auto setc) {
+            constexpr int ks = decltype(ksc)::value, st = decltype(setc)::value;
+            const uint8_t* sA = lds + slot * STAGE_BYTES;
+            const uint8_t* sB = sA + BM * BK;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fa[st][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template load<BK>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+        };
+        auto mma_set = [&](auto setc) {
+            constexpr int st = decltype(setc)::value;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[st][i], fa[st][j]);
+        };
+        // stage 0 landed for every wave -> top up the ring (slot NS-1) -> first fragment set
+        wait_vmcnt<(AHEAD - 1) * PPW>();
+        __builtin_amdgcn_s_barrier();
+        issue(AHEAD);
+        load_set(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+#pragma nounroll
+        for (int kt = 0; kt < nk; kt += U) {
+            static_for_up<U * KS>([&](auto subc) {
+                constexpr int sub = decltype(subc)::value, u = sub / KS, ks = sub % KS, cur = sub & 1;
+                if constexpr (ks + 1 < KS) {
+                    load_set(slot_c, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, cur ^ 1>{});
+                } else {
+                    // end of stage kt+u: stage kt+u+1 must have landed (counted vmcnt: the NS-2 younger stages stay in
+                    // flight), this wave's own LDS reads of the finished stage must have completed (its slot is about
+                    // to be refilled), one barrier, refill, and the first fragments of the next stage start flowing
+                    // while the last MFMAs of this one run.
+                    wait_vmcnt<(AHEAD - 1) * PPW>();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    issue(kt + u + 1 + AHEAD);
+                    slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+                    load_set(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, cur ^ 1>{});
+                }
+                mma_set(std::integral_constant<int, cur>{});
+            });
+        }
+    } else if constexpr (LD == LD_DMA) {
         // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
         // single raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs.
 #pragma nounroll
@@ -585,7 +668,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB>
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int MAIN = (LD == LD_DMA ? NS : 2) * (BM + BN) * BK;
+    constexpr int MAIN = (LD != LD_REG ? NS : 2) * (BM + BN) * BK;
     constexpr int EPIB = (BM > 128 ? 64 : BM) * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1);
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 4 * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -621,9 +704,9 @@ template <int MM, int OUT_T, int EPI>
 int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     static const int force = [] { const char* e = getenv("SDNQ_HIP_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
-    if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_DMA, 64>(p, s);
-    if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);
-    if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);
+    if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
+    if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt). Every kernel launch starts with cold
     // L2s (data comes from MALL/HBM at ~2 us loaded latency) and the L2->LDS fill rate per CU is ~30 B/clk, so:
     //  * large problems: 256x256 tiles (8 waves of 128x64, 64-byte K stages, 4-deep ring) -- twice the MACs per byte
@@ -631,9 +714,11 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     //  * diffusion-size GEMMs (1-30 GOP): 64x128 tiles, two waves per SIMD and TWO co-resident workgroups per CU
     //    (3-deep ring, 72 KB LDS each);
     //  * few-row GEMMs (M <= 128, e.g. the 77-token text projections): 64x64 tiles.
-    if (tiles(256, 256) >= 200) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_DMA, 64>(p, s);
-    if (p.M > 128) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3>(p, s);
-    return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4>(p, s);
+    // Software-pipelined fragment reads (LD_PIPE) measured +3..9 % on the 256x256 tiles and +8 % on the 64x64 ones, -1.5 % on
+    // the SDXL step for the 64x128 tiles (one MFMA per sub-step leaves nothing to hide behind), so those keep LD_DMA.
+    if (tiles(256, 256) >= 200) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    if (p.M > 128) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
+    return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
 }
 
 template <int MM, int EPI>
