@@ -87,6 +87,9 @@ typedef struct SdnqWeight {
     int32_t exponent;        /* float kinds: exponent bits */
     int32_t mantissa;        /* float kinds: mantissa bits */
     int32_t native_float;    /* 1: codes are IEEE/OCP native (float8_e4m3fn, float8_e5m2, float16) */
+    int32_t positions;       /* 0 / 1: Linear.  P > 1: conv weight [N][C_in][P] quantized along C_in (quantizer.py:120-123,
+                                205-209): k = C_in * P, group_size counts CHANNELS, scale / zero_point are
+                                [N][C_in / group_size][P] (one per output channel, channel group and kernel position) */
 } SdnqWeight;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -198,6 +201,15 @@ int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, const void* 
  * nan_to_num, clamp, then the native conversion (fp8 e4m3fn / e5m2, fp16, bf16) or the reference's eXmY encoder. */
 int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, const SdnqWeight* w, float qmin,
                              float qmax, sdnq_stream_t stream);
+
+/* ---- 8(f) rank 3: convolution as GEMM -----------------------------------------------------------
+ * replaces the F.unfold(...).transpose(1, 2) of process_conv_input (layers/conv/forward.py:30-76) for Conv1d (height = 1,
+ * kh = 1) and Conv2d inputs x [batch][channels][height][width] of `dtype`: out [M][K] with rows m = (b, h_out, w_out),
+ * columns k = (c, i, j), zero padding; K * sizeof(dtype) must be a multiple of 16.  The result feeds sdnq_hip_rowquant /
+ * sdnq_hip_scaled_mm (conv_int8_matmul, layers/conv/conv_int8.py:18-91) or sdnq_hip_linear_float exactly like a Linear
+ * activation; the [M][C_out] product is the NHWC image of the convolution. */
+int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw, int stride_h,
+                    int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* out, sdnq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -319,19 +319,40 @@ class OracleLinear:
         if self.transposed:  # logical [K,N]
             vals = np.ascontiguousarray(vals.reshape(K, N).T)
         vals = vals.reshape(N, K)
-        group = d["group_size"] if d["group_size"] > 0 else K
-        G = K // group
+        P = self.positions
+        group = d["group_size"] if d["group_size"] > 0 else K // P
+        G = (K // P) // group * P
         sc = _c(self.scale, np.float32).reshape(-1)
         assert sc.size == N * G, (sc.size, N, G)
         zp = None if self.zero_point is None else _c(self.zero_point, np.float32).reshape(-1)
         return vals, sc, zp, group
 
+    @property
+    def positions(self) -> int:
+        """Conv weights quantized along C_in keep one scale per (output channel, channel group, kernel position)
+        (quantizer.py:120-123, 205-209); the flattened direct-matmul layout and Linear layers have P = 1."""
+        d = self.deq
+        if not str(d.get("layer_class_name", "Linear")).endswith(("Conv1d", "Conv2d")) or self.transposed:
+            return 1
+        return int(np.prod(d["original_shape"][2:]))
+
     def dequant_f32_nk(self) -> np.ndarray:
         """a4 core: W[n][k] = f32(w)*s (dequantizer.py:63) or fma(f32(w), s, zp) (:27)."""
         vals, sc, zp, group = self._nk_values_scale()
-        out = np.empty((self.N, self.K), dtype=np.float32)
-        lib().orc_dequant_f32(_p(_c(vals, np.float32)), _p(sc), _p(zp), self.N, self.K, group, _p(out))
-        return out
+        N, K, P = self.N, self.K, self.positions
+        out = np.empty((N, K), dtype=np.float32)
+        if P == 1:
+            lib().orc_dequant_f32(_p(_c(vals, np.float32)), _p(sc), _p(zp), N, K, group, _p(out))
+            return out
+        # conv: k = (c, pos) with scales [N][C/group][P].  Moving the position axis in front of the channel axis turns this
+        # into the contiguous-group layout of the C routine (k' = pos * C + c, scales [N][P][C/group]); element-wise, so exact.
+        C = K // P
+        G = C // group
+        v2 = _c(vals.reshape(N, C, P).transpose(0, 2, 1).reshape(N, K), np.float32)
+        sc2 = _c(sc.reshape(N, G, P).transpose(0, 2, 1).reshape(-1), np.float32)
+        zp2 = None if zp is None else _c(zp.reshape(N, G, P).transpose(0, 2, 1).reshape(-1), np.float32)
+        lib().orc_dequant_f32(_p(v2), _p(sc2), _p(zp2), N, K, group, _p(out))
+        return np.ascontiguousarray(out.reshape(N, P, C).transpose(0, 2, 1).reshape(N, K))
 
     def svd_nr_rk(self):
         """svd_up as [N,R], svd_down as [R,K] (the qmm layout stores them transposed, quantizer.py:164-167)."""
@@ -413,8 +434,47 @@ def lowrank_bias(t, up_nr, bias, tag: str) -> np.ndarray:
 # ------------------------------------------------------------------------------------------------
 # a1/a3/a12/a14: the forwards
 # ------------------------------------------------------------------------------------------------
-def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool = False):
-    """SDNQLinear.forward: dispatch of get_forward_func (forward.py:39-57) + the four Linear forwards."""
+def im2col(x: np.ndarray, kernel, stride, padding, dilation) -> tuple[np.ndarray, tuple]:
+    """F.unfold(x, ...).transpose(1, 2) (process_conv_input, layers/conv/forward.py:75): x [B,C,H,W] ->
+    ([B*Ho*Wo, C*kh*kw], (B, Ho, Wo)); columns ordered (c, i, j), zero padding."""
+    B, C, H, W = x.shape
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = kernel, stride, padding, dilation
+    Ho = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    xp = np.zeros((B, C, H + 2 * ph, W + 2 * pw), dtype=x.dtype)
+    xp[:, :, ph:ph + H, pw:pw + W] = x
+    cols = np.empty((B, Ho, Wo, C, kh, kw), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            cols[:, :, :, :, i, j] = xp[:, :, i * dh:i * dh + (Ho - 1) * sh + 1:sh, j * dw:j * dw + (Wo - 1) * sw + 1:sw].transpose(0, 2, 3, 1)
+    return np.ascontiguousarray(cols.reshape(B * Ho * Wo, C * kh * kw)), (B, Ho, Wo)
+
+
+def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.ndarray:
+    """SDNQConv1d / SDNQConv2d forward (layers/conv/forward.py:80-81, conv_int8.py:94-123, conv_fp8.py): unfold, the Linear
+    arithmetic on [M, K] rows, fold back to NCHW.  `conv` = {"nd", "kernel_size", "stride", "padding", "dilation",
+    "padding_mode", "groups"} as in the fixtures' meta."""
+    assert conv["groups"] == 1
+    nd = conv["nd"]
+    k, s, p, dl = (tuple(conv[f]) for f in ("kernel_size", "stride", "padding", "dilation"))
+    small = x.size / x.shape[2] < 32  # conv_int8.py:96 (evaluated on the conv input, before unfolding)
+    if conv["padding_mode"] != "zeros":  # forward.py:57-59
+        pads = [(0, 0), (0, 0)] + [(int(q), int(q)) for q in p]
+        x = np.pad(x, pads, mode={"reflect": "reflect", "replicate": "edge", "circular": "wrap"}[conv["padding_mode"]])
+        p = (0,) * nd
+    if nd == 1:
+        x = x[:, :, None, :]
+        k, s, p, dl = (1, k[0]), (1, s[0]), (0, p[0]), (1, dl[0])
+    x2d, (B, Ho, Wo) = im2col(np.asarray(x, dtype=np.float32), k, s, p, dl)
+    y = forward(mod, x2d, tag, small_batch=small)
+    if nd == 1:
+        return np.ascontiguousarray(y.reshape(B, Wo, mod.N).transpose(0, 2, 1))
+    return np.ascontiguousarray(y.reshape(B, Ho, Wo, mod.N).transpose(0, 3, 1, 2))
+
+
+def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool = False, small_batch=None):
+    """SDNQLinear.forward: dispatch of get_forward_func (forward.py:39-57) + the four Linear forwards.
+    small_batch: override of the M < 32 branch predicate (the conv forwards evaluate it on the un-folded input)."""
     d = mod.deq
     K, N = mod.K, mod.N
     lead = x.shape[:-1]
@@ -422,7 +482,9 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
     M = x2.shape[0]
     inter = {}
     mmd = d["quantized_matmul_dtype"]
-    if not d["use_quantized_matmul"] or M < 32:
+    if small_batch is None:
+        small_batch = M < 32
+    if not d["use_quantized_matmul"] or small_batch:
         # quantized_linear_forward (layers/linear/forward.py:25-26) and the M<32 branch (linear_int8.py:102-103)
         W = mod.dequantize(mod.result_tag)  # dtype defaults to result_dtype (dequantizer.py:402-403)
         y = linear_float(x2, W, mod.bias, tag)

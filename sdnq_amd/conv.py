@@ -1,0 +1,76 @@
+"""Conv1d / Conv2d forwards of SDNQ-quantized layers as im2col + the Linear kernels.
+
+Mirrors the reference's conv forwards (layers/conv/forward.py:80-81 ``quantized_conv_forward``,
+layers/conv/conv_int8.py:94-123 ``quantized_conv_forward_int8_matmul``, conv_fp8.py): the input is unfolded to
+``[B * H_out * W_out, C_in * kh * kw]`` (``process_conv_input``, forward.py:30-76) by ``sdnq_hip_im2col``; from there the
+arithmetic is the Linear one -- row quantization, int8 / fp8 MFMA scaled matmul with the fused epilogue, or dequantize +
+float GEMM -- and the ``[M, C_out]`` product is viewed back to NCHW (conv_int8.py:81-88).  The float branch uses this build's
+own GEMM instead of the library convolution the reference calls (``_conv_forward``): same sum, fp32 accumulation.
+
+Not built (raise): groups != 1 (the reference loops ``int_mm`` per group, conv_int8.py:73-79), Conv3d, uint8 / fp16 matmul,
+Hadamard on conv layers.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import linear, ops
+
+
+def _pair(v, n):
+    return (int(v),) * n if isinstance(v, int) else tuple(int(e) for e in v)
+
+
+def _unfold(self, input: torch.Tensor):
+    """-> (x2d [M, K], fold) where fold(y2d [M, N]) gives the conv output in the reference's layout."""
+    if self.groups != 1:
+        raise NotImplementedError("SDNQ conv with groups != 1 is not built for MI355X")
+    if self.sdnq_dequantizer.use_hadamard:
+        raise NotImplementedError("Hadamard-rotated conv layers are not built for MI355X")
+    if isinstance(self.padding, str):
+        raise NotImplementedError("string padding modes ('same' / 'valid') are not supported by the reference's conv matmul either")
+    nd = input.ndim - 2
+    if nd not in (1, 2):
+        raise NotImplementedError(f"{input.ndim}-D conv input: only Conv1d / Conv2d are built")
+    stride, padding, dilation = _pair(self.stride, nd), _pair(self.padding, nd), _pair(self.dilation, nd)
+    kernel = tuple(int(k) for k in self.sdnq_dequantizer.original_shape[2:])
+    if self.padding_mode != "zeros":  # forward.py:57-59: explicit padding first, then an unpadded unfold
+        input = torch.nn.functional.pad(input, self._reversed_padding_repeated_twice, mode=self.padding_mode)
+        padding = (0,) * nd
+    if nd == 1:  # forward.py:24-27, 66-67: Conv1d is the H = 1 case
+        input = input.unsqueeze(2)
+        kernel, stride, padding, dilation = (1, kernel[0]), (1, stride[0]), (0, padding[0]), (1, dilation[0])
+    x2d, (b, ho, wo) = ops.im2col(input, kernel, stride, padding, dilation)
+    n = self.sdnq_dequantizer.out_features
+
+    def fold(y2d: torch.Tensor) -> torch.Tensor:
+        if nd == 1:
+            return y2d.view(b, wo, n).transpose(1, 2).contiguous()  # conv_int8.py:81-82
+        return y2d.view(b, ho, wo, n).permute(0, 3, 1, 2).contiguous()  # conv_int8.py:83-84, 87
+    return x2d, fold
+
+
+@torch.no_grad()
+def quantized_conv_forward(self, input: torch.Tensor) -> torch.Tensor:
+    x2d, fold = _unfold(self, input)
+    return fold(linear._float_forward(self, x2d, linear._state(self)))
+
+
+def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
+    dq = self.sdnq_dequantizer
+    if dq.is_packed and not dq.re_quantize_for_matmul:
+        raise NotImplementedError("packed conv weights with a direct quantized matmul have no valid layout in the reference")
+    x2d, fold = _unfold(self, input)
+    if input.numel() / input.shape[2] < 32:  # conv_int8.py:96-97 (the reference's criterion, not the row count)
+        return fold(linear._float_forward(self, x2d, linear._state(self)))
+    return fold(linear._quantized_matmul_forward(self, x2d, mm, small_batch_branch=False))
+
+
+@torch.no_grad()
+def quantized_conv_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    return _conv_matmul_forward(self, input, ops.MM_I8)
+
+
+@torch.no_grad()
+def quantized_conv_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    return _conv_matmul_forward(self, input, ops.MM_FP8)

@@ -8,10 +8,10 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argum
 OBJ="$HERE/../../build/obj"
 mkdir -p "$OBJ"
 pids=()
-for f in api rowquant gemm dequant quantize; do
+for f in api rowquant gemm dequant quantize conv; do
   ( "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" "$OBJ"/api.o "$OBJ"/rowquant.o "$OBJ"/gemm.o "$OBJ"/dequant.o "$OBJ"/quantize.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" "$OBJ"/api.o "$OBJ"/rowquant.o "$OBJ"/gemm.o "$OBJ"/dequant.o "$OBJ"/quantize.o "$OBJ"/conv.o
 echo "built $OUT"

@@ -24,15 +24,25 @@ struct DeqParams {
     const void* svd_down;  // [R][K]
     int64_t N, K;
     int group_size, G, rank;
+    int P, SG;  // conv weights: kernel positions per channel (1 for Linear) and scales per output row (G * P)
     WeightFmt fmt;
 };
 
 // dequantize 16 elements (row n, columns k0..k0+15) to fp32: f32(w)*s or fma(f32(w), s, zp)
 __device__ __forceinline__ void dequant16(const DeqParams& p, int64_t n, int64_t k0, float (&v)[16]) {
     load16_values(p.w, n * p.K + k0, p.fmt, v);
-    const float* srow = p.scale + n * p.G;
-    const float* zrow = p.zp ? p.zp + n * p.G : nullptr;
-    if ((p.group_size & 15) == 0) {  // one group covers the whole 16-run (wave-uniform branch)
+    const float* srow = p.scale + n * p.SG;
+    const float* zrow = p.zp ? p.zp + n * p.SG : nullptr;
+    if (p.P > 1) {
+        // conv weight [C_out][C_in][positions] quantized along C_in (quantizer.py:120-123, 205-209): one scale per
+        // (output channel, channel group, kernel position); flattened k = c * P + pos
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = (int)(k0 + j), c = k / p.P;
+            const int g = (c / p.group_size) * p.P + (k - c * p.P);
+            v[j] = zrow ? fmaf(v[j], srow[g], zrow[g]) : v[j] * srow[g];
+        }
+    } else if ((p.group_size & 15) == 0) {  // one group covers the whole 16-run (wave-uniform branch)
         const int g = (int)(k0 / p.group_size);
         const float s = srow[g];
         if (zrow) {
@@ -317,7 +327,8 @@ __global__ __launch_bounds__(512) void lowrank_down_kernel(const uint16_t* __res
 
 int fill_params(const SdnqWeight* w, DeqParams& p) {
     if (!w || !w->weight || !w->scale) return SDNQ_ERR_NULL;
-    if (w->n <= 0 || w->k <= 0 || w->group_size <= 0 || (w->k % w->group_size) != 0) return SDNQ_ERR_SHAPE;
+    const int pos = w->positions > 1 ? w->positions : 1;
+    if (w->n <= 0 || w->k <= 0 || w->group_size <= 0 || (w->k % pos) != 0 || ((w->k / pos) % w->group_size) != 0) return SDNQ_ERR_SHAPE;
     if ((w->k % 16) != 0) return SDNQ_ERR_SHAPE;
     if (w->storage < 0 || w->storage > 3 || w->kind < 0 || w->kind > 3) return SDNQ_ERR_DTYPE;
     if (w->bits < 1 || w->bits > 16) return SDNQ_ERR_DTYPE;
@@ -334,7 +345,8 @@ int fill_params(const SdnqWeight* w, DeqParams& p) {
     if ((w->svd_up == nullptr) != (w->svd_down == nullptr)) return SDNQ_ERR_NULL;
     if (w->svd_up && (w->svd_rank <= 0 || w->svd_dtype < 0 || w->svd_dtype > 2)) return SDNQ_ERR_SHAPE;
     p.w = w->weight; p.scale = w->scale; p.zp = w->zero_point; p.svd_up = w->svd_up; p.svd_down = w->svd_down;
-    p.N = w->n; p.K = w->k; p.group_size = w->group_size; p.G = w->k / w->group_size; p.rank = w->svd_rank;
+    p.N = w->n; p.K = w->k; p.group_size = w->group_size; p.G = (w->k / pos) / w->group_size; p.rank = w->svd_rank;
+    p.P = pos; p.SG = p.G * pos;
     p.fmt = WeightFmt{w->storage, w->kind, w->bits, w->exponent, w->mantissa, w->native_float};
     return SDNQ_OK;
 }

@@ -37,6 +37,7 @@ struct QuantParams {
     const void* src;
     int64_t ld, N, K;
     int group_size, G;
+    int P, SG;  // conv: kernel positions per channel (1 for Linear), scales per output row = G * P
     void* q;
     float* scale;
     float* zp;
@@ -62,14 +63,16 @@ template <int SRC_T, int LANES>
 __global__ __launch_bounds__(256) void quant_stats_kernel(const QuantParams p) {
     const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LANES;
     const int l = threadIdx.x % LANES;
-    const bool live = gid < p.N * p.G;
-    const int64_t n = live ? gid / p.G : 0;
-    const int g = live ? (int)(gid % p.G) : 0;
-    const int64_t base = n * p.ld + (int64_t)g * p.group_size;
+    const bool live = gid < p.N * p.SG;
+    const int64_t n = live ? gid / p.SG : 0;
+    const int sg = live ? (int)(gid % p.SG) : 0;
+    // Linear: group g = sg, elements contiguous.  Conv (P > 1): sg = (channel group, position); the group's elements are the
+    // group's channels at that kernel position: k = (cg * group_size + j) * P + pos
+    const int64_t base = n * p.ld + (int64_t)(sg / p.P) * p.group_size * p.P + (sg % p.P);
     float lo = __builtin_inff(), hi = -__builtin_inff(), amax = 0.0f;
     if (live) {
         for (int j = l; j < p.group_size; j += LANES) {
-            const float v = FT<SRC_T>::load(p.src, base + j);
+            const float v = FT<SRC_T>::load(p.src, base + (int64_t)j * p.P);
             lo = fminf(lo, v);
             hi = fmaxf(hi, v);
             amax = fmaxf(amax, fabsf(v));
@@ -144,7 +147,8 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const QuantParams p, co
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const float w = FT<SRC_T>::load(p.src, n * p.ld + k0 + j);
-        const int64_t gi = n * p.G + (k0 + j) / p.group_size;
+        const int kk = (int)(k0 + j), cc = kk / p.P;
+        const int64_t gi = n * p.SG + (p.P > 1 ? (cc / p.group_size) * p.P + (kk - cc * p.P) : kk / p.group_size);
         const float s = p.scale[gi];
         float q = asym ? (w - p.zp[gi]) / s : w / s;
         u32 code;
@@ -257,7 +261,7 @@ int build_table(int storage, int bits, PackTable& t) {
 
 template <int SRC_T>
 int launch(const QuantParams& p, const PackTable& t, hipStream_t s) {
-    const int64_t groups = p.N * p.G;
+    const int64_t groups = p.N * p.SG;
     const int gs = p.group_size;
 #define STATS(L)                                                                                              \
     hipLaunchKernelGGL((quant_stats_kernel<SRC_T, L>), dim3((unsigned)((groups * L + 255) / 256)), dim3(256), 0, s, p)
@@ -279,7 +283,8 @@ extern "C" int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t 
                                         float qmax, sdnq_stream_t stream) {
     if (!src || !w || !w->weight || !w->scale) return SDNQ_ERR_NULL;
     if (src_dtype < 0 || src_dtype > 2) return SDNQ_ERR_DTYPE;
-    if (w->n <= 0 || w->k <= 0 || w->group_size <= 0 || (w->k % w->group_size) != 0 || (w->k % 16) != 0) return SDNQ_ERR_SHAPE;
+    const int pos = w->positions > 1 ? w->positions : 1;
+    if (w->n <= 0 || w->k <= 0 || w->group_size <= 0 || (w->k % pos) != 0 || ((w->k / pos) % w->group_size) != 0 || (w->k % 16) != 0) return SDNQ_ERR_SHAPE;
     if (w->storage < 0 || w->storage > 3 || w->kind < 0 || w->kind > 3 || w->bits < 1 || w->bits > 16) return SDNQ_ERR_DTYPE;
     if (w->storage == SDNQ_ST_PACKED_U8 && w->bits > 7) return SDNQ_ERR_DTYPE;
     if (w->storage == SDNQ_ST_PACKED_I16 && (w->bits < 9 || w->bits > 15)) return SDNQ_ERR_DTYPE;
@@ -300,7 +305,7 @@ extern "C" int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t 
     if (!(qmax > qmin)) return SDNQ_ERR_SHAPE;
     if ((uintptr_t)w->weight % 16) return SDNQ_ERR_ALIGN;
     QuantParams p{};
-    p.src = src; p.ld = ld_src; p.N = w->n; p.K = w->k; p.group_size = w->group_size; p.G = w->k / w->group_size;
+    p.src = src; p.ld = ld_src; p.N = w->n; p.K = w->k; p.group_size = w->group_size; p.G = (w->k / pos) / w->group_size; p.P = pos; p.SG = p.G * pos;
     p.q = const_cast<void*>(w->weight); p.scale = const_cast<float*>(w->scale); p.zp = const_cast<float*>(w->zero_point);
     p.fmt = WeightFmt{w->storage, w->kind, w->bits, w->exponent, w->mantissa, w->native_float};
     p.qmin = qmin; p.qmax = qmax;

@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import torch
 
 from . import ops
-from .common import dtype_dict
+from .common import conv_types, dtype_dict, linear_types
 
 
 @dataclass
@@ -73,7 +73,26 @@ class SDNQDequantizer:
 
     @property
     def in_features(self) -> int:
-        return int(self.original_shape[-1])
+        """K of the matmul: in_features of a Linear, C_in * prod(kernel) of a conv weight (flatten(1, -1), quantizer.py:123)."""
+        k = 1
+        for d in self.original_shape[1:]:
+            k *= int(d)
+        return k
+
+    @property
+    def is_conv(self) -> bool:
+        return self.layer_class_name in conv_types
+
+    @property
+    def kernel_positions(self) -> int:
+        """P of the scale layout: conv weights that were NOT flattened before quantization carry one scale per
+        (output channel, channel group, kernel position) (quantizer.py:120-123, 205-209); 1 otherwise."""
+        if not self.is_conv or self.weight_is_transposed:
+            return 1
+        p = 1
+        for d in self.original_shape[2:]:
+            p *= int(d)
+        return p
 
     @property
     def weight_is_transposed(self) -> bool:
@@ -83,12 +102,13 @@ class SDNQDequantizer:
     def quant_weight(self, weight, scale, zero_point=None, svd_up=None, svd_down=None) -> ops.QuantWeight:
         if self.use_codebook:
             raise NotImplementedError("use_codebook (Lloyd-Max LUT) is outside the MI355X hot path (SURVEY 8a note)")
-        if self.layer_class_name not in ("Linear", "SDNQLinear"):
-            raise NotImplementedError(f"{self.layer_class_name}: only Linear layers are on the MI355X hot path")
-        n, k = self.out_features, self.in_features
-        group = self.group_size if self.group_size > 0 else k
+        if self.layer_class_name not in linear_types and self.layer_class_name not in conv_types:
+            raise NotImplementedError(f"{self.layer_class_name}: only Linear and Conv1d/Conv2d layers are built for MI355X")
+        n, k, pos = self.out_features, self.in_features, self.kernel_positions
+        group = self.group_size if self.group_size > 0 else k // pos
         return ops.make_quant_weight(self.weights_dtype, weight, scale, zero_point, svd_up, svd_down, n, k, group,
-                                     transposed=self.weight_is_transposed, svd_transposed=bool(self.use_quantized_matmul))
+                                     transposed=self.weight_is_transposed, svd_transposed=bool(self.use_quantized_matmul),
+                                     positions=pos)
 
     @torch.no_grad()
     def re_quantize_matmul(self, weight, scale, zero_point=None, svd_up=None, svd_down=None, hadamard=None,

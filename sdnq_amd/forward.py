@@ -8,10 +8,20 @@ from .common import conv_transpose_types, conv_types, dtype_dict, embedding_type
 
 
 def get_forward_func(layer_class_name: str, quantized_matmul_dtype: str, use_quantized_matmul: bool) -> Callable:
-    if layer_class_name in embedding_types or layer_class_name in conv_types or layer_class_name in conv_transpose_types:
+    if layer_class_name in embedding_types or layer_class_name in conv_transpose_types or layer_class_name in ("Conv3d", "SDNQConv3d"):
         raise NotImplementedError(
-            f"{layer_class_name}: only Linear layers are on the MI355X hot path (quant_conv / quant_embedding are off by "
-            "default in the reference, quantizer.py:952-953)")
+            f"{layer_class_name}: only Linear and Conv1d / Conv2d layers are built for MI355X (quant_embedding and transposed / "
+            "3-D convolutions are outside SURVEY 8)")
+    if layer_class_name in conv_types:  # forward.py:10-28
+        from . import conv
+        if use_quantized_matmul:
+            ent = dtype_dict[quantized_matmul_dtype]
+            if ent["is_integer"] and not ent["is_unsigned"]:
+                return conv.quantized_conv_forward_int8_matmul
+            if not ent["is_integer"] and ent["num_bits"] == 8:
+                return conv.quantized_conv_forward_fp8_matmul
+            raise NotImplementedError(f"conv matmul in {quantized_matmul_dtype} is not built (int8 and fp8 are)")
+        return conv.quantized_conv_forward
     from . import linear
     if use_quantized_matmul:
         ent = dtype_dict[quantized_matmul_dtype]

@@ -52,11 +52,24 @@ class SDNQLinear(SDNQLayer, torch.nn.Linear):
     original_class: torch.nn.Linear
 
 
-torch.serialization.add_safe_globals([SDNQLayer, SDNQLinear])
+class SDNQConv1d(SDNQLayer, torch.nn.Conv1d):
+    original_class: torch.nn.Conv1d
+
+
+class SDNQConv2d(SDNQLayer, torch.nn.Conv2d):
+    original_class: torch.nn.Conv2d
+
+
+torch.serialization.add_safe_globals([SDNQLayer, SDNQLinear, SDNQConv1d, SDNQConv2d])
 
 
 def get_sdnq_wrapper_class(original_layer: torch.nn.Module, forward_func: Callable) -> SDNQLayer:
-    if original_layer.__class__.__name__ == "Linear":
+    name = original_layer.__class__.__name__
+    if name == "Linear":
         return SDNQLinear(original_layer, forward_func)
-    # conv / embedding wrappers are outside the hot path this build covers
+    if name == "Conv1d":
+        return SDNQConv1d(original_layer, forward_func)
+    if name == "Conv2d":
+        return SDNQConv2d(original_layer, forward_func)
+    # Conv3d / transposed conv / embedding wrappers are not built
     return SDNQLayer(original_layer, forward_func)

@@ -124,6 +124,10 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
     if input.dtype != dq.result_dtype:
         raise RuntimeError(f"expected input dtype {dq.result_dtype} (the layer's result_dtype) but got {input.dtype}")
     m = input.numel() // input.shape[-1]
+    if m == 0:  # empty batch: nothing to launch (F.linear returns an empty [.., N] tensor)
+        if not input.is_cuda:
+            raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
+        return input.new_empty(*input.shape[:-1], n)
     if FUSED_SKINNY and m <= 32 and st.svd_up is None and k % 16 == 0:
         # few rows (time/AdaLN embeddings, the M < 32 branch): stream the quantized weight once instead of writing and
         # re-reading a dequantized copy; on Hadamard layers the kernel un-rotates each weight run in registers.
@@ -176,12 +180,12 @@ def _prepare_mm_weights(mod, st: _State, mm: int):
     return wq, ws, zp
 
 
-def _quantized_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
+def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_branch: bool = True) -> torch.Tensor:
     dq = self.sdnq_dequantizer
     st = _state(self)
     k, n = dq.in_features, dq.out_features
     m = input.numel() // input.shape[-1]
-    if m < 32:  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
+    if m == 0 or (small_batch_branch and m < 32):  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
         return _float_forward(self, input, st)
     wq, ws, zp = _prepare_mm_weights(self, st, mm)
     had = dq.hadamard_group_size if dq.use_hadamard else 0

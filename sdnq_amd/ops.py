@@ -92,7 +92,8 @@ def _storage_kind(weights_dtype: str):
 
 
 def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Tensor, zero_point, svd_up, svd_down,
-                      n: int, k: int, group_size: int, transposed: bool, svd_transposed: bool | None = None) -> QuantWeight:
+                      n: int, k: int, group_size: int, transposed: bool, svd_transposed: bool | None = None,
+                      positions: int = 1) -> QuantWeight:
     """Canonicalise module tensors (reference layouts) into the kernels' physical layout.
 
     transposed=False: weight is packed bytes / [N,K] / [N,G,g] (element order [N][K]); svd_up [N,R], svd_down [R,K].
@@ -103,6 +104,8 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
                       scale [1,N].
     svd_transposed  : svd_up [R,N], svd_down [K,R] -- the quantizer transposes the SVD factors whenever
                       use_quantized_matmul is on, independent of the weight layout (quantizer.py:164-167).
+    positions       : P > 1 for conv weights [N, C_in, *kernel] quantized along C_in (quantizer.py:120-123, 205-209):
+                      k = C_in * P, group_size counts channels, scale / zero_point hold N * (C_in / group_size) * P values.
     """
     if svd_transposed is None:
         svd_transposed = transposed
@@ -122,7 +125,7 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
             w_phys = w_phys.to(torch.uint8)
     if scale.dtype != torch.float32:
         raise _lib.SdnqHipError("scale must be float32 (dequantize_fp32=True, the reference default)")
-    g = k // group_size
+    g = (k // positions) // group_size * positions
     sc = scale.contiguous().view(-1)
     if sc.numel() != n * g:
         raise _lib.SdnqHipError(f"scale has {sc.numel()} elements, expected N*G = {n * g}")
@@ -144,7 +147,7 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
         svd_dt = float_code(up.dtype)
     d = SdnqWeight(weight=_ptr(w_phys), scale=_ptr(sc), zero_point=_ptr(zp), svd_up=_ptr(up), svd_down=_ptr(down),
                    n=n, k=k, group_size=group_size, svd_rank=rank, svd_dtype=svd_dt, storage=storage, kind=kind,
-                   bits=bits, exponent=ebits, mantissa=mbits, native_float=native)
+                   bits=bits, exponent=ebits, mantissa=mbits, native_float=native, positions=positions)
     return QuantWeight(desc=d, n=n, k=k, group_size=group_size, keep=(w_phys, sc, zp, up, down))
 
 
@@ -293,11 +296,31 @@ def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor
     return t
 
 
-def quantize_weight(weight2d: torch.Tensor, weights_dtype: str, group_size: int):
+def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Tensor, tuple]:
+    """F.unfold(x, ...).transpose(1, 2) for x [B, C, H, W] -> ([B * H_out * W_out, C * kh * kw], (B, H_out, W_out));
+    HIP replacement of process_conv_input's unfold (layers/conv/forward.py:75)."""
+    _require_cuda(x)
+    if x.ndim != 4:
+        raise _lib.SdnqHipError("im2col expects [B, C, H, W]")
+    x = x if x.is_contiguous() else x.contiguous()
+    b, c, h, w = x.shape
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = kernel, stride, padding, dilation
+    ho = (h + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (w + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if ho <= 0 or wo <= 0:
+        raise _lib.SdnqHipError(f"convolution output would be empty ({ho} x {wo})")
+    out = torch.empty((b * ho * wo, c * kh * kw), device=x.device, dtype=x.dtype)
+    check(_lib.load().sdnq_hip_im2col(x.data_ptr(), float_code(x.dtype), b, c, h, w, kh, kw, sh, sw, ph, pw, dh, dw, out.data_ptr(),
+                                      _stream(x)), "im2col")
+    return out, (b, ho, wo)
+
+
+def quantize_weight(weight2d: torch.Tensor, weights_dtype: str, group_size: int, positions: int = 1):
     """Float [N,K] weight -> (codes, scale [N,G] f32, zero_point [N,G] f32 | None) with the codes in the reference's storage
     (packed words shaped like the reference's packers return them, or [N,K] raw int8/uint8/int16/fp8/fp16...).
     HIP replacement of quantize_weight + pack_int / pack_float (quant_utils.py:28-56, packed_int/__init__.py:77-80,
-    packed_float.py:27-82); `group_size` == K for row-wise."""
+    packed_float.py:27-82); `group_size` == K for row-wise.  positions = P > 1: conv weight flattened to [N, C_in * P],
+    group_size counts channels, scales are [N, (C_in / group_size) * P]."""
     from .common import dtype_dict
     from . import packed as _packed
     _require_cuda(weight2d)
@@ -307,7 +330,7 @@ def quantize_weight(weight2d: torch.Tensor, weights_dtype: str, group_size: int)
     n, k = w.shape
     ent = dtype_dict[weights_dtype]
     storage, kind, bits, ebits, mbits, native = _storage_kind(weights_dtype)
-    g = k // group_size
+    g = (k // positions) // group_size * positions
     dev = w.device
     if storage == _lib.ST_PACKED_U8:
         raw = torch.empty((n * k // 8 * bits,), device=dev, dtype=torch.uint8)
@@ -321,7 +344,7 @@ def quantize_weight(weight2d: torch.Tensor, weights_dtype: str, group_size: int)
     zp = torch.empty((n, g), device=dev, dtype=torch.float32) if ent["is_unsigned"] else None
     d = SdnqWeight(weight=raw.data_ptr(), scale=scale.data_ptr(), zero_point=_ptr(zp), svd_up=None, svd_down=None, n=n, k=k,
                    group_size=group_size, svd_rank=0, svd_dtype=0, storage=storage, kind=kind, bits=bits, exponent=ebits,
-                   mantissa=mbits, native_float=native)
+                   mantissa=mbits, native_float=native, positions=positions)
     check(_lib.load().sdnq_hip_quantize_weight(w.data_ptr(), float_code(w.dtype), w.stride(0), ctypes.byref(d), float(ent["min"]),
                                                float(ent["max"]), _stream(w)), "quantize_weight")
     if ent["is_packed"] and bits not in (8, 16):

@@ -64,6 +64,9 @@ def apply_hadamard(weight: torch.Tensor, group_size: int = 256):
 
 def apply_svdquant(weight: torch.Tensor, rank: int = 32, steps: int = 8, dtype: torch.dtype | None = None):
     """Split W = svd_up @ svd_down + residual with a randomized low-rank SVD; the residual is what gets quantized."""
+    shape = weight.shape
+    if weight.ndim > 2:  # conv weights: factor the flattened [C_out, C_in * kernel] matrix (quant_utils.py:126-129)
+        weight = weight.flatten(1, -1)
     w = weight.to(torch.float32) if weight.dtype != torch.float64 else weight
     u, s, v = torch.svd_lowrank(w, q=rank, niter=steps)
     svd_up = u * s.unsqueeze(0)
@@ -71,6 +74,8 @@ def apply_svdquant(weight: torch.Tensor, rank: int = 32, steps: int = 8, dtype: 
     if dtype is not None:
         svd_up, svd_down = svd_up.to(dtype), svd_down.to(dtype)
     residual = w - torch.mm(svd_up, svd_down)
+    if len(shape) > 2:
+        residual = residual.unflatten(-1, tuple(shape[1:]))
     return residual, svd_up, svd_down
 
 

@@ -16,7 +16,7 @@ from enum import Enum
 import torch
 
 from . import packed
-from .common import dtype_dict, linear_types, sdnq_version
+from .common import conv_types, dtype_dict, linear_types, sdnq_version
 from .dequantizer import SDNQDequantizer
 from .forward import get_forward_func
 from .layers import get_sdnq_wrapper_class
@@ -62,7 +62,7 @@ class SDNQConfig:
             raise ValueError(f"SDNQ only support weight dtypes in {sorted(dtype_dict)} but found {weights_dtype}")
         if quantized_matmul_dtype is not None and quantized_matmul_dtype not in {"int8", "uint8", "fp8", "fp16", "float8_e4m3fn", "float16"}:
             raise ValueError(f"unsupported quantized_matmul_dtype {quantized_matmul_dtype}")
-        for name in ("use_codebook", "use_dynamic_quantization", "use_stochastic_rounding", "quant_conv", "quant_embedding",
+        for name in ("use_codebook", "use_dynamic_quantization", "use_stochastic_rounding", "quant_embedding",
                      "is_training"):
             if locals()[name]:
                 raise NotImplementedError(f"SDNQConfig({name}=True) is outside the MI355X Linear hot path")
@@ -164,20 +164,37 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
     Order of operations as in the reference (quantizer.py:158-253): Hadamard -> SVD split -> grouping ->
     quantize -> (transpose for direct matmul) -> pack.
     """
-    if layer_class_name not in linear_types:
-        raise NotImplementedError(f"{layer_class_name}: only Linear layers are on the MI355X hot path")
+    is_conv = layer_class_name in conv_types
+    if layer_class_name not in linear_types and not is_conv:
+        raise NotImplementedError(f"{layer_class_name}: only Linear and Conv1d / Conv2d layers are built for MI355X")
+    if is_conv and weight.ndim not in (3, 4):
+        raise NotImplementedError("Conv3d weights are not built for MI355X")
     if not dequantize_fp32:
         raise NotImplementedError("dequantize_fp32=False (low-precision scales) is not supported by the HIP kernels")
     weight = weight.detach()
     original_shape, original_stride = weight.shape, weight.stride()
     torch_dtype = weight.dtype if torch_dtype is None else torch_dtype
-    n, k = weight.shape
+    n = weight.shape[0]
+    channels = weight.shape[1] if is_conv else weight.shape[-1]  # the quantization axis (quantizer.py:121-123, 136-137)
+    kpos = 1
+    for d in weight.shape[2:]:
+        kpos *= int(d)
+    k = channels * kpos
     mm_dtype = get_quantized_matmul_dtype(weights_dtype, quantized_matmul_dtype)
-    use_qmm = check_quantized_matmul_is_allowed(use_quantized_matmul, n, k)
+    use_qmm = check_quantized_matmul_is_allowed(use_quantized_matmul, n, channels)
     requant = _needs_requant(weights_dtype, mm_dtype)
     ent = dtype_dict[weights_dtype]
+    result_shape = None
+    # conv weights feeding the matmul directly are flattened BEFORE quantization: one scale per output channel over all of
+    # (C_in, kernel); every other conv layout keeps one scale per kernel position (quantizer.py:120-125)
+    flat = is_conv and use_qmm and not requant and not ent["is_packed"]
+    if flat:
+        result_shape = weight.shape
+        weight = weight.flatten(1, -1)
 
     if use_hadamard:
+        if is_conv:
+            raise NotImplementedError("Hadamard rotation of conv weights is not built for MI355X")
         weight, use_hadamard, hadamard_group_size = apply_hadamard(weight, hadamard_group_size)
     svd_up = svd_down = None
     if use_svd:
@@ -185,38 +202,46 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
         if use_qmm:  # the matmul branch consumes x @ svd_down then @ svd_up: store both transposed (:164-167)
             svd_up, svd_down = svd_up.t(), svd_down.t()
 
-    group_size, groups = _pick_group_size(group_size, k, weights_dtype, True, svd_up is not None,
+    group_size, groups = _pick_group_size(group_size, channels, weights_dtype, not is_conv, svd_up is not None,
                                           direct_matmul=use_qmm and not requant)
-    result_shape = None
+    dim = 1 if (is_conv and not flat) else -1
     if groups > 1:
-        result_shape = weight.shape
-        weight = weight.unflatten(-1, (groups, group_size))
+        if flat:
+            raise ValueError("group-wise scales cannot be combined with the flattened conv matmul layout (the reference fails too)")
+        if result_shape is None:
+            result_shape = weight.shape
+        if is_conv:  # [N, C_in, *kernel] -> [N, groups, group_size, *kernel], reduce over group_size (quantizer.py:205-209)
+            weight = weight.unflatten(1, (groups, group_size))
+            dim = 2
+        else:
+            weight = weight.unflatten(-1, (groups, group_size))
     requant = requant or groups > 1
     transpose = use_qmm and not requant and not ent["is_packed"]
+    positions = kpos if (is_conv and not flat) else 1
 
     if weight.is_cuda and USE_HIP_QUANTIZER and weight.dtype in (torch.float32, torch.bfloat16, torch.float16) and k % 16 == 0 \
             and (ent["is_packed"] or ent["num_bits"] in (8, 16)) and weights_dtype not in _HIP_QUANTIZER_SKIP:
         # GPU tensors: one HIP launch pair does scale/zero-point, quantize and pack (csrc/quantize.hip); the element order
-        # [N][K] is the same for the plain, grouped and transposed layouts, only the logical views differ
+        # [N][K] is the same for the plain, grouped, conv and transposed layouts, only the logical views differ
         from . import ops
         w2d = weight.reshape(n, k)
-        q, scale, zero_point = ops.quantize_weight(w2d, weights_dtype, group_size if groups > 1 else k)
-        if groups > 1:
-            scale = scale.view(n, groups, 1)
-            zero_point = None if zero_point is None else zero_point.view(n, groups, 1)
-            quantized_weight_shape = torch.Size((n, groups, group_size))
-        elif transpose:
-            scale = scale.view(1, n)
-            zero_point = None if zero_point is None else zero_point.view(1, n)
-            quantized_weight_shape = torch.Size((k, n))
+        unit = (group_size if groups > 1 else channels) if positions > 1 else (group_size if groups > 1 else k)
+        q, scale, zero_point = ops.quantize_weight(w2d, weights_dtype, unit, positions=positions)
+        quantized_weight_shape = torch.Size((k, n)) if transpose else weight.shape
+        if positions > 1:
+            sshape = (n, groups, 1, *weight.shape[3:]) if groups > 1 else (n, 1, *weight.shape[2:])
+        elif groups > 1:
+            sshape = (n, groups, 1)
         else:
-            quantized_weight_shape = torch.Size((n, k))
+            sshape = (1, n) if transpose else (n, 1)
+        scale = scale.view(sshape)
+        zero_point = None if zero_point is None else zero_point.view(sshape)
         if not ent["is_packed"]:
-            q = q.view(n, groups, group_size) if groups > 1 else (q.t() if transpose else q)
+            q = q.t() if transpose else q.view(weight.shape)
         elif ent["num_bits"] in (8, 16):  # custom float8 / float16 codes keep the tensor shape (pack_float :75-80)
             q = q.view(quantized_weight_shape)
     else:
-        q, scale, zero_point = quantize_weight(weight, -1, weights_dtype)
+        q, scale, zero_point = quantize_weight(weight, dim, weights_dtype)
         if transpose:  # logical [K,N] with strides (1,K): the bytes stay [N][K] (prepare_weight_for_matmul on gfx950)
             q = q.t()
             scale = scale.t().contiguous()
@@ -236,7 +261,7 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
     return dq, {"weight": q, "scale": scale, "zero_point": zero_point, "svd_up": svd_up, "svd_down": svd_down}
 
 
-def _quant_kwargs(cfg: SDNQConfig, torch_dtype, param_name: str) -> dict:
+def _quant_kwargs(cfg: SDNQConfig, torch_dtype, param_name: str, layer_class_name: str = "Linear") -> dict:
     kw = dict(weights_dtype=cfg.weights_dtype, quantized_matmul_dtype=cfg.quantized_matmul_dtype, group_size=cfg.group_size,
               hadamard_group_size=cfg.hadamard_group_size, svd_rank=cfg.svd_rank, svd_steps=cfg.svd_steps,
               use_svd=cfg.use_svd, use_hadamard=cfg.use_hadamard, use_quantized_matmul=cfg.use_quantized_matmul,
@@ -244,6 +269,8 @@ def _quant_kwargs(cfg: SDNQConfig, torch_dtype, param_name: str) -> dict:
     for dt, names in cfg.modules_dtype_dict.items():
         if any(nm and nm in param_name for nm in names):
             kw["weights_dtype"] = dt
+    if layer_class_name in conv_types:  # utils.py:188-189: convs follow their own matmul switch
+        kw["use_quantized_matmul"] = cfg.use_quantized_matmul_conv
     if any(nm and nm in param_name for nm in cfg.modules_to_not_use_matmul):
         kw["use_quantized_matmul"] = False
     return kw
@@ -256,10 +283,10 @@ def sdnq_quantize_layer(layer: torch.nn.Module, quantization_config: SDNQConfig,
     if torch_dtype is None:
         torch_dtype = layer.weight.dtype
     name = layer.__class__.__name__
-    if name not in linear_types:
+    if name not in linear_types and not (name in ("Conv1d", "Conv2d") and quantization_config.quant_conv):  # quantizer.py:429-435
         quantization_config.modules_to_not_convert.append(param_name)
         return layer, quantization_config
-    kw = quant_kwargs or _quant_kwargs(quantization_config, torch_dtype, param_name)
+    kw = quant_kwargs or _quant_kwargs(quantization_config, torch_dtype, param_name, name)
     layer.weight.requires_grad_(False)
     dev = layer.weight.device if quantization_config.return_device is None else quantization_config.return_device
     w = layer.weight if quantization_config.quantization_device is None else layer.weight.to(quantization_config.quantization_device)
@@ -279,10 +306,11 @@ def apply_sdnq_to_module(model: torch.nn.Module, quantization_config: SDNQConfig
     """Recursively replace eligible nn.Linear children by SDNQLinear (reference quantizer.py:477-495)."""
     for child_name, child in list(model.named_children()):
         pname = f"{full_param_name}.{child_name}" if full_param_name else child_name
-        if child.__class__.__name__ == "Linear" and child.weight is not None:
+        cname = child.__class__.__name__
+        if (cname == "Linear" or (cname in ("Conv1d", "Conv2d") and quantization_config.quant_conv)) and child.weight is not None:
             wname = pname + ".weight"
             skip = any(s and s in wname for s in quantization_config.modules_to_not_convert)
-            big = (child.weight.shape[-1] >= quantization_config.minimum_allowed_channel_size
+            big = (child.weight.shape[-1 if cname == "Linear" else 1] >= quantization_config.minimum_allowed_channel_size
                    and child.weight.numel() >= quantization_config.minimum_allowed_numel)
             if not skip and big and child.weight.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
                 child, quantization_config = sdnq_quantize_layer(child, quantization_config, torch_dtype=torch_dtype, param_name=wname)

@@ -267,6 +267,94 @@ def run_case(case):
     print("wrote", name, {k: v.shape for k, v in out.items() if k.startswith("y_")})
 
 
+CONV_CASES = [
+    # name, conv ctor args, input shapes, dtype, config kwargs (quant_conv is always on)
+    dict(name="conv2d_int8_qmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(2, 12, 12), (1, 4, 5)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_int8_qmm_s2_f16_nobias", nd=2, cin=32, cout=48, k=3, conv=dict(padding=1, stride=2, bias=False), xs=[(1, 17, 13)],
+         dtype="f16", cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_int8_qmm_1x1_bf16", nd=2, cin=64, cout=32, k=1, conv=dict(), xs=[(1, 9, 7)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_int8_qmm_dil_reflect_bf16", nd=2, cin=32, cout=32, k=(3, 2), conv=dict(padding=(2, 1), dilation=(2, 1), padding_mode="reflect"),
+         xs=[(1, 10, 11)], dtype="bf16", cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_int4_g16_qmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True)),
+    dict(name="conv2d_uint4_noqmm_f32", nd=2, cin=16, cout=32, k=3, conv=dict(padding=1), xs=[(1, 6, 6)], dtype="f32",
+         cfg=dict(weights_dtype="uint4")),
+    dict(name="conv2d_int8_noqmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=0), xs=[(2, 9, 9)], dtype="bf16",
+         cfg=dict(weights_dtype="int8")),
+    dict(name="conv1d_int8_qmm_bf16", nd=1, cin=32, cout=64, k=3, conv=dict(padding=1, stride=2), xs=[(2, 50)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_fp8_qmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_int8_svd16_qmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_svd=True, svd_rank=16, use_quantized_matmul_conv=True)),
+    dict(name="conv2d_uint8_int8mm_qmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),
+]
+
+
+def run_conv_case(case):
+    """Conv1d / Conv2d layers through the reference quantizer and conv forwards (layers/conv/*)."""
+    name = case["name"]
+    dtype = TORCH_DT[case["dtype"]]
+    seed = zlib.crc32(name.encode()) % 1000
+    g = torch.Generator().manual_seed(seed)
+    ctor = torch.nn.Conv2d if case["nd"] == 2 else torch.nn.Conv1d
+    conv = ctor(case["cin"], case["cout"], case["k"], **case["conv"])
+    with torch.no_grad():
+        w = torch.randn(conv.weight.shape, generator=g) * 0.05
+        w[:, 3] *= 6.0  # an outlier input channel
+        conv.weight.copy_(w)
+        if conv.bias is not None:
+            conv.bias.copy_(torch.randn(conv.bias.shape, generator=g) * 0.1)
+    conv = conv.to(dtype)
+    w_float = conv.weight.detach().clone()
+    cfg = SDNQConfig(quant_conv=True, **case["cfg"])
+    layer = sdnq_quantize_layer(conv, cfg)[0]
+    dq = layer.sdnq_dequantizer
+    out = {}
+    meta = {"name": name, "dtype": case["dtype"], "cfg": dict(quant_conv=True, **case["cfg"]), "deq": deq_fields(dq),
+            "forward_func": layer.forward_func.__name__, "tensors": {},
+            "conv": {"nd": case["nd"], "in_channels": case["cin"], "out_channels": case["cout"], "kernel_size": list(layer.kernel_size),
+                     "stride": list(layer.stride), "padding": list(layer.padding), "dilation": list(layer.dilation),
+                     "groups": layer.groups, "padding_mode": layer.padding_mode, "bias": layer.bias is not None},
+            "inputs": []}
+
+    def put(key, t):
+        arr, tag = to_np(t)
+        if arr is not None:
+            out[key] = arr
+        meta["tensors"][key] = {"dtype": tag, "shape": (list(t.shape) if t is not None else None),
+                                "stride": (list(t.stride()) if t is not None else None)}
+
+    put("w_float", w_float)
+    for k in ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias"):
+        put(k, getattr(layer, k, None))
+    with torch.no_grad():
+        try:
+            put("w_dequant", dq(layer.weight, layer.scale, zero_point=layer.zero_point, svd_up=layer.svd_up, svd_down=layer.svd_down,
+                                skip_quantized_matmul=dq.use_quantized_matmul))
+        except RuntimeError as e:  # the reference cannot dequantize a flattened conv weight with SVD factors (addmm_ shape error)
+            meta["w_dequant_error"] = str(e)[:120]
+        if dq.use_quantized_matmul and dq.re_quantize_for_matmul:
+            rq = dq.re_quantize_matmul(layer.weight, layer.scale, zero_point=layer.zero_point)
+            put("requant_weight", rq[0])
+            put("requant_scale", rq[1])
+        for i, shp in enumerate(case["xs"]):
+            x = torch.randn(shp[0], case["cin"], *shp[1:], generator=g)
+            x[:, 1] *= 15.0
+            x = x.to(dtype)
+            y = layer(x)
+            put(f"x_{i}", x)
+            put(f"y_{i}", y)
+            meta["inputs"].append(i)
+    np.savez_compressed(os.path.join(HERE, f"conv_{name}.npz"), **out)
+    with open(os.path.join(HERE, f"conv_{name}.json"), "w") as f:
+        json.dump(meta, f, indent=1, default=str)
+    print("wrote conv", name, {k: v.shape for k, v in out.items() if k.startswith("y_")}, meta["forward_func"])
+
+
 def run_dequant_dtypes():
     out, meta = {}, {"dtypes": {}}
     N, K = 16, 128
@@ -389,3 +477,6 @@ if __name__ == "__main__":
     for c in CASES:
         if only is None or "cases" in only or c["name"] in only:
             run_case(c)
+    for c in CONV_CASES:
+        if only is None or "conv" in only or c["name"] in only:
+            run_conv_case(c)

@@ -12,13 +12,21 @@ def case_names():
     return sorted(f[5:-5] for f in os.listdir(GOLD) if f.startswith("case_") and f.endswith(".json"))
 
 
+def conv_case_names():
+    return sorted(f[5:-5] for f in os.listdir(GOLD) if f.startswith("conv_") and f.endswith(".json"))
+
+
 class Case:
-    def __init__(self, name):
+    def __init__(self, name, prefix="case"):
         self.name = name
-        self.meta = json.load(open(os.path.join(GOLD, f"case_{name}.json")))
-        self.z = np.load(os.path.join(GOLD, f"case_{name}.npz"))
+        self.meta = json.load(open(os.path.join(GOLD, f"{prefix}_{name}.json")))
+        self.z = np.load(os.path.join(GOLD, f"{prefix}_{name}.npz"))
         self.deq = self.meta["deq"]
-        self.N, self.K = self.meta["N"], self.meta["K"]
+        if "N" in self.meta:
+            self.N, self.K = self.meta["N"], self.meta["K"]
+        else:  # conv fixtures: [C_out, C_in, *kernel] flattened (quantizer.py:123)
+            shp = self.deq["original_shape"]
+            self.N, self.K = int(shp[0]), int(np.prod(shp[1:]))
         self.tag = self.meta["dtype"]  # bf16 | f16 | f32
 
     def info(self, key):
@@ -76,3 +84,32 @@ class Case:
             else:
                 t = t.to(device)
         return t
+
+
+class ConvCase(Case):
+    """conv_<name>.{json,npz}: Conv1d / Conv2d layers quantized and run by the reference (make_golden.run_conv_case)."""
+
+    def __init__(self, name):
+        super().__init__(name, prefix="conv")
+        self.conv = self.meta["conv"]
+
+    def inputs(self):
+        return list(self.meta["inputs"])
+
+    def torch_module(self, device):
+        """An SDNQConv1d / SDNQConv2d holding exactly the reference's tensors."""
+        import torch
+        from sdnq_amd.forward import get_forward_func
+        from sdnq_amd.layers import get_sdnq_wrapper_class
+        from tests.modules_util import dequantizer_from_fields
+        c = self.conv
+        ctor = torch.nn.Conv2d if c["nd"] == 2 else torch.nn.Conv1d
+        skel = ctor(c["in_channels"], c["out_channels"], tuple(c["kernel_size"]), stride=tuple(c["stride"]), padding=tuple(c["padding"]),
+                    dilation=tuple(c["dilation"]), groups=c["groups"], bias=c["bias"], padding_mode=c["padding_mode"])
+        dq = dequantizer_from_fields(self.deq)
+        skel.sdnq_dequantizer = dq
+        mod = get_sdnq_wrapper_class(skel, get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul))
+        for key in ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias"):
+            t = self.torch_tensor(key, device=device)
+            setattr(mod, key, None if t is None else torch.nn.Parameter(t, requires_grad=False))
+        return mod

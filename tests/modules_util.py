@@ -13,7 +13,7 @@ TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, 
 def dequantizer_from_fields(d: dict) -> SDNQDequantizer:
     return SDNQDequantizer(
         result_dtype=TORCH_DT[d["result_dtype"]], result_shape=None if d["result_shape"] is None else torch.Size(d["result_shape"]),
-        original_shape=torch.Size(d["original_shape"]), original_stride=[d["original_shape"][1], 1],
+        original_shape=torch.Size(d["original_shape"]), original_stride=list(torch.empty(d["original_shape"]).stride()),
         quantized_weight_shape=torch.Size(d["quantized_weight_shape"]), weights_dtype=d["weights_dtype"],
         quantized_matmul_dtype=d["quantized_matmul_dtype"], hadamard_group_size=d["hadamard_group_size"],
         group_size=d["group_size"], svd_rank=d["svd_rank"], svd_steps=8, codebook_steps=24,

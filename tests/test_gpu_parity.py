@@ -429,3 +429,87 @@ def test_float_gemm_vs_oracle(shape, dt, with_bias, gpu_device):
     if m >= 64:  # row-slab consistency: the GEMM path is independent of which rows share a tile
         y2 = ops.linear_float(x[5:70].contiguous().to(gpu_device), w.to(gpu_device), None if b is None else b.to(gpu_device))
         assert torch.equal(y2, y[5:70])
+
+
+@pytest.mark.parametrize("name", ["int8_rowwise_qmm_bf16", "int5_group32_noqmm_bf16", "uint8_uint8mm_qmm_bf16"])
+def test_edge_shapes_empty_single_row_and_leading_dims(name, gpu_device):
+    """Empty batch, one row, [B, T, K] inputs and non-contiguous rows go through every forward like F.linear would."""
+    c = Case(name)
+    mod = module_from_case(c, gpu_device)
+    dt = TORCH_DT[c.tag]
+    y0 = mod(torch.empty(0, c.K, device=gpu_device, dtype=dt))
+    assert tuple(y0.shape) == (0, c.N) and y0.dtype == dt
+    y0b = mod(torch.empty(2, 0, c.K, device=gpu_device, dtype=dt))
+    assert tuple(y0b.shape) == (2, 0, c.N)
+    M = max(c.ms())
+    x = c.torch_tensor(f"x_{M}", device=gpu_device).reshape(-1, c.K)
+    y = mod(x)
+    y1 = mod(x[:1])
+    assert tuple(y1.shape) == (1, c.N)
+    x3 = x[: (M // 4) * 4].reshape(4, M // 4, c.K)
+    assert torch.equal(mod(x3).reshape(-1, c.N), mod(x[: (M // 4) * 4]))
+    wide = torch.zeros(M, c.K + 16, device=gpu_device, dtype=dt)
+    wide[:, : c.K] = x
+    assert torch.equal(mod(wide[:, : c.K]), y)  # row stride != K
+
+
+# ---- conv as GEMM (SURVEY 8(f) rank 3) ---------------------------------------------------------------
+from tests.golden_util import ConvCase, conv_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", conv_case_names())
+def test_conv_forward_vs_golden_and_oracle(name, gpu_device):
+    """SDNQConv1d / SDNQConv2d on the HIP path (im2col + rowquant + MFMA scaled-mm, or dequant + float GEMM) against the
+    reference's conv forwards and the oracle; int8 direct paths bit-exact."""
+    c = ConvCase(name)
+    d = c.deq
+    mod = c.torch_module(gpu_device)
+    omod = c.oracle_module()
+    assert mod.forward_func.__name__ == c.meta["forward_func"]
+    for i in c.inputs():
+        x = c.torch_tensor(f"x_{i}", device=gpu_device)
+        y = mod(x)
+        ref = c.f32(f"y_{i}")
+        assert y.dtype == x.dtype and tuple(y.shape) == ref.shape and y.is_contiguous()
+        got = to_f32_numpy(y)
+        orc = O.conv_forward(omod, c.f32(f"x_{i}"), c.conv, c.tag)
+        exact = d["use_quantized_matmul"] and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up")
+        if exact:
+            assert np.array_equal(got, ref), (name, i, "golden", int((got != ref).sum()))
+            assert np.array_equal(got, orc), (name, i, "oracle")
+        else:
+            assert_close_float(got, ref, c.tag, (name, i, "golden"))
+            assert_close_float(got, orc, c.tag, (name, i, "oracle"))
+
+
+@pytest.mark.parametrize("name", [n for n in conv_case_names() if "svd" not in n])
+def test_conv_dequant_and_hip_quantizer_vs_golden(name, gpu_device):
+    c = ConvCase(name)
+    mod = c.torch_module(gpu_device)
+    dq = mod.sdnq_dequantizer
+    if c.has("w_dequant"):
+        wd = dq(mod.weight, mod.scale, mod.zero_point, None, None, skip_quantized_matmul=dq.use_quantized_matmul)
+        assert tuple(wd.shape) == tuple(c.info("w_dequant")["shape"])
+        assert np.array_equal(to_f32_numpy(wd), c.f32("w_dequant")), (name, "dequant")
+    if c.has("requant_weight"):
+        wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, mod.zero_point)
+        assert np.array_equal(bits_of(wq.contiguous()), c.raw("requant_weight").view(np.uint8).reshape(bits_of(wq.contiguous()).shape))
+        assert np.array_equal(ws.cpu().numpy().reshape(-1), c.raw("requant_scale").reshape(-1))
+    from sdnq_amd import quantizer as Q
+    from tests.test_quantizer import _conv_quant_kwargs, check_conv_state_dict
+    dq2, tensors = Q.sdnq_quantize_layer_weight(c.torch_tensor("w_float", device=gpu_device), layer_class_name=c.deq["layer_class_name"],
+                                                **_conv_quant_kwargs(c))
+    check_conv_state_dict(c, tensors, dq2, name)
+
+
+@pytest.mark.parametrize("geom", [((2, 5, 9, 11), (3, 3), (1, 1), (1, 1), (1, 1)), ((1, 8, 16, 7), (3, 2), (2, 1), (1, 0), (1, 2)),
+                                  ((3, 16, 1, 40), (1, 5), (1, 3), (0, 2), (1, 1)), ((1, 4, 70, 70), (1, 1), (1, 1), (0, 0), (1, 1))])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_im2col_equals_unfold(geom, dt, gpu_device):
+    shape, kernel, stride, padding, dilation = geom
+    if (shape[1] * kernel[0] * kernel[1] * (2 if dt == torch.bfloat16 else 4)) % 16:
+        shape = (shape[0], shape[1] * 8, shape[2], shape[3])
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(1)).to(dt)
+    got, (b, ho, wo) = ops.im2col(x.to(gpu_device), kernel, stride, padding, dilation)
+    ref = torch.nn.functional.unfold(x.float(), kernel, dilation=dilation, padding=padding, stride=stride).transpose(1, 2).reshape(-1, got.shape[1])
+    assert got.shape[0] == b * ho * wo and torch.equal(got.float().cpu(), ref)

@@ -146,3 +146,39 @@ def test_case_forward(name):
             assert err <= (2e-2 if d["use_hadamard"] else 8e-3), (name, M, err)
             rel_l2 = np.linalg.norm(y - y_ref) / np.linalg.norm(y_ref)
             assert rel_l2 <= (2e-3 if c.tag != "f32" else 1e-5), (name, M, rel_l2)
+
+
+# ---- conv ---------------------------------------------------------------------
+from tests.golden_util import ConvCase, conv_case_names  # noqa: E402
+
+
+@pytest.mark.parametrize("name", conv_case_names())
+def test_conv_case_dequant_and_forward(name):
+    """Oracle conv = im2col + the Linear arithmetic with per-kernel-position scales, against the reference's conv forwards."""
+    c = ConvCase(name)
+    d = c.deq
+    omod = c.oracle_module()
+    if c.has("w_dequant"):
+        W = omod.dequantize(c.tensor_tag("w_dequant"), use_svd=True)
+        ref = c.f32("w_dequant").reshape(c.N, c.K)
+        if c.has("svd_up"):
+            assert np.abs(W - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+        else:
+            assert np.array_equal(W, ref), (name, "dequant")
+    if c.has("requant_weight"):
+        wq, ws = omod.re_quantize_matmul()
+        rw = c.raw("requant_weight")  # logical [K, N]
+        assert np.array_equal(wq.view(np.uint8), np.ascontiguousarray(rw.T).view(np.uint8)), (name, "requant codes")
+        assert np.array_equal(ws, c.raw("requant_scale").reshape(-1)), (name, "requant scale")
+    for i in c.inputs():
+        x = c.f32(f"x_{i}")
+        y = O.conv_forward(omod, x, c.conv, c.tag)
+        ref = c.f32(f"y_{i}")
+        assert y.shape == ref.shape
+        exact = d["use_quantized_matmul"] and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up")
+        if exact:
+            assert np.array_equal(y, ref), (name, i, int((y != ref).sum()))
+        else:
+            scale = float(np.abs(ref).max())
+            lim = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10, "f32": 2e-6}[c.tag]
+            assert np.abs(y - ref).max() <= lim * scale, (name, i, float(np.abs(y - ref).max()), scale)

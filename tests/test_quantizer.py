@@ -96,3 +96,40 @@ def test_host_quantizer_reproduces_every_storage_dtype(key):
         assert np.array_equal(t["zero_point"].numpy().view(np.uint32), z[key + ".zero_point"].view(np.uint32)), (key, "zero_point")
     else:
         assert t["zero_point"] is None
+
+
+from tests.golden_util import ConvCase, conv_case_names  # noqa: E402
+
+
+def _conv_quant_kwargs(c):
+    cfg = dict(c.meta["cfg"])
+    cfg.pop("quant_conv", None)
+    cfg["use_quantized_matmul"] = cfg.pop("use_quantized_matmul_conv", False)
+    return cfg
+
+
+def check_conv_state_dict(c, tensors, dq, name):
+    d = c.deq
+    for f in ("weights_dtype", "group_size", "use_quantized_matmul", "re_quantize_for_matmul", "is_packed"):
+        assert getattr(dq, f) == d[f], (name, f, getattr(dq, f), d[f])
+    assert list(dq.quantized_weight_shape) == d["quantized_weight_shape"]
+    assert (None if dq.result_shape is None else list(dq.result_shape)) == d["result_shape"]
+    for key in ("weight", "scale", "zero_point"):
+        ref, mine = c.torch_tensor(key), tensors[key]
+        assert (ref is None) == (mine is None), (name, key)
+        if ref is None:
+            continue
+        mine = mine.cpu()
+        assert tuple(mine.shape) == tuple(ref.shape), (name, key, mine.shape, ref.shape)
+        a = mine.contiguous().view(torch.uint8) if mine.dtype in (torch.float8_e4m3fn, torch.int8) else mine.contiguous()
+        b = ref.contiguous().view(torch.uint8) if ref.dtype in (torch.float8_e4m3fn, torch.int8) else ref.contiguous()
+        assert torch.equal(a.to(b.dtype) if a.dtype != b.dtype else a, b), (name, key)
+
+
+@pytest.mark.parametrize("name", [n for n in conv_case_names() if "svd" not in n])
+def test_host_quantizer_reproduces_conv_state_dict(name):
+    """Conv1d / Conv2d weights: flattened direct-matmul layout, per-kernel-position scales, grouped, asymmetric."""
+    c = ConvCase(name)
+    dq, tensors = quantizer.sdnq_quantize_layer_weight(c.torch_tensor("w_float"), layer_class_name=c.deq["layer_class_name"],
+                                                       **_conv_quant_kwargs(c))
+    check_conv_state_dict(c, tensors, dq, name)

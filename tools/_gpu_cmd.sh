@@ -1,7 +1,1 @@
-R=$PWD; cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L 2>/dev/null | grep -o "TCC_HIT_sum\|TCC_MISS_sum\|TCC_REQ_sum\|SQ_VALU_MFMA_BUSY_CYCLES\|SQ_BUSY_CU_CYCLES\|SQ_INSTS_VALU_MFMA_I8\|SQ_WAIT_INST_ANY\|SQ_WAVE_CYCLES\|TCP_TCC_READ_REQ_sum\|TCC_EA0_RDREQ_sum\|TCC_EA0_RDREQ_32B_sum\|SQ_INST_LEVEL_VMEM\|TCP_TCC_READ_REQ_LATENCY_sum\|TCC_EA0_RD_UNCACHED_32B_sum\|SQ_ACTIVE_INST_MISC\|SQ_LDS_BANK_CONFLICT\|SQ_LDS_ACTIVE\|SQ_ACTIVE_INST_LDS\|SQ_INST_CYCLES_VMEM\|SQ_LDS_IDX_ACTIVE\|SQ_LDS_DATA_FIFO_FULL\|SQ_LDS_ADDR_CONFLICT\|SQ_LDS_UNALIGNED_STALL\|TCP_PENDING_STALL_CYCLES_sum\|TCP_TCR_TCP_STALL_CYCLES_sum\|TCP_GATE_EN1_sum\|TCP_TA_TCP_STATE_READ_sum\|TA_BUSY_avr\|TA_TA_BUSY_sum\|TD_TD_BUSY_sum\|TCP_TOTAL_CACHE_ACCESSES_sum" | sort -u | tr '\n' ' ' > $R/gpurun_out/pmc_names.txt; cat $R/gpurun_out/pmc_names.txt; echo
-for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
-  n=$(echo $set | tr ' ' '_' | cut -c1-40)
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$n -- python $R/tools/run_one_gemm.py 8192 8192 8192 3 > /dev/null 2>&1
-  python $R/tools/pmc_csv.py /tmp/pmc_$n gemm_kernel 2>&1 | tail -6
-done | tee $R/gpurun_out/pmc_big_gemm.txt
+python -m pytest tests -m gpu -q --tb=short > gpurun_out/pytest_gpu_r2.log 2>&1; tail -25 gpurun_out/pytest_gpu_r2.log
