@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8"])
+    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -65,6 +65,8 @@ def workload_config(name: str):
     if name == "flux_int8_svd":
         return shapes.flux_dev_layer_sequence(), dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
                                                use_quantized_matmul=True), "int8", 4608
+    if name == "sdxl_conv_int8":  # the UNet's Conv2d layers through the same int8 matmul (use_quantized_matmul_conv)
+        return shapes.sdxl_unet_convs(), dict(weights_dtype="int8", group_size=-1, quant_conv=True, use_quantized_matmul_conv=True), "int8", 16384
     if name == "linear_int8":  # the reference's own micro-benchmark shape (scripts/benchmark_sdnq_inference_matmul.py)
         return [("bench.linear", 16384, 4096, 8192, True, 1)], dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), "int8", 16384
     raise ValueError(name)
@@ -112,6 +114,25 @@ def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=
     return layers
 
 
+def build_conv_layers(conv_list, cfg_kwargs, device, seed=0):
+    """-> list of (name, module, x [1,C,H,W], M, K, N, bias) for sdxl_unet_convs entries (distinct weights and inputs per layer)."""
+    import sdnq_amd
+    from sdnq_amd import shapes
+    g = torch.Generator(device=device).manual_seed(seed)
+    layers = []
+    for e in conv_list:
+        name, cin, h, w, cout, k, stride, pad = e
+        conv = torch.nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=True, device=device, dtype=torch.bfloat16)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, device=device, generator=g) * 0.02)
+            conv.bias.copy_(torch.randn(cout, device=device, generator=g) * 0.1)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(conv, sdnq_amd.SDNQConfig(**cfg_kwargs))
+        x = torch.randn(1, cin, h, w, device=device, dtype=torch.bfloat16, generator=g)
+        m, kk, n = shapes.conv_gemm_dims(e)
+        layers.append((name, mod, x, m, kk, n, True))
+    return layers
+
+
 def run_step(layers):
     """One pass over every layer.  The activation-quantization cache is emptied first: within a step a tensor consumed by
     several layers is quantized once (sdnq_amd/linear.py:_ActivationCache), but nothing is carried across steps."""
@@ -137,6 +158,9 @@ def time_gemm_kernel(layers, mm_name, device):
             continue
         st = L._state(mod)
         wq, ws, zp = L._prepare_mm_weights(mod, st, mm)
+        if x.ndim == 4:  # conv layer: the GEMM sees the unfolded input
+            from sdnq_amd import conv as C
+            x = C._unfold(mod, x)[0]
         xq, xs, _, _ = ops.rowquant(x, mm, dq.hadamard_group_size if dq.use_hadamard else 0)
         calls.append((xq, wq, xs, ws, mod.bias))
         total_ops += 2 * m * k * n + (m * n if has_bias else 0)
@@ -227,8 +251,12 @@ def main():
 
     shape_list, cfg_kwargs, mm_name, tokens = workload_config(args.workload)
     tp = args.tp and distributed
-    layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
-                          tp_world=world if tp else 1, seed=0 if tp else rank)
+    is_conv = args.workload.startswith("sdxl_conv")
+    if is_conv:
+        layers = build_conv_layers(shape_list, cfg_kwargs, device, seed=rank)
+    else:
+        layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
+                              tp_world=world if tp else 1, seed=0 if tp else rank)
     ops_per_step = sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in layers)
 
     # eager warm-up (builds the per-module weight caches), then capture the whole step
@@ -312,7 +340,7 @@ def main():
                                   "frac": round(ach / INT8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                   "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
                                   "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:
                 result["cpu_baseline"] = cpu_baseline(shape_list, mm_name, args.cpu_seconds)
             except Exception as e:  # noqa: BLE001

@@ -211,6 +211,24 @@ int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, con
 int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw, int stride_h,
                     int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* out, sdnq_stream_t stream);
 
+/* the scaled matmul of the conv forwards with the channel-major store fused into the epilogue: out is the conv output
+ * [B][N][hw] (NCHW / NCL), rows m = b * hw + pixel -- replaces int_scaled_mm_func(...).view(mm_output_shape) followed by
+ * .permute(0, 3, 1, 2).contiguous() (conv_int8.py:71, 81-88).  bias: NULL or [N] of bias_dtype; hw % 8 == 0, m % hw == 0,
+ * out_dtype bf16 / f16. */
+int sdnq_hip_scaled_mm_nchw(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                            int bias_dtype, void* out, int out_dtype, int64_t m, int64_t n, int64_t k, int64_t hw,
+                            sdnq_stream_t stream);
+
+/* fused variant for the quantized-matmul conv forwards: row scales xs[m] = amax_k |x_unfold[m][k]| / qmax straight from the
+ * image, then the unfold writes the QUANTIZED operand xq [M][K] (int8 or fp8-e4m3fn bytes) -- the bf16 [M][K] matrix of
+ * process_conv_input + quantize_int_mm_input / quantize_fp_mm_input (conv_int8.py:31, 64; quant_utils.py:265-273, 290-299)
+ * is never materialised; values are identical to sdnq_hip_im2col followed by sdnq_hip_rowquant.  K % 16 == 0,
+ * kh * kw <= 25 and height * width % 8 == 0 (SDNQ_ERR_UNSUPPORTED otherwise: use im2col + rowquant).  amax_ws:
+ * caller-provided workspace of batch * height * width 32-bit words (the per-pixel channel amax map; zeroed here). */
+int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
+                             int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
+                             void* xq, float* xs, void* amax_ws, sdnq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

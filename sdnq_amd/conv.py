@@ -14,15 +14,19 @@ from __future__ import annotations
 
 import torch
 
+import os
+
 from . import linear, ops
+
+FUSED_CONV_QUANT = os.environ.get("SDNQ_HIP_FUSED_CONV_QUANT", "1").lower() not in {"0", "false", "no"}
 
 
 def _pair(v, n):
     return (int(v),) * n if isinstance(v, int) else tuple(int(e) for e in v)
 
 
-def _unfold(self, input: torch.Tensor):
-    """-> (x2d [M, K], fold) where fold(y2d [M, N]) gives the conv output in the reference's layout."""
+def _geometry(self, input: torch.Tensor):
+    """-> (input [B, C, H, W] (explicitly padded for non-zero padding modes), kernel, stride, padding, dilation, nd)."""
     if self.groups != 1:
         raise NotImplementedError("SDNQ conv with groups != 1 is not built for MI355X")
     if self.sdnq_dequantizer.use_hadamard:
@@ -40,14 +44,24 @@ def _unfold(self, input: torch.Tensor):
     if nd == 1:  # forward.py:24-27, 66-67: Conv1d is the H = 1 case
         input = input.unsqueeze(2)
         kernel, stride, padding, dilation = (1, kernel[0]), (1, stride[0]), (0, padding[0]), (1, dilation[0])
-    x2d, (b, ho, wo) = ops.im2col(input, kernel, stride, padding, dilation)
+    return input, kernel, stride, padding, dilation, nd
+
+
+def _folder(self, nd: int, b: int, ho: int, wo: int):
     n = self.sdnq_dequantizer.out_features
 
     def fold(y2d: torch.Tensor) -> torch.Tensor:
         if nd == 1:
             return y2d.view(b, wo, n).transpose(1, 2).contiguous()  # conv_int8.py:81-82
         return y2d.view(b, ho, wo, n).permute(0, 3, 1, 2).contiguous()  # conv_int8.py:83-84, 87
-    return x2d, fold
+    return fold
+
+
+def _unfold(self, input: torch.Tensor):
+    """-> (x2d [M, K], fold) where fold(y2d [M, N]) gives the conv output in the reference's layout."""
+    input, kernel, stride, padding, dilation, nd = _geometry(self, input)
+    x2d, (b, ho, wo) = ops.im2col(input, kernel, stride, padding, dilation)
+    return x2d, _folder(self, nd, b, ho, wo)
 
 
 @torch.no_grad()
@@ -60,9 +74,22 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
     dq = self.sdnq_dequantizer
     if dq.is_packed and not dq.re_quantize_for_matmul:
         raise NotImplementedError("packed conv weights with a direct quantized matmul have no valid layout in the reference")
-    x2d, fold = _unfold(self, input)
     if input.numel() / input.shape[2] < 32:  # conv_int8.py:96-97 (the reference's criterion, not the row count)
+        x2d, fold = _unfold(self, input)
         return fold(linear._float_forward(self, x2d, linear._state(self)))
+    st = linear._state(self)
+    wq, ws, zp = linear._prepare_mm_weights(self, st, mm)
+    if FUSED_CONV_QUANT and st.svd_up is None and zp is None:
+        # no SVD / zero-point terms: the float [M, K] matrix is never needed -- row scales straight from the image, then the
+        # unfold writes the quantized operand (same values as im2col + rowquant)
+        x4, kernel, stride, padding, dilation, nd = _geometry(self, input)
+        if kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
+            xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
+            if (ho * wo) % 8 == 0 and input.dtype != torch.float32:  # channel-major store fused into the GEMM epilogue
+                y = ops.scaled_mm_nchw(mm, xq, wq, xs, ws, self.bias, input.dtype, b, ho * wo)
+                return y.view(b, -1, wo) if nd == 1 else y.view(b, -1, ho, wo)
+            return _folder(self, nd, b, ho, wo)(ops.scaled_mm(mm, xq, wq, xs, ws, self.bias, input.dtype))
+    x2d, fold = _unfold(self, input)
     return fold(linear._quantized_matmul_forward(self, x2d, mm, small_batch_branch=False))
 
 

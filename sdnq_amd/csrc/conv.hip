@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/sdnq_hip.h"
+#include <type_traits>
+
 #include "sdnq_dev.h"
 
 namespace {
@@ -21,10 +23,132 @@ struct Im2colParams {
     int64_t M, K;
 };
 
+// ---- fused activation quantization of the conv matmul: thread = (output position m, input channel c) --------------------
+// A thread walks the KH x KW patch of its channel: adjacent lanes are adjacent w_out, so every load is a coalesced run of the
+// image row, there is no integer division in the loops, and the P = KH*KW values are P CONSECUTIVE columns k = c*P .. c*P+P-1
+// of row m.  Reads hit L2 / MALL after the first touch (each pixel is visited once per kernel position).
+
+// The row amax of the unfolded activation is a WINDOW maximum of the per-pixel channel amax: with
+// A[b][h][w] = max_c |x[b][c][h][w]|, max_k |x_unfold[m][k]| = max over the KH x KW taps of A (zero padding adds nothing).
+// So x is read ONCE (not once per tap) to build A, and the quantizing kernel derives its 64 row scales from <= P floats each.
+// A is accumulated as the bit pattern of a non-negative float with atomicMax (zeroed by the host).  Workgroup = 32 groups of 8
+// consecutive pixels (one 16-byte load per channel, 512 contiguous bytes per wave-half) x 8 channel lanes; blockIdx.y splits the
+// channels so that small images still fill the chip; partial maxima are combined in LDS, one atomic per pixel per workgroup.
+template <int T_ID>
+__global__ __launch_bounds__(256) void conv_pixel_amax_kernel(const void* __restrict__ x, int64_t pixels, int channels, int64_t total,
+                                                              int cpb, unsigned int* __restrict__ amap) {
+    __shared__ float red[8][32][9];
+    const int tid = threadIdx.x, pg = tid & 31, cl = tid >> 5;
+    const int64_t q = (int64_t)blockIdx.x * 32 + pg;  // group of 8 consecutive pixels of one image (pixels % 8 == 0)
+    const bool ok = q * 8 < total;
+    const int64_t b = ok ? (q * 8) / pixels : 0, px = ok ? (q * 8) - b * pixels : 0;
+    const int c_begin = blockIdx.y * cpb, c_end = (c_begin + cpb < channels) ? c_begin + cpb : channels;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.0f;
+    if (ok) {
+#pragma unroll 4
+        for (int c = c_begin + cl; c < c_end; c += 8) {
+            float v[8];
+            const int64_t off = (b * channels + c) * pixels + px;
+            if constexpr (T_ID == SDNQ_F32) {
+                Vec16<SDNQ_F32>::unpack(*(const uint4*)((const float*)x + off), v);
+                Vec16<SDNQ_F32>::unpack(*(const uint4*)((const float*)x + off + 4), v + 4);
+            } else {
+                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + off), v);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = fmaxf(a[e], fabsf(v[e]));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[cl][pg][e] = a[e];
+    __syncthreads();
+    // 256 threads -> the 256 pixels of the workgroup
+    const int pg2 = tid >> 3, e2 = tid & 7;
+    const int64_t q2 = (int64_t)blockIdx.x * 32 + pg2;
+    if (q2 * 8 < total) {
+        float r = red[0][pg2][e2];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) r = fmaxf(r, red[l][pg2][e2]);
+        atomicMax(amap + q2 * 8 + e2, __float_as_uint(r));
+    }
+}
+
+// xq[m][c*P + pos] = quantize(x patch) with xs[m] = amax_ws[m] / qmax -- the arithmetic of rowquant.hip (IEEE division,
+// round-half-even, clamp; 0/0 -> 0).  64 rows x CT channels per workgroup (CT*P % 16 == 0), bytes staged in LDS rows of
+// CT*P (+4 pad) bytes, written out as 16-byte pieces of the [M][K] rows.  Workgroups with blockIdx.y == 0 also write xs.
+template <int T_ID, int MM, int CT>
+__global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, const unsigned int* __restrict__ amap, float qmax,
+                                                         uint8_t* __restrict__ xq, float* __restrict__ xs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int P = p.KH * p.KW;
+    const int pitch = CT * P + 4;  // words per row odd -> the 64 lanes of a byte store hit distinct banks
+    const int64_t m0 = (int64_t)blockIdx.x * 64, m = m0 + lane;
+    const bool mok = m < p.M;
+    const int c_base = blockIdx.y * CT;
+    if (mok) {
+        const int wo = (int)(m % p.WO), ho = (int)((m / p.WO) % p.HO), b = (int)(m / ((int64_t)p.WO * p.HO));
+        const int64_t img = (int64_t)p.H * p.W;
+        float amax = 0.0f;  // window maximum of the channel-amax map = amax of this unfolded row
+        for (int i = 0; i < p.KH; ++i) {
+            const int h = ho * p.SH - p.PH + i * p.DH;
+            if (h < 0 || h >= p.H) continue;
+            for (int j = 0; j < p.KW; ++j) {
+                const int ww = wo * p.SW - p.PW + j * p.DW;
+                if (ww >= 0 && ww < p.W) amax = fmaxf(amax, __uint_as_float(amap[(int64_t)b * img + (int64_t)h * p.W + ww]));
+            }
+        }
+        const float scale = amax / qmax;
+        if (blockIdx.y == 0 && w == 0) xs[m] = scale;
+        constexpr int CPT = CT / 4;  // channels per thread
+        const int c0 = c_base + w * CPT;
+        uint8_t* row = tile + lane * pitch + (w * CPT) * P;
+        for (int i = 0; i < p.KH; ++i) {
+            const int h = ho * p.SH - p.PH + i * p.DH;
+            for (int j = 0; j < p.KW; ++j) {
+                const int ww = wo * p.SW - p.PW + j * p.DW;
+                const bool inb = h >= 0 && h < p.H && ww >= 0 && ww < p.W;
+                const int64_t base = ((int64_t)b * p.C) * img + (int64_t)h * p.W + ww;
+                float v[CPT];
+#pragma unroll
+                for (int u = 0; u < CPT; ++u) v[u] = (inb && c0 + u < p.C) ? FT<T_ID>::load(p.x, base + (int64_t)(c0 + u) * img) : 0.0f;
+#pragma unroll
+                for (int u = 0; u < CPT; ++u) {
+                    uint8_t byte;
+                    if constexpr (MM == SDNQ_MM_I8) {
+                        float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[u] / scale);
+                        q = fminf(fmaxf(q, -128.0f), 127.0f);
+                        byte = (uint8_t)((int)q & 0xff);
+                    } else {
+                        float q = v[u] / scale;
+                        if (q != q) q = 0.0f;
+                        q = fminf(fmaxf(q, -448.0f), 448.0f);
+                        byte = f32_to_e4m3fn(q);
+                    }
+                    row[u * P + i * p.KW + j] = byte;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int c_valid = (p.C - c_base) < CT ? (p.C - c_base) : CT;
+    const int cpr = c_valid * P / 16;  // 16-byte pieces per row (C*P % 16 == 0 and CT*P % 16 == 0)
+    for (int ch = tid; ch < 64 * cpr; ch += 256) {
+        const int r = ch / cpr, idx = ch - r * cpr;
+        if (m0 + r >= p.M) continue;
+        const u32* src = (const u32*)(tile + r * pitch + idx * 16);
+        *(uint4*)(xq + (m0 + r) * p.K + (int64_t)c_base * P + idx * 16) = make_uint4(src[0], src[1], src[2], src[3]);
+    }
+}
+
+// explicit copy (float [M][K] matrix for the float / SVD / zero-point branches); T = element type, 2 or 4 bytes
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
-    constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
-    __shared__ T tile[64][64 + EPC];     // [k][m]
+    typedef T O;
+    constexpr int EPC = 16 / sizeof(O);  // elements per 16-byte chunk
+    __shared__ O tile[64][64 + EPC];     // [k][m]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * 64, k0 = (int64_t)blockIdx.y * 64;
     const int64_t m = m0 + lane;
@@ -49,23 +173,19 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
         const int r = ch / CPR, c16 = ch % CPR;
         const int64_t gm = m0 + r, gk = k0 + c16 * EPC;
         if (gm >= p.M || gk >= p.K) continue;  // K % EPC == 0: a chunk never straddles K
-        T tmp[EPC];
+        O tmp[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) tmp[e] = tile[c16 * EPC + e][r];
-        *(uint4*)((T*)p.out + gm * p.K + gk) = *(const uint4*)tmp;
+        *(uint4*)((O*)p.out + gm * p.K + gk) = *(const uint4*)tmp;
     }
 }
 
-}  // namespace
-
-extern "C" int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw, int stride_h,
-                               int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* out, sdnq_stream_t stream) {
+int fill_geometry(Im2colParams& p, const void* x, void* out, int batch, int channels, int height, int width, int kh, int kw,
+                  int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w) {
     if (!x || !out) return SDNQ_ERR_NULL;
-    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0 || kh <= 0 || kw <= 0 || stride_h <= 0 || stride_w <= 0 ||
         pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0)
         return SDNQ_ERR_SHAPE;
-    Im2colParams p{};
     p.x = x; p.out = out; p.B = batch; p.C = channels; p.H = height; p.W = width; p.KH = kh; p.KW = kw;
     p.SH = stride_h; p.SW = stride_w; p.PH = pad_h; p.PW = pad_w; p.DH = dil_h; p.DW = dil_w;
     p.HO = (height + 2 * pad_h - dil_h * (kh - 1) - 1) / stride_h + 1;
@@ -73,9 +193,68 @@ extern "C" int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels
     if (p.HO <= 0 || p.WO <= 0) return SDNQ_ERR_SHAPE;
     p.M = (int64_t)batch * p.HO * p.WO;
     p.K = (int64_t)channels * kh * kw;
+    if ((uintptr_t)out % 16) return SDNQ_ERR_ALIGN;
+    return SDNQ_OK;
+}
+
+}  // namespace
+
+extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
+                                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
+                                        void* xq, float* xs, void* amax_ws, sdnq_stream_t stream) {
+    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
+    if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
+    if (!xs || !amax_ws) return SDNQ_ERR_NULL;
+    Im2colParams p{};
+    int st = fill_geometry(p, x, xq, batch, channels, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w);
+    if (st != SDNQ_OK) return st;
+    const int P = kh * kw;
+    if (p.K % 16) return SDNQ_ERR_SHAPE;
+    if (P > 25) return SDNQ_ERR_UNSUPPORTED;  // LDS tile of 64 x 16*P bytes; larger kernels take im2col + rowquant
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t pixels = (int64_t)height * width, total = (int64_t)batch * pixels;
+    if (pixels % 8) return SDNQ_ERR_UNSUPPORTED;  // the channel-amax pass reads 8 pixels per 16-byte load
+    if ((uintptr_t)x % 16) return SDNQ_ERR_ALIGN;
+    if (hipMemsetAsync(amax_ws, 0, sizeof(unsigned int) * total, s) != hipSuccess) return SDNQ_ERR_LAUNCH;
+    const float qmax = (mm_dtype == SDNQ_MM_I8) ? 127.0f : 448.0f;
+    const unsigned mb = (unsigned)((p.M + 63) / 64);
+    const int ct = (P <= 9) ? 32 : 16;
+    const unsigned nx = (unsigned)((total / 8 + 31) / 32);
+    unsigned ny = (1024 + nx - 1) / nx;  // enough workgroups for 256 CUs, at least 8 channels (one per channel lane) each
+    if (ny > (unsigned)(channels + 7) / 8) ny = (unsigned)(channels + 7) / 8;
+    if (ny < 1) ny = 1;
+    const int cpb = (int)(((channels + ny - 1) / ny + 7) / 8 * 8);
+    ny = (unsigned)((channels + cpb - 1) / cpb);
+    dim3 g1(nx, ny), g2(mb, (unsigned)((channels + ct - 1) / ct)), block(256);
+    const size_t lds = (size_t)64 * (ct * P + 4);
+#define CQ2(TID, MMV)                                                                                                      \
+    do {                                                                                                                   \
+        if (ct == 32) hipLaunchKernelGGL((conv_quant_kernel<TID, MMV, 32>), g2, block, lds, s, p, (const unsigned int*)amax_ws, qmax, (uint8_t*)xq, xs); \
+        else hipLaunchKernelGGL((conv_quant_kernel<TID, MMV, 16>), g2, block, lds, s, p, (const unsigned int*)amax_ws, qmax, (uint8_t*)xq, xs);          \
+    } while (0)
+#define CQ(TID)                                                                                      \
+    do {                                                                                             \
+        hipLaunchKernelGGL((conv_pixel_amax_kernel<TID>), g1, block, 0, s, x, pixels, channels, total, cpb, (unsigned int*)amax_ws); \
+        if (mm_dtype == SDNQ_MM_I8) CQ2(TID, SDNQ_MM_I8);                                            \
+        else CQ2(TID, SDNQ_MM_FP8);                                                                  \
+    } while (0)
+    if (dtype == SDNQ_F32) CQ(SDNQ_F32);
+    else if (dtype == SDNQ_BF16) CQ(SDNQ_BF16);
+    else CQ(SDNQ_F16);
+#undef CQ
+#undef CQ2
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw, int stride_h,
+                               int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* out, sdnq_stream_t stream) {
+    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
+    Im2colParams p{};
+    int st = fill_geometry(p, x, out, batch, channels, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w);
+    if (st != SDNQ_OK) return st;
     const int eb = (dtype == SDNQ_F32) ? 4 : 2;
     if ((p.K * eb) % 16) return SDNQ_ERR_SHAPE;
-    if ((uintptr_t)out % 16) return SDNQ_ERR_ALIGN;
     dim3 grid((unsigned)((p.M + 63) / 64), (unsigned)((p.K + 63) / 64)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (eb == 4) hipLaunchKernelGGL((im2col_kernel<uint32_t>), grid, block, 0, s, p);

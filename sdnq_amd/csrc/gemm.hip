@@ -61,6 +61,7 @@ struct GemmParams {
     const float* wcs;          // [N] f32(colsum(b)) * sb (uint8 matmul) or null
     int64_t M, N, K;   // K in BYTES of one operand row (== elements for int8 / fp8)
     int64_t lda, ldb;  // operand row strides in bytes (0: K)
+    int64_t out_hw;    // 0: out is [M][N].  > 0: conv output [B][N][out_hw] with m = b * out_hw + pixel (NCHW, conv_int8.py:81-87)
     int64_t ld_bias;
     int bias_ndim;
     int bias_dtype;  // SdnqFloat of bias (and of lr_t / lr_up, which share the svd dtype)
@@ -570,6 +571,36 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // (2) one compact loop: 8 consecutive channels of one row per thread -> scale, bias, cast, 16/32-byte store
     constexpr int G8 = BN / 8;
     const bool has_bias = p.bias != nullptr;
+    if constexpr (EPI <= EPI_BIAS1D && OUT_T != SDNQ_F32) {
+        if (p.out_hw > 0) {
+            // channel-major store for the conv forwards: 8 consecutive output positions of ONE channel per thread (they are
+            // contiguous in the [B][N][HW] image: HW % 8 == 0 and tiles start on multiples of 64), same fma as below
+#pragma nounroll
+            for (int v = tid; v < (CH / 8) * BN; v += NT) {
+                const int n = v / (CH / 8), r8 = (v % (CH / 8)) * 8;
+                const int64_t gm = m0 + ch * CH + r8, gn = n0 + n;
+                if (gm >= p.M || gn >= p.N) continue;
+                const float sbn = is_float_mm<MM> ? 1.0f : s_sb[n];
+                const float bn = (EPI == EPI_BIAS1D) ? s_bias[n] : 0.0f;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float a;
+                    if constexpr (MM == SDNQ_MM_I8) a = (float)*(const int*)(stage + (r8 + e) * ACC_ROW + n * 4);
+                    else a = *(const float*)(stage + (r8 + e) * ACC_ROW + n * 4);
+                    if constexpr (is_float_mm<MM>) {
+                        o[e] = (EPI == EPI_BIAS1D) ? a + bn : a;
+                    } else {
+                        const float vv = a * p.sa[gm + e];
+                        o[e] = (EPI == EPI_BIAS1D) ? fmaf(vv, sbn, bn) : vv * sbn;
+                    }
+                }
+                const int64_t img = gm / p.out_hw, px = gm - img * p.out_hw;
+                *(uint4*)((uint8_t*)p.out + ((img * p.N + gn) * p.out_hw + px) * OUT_B) = Vec16<OUT_T>::pack(o);
+            }
+            return;
+        }
+    }
     const bool lr_fast = EPI == EPI_LOWRANK && lr_mfma && p.bias_dtype == SDNQ_BF16 && p.zp == nullptr && p.a_zp == nullptr;
 #pragma nounroll
     for (int v = tid; v < CH * G8; v += NT) {
@@ -792,6 +823,23 @@ extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, co
     hipStream_t s = (hipStream_t)stream;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, bias_ndim, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, bias_ndim, out_dtype, s);
+}
+
+extern "C" int sdnq_hip_scaled_mm_nchw(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                       int bias_dtype, void* out, int out_dtype, int64_t m, int64_t n, int64_t k, int64_t hw,
+                                       sdnq_stream_t stream) {
+    int st = check_common(mm_dtype, a, b, sa, sb, out, out_dtype, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (out_dtype == SDNQ_F32) return SDNQ_ERR_UNSUPPORTED;
+    if (hw <= 0 || (hw % 8) != 0 || (m % hw) != 0) return SDNQ_ERR_SHAPE;
+    if (!bias) bias_dtype = out_dtype;
+    if (bias_dtype < 0 || bias_dtype > 2) return SDNQ_ERR_DTYPE;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias_dtype; p.out_hw = hw;
+    hipStream_t s = (hipStream_t)stream;
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);
 }
 
 extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,

@@ -194,6 +194,24 @@ def scaled_mm(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, 
     return out
 
 
+def scaled_mm_nchw(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype,
+                   batch: int, pixels: int) -> torch.Tensor:
+    """Conv flavour of scaled_mm: rows m = (b, pixel); returns the channel-major image [batch, N, pixels] (the reference's
+    .view(B, H, W, C).permute(0, 3, 1, 2).contiguous(), conv_int8.py:81-88, fused into the epilogue)."""
+    _require_cuda(a, b_phys, sa, sb, bias)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    assert m == batch * pixels
+    out = torch.empty((batch, n, pixels), device=a.device, dtype=out_dtype)
+    bias_dt = 0
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_dt = float_code(bias.dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_nchw(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), bias_dt,
+                                              out.data_ptr(), float_code(out_dtype), m, n, k, pixels, _stream(a)), "scaled_mm_nchw")
+    return out
+
+
 def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, zp, out_dtype: torch.dtype, a_zp=None,
                       w_colsum_scaled=None):
     _require_cuda(a, b_phys)
@@ -313,6 +331,28 @@ def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Te
     check(_lib.load().sdnq_hip_im2col(x.data_ptr(), float_code(x.dtype), b, c, h, w, kh, kw, sh, sw, ph, pw, dh, dw, out.data_ptr(),
                                       _stream(x)), "im2col")
     return out, (b, ho, wo)
+
+
+def im2col_rowquant(x: torch.Tensor, kernel, stride, padding, dilation, mm: int):
+    """Fused unfold + row-wise activation quantization for the conv matmul forwards:
+    -> (xq [M, K] int8 | fp8, xs [M, 1] f32, (B, H_out, W_out)); equals rowquant(im2col(x))."""
+    _require_cuda(x)
+    if x.ndim != 4:
+        raise _lib.SdnqHipError("im2col_rowquant expects [B, C, H, W]")
+    x = x if x.is_contiguous() else x.contiguous()
+    b, c, h, w = x.shape
+    (kh, kw), (sh, sw), (ph, pw), (dh, dw) = kernel, stride, padding, dilation
+    ho = (h + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    wo = (w + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+    if ho <= 0 or wo <= 0:
+        raise _lib.SdnqHipError(f"convolution output would be empty ({ho} x {wo})")
+    m, k = b * ho * wo, c * kh * kw
+    xq = torch.empty((m, k), device=x.device, dtype=_MM_TORCH[mm])
+    xs = torch.empty((m, 1), device=x.device, dtype=torch.float32)
+    ws = torch.empty((b * h * w,), device=x.device, dtype=torch.int32)  # per-pixel channel-amax map (zeroed by the library)
+    check(_lib.load().sdnq_hip_im2col_rowquant(x.data_ptr(), float_code(x.dtype), b, c, h, w, kh, kw, sh, sw, ph, pw, dh, dw, mm,
+                                               xq.data_ptr(), xs.data_ptr(), ws.data_ptr(), _stream(x)), "im2col_rowquant")
+    return xq, xs, (b, ho, wo)
 
 
 def quantize_weight(weight2d: torch.Tensor, weights_dtype: str, group_size: int, positions: int = 1):

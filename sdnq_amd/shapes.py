@@ -61,6 +61,40 @@ def sdxl_unet_layer_sequence(latent: int = 128, text_tokens: int = 77):
     return seq
 
 
+def sdxl_unet_convs(latent: int = 128):
+    """Conv2d layers of the SDXL-base UNet at bs=1 whose channel counts allow the quantized matmul (C_in, C_out >= 32; conv_in
+    4->320 and conv_out 320->4 stay float): (name, C_in, H, W, C_out, kernel, stride, padding), in execution order.
+    block_out_channels (320, 640, 1280), 2 resnets per down block, 3 per up block (public model config)."""
+    out = []
+    h0, h1, h2 = latent, latent // 2, latent // 4
+
+    def resnet(tag, cin, cout, h):
+        out.append((f"{tag}.conv1", cin, h, h, cout, 3, 1, 1))
+        out.append((f"{tag}.conv2", cout, h, h, cout, 3, 1, 1))
+        if cin != cout:
+            out.append((f"{tag}.conv_shortcut", cin, h, h, cout, 1, 1, 0))
+
+    resnet("down0.res0", 320, 320, h0); resnet("down0.res1", 320, 320, h0)
+    out.append(("down0.downsample", 320, h0, h0, 320, 3, 2, 1))
+    resnet("down1.res0", 320, 640, h1); resnet("down1.res1", 640, 640, h1)
+    out.append(("down1.downsample", 640, h1, h1, 640, 3, 2, 1))
+    resnet("down2.res0", 640, 1280, h2); resnet("down2.res1", 1280, 1280, h2)
+    resnet("mid.res0", 1280, 1280, h2); resnet("mid.res1", 1280, 1280, h2)
+    resnet("up0.res0", 2560, 1280, h2); resnet("up0.res1", 2560, 1280, h2); resnet("up0.res2", 1920, 1280, h2)
+    out.append(("up0.upsample", 1280, h1, h1, 1280, 3, 1, 1))
+    resnet("up1.res0", 1920, 640, h1); resnet("up1.res1", 1280, 640, h1); resnet("up1.res2", 960, 640, h1)
+    out.append(("up1.upsample", 640, h0, h0, 640, 3, 1, 1))
+    resnet("up2.res0", 960, 320, h0); resnet("up2.res1", 640, 320, h0); resnet("up2.res2", 640, 320, h0)
+    return out
+
+
+def conv_gemm_dims(e):
+    """(M, K, N) of the im2col GEMM of one sdxl_unet_convs entry."""
+    _, cin, h, w, cout, k, s, p = e
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    return ho * wo, cin * k * k, cout
+
+
 def flux_dev_linears(img_tokens: int = 4096, txt_tokens: int = 512, d: int = 3072):
     """FLUX.1-dev transformer, 1024^2 px: 19 double blocks + 38 single blocks."""
     t_all = img_tokens + txt_tokens

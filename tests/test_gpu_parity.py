@@ -513,3 +513,22 @@ def test_im2col_equals_unfold(geom, dt, gpu_device):
     got, (b, ho, wo) = ops.im2col(x.to(gpu_device), kernel, stride, padding, dilation)
     ref = torch.nn.functional.unfold(x.float(), kernel, dilation=dilation, padding=padding, stride=stride).transpose(1, 2).reshape(-1, got.shape[1])
     assert got.shape[0] == b * ho * wo and torch.equal(got.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("geom", [((2, 32, 8, 11), (3, 3), (1, 1), (1, 1), (1, 1)), ((1, 16, 16, 7), (3, 2), (2, 1), (1, 0), (1, 2)),
+                                  ((1, 64, 32, 31), (1, 1), (1, 1), (0, 0), (1, 1)), ((2, 48, 12, 10), (5, 5), (1, 2), (2, 2), (1, 1))])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("mm_name", ["int8", "fp8"])
+def test_fused_conv_quant_equals_im2col_then_rowquant(geom, dt, mm_name, gpu_device):
+    """sdnq_hip_im2col_rowquant == sdnq_hip_rowquant(sdnq_hip_im2col(x)) bit for bit (codes and scales), incl. an all-zero row."""
+    shape, kernel, stride, padding, dilation = geom
+    mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
+    x = torch.randn(shape, generator=torch.Generator().manual_seed(2)).to(dt)
+    x[:, 3] *= 12
+    x[0, :, :2, :2] = 0  # with padding, the first output position only sees zeros -> scale 0
+    xg = x.to(gpu_device)
+    xq, xs, dims = ops.im2col_rowquant(xg, kernel, stride, padding, dilation, mm)
+    x2d, dims2 = ops.im2col(xg, kernel, stride, padding, dilation)
+    rq, rs, _, _ = ops.rowquant(x2d, mm)
+    assert dims == dims2 and torch.equal(xs, rs)
+    assert np.array_equal(bits_of(xq), bits_of(rq))
