@@ -310,7 +310,7 @@ def main():
         "value": round(value, 1), "unit": "GOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "i8" if mm_name == "int8" else "fp8", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {len(layers)} quantized Linear layers of one denoising step, bs=1 "
+        "config": {"workload": f"{args.workload}: {len(layers)} quantized {'Conv2d' if is_conv else 'Linear'} layers of one denoising step, bs=1 "
                                f"({sum(1 for l in layers if l[3] >= 32)} w8a8 GEMMs + {sum(1 for l in layers if l[3] < 32)} M=1 layers)",
                    "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
                    "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16",

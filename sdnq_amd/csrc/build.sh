@@ -4,7 +4,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/../libsdnq_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
+FLAGS="${SDNQ_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
 OBJ="$HERE/../../build/obj"
 mkdir -p "$OBJ"
 pids=()
