@@ -48,6 +48,8 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--fuse-projections", action="store_true",
+                   help="variant: q/k/v (and cross-attention k/v) projections fused into one layer each, like diffusers' fuse_projections()")
     p.add_argument("--layers-scale", type=float, default=1.0, help="debug: fraction of each layer's repeat count")
     return p.parse_args()
 
@@ -131,6 +133,26 @@ def build_conv_layers(conv_list, cfg_kwargs, device, seed=0):
         m, kk, n = shapes.conv_gemm_dims(e)
         layers.append((name, mod, x, m, kk, n, True))
     return layers
+
+
+def fuse_shared_input_layers(layers):
+    """--fuse-projections: what sdnq_amd.fuse_projections does to a diffusers model -- consecutive layers that consume the SAME
+    tensor (self-attention q/k/v, cross-attention k/v) become one layer with the concatenated output channels."""
+    from sdnq_amd import loader
+    out, i = [], 0
+    while i < len(layers):
+        j = i + 1
+        is_proj = lambda nm: any(t in nm for t in (".to_q", ".to_k", ".to_v", ".qkv"))  # noqa: E731  (attention projections only)
+        while j < len(layers) and layers[j][2] is layers[i][2] and j - i < 3 and is_proj(layers[i][0]) and is_proj(layers[j][0]):
+            j += 1
+        group = layers[i:j]
+        if len(group) > 1 and loader._fusable([g[1] for g in group]):
+            name, _, x, m, k, _, has_bias = group[0]
+            out.append((name + "+%d" % (len(group) - 1), loader._concat_linears([g[1] for g in group]), x, m, k, sum(g[5] for g in group), has_bias))
+        else:
+            out.extend(group)
+        i = j
+    return out
 
 
 def run_step(layers):
@@ -257,6 +279,8 @@ def main():
     else:
         layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
                               tp_world=world if tp else 1, seed=0 if tp else rank)
+    if args.fuse_projections and not is_conv and not tp:
+        layers = fuse_shared_input_layers(layers)
     ops_per_step = sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in layers)
 
     # eager warm-up (builds the per-module weight caches), then capture the whole step
@@ -315,7 +339,7 @@ def main():
                    "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
                    "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16",
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
-                   "requantized_weight_cache": L.CACHE_WEIGHTS,
+                   "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
         "step_latency_ms": round(ms_per_step, 4),
@@ -328,7 +352,7 @@ def main():
             gk, result["roofline_error"] = None, repr(e)
         traffic, traffic_src = None, None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
-        if args.workload == "sdxl_int8" and os.path.exists(pmc):
+        if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             # (tools/pmc_shapes.py + tools/pmc_traffic.py; counters cannot be read inside this process)
             with open(pmc) as f:

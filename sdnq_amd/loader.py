@@ -34,16 +34,89 @@ def is_hot_path_linear(module: torch.nn.Module) -> bool:
     return dq is not None and getattr(dq, "layer_class_name", None) in ("Linear", "SDNQLinear") and not getattr(dq, "use_codebook", False)
 
 
+def is_hot_path_conv(module: torch.nn.Module) -> bool:
+    dq = getattr(module, "sdnq_dequantizer", None)
+    return (dq is not None and getattr(dq, "layer_class_name", None) in ("Conv1d", "Conv2d", "SDNQConv1d", "SDNQConv2d")
+            and not getattr(dq, "use_codebook", False) and not getattr(dq, "use_hadamard", False) and getattr(module, "groups", 1) == 1
+            and getattr(dq, "quantized_matmul_dtype", "int8") in ("int8", "fp8", "float8_e4m3fn"))
+
+
 @torch.no_grad()
 def accelerate(model: torch.nn.Module) -> int:
-    """Route every quantized Linear of ``model`` through the HIP forwards. Returns the number of re-pointed modules."""
+    """Route every quantized Linear (and Conv1d / Conv2d with groups = 1) of ``model`` through the HIP forwards.
+    Returns the number of re-pointed modules."""
     count = 0
     for module in model.modules():
-        if is_hot_path_linear(module):
+        if is_hot_path_linear(module) or is_hot_path_conv(module):
             dq = adopt_dequantizer(module.sdnq_dequantizer)
             module.sdnq_dequantizer = dq
-            module.forward_func = get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul)
+            module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
             module.__dict__.pop("_sdnq_hip_state", None)
+            count += 1
+    return count
+
+
+def _fusable(mods) -> bool:
+    """Row-wise, directly-multipliable layers (one scale per output channel, weights stored in the matmul layout) of equal
+    in_features and configuration: their concatenation along the output channels is itself such a layer, bit for bit."""
+    dqs = [getattr(m, "sdnq_dequantizer", None) for m in mods]
+    if any(d is None for d in dqs) or not all(is_hot_path_linear(m) for m in mods):
+        return False
+    d0 = dqs[0]
+    same = ("weights_dtype", "quantized_matmul_dtype", "group_size", "use_quantized_matmul", "re_quantize_for_matmul", "use_hadamard",
+            "result_dtype", "in_features")
+    if not all(all(getattr(d, f) == getattr(d0, f) for f in same) for d in dqs):
+        return False
+    if not (d0.use_quantized_matmul and not d0.re_quantize_for_matmul and not d0.is_packed and not d0.use_hadamard):
+        return False
+    if any(getattr(m, "svd_up", None) is not None for m in mods):
+        return False
+    return len({m.bias is None for m in mods}) == 1
+
+
+@torch.no_grad()
+def _concat_linears(mods):
+    from .layers import SDNQLinear
+    d0 = mods[0].sdnq_dequantizer
+    k = d0.in_features
+    n = sum(m.sdnq_dequantizer.out_features for m in mods)
+    skeleton = torch.nn.Linear(8, 8, bias=False)
+    skeleton.in_features, skeleton.out_features = k, n
+    dq = SDNQDequantizer(**{f: getattr(d0, f) for f in _DQ_FIELDS})
+    dq.original_shape = torch.Size((n, k))
+    dq.original_stride = [k, 1]
+    dq.quantized_weight_shape = torch.Size((k, n))
+    skeleton.sdnq_dequantizer = dq
+    fused = SDNQLinear(skeleton, get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul))
+    phys = torch.cat([m.weight.t() for m in mods], dim=0).contiguous()  # [N][K] bytes of the matmul layout
+    fused.weight = torch.nn.Parameter(phys.t(), requires_grad=False)    # logical [K, N], strides (1, K)
+    fused.scale = torch.nn.Parameter(torch.cat([m.scale.reshape(1, -1) for m in mods], dim=1), requires_grad=False)
+    zps = [getattr(m, "zero_point", None) for m in mods]
+    fused.zero_point = None if zps[0] is None else torch.nn.Parameter(torch.cat([z.reshape(1, -1) for z in zps], dim=1), requires_grad=False)
+    fused.svd_up = fused.svd_down = None
+    fused.bias = None if mods[0].bias is None else torch.nn.Parameter(torch.cat([m.bias for m in mods], dim=0), requires_grad=False)
+    return fused
+
+
+@torch.no_grad()
+def fuse_projections(model: torch.nn.Module) -> int:
+    """diffusers' ``Attention.fuse_projections()`` for SDNQ layers: for every attention block whose ``to_q / to_k / to_v``
+    (self-attention) or ``to_k / to_v`` (cross-attention) are row-wise direct-matmul SDNQLinear layers of one input size, add
+    ``to_qkv`` / ``to_kv`` holding the concatenated quantized weights and set ``fused_projections = True`` (the attribute the
+    fused attention processors read).  One activation quantization + one GEMM launch instead of three (two); outputs are
+    bit-identical to the separate layers because every output channel keeps its own scale.  Returns the number of fused blocks."""
+    count = 0
+    for module in model.modules():
+        q, k, v = (getattr(module, a, None) for a in ("to_q", "to_k", "to_v"))
+        if k is None or v is None:
+            continue
+        if q is not None and _fusable([q, k, v]):
+            module.to_qkv = _concat_linears([q, k, v])
+            module.fused_projections = True
+            count += 1
+        elif _fusable([k, v]):
+            module.to_kv = _concat_linears([k, v])
+            module.fused_projections = True
             count += 1
     return count
 

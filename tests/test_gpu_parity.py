@@ -532,3 +532,30 @@ def test_fused_conv_quant_equals_im2col_then_rowquant(geom, dt, mm_name, gpu_dev
     rq, rs, _, _ = ops.rowquant(x2d, mm)
     assert dims == dims2 and torch.equal(xs, rs)
     assert np.array_equal(bits_of(xq), bits_of(rq))
+
+
+def test_fuse_projections_is_bit_identical(gpu_device):
+    """sdnq_amd.fuse_projections: to_qkv / to_kv built from row-wise int8 layers reproduce the separate layers bit for bit."""
+    import sdnq_amd
+    torch.manual_seed(9)
+
+    class Attn(torch.nn.Module):
+        def __init__(self, qd, kd, inner):
+            super().__init__()
+            self.to_q = torch.nn.Linear(qd, inner, bias=False)
+            self.to_k = torch.nn.Linear(kd, inner, bias=False)
+            self.to_v = torch.nn.Linear(kd, inner, bias=False)
+            self.to_out = torch.nn.Linear(inner, qd)
+
+    model = torch.nn.ModuleDict({"self_attn": Attn(320, 320, 320), "cross_attn": Attn(320, 512, 320)}).to(torch.bfloat16).to(gpu_device)
+    model, _ = sdnq_amd.apply_sdnq_to_module(model, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True))
+    assert sdnq_amd.fuse_projections(model) == 2
+    sa, ca = model["self_attn"], model["cross_attn"]
+    assert sa.fused_projections and hasattr(sa, "to_qkv") and not hasattr(sa, "to_kv")
+    assert ca.fused_projections and hasattr(ca, "to_kv") and not hasattr(ca, "to_qkv")
+    x = torch.randn(2, 100, 320, device=gpu_device, dtype=torch.bfloat16)
+    e = torch.randn(2, 77, 512, device=gpu_device, dtype=torch.bfloat16)
+    q, k, v = sa.to_qkv(x).split(320, dim=-1)
+    assert torch.equal(q, sa.to_q(x)) and torch.equal(k, sa.to_k(x)) and torch.equal(v, sa.to_v(x))
+    k2, v2 = ca.to_kv(e).split(320, dim=-1)
+    assert torch.equal(k2, ca.to_k(e)) and torch.equal(v2, ca.to_v(e))

@@ -47,3 +47,31 @@ def test_activation_cache_identity_version_and_lru():
     assert c.get(b, p) is None and c.get(a, p) == "qa2" and c.get(d, p) == "qd"
     c.clear()
     assert c.get(a, p) is None
+
+
+def test_fuse_projections_layout_on_cpu():
+    """to_qkv / to_kv carry the concatenated matmul-layout bytes, per-channel scales and biases of their parts."""
+    import sdnq_amd
+
+    class Attn(torch.nn.Module):
+        def __init__(self, qd, kd, inner, bias):
+            super().__init__()
+            self.to_q = torch.nn.Linear(qd, inner, bias=bias)
+            self.to_k = torch.nn.Linear(kd, inner, bias=bias)
+            self.to_v = torch.nn.Linear(kd, inner, bias=bias)
+
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"a": Attn(64, 64, 96, True), "b": Attn(64, 128, 96, False), "c": Attn(64, 64, 96, True)})
+    model, _ = sdnq_amd.apply_sdnq_to_module(model, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True,
+                                                                        modules_to_not_use_matmul=["c.to_v"], minimum_allowed_numel=1024,
+                                                                        minimum_allowed_channel_size=32))
+    assert sdnq_amd.fuse_projections(model) == 2  # block c mixes a matmul and a non-matmul layer: left alone
+    a, b, c = model["a"], model["b"], model["c"]
+    assert not hasattr(c, "to_qkv") and not getattr(c, "fused_projections", False)
+    f = a.to_qkv
+    assert tuple(f.weight.shape) == (64, 288) and f.weight.stride() == (1, 64) and tuple(f.scale.shape) == (1, 288)
+    assert f.sdnq_dequantizer.out_features == 288 and f.sdnq_dequantizer.in_features == 64 and tuple(f.bias.shape) == (288,)
+    for i, part in enumerate((a.to_q, a.to_k, a.to_v)):
+        assert torch.equal(f.weight[:, 96 * i:96 * (i + 1)], part.weight) and torch.equal(f.scale[:, 96 * i:96 * (i + 1)], part.scale)
+        assert torch.equal(f.bias[96 * i:96 * (i + 1)], part.bias)
+    assert tuple(b.to_kv.weight.shape) == (128, 192) and b.to_kv.bias is None
