@@ -745,6 +745,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     //  * diffusion-size GEMMs (1-30 GOP): 64x128 tiles, two waves per SIMD and TWO co-resident workgroups per CU
     //    (3-deep ring, 72 KB LDS each);
     //  * few-row GEMMs (M <= 128, e.g. the 77-token text projections): 64x64 tiles.
+    // Deeper rings for the 64x128 tiles (5-6 stages, one workgroup per CU) measured 5-30 % slower than 3 stages x 2 workgroups.
     // Software-pipelined fragment reads (LD_PIPE) measured +3..9 % on the 256x256 tiles and +8 % on the 64x64 ones, -1.5 % on
     // the SDXL step for the 64x128 tiles (one MFMA per sub-step leaves nothing to hide behind), so those keep LD_DMA.
     if (tiles(256, 256) >= 200) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
