@@ -102,7 +102,6 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
         }
         const float scale = amax / qmax;
         if (blockIdx.y == 0 && w == 0) xs[m] = scale;
-
         constexpr int CPT = CT / 4;  // channels per thread
         const int c0 = c_base + w * CPT;
         uint8_t* row = tile + lane * pitch + (w * CPT) * P;

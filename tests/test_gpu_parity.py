@@ -559,3 +559,20 @@ def test_fuse_projections_is_bit_identical(gpu_device):
     assert torch.equal(q, sa.to_q(x)) and torch.equal(k, sa.to_k(x)) and torch.equal(v, sa.to_v(x))
     k2, v2 = ca.to_kv(e).split(320, dim=-1)
     assert torch.equal(k2, ca.to_k(e)) and torch.equal(v2, ca.to_v(e))
+
+
+def test_fused_conv_quant_ties_and_large_image(gpu_device):
+    """conv_quant_kernel vs im2col + rowquant on a large image with many quotients on or next to rounding ties (a reciprocal
+    shortcut for the division was tried and dropped: exact, but the branch cost more than the division saved)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, 64, 64, 64, generator=g)
+    x[:, ::2] = torch.round(x[:, ::2] * 37) / 37.0 * 1.5  # many repeated magnitudes -> many exact .5 quotients after scaling
+    x[0, 5, 3, 3] = 40.0  # a dominant value: scale = 40 / 127 for its neighbourhood
+    x[:, 7] = torch.round(x[:, 7] * 4) * (40.0 / 127.0) * 0.5  # exact multiples of scale / 2 -> ties where that scale applies
+    for dt in (torch.bfloat16, torch.float32):
+        xg = x.to(dt).to(gpu_device)
+        xq, xs, dims = ops.im2col_rowquant(xg, (3, 3), (1, 1), (1, 1), (1, 1), ops.MM_I8)
+        x2d, _ = ops.im2col(xg, (3, 3), (1, 1), (1, 1), (1, 1))
+        rq, rs, _, _ = ops.rowquant(x2d, ops.MM_I8)
+        assert torch.equal(xs, rs)
+        assert torch.equal(xq, rq), int((xq != rq).sum())
