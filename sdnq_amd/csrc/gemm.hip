@@ -195,13 +195,12 @@ template <> struct FragOps<SDNQ_MM_FP8> {
 // LD selects how HBM/L2 -> LDS is done:
 //   LD_DMA : global_load_lds_dwordx4 into an NS-deep LDS ring (no VGPR round trip, but ~100+ issue cycles per 1-KiB
 //            piece and ~1 us latency: bytes in flight are bounded by the LDS ring);
-//   LD_REG : global_load_dwordx4 into an NS-deep ring of VGPRs, then ds_write_b128 into a 2-buffer LDS: cheap to
-//            issue, in-flight bytes live in the (much larger) register file, the compiler counts vmcnt itself.
+//            (a register-ring loader -- global_load_dwordx4 into VGPRs, then ds_write_b128 -- measured the same and was removed)
 //   LD_PIPE: the LD_DMA ring, plus software pipelining of the LDS->register fragment reads: while the MFMAs of K sub-step
 //            ks run, the fragments of sub-step ks+1 (or of the next stage, right after the barrier) are already being
 //            read into the other of two fragment sets, so neither the LDS latency nor the two waves of a SIMD reading
 //            LDS in lock-step after every barrier leave the matrix pipe idle.
-enum { LD_DMA = 0, LD_REG = 1, LD_PIPE = 2 };
+enum { LD_DMA = 0, LD_PIPE = 2 };
 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
@@ -215,7 +214,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     static_assert(BK == 64 || BK == 128, "stage rows are 64 or 128 bytes");
     static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
     constexpr int STAGE_BYTES = (BM + BN) * BK;
-    constexpr int LDS_STAGES = LD != LD_REG ? NS : 2;
+    constexpr int LDS_STAGES = NS;
     constexpr int OUT_B = FT<OUT_T>::bytes;
     constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [CH][ACC_ROW]
     constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // the tile leaves in ECH chunks of CH rows (LDS budget)
@@ -304,30 +303,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 
     const int nk = (K + BK - 1) / BK;
     constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed (LD_DMA)
-    uint4 R[LD == LD_REG ? NS : 1][PPW];  // LD_REG: register ring of in-flight stages
-    auto gload = [&](auto dc, int kt) {  // stage kt -> R[d]
-        constexpr int d = decltype(dc)::value;
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            R[d][i] = (k0 + kofs(i) < K) ? *(const uint4*)(src[i] + k0) : make_uint4(0u, 0u, 0u, 0u);
-    };
-    auto lwrite = [&](auto dc, int buf) {  // R[d] -> LDS buffer `buf`, same lane-linear image the DMA produces
-        constexpr int d = decltype(dc)::value;
-        uint8_t* stage = lds + buf * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const bool isA = i < A_PIECES;
-            const int piece = (isA ? i : i - A_PIECES) * NW + wave;
-            *(uint4*)(stage + (isA ? 0 : BM * BK) + piece * 1024 + lane * 16) = R[d][i];
-        }
-    };
-    if constexpr (LD != LD_REG) {
 #pragma nounroll
-        for (int s = 0; s < AHEAD; ++s) issue(s);
-    } else {
-        static_for_up<NS>([&](auto dc) { gload(dc, decltype(dc)::value); });
-    }
+    for (int s = 0; s < AHEAD; ++s) issue(s);
     TRACE(1);
 
     // per-output-channel epilogue vectors -> LDS once per workgroup (after the DMA prologue so its load latency hides
@@ -348,76 +325,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
         constexpr int KS = BK / MT::KB;
         static_assert(KS >= 1, "stage row shorter than one MFMA K step");
-        if constexpr (MM == SDNQ_MM_I8) {
-            // all fragment reads of the stage are issued before the first MFMA, so LDS latency overlaps the matrix pipe
-            v4i fa[KS][TM], fb[KS][TN];
+        // all fragment reads of the stage are issued before the first MFMA, so LDS latency overlaps the matrix pipe
+        typename FragOps<MM>::frag_t fa[KS][TM], fb[KS][TN];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off<BK>(wm * WM + j * 32 + frow, ks * 2 + fgrp, p.swz));
+            for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off<BK>(wn * WN + i * 32 + frow, ks * 2 + fgrp, p.swz));
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
-        } else if constexpr (is_float_mm<MM>) {
-            v4i fa[KS][TM], fb[KS][TN];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int j = 0; j < TM; ++j) fa[ks][j] = *(const v4i*)(sA + lds_off<BK>(wm * WM + j * 32 + frow, ks * 2 + fgrp, p.swz));
-#pragma unroll
-                for (int i = 0; i < TN; ++i) fb[ks][i] = *(const v4i*)(sB + lds_off<BK>(wn * WN + i * 32 + frow, ks * 2 + fgrp, p.swz));
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) {
-                        if constexpr (MM == MM_BF16) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fb[ks][i]), __builtin_bit_cast(v8bf, fa[ks][j]), acc[i][j], 0, 0, 0);
-                        } else if constexpr (MM == MM_F16) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fb[ks][i]), __builtin_bit_cast(v8h, fa[ks][j]), acc[i][j], 0, 0, 0);
-                        } else {
-                            const v4f wb = __builtin_bit_cast(v4f, fb[ks][i]), xa = __builtin_bit_cast(v4f, fa[ks][j]);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[r], xa[r], acc[i][j], 0, 0, 0);
-                        }
-                    }
-        } else {
-            v8i fa[KS][TM], fb[KS][TN];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    const int r = wm * WM + j * 32 + frow;
-                    const v4i lo = *(const v4i*)(sA + lds_off<BK>(r, ks * 4 + fgrp * 2, p.swz));
-                    const v4i hi = *(const v4i*)(sA + lds_off<BK>(r, ks * 4 + fgrp * 2 + 1, p.swz));
-                    fa[ks][j] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    const int r = wn * WN + i * 32 + frow;
-                    const v4i lo = *(const v4i*)(sB + lds_off<BK>(r, ks * 4 + fgrp * 2, p.swz));
-                    const v4i hi = *(const v4i*)(sB + lds_off<BK>(r, ks * 4 + fgrp * 2 + 1, p.swz));
-                    fb[ks][i] = (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[ks][i], fa[ks][j], acc[i][j], 0, 0, 0,
-                                                                                    0x7f7f7f7f, 0, 0x7f7f7f7f);
+            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template load<BK>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j]);
     };
 
     if constexpr (LD == LD_PIPE) {
@@ -477,22 +399,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             if (kt == 0) TRACE(2);
             issue(kt + AHEAD);
             compute();
-        }
-    } else {
-        // register ring: stage kt sits in R[kt % NS]; write it to LDS buffer kt & 1, immediately re-issue the same
-        // registers for stage kt + NS, one barrier, MFMAs. The loop is unrolled NS times so R is statically indexed.
-#pragma nounroll
-        for (int kt0 = 0; kt0 < nk; kt0 += NS) {
-            static_for_up<NS>([&](auto dc) {
-                const int kt = kt0 + decltype(dc)::value;
-                if (kt < nk) {  // workgroup-uniform
-                    lwrite(dc, kt & 1);
-                    gload(dc, kt + NS);
-                    __syncthreads();
-                    slot_c = kt & 1;
-                    compute();
-                }
-            });
         }
     }
     TRACE(3);
@@ -699,7 +605,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB>
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int MAIN = (LD != LD_REG ? NS : 2) * (BM + BN) * BK;
+    constexpr int MAIN = NS * (BM + BN) * BK;
     constexpr int EPIB = (BM > 128 ? 64 : BM) * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1);
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 4 * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
