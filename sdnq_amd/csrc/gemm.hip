@@ -644,6 +644,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
     if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
+    if (force == 3) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt). Every kernel launch starts with cold
     // L2s (data comes from MALL/HBM at ~2 us loaded latency) and the L2->LDS fill rate per CU is ~30 B/clk, so:
     //  * large problems: 256x256 tiles (8 waves of 128x64, 64-byte K stages, 4-deep ring) -- twice the MACs per byte
@@ -655,6 +656,9 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     // Software-pipelined fragment reads (LD_PIPE) measured +3..9 % on the 256x256 tiles and +8 % on the 64x64 ones, -1.5 % on
     // the SDXL step for the 64x128 tiles (one MFMA per sub-step leaves nothing to hide behind), so those keep LD_DMA.
     if (tiles(256, 256) >= 200) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    //  * tall problems that cannot fill the chip with 256x256 tiles (conv GEMMs 16384 x 320 x 2880..8640, 4096 x 5120 x 640):
+    //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
+    if (p.M >= 2048 && tiles(256, 128) >= 150) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
     if (p.M > 128) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
 }

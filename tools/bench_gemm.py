@@ -14,7 +14,8 @@ mm = ops.MM_FP8 if (len(sys.argv) > 1 and sys.argv[1] == "fp8") else ops.MM_I8
 SDXL = [(4096, 640, 640), (4096, 5120, 640), (4096, 640, 2560), (1024, 1280, 1280), (1024, 10240, 1280), (1024, 1280, 5120),
         (77, 640, 2048), (77, 1280, 2048)]
 BIG = [(16384, 8192, 4096), (4608, 3072, 3072), (4608, 12288, 3072), (4608, 3072, 15360), (8192, 8192, 8192)]
-shapes = SDXL + (BIG if (len(sys.argv) > 2 and sys.argv[2] == "all") else BIG[:1])
+CONV = [(16384, 320, 2880), (16384, 320, 8640), (4096, 640, 5760), (4096, 640, 17280), (1024, 1280, 11520), (1024, 1280, 23040), (4096, 1280, 11520)]
+shapes = CONV if (len(sys.argv) > 2 and sys.argv[2] == "conv") else SDXL + (BIG if (len(sys.argv) > 2 and sys.argv[2] == "all") else BIG[:1])
 
 
 def timed(fn, reps=20):
