@@ -37,3 +37,33 @@ def module_from_case(case, device) -> SDNQLinear:
 
 def to_f32_numpy(t: torch.Tensor):
     return t.detach().float().cpu().numpy()
+
+
+def oracle_from_module(mod):
+    """OracleLinear mirroring a live SDNQLinear / SDNQConv module (tensors copied to numpy in their logical layouts)."""
+    import numpy as np
+    from oracle import oracle as O
+    dq = mod.sdnq_dequantizer
+    deq = {f: getattr(dq, f) for f in ("weights_dtype", "quantized_matmul_dtype", "hadamard_group_size", "group_size", "svd_rank",
+                                       "use_quantized_matmul", "re_quantize_for_matmul", "use_hadamard", "use_codebook", "is_packed",
+                                       "is_unsigned", "is_integer", "layer_class_name")}
+    deq.update(result_dtype=str(dq.result_dtype).replace("torch.", ""), quantized_weight_shape=list(dq.quantized_weight_shape),
+               original_shape=list(dq.original_shape), result_shape=None if dq.result_shape is None else list(dq.result_shape))
+
+    def raw(t):
+        if t is None:
+            return None
+        t = t.detach().cpu()
+        if t.dtype in (torch.bfloat16, torch.float16):
+            return t.float().numpy()
+        if t.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+            return t.view(torch.uint8).numpy()
+        if not t.is_contiguous():  # transposed matmul layout: logical [K, N] values
+            return np.ascontiguousarray(t.numpy())
+        return t.numpy()
+
+    tag = {torch.bfloat16: "bf16", torch.float16: "f16", torch.float32: "f32"}
+    svd_up = getattr(mod, "svd_up", None)
+    return O.OracleLinear(deq, raw(mod.weight), raw(mod.scale), raw(getattr(mod, "zero_point", None)), raw(svd_up),
+                          raw(getattr(mod, "svd_down", None)), raw(mod.bias), svd_tag=tag[svd_up.dtype] if svd_up is not None else "bf16",
+                          bias_tag=tag[mod.bias.dtype] if mod.bias is not None else None, N=dq.out_features, K=dq.in_features)

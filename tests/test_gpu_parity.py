@@ -576,3 +576,42 @@ def test_fused_conv_quant_ties_and_large_image(gpu_device):
         rq, rs, _, _ = ops.rowquant(x2d, ops.MM_I8)
         assert torch.equal(xs, rs)
         assert torch.equal(xq, rq), int((xq != rq).sum())
+
+
+def test_flux_size_int4_hadamard_layer_vs_oracle(gpu_device):
+    """BASELINE configs[3] geometry (FLUX.1-dev: 4096 + 512 tokens, d = 3072), int4 + Hadamard-256, int8 MFMA: one full-size
+    layer against the oracle on all rows (rel-L2 bound of the Hadamard configs) plus row-slab independence (bit-exact)."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(3)
+    m, k, n = 4608, 3072, 1024
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256,
+                                                                   use_quantized_matmul=True))
+    assert mod.sdnq_dequantizer.re_quantize_for_matmul and mod.sdnq_dequantizer.use_hadamard
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16)
+    x[:, 7] *= 25
+    xg = x.to(gpu_device)
+    y = mod(xg)
+    assert torch.equal(mod(xg[1000:1300].contiguous()), y[1000:1300])
+    ref = O.forward(oracle_from_module(mod), x.float().numpy(), "bf16")
+    assert_close_float(to_f32_numpy(y), ref, "bf16", "flux-size int4+hadamard", hadamard=True)
+
+
+def test_sdxl_size_conv_int8_vs_oracle(gpu_device):
+    """An SDXL-UNet resnet conv at full size (320 -> 320, 3x3, 128 x 128 latent, bs=1) through the fused conv matmul path,
+    bit-exact against the oracle (16384 x 2880 x 320 int8 GEMM)."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(6)
+    conv = torch.nn.Conv2d(320, 320, 3, padding=1).to(torch.bfloat16).to(gpu_device)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(conv, sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))
+    assert mod.forward_func.__name__ == "quantized_conv_forward_int8_matmul"
+    x = torch.randn(1, 320, 128, 128, generator=torch.Generator().manual_seed(8)).to(torch.bfloat16)
+    x[:, 11] *= 30
+    y = mod(x.to(gpu_device))
+    meta = {"nd": 2, "kernel_size": [3, 3], "stride": [1, 1], "padding": [1, 1], "dilation": [1, 1], "padding_mode": "zeros", "groups": 1}
+    ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, "bf16")
+    got = to_f32_numpy(y)
+    assert got.shape == ref.shape == (1, 320, 128, 128)
+    assert np.array_equal(got, ref), int((got != ref).sum())
