@@ -11,6 +11,39 @@
 #pragma once
 #include "sdnq_dev.h"
 
+// Value of `v` held by lane (lane ^ mask), mask a compile-time constant after unrolling.  ds_bpermute (what __shfl_xor compiles
+// to) costs an LDS-crossbar pass per call and made the FWHT twice as slow as the rest of the row quantization; the xor patterns of
+// the butterflies map onto DPP row operations of the VALU instead (gfx9 DPP: quad_perm for bits 0-1, row_half_mirror / row_mirror
+// composed with quad_perm for bit 2, row_ror:8 for bit 3) and onto ds_swizzle's xor mode for bit 4; only bit 5 (group 512) still
+// takes the crossbar.  Measured at 4608 x 15360, group 256: 198 us (bpermute) -> 174 us; gfx950's v_permlane16_swap + select for
+// bit 4 was slower (191 us) than ds_swizzle.
+__device__ __forceinline__ float lane_xor(float v, const int mask) {
+    int x = __float_as_int(v);
+    if (mask & 32) x = __shfl_xor(x, 32, 64);
+    if (mask & 16) x = __builtin_amdgcn_ds_swizzle(x, 0x401F);                    // bitmask mode: and 0x1f, or 0, xor 0x10
+    if (mask & 8) x = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);  // row_ror:8  == lane ^ 8 inside a 16-lane row
+    switch (mask & 7) {
+        case 1: x = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); break;  // quad_perm [1,0,3,2]
+        case 2: x = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false); break;  // quad_perm [2,3,0,1]
+        case 3: x = __builtin_amdgcn_update_dpp(0, x, 0x1B, 0xf, 0xf, false); break;  // quad_perm [3,2,1,0]
+        case 4:  // lane ^ 7 (row_half_mirror) then ^ 3
+            x = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);
+            x = __builtin_amdgcn_update_dpp(0, x, 0x1B, 0xf, 0xf, false);
+            break;
+        case 5:
+            x = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);
+            x = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);
+            break;
+        case 6:
+            x = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);
+            x = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);
+            break;
+        case 7: x = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false); break;
+        default: break;
+    }
+    return __int_as_float(x);
+}
+
 // scale constants c(g) = |H_g[0][0]| as the reference materialises them (H.div_(n**0.5) in the
 // activation dtype); powers of 4 are exact powers of two. Values for the Sylvester sizes were read
 // from the reference (tests/golden/hadamard.npz for f32; bf16/f16 are the dtype-rounded values).
@@ -62,7 +95,7 @@ __device__ __forceinline__ void wave_hadamard(float (&v)[8], int log2g, float sc
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a = v[e], b = v[e + 4];
-                const float xa = __shfl_xor(a, 1, 64), xb = __shfl_xor(b, 1, 64);
+                const float xa = lane_xor(a, 1), xb = lane_xor(b, 1);
                 const float s = (a + b) + (xa + xb);
                 // partner with both bits flipped: for register e -> other lane's e+4, for e+4 -> other lane's e
                 v[e] = s - 2.0f * xb;
@@ -75,7 +108,7 @@ __device__ __forceinline__ void wave_hadamard(float (&v)[8], int log2g, float sc
                 const int ma = 1 << (d - 5), mb = 1 << (d - 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float p1 = __shfl_xor(v[e], ma, 64), p2 = __shfl_xor(v[e], mb, 64), p3 = __shfl_xor(v[e], ma | mb, 64);
+                    const float p1 = lane_xor(v[e], ma), p2 = lane_xor(v[e], mb), p3 = lane_xor(v[e], ma | mb);
                     const float s = (v[e] + p1) + (p2 + p3);
                     v[e] = s - 2.0f * p3;
                 }
@@ -102,7 +135,7 @@ __device__ __forceinline__ void wave_hadamard(float (&v)[8], int log2g, float sc
                 const bool hi = (lane & m) != 0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float p = __shfl_xor(v[e], m, 64);
+                    const float p = lane_xor(v[e], m);
                     v[e] = hi ? (p - v[e]) : (v[e] + p);
                 }
             }
@@ -129,7 +162,7 @@ __device__ __forceinline__ void wave_hadamard16(float (&v)[16], int log2g, float
                 const int ma = 1 << (d - 6), mb = 1 << (d - 5);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float p1 = __shfl_xor(v[e], ma, 64), p2 = __shfl_xor(v[e], mb, 64), p3 = __shfl_xor(v[e], ma | mb, 64);
+                    const float p1 = lane_xor(v[e], ma), p2 = lane_xor(v[e], mb), p3 = lane_xor(v[e], ma | mb);
                     const float s = (v[e] + p1) + (p2 + p3);
                     v[e] = s - 2.0f * p3;
                 }
@@ -157,7 +190,7 @@ __device__ __forceinline__ void wave_hadamard16(float (&v)[16], int log2g, float
                 const bool hi = (lane & m) != 0;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float p = __shfl_xor(v[e], m, 64);
+                    const float p = lane_xor(v[e], m);
                     v[e] = hi ? (p - v[e]) : (v[e] + p);
                 }
             }

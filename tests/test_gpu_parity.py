@@ -615,3 +615,25 @@ def test_sdxl_size_conv_int8_vs_oracle(gpu_device):
     got = to_f32_numpy(y)
     assert got.shape == ref.shape == (1, 320, 128, 128)
     assert np.array_equal(got, ref), int((got != ref).sum())
+
+
+@pytest.mark.parametrize("k", [6144, 12288, 15360])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("mm_name", ["int8", "fp8"])
+def test_long_row_hadamard_rowquant_equals_rotate_then_quantize(k, dt, mm_name, gpu_device):
+    """Rows beyond the register cache (K > 5120) with Hadamard (two-phase kernel: rotate for the amax, rotate again to quantize)
+    must equal sdnq_hip_hadamard followed by the plain row quantization: codes, scales, rowsum and the rotated copy alike.
+    (Parking the rotated row in LDS between the phases was tried: 20 % slower, one workgroup per CU starves the FWHT.)"""
+    mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
+    x = torch.randn(37, k, generator=torch.Generator().manual_seed(k)).to(dt)
+    x[:, 100] *= 40
+    x[5] = 0
+    xg = x.to(gpu_device)
+    want_rs = mm == ops.MM_I8
+    xq, xs, rs, xrot = ops.rowquant(xg, mm, 256, want_rowsum=want_rs, want_xrot=True)
+    rot = ops.hadamard(xg, 256)
+    q2, s2, rs2, _ = ops.rowquant(rot, mm, 0, want_rowsum=want_rs)
+    assert torch.equal(xrot, rot) and torch.equal(xs, s2)
+    assert np.array_equal(bits_of(xq), bits_of(q2))
+    if want_rs:
+        assert torch.equal(rs, rs2)
