@@ -105,7 +105,9 @@ int sdnq_hip_device_supported(int ordinal);
  * quant_utils.py:194-209).  xs[m] = amax_k|x| / qmax ; xq = cast(clamp(round_half_even(x / xs))).
  * x: [M][K] of x_dtype, row stride ldx elements. xq: [M][K] int8 or fp8-e4m3fn bytes. xs: [M] f32.
  * rowsum: optional [M] int32 = sum_k xq (zero-point bias, linear_int8.py:65-69); NULL to skip.
- * xrot: optional [M][K] of x_dtype receiving the rotated activation (needed by the SVD branch).
+ * xrot: optional [M][K] of x_dtype receiving the rotated activation (needed by the SVD branch).  For rotated rows longer
+ * than 5120 elements it doubles as the kernel's parking space (rotate once, quantize from the copy): pass it whenever
+ * K > 5120 and hadamard_group != 0 -- without it the rotation is simply computed twice.
  * hadamard_group: 0 = no rotation, else power of two in [4, 512] dividing K.
  * prefetch / prefetch_bytes: optional software prefetch (may be NULL / 0): extra workgroups of the same launch read
  * this range (the weight operand of the matmul that follows) so that it is resident in the last-level cache when

@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 wave_hadamard(v, log2g, hscale);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+                // with a rotated-copy buffer the FWHT -- the expensive part of a rotated row -- runs only once: the rounded row
+                // is parked there (L2-resident, 2-4 bytes per element) and phase 2 reads it back
+                if (xrot != nullptr && idx < K) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
@@ -180,12 +183,15 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
             const int64_t idx = p * 512 + lane * 8;
             const bool ok = idx < K;
             float v[8];
-            load8<T_ID>(row, idx, ok, v);
-            if constexpr (HAD) {
-                wave_hadamard(v, log2g, hscale);
+            if (HAD && xrot != nullptr) {  // wave-uniform
+                load8<T_ID>((const char*)xrot + m * K * FT<T_ID>::bytes, idx, ok, v);  // this lane's own stores of phase 1
+            } else {
+                load8<T_ID>(row, idx, ok, v);
+                if constexpr (HAD) {
+                    wave_hadamard(v, log2g, hscale);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
-                if (xrot != nullptr && ok) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v);
+                    for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+                }
             }
             const uint2 w = quant8<MM>(v, scale, isum);
             if (ok) *(uint2*)(qrow + idx) = w;

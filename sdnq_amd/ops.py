@@ -165,12 +165,17 @@ def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: b
     xq = torch.empty((m, k), device=x2d.device, dtype=_MM_TORCH[mm])
     xs = torch.empty((m, 1), device=x2d.device, dtype=torch.float32)
     rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
-    xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if (want_xrot and hadamard_group) else None
+    # rows beyond the kernel's register cache (K > 5120) are rotated once into this buffer and quantized from it, so it is
+    # allocated for them even when the caller does not want the rotated copy
+    need_rot = bool(hadamard_group) and (want_xrot or k > 5120)
+    xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if need_rot else None
     xzp = torch.empty((m,), device=x2d.device, dtype=torch.float32) if asymmetric else None
     check(_lib.load().sdnq_hip_rowquant(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), mm, hadamard_group,
                                         xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _ptr(prefetch),
                                         0 if prefetch is None else prefetch.numel() * prefetch.element_size(), _ptr(xzp),
                                         _stream(x2d)), "rowquant")
+    if not want_xrot:
+        xrot = None  # scratch only: released here (stream-ordered reuse by the caching allocator)
     if asymmetric:
         return xq, xs, rowsum, xrot, xzp
     return xq, xs, rowsum, xrot
