@@ -77,8 +77,16 @@ __global__ __launch_bounds__(256) void dequant_kernel(const DeqParams p, void* _
         for (int j = 0; j < 16; ++j) { v[j] = FT<SVD_T>::round(v[j]); acc[j] = 0.0f; }
         for (int r = 0; r < p.rank; ++r) {
             const float up = FT<SVD_T>::load(p.svd_up, n * p.rank + r);
+            float dn[16];  // svd_down[r][k0 .. k0+15]: 16-byte vector loads (k0 % 16 == 0, K % 16 == 0)
+            if constexpr (SVD_T == SDNQ_F32) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = fmaf(up, FT<SVD_T>::load(p.svd_down, (int64_t)r * p.K + k0 + j), acc[j]);
+                for (int q = 0; q < 4; ++q) Vec16<SDNQ_F32>::unpack(*(const uint4*)((const float*)p.svd_down + (int64_t)r * p.K + k0 + 4 * q), dn + 4 * q);
+            } else {
+                Vec16<SVD_T>::unpack(*(const uint4*)((const uint16_t*)p.svd_down + (int64_t)r * p.K + k0), dn);
+                Vec16<SVD_T>::unpack(*(const uint4*)((const uint16_t*)p.svd_down + (int64_t)r * p.K + k0 + 8), dn + 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(up, dn[j], acc[j]);
         }
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = FT<SVD_T>::round(v[j] + acc[j]);

@@ -409,43 +409,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // ---- low-rank (SVD) term on the matrix cores: lr[n][m] = sum_r up[n][r] * t[m][r] -----------------------------
     // same 32x32 MFMA shape as the main product, so every lane gets the low-rank value of exactly the outputs it owns;
     // operands are 16-byte rows of t [M][R] / svd_up [N][R] straight from global (R/16 MFMAs per sub-tile).
-    v16f lr[TN][TM];
+    // (computed per 32x32 sub-tile right before that sub-tile is staged: only 16 extra accumulator registers are live at a
+    // time -- holding all TN x TM low-rank tiles next to the main accumulators spilled 104 VGPRs in the 256x256 kernel)
     bool lr_mfma = false;
-    if constexpr (EPI == EPI_LOWRANK) {
-        lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
-        if (lr_mfma) {
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) lr[i][j][e] = 0.0f;
-            for (int kr = 0; kr < p.rank; kr += 16) {
-                uint4 fu[TN], ft[TM];
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    int64_t gn = n0 + wn * WN + i * 32 + (lane & 31);
-                    if (gn >= p.N) gn = p.N - 1;
-                    fu[i] = *(const uint4*)((const uint16_t*)p.lr_up + gn * p.rank + kr + (lane >> 5) * 8);
-                }
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    int64_t gm = m0 + wm * WM + j * 32 + (lane & 31);
-                    if (gm >= p.M) gm = p.M - 1;
-                    ft[j] = *(const uint4*)((const uint16_t*)p.lr_t + gm * p.rank + kr + (lane >> 5) * 8);
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j) {
-                        if (p.bias_dtype == SDNQ_BF16)
-                            lr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fu[i]), __builtin_bit_cast(v8bf, ft[j]), lr[i][j], 0, 0, 0);
-                        else
-                            lr[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fu[i]), __builtin_bit_cast(v8h, ft[j]), lr[i][j], 0, 0, 0);
-                    }
-            }
-        }
-    }
+    if constexpr (EPI == EPI_LOWRANK) lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
@@ -457,10 +424,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i) {
+            if (ECH > 1 && (wm * WM + j * 32) / CH != ch) continue;  // wave-uniform: this 32-row block is in another chunk
+            v16f lrt;
+            if constexpr (EPI == EPI_LOWRANK) {
+                if (lr_mfma) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) lrt[e] = 0.0f;
+                    int64_t gn = n0 + wn * WN + i * 32 + (lane & 31), gm = m0 + wm * WM + j * 32 + (lane & 31);
+                    if (gn >= p.N) gn = p.N - 1;
+                    if (gm >= p.M) gm = p.M - 1;
+                    const uint16_t* up = (const uint16_t*)p.lr_up + gn * p.rank + (lane >> 5) * 8;
+                    const uint16_t* tt = (const uint16_t*)p.lr_t + gm * p.rank + (lane >> 5) * 8;
+                    for (int kr = 0; kr < p.rank; kr += 16) {
+                        const uint4 fu = *(const uint4*)(up + kr), ft = *(const uint4*)(tt + kr);
+                        if (p.bias_dtype == SDNQ_BF16)
+                            lrt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fu), __builtin_bit_cast(v8bf, ft), lrt, 0, 0, 0);
+                        else
+                            lrt = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fu), __builtin_bit_cast(v8h, ft), lrt, 0, 0, 0);
+                    }
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (ECH > 1 && (wm * WM + j * 32) / CH != ch) continue;  // wave-uniform: this 32-row block is in another chunk
                 const int ml = wm * WM + j * 32 + frow - ch * CH;
                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
                 if constexpr (MM == SDNQ_MM_I8)
@@ -469,9 +455,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     *(v4f*)(stage + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 if constexpr (EPI == EPI_LOWRANK) {
                     if (lr_mfma)
-                        *(v4f*)(stage + CH * ACC_ROW + ml * ACC_ROW + nl0 * 4) = (v4f){lr[i][j][4 * q], lr[i][j][4 * q + 1], lr[i][j][4 * q + 2], lr[i][j][4 * q + 3]};
+                        *(v4f*)(stage + CH * ACC_ROW + ml * ACC_ROW + nl0 * 4) = (v4f){lrt[4 * q], lrt[4 * q + 1], lrt[4 * q + 2], lrt[4 * q + 3]};
                 }
             }
+        }
     __syncthreads();
     TRACE(5);
     // (2) one compact loop: 8 consecutive channels of one row per thread -> scale, bias, cast, 16/32-byte store
