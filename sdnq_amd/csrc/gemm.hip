@@ -216,9 +216,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int STAGE_BYTES = (BM + BN) * BK;
     constexpr int LDS_STAGES = NS;
     constexpr int OUT_B = FT<OUT_T>::bytes;
-    constexpr int ACC_ROW = BN * 4 + 16;  // epilogue staging: raw 32-bit accumulators, [CH][ACC_ROW]
     constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // the tile leaves in ECH chunks of CH rows (LDS budget)
-    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES, EPI_BYTES = CH * ACC_ROW * (EPI == EPI_LOWRANK ? 2 : 1);
+    // epilogue staging: final values (simple epilogues) or raw accumulators + low-rank tile (EPI_LOWRANK)
+    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES;
+    constexpr int EPI_BYTES = (EPI == EPI_LOWRANK || BM > 128) ? CH * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : CH * (BN * OUT_B + 16);
     constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
@@ -415,6 +416,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     if constexpr (EPI == EPI_LOWRANK) lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    constexpr bool STAGED_EPILOGUE = (EPI == EPI_LOWRANK) || (BM > 128);
+    if constexpr (STAGED_EPILOGUE) {
+    // ======== LDS-staged epilogue with a compact runtime loop: low-rank / zero-point terms, and every 256-row tile ====
+    // The low-rank arithmetic is long; fully unrolled over the accumulator registers (as the epilogue below is) it becomes
+    // ~8k instructions of straight-line code that every wave executes once at instruction-fetch speed (measured: 2.5x slower
+    // GEMM).  The 256-row tiles (128 accumulator registers per lane) also measured 2 % faster this way.  So the raw
+    // accumulators (and the low-rank tile) are staged as 32-bit values and a small loop finishes them.
+    constexpr int ACC_ROW = BN * 4 + 16;
     // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
     //     acc[i][j][reg]: n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = wm*WM + j*32 + (lane&31)
     uint8_t* stage = lds;
@@ -586,6 +595,96 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
     }
     });
+    } else {
+    // ======== simple epilogues of the 64-row tiles: arithmetic in the MFMA register layout (+2.6 % on the SDXL step's GEMMs) ==
+    // Every lane owns output position m = wm*WM + j*32 + (lane&31) and channels n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) +
+    // 4*(lane>>5); per-channel vectors come from LDS; only the FINAL values (OUT_B bytes each) are staged through LDS
+    // [CH rows][BN] to leave as 16-byte row pieces (or, for the conv forwards, channel-major runs of 8 positions): half the LDS
+    // traffic of staging raw 32-bit accumulators, and ~6 instructions per output, so unrolling it stays small.
+    constexpr int OUT_ROW = BN * OUT_B + 16;  // staging row pitch in bytes
+    uint8_t* stage = lds;
+    static_for_up<ECH>([&](auto chc) {
+    constexpr int ch = decltype(chc)::value;
+    if (ch > 0) __syncthreads();  // previous chunk fully stored before its staging area is overwritten
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        if (ECH > 1 && (wm * WM + j * 32) / CH != ch) continue;  // wave-uniform: this 32-row block is in another chunk
+        const int ml = wm * WM + j * 32 + frow - ch * CH;        // row inside the chunk
+        int64_t gm = m0 + wm * WM + j * 32 + frow;
+        const bool m_ok = gm < p.M;
+        if (!m_ok) gm = p.M - 1;
+        const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;  // 4 consecutive channels
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cn = nl0 + e;
+                    const float a = MT::tof(acc[i][j], 4 * q + e);  // int32 -> f32 (RNE above 2^24) | f32
+                    float res;
+                    if constexpr (is_float_mm<MM>) {  // F.linear: f32 accumulate, bias added in f32, one rounding
+                        res = (EPI == EPI_BIAS1D) ? a + s_bias[cn] : a;
+                    } else {
+                        const float vv = a * sa;
+                        const float sbn = s_sb[cn];
+                        if constexpr (EPI == EPI_NONE) {
+                            res = vv * sbn;
+                        } else if constexpr (EPI == EPI_BIAS1D) {
+                            res = fmaf(vv, sbn, s_bias[cn]);
+                        } else {
+                            int64_t gn = n0 + cn;
+                            if (gn >= p.N) gn = p.N - 1;
+                            res = fmaf(vv, sbn, ldf_rt(p.bias, gm * p.ld_bias + gn, p.bias_dtype));  // EPI_BIAS2D
+                        }
+                    }
+                    o[e] = res;
+                }
+                uint8_t* dst = stage + ml * OUT_ROW + nl0 * OUT_B;
+                if constexpr (OUT_T == SDNQ_F32) {
+                    *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
+                } else {
+                    const uint32_t lo = (uint32_t)FT<OUT_T>::bits(o[0]) | ((uint32_t)FT<OUT_T>::bits(o[1]) << 16);
+                    const uint32_t hi = (uint32_t)FT<OUT_T>::bits(o[2]) | ((uint32_t)FT<OUT_T>::bits(o[3]) << 16);
+                    *(uint2*)dst = make_uint2(lo, hi);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    TRACE(5);
+    if constexpr (EPI <= EPI_BIAS1D && OUT_T != SDNQ_F32) {
+        if (p.out_hw > 0) {
+            // channel-major store for the conv forwards: 8 consecutive output positions of ONE channel per thread (they are
+            // contiguous in the [B][N][HW] image: HW % 8 == 0 and tiles start on multiples of 64)
+#pragma nounroll
+            for (int v = tid; v < (CH / 8) * BN; v += NT) {
+                const int n = v / (CH / 8), r8 = (v % (CH / 8)) * 8;
+                const int64_t gm = m0 + ch * CH + r8, gn = n0 + n;
+                if (gm >= p.M || gn >= p.N) continue;
+                uint16_t h8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8[e] = *(const uint16_t*)(stage + (r8 + e) * OUT_ROW + n * 2);
+                const int64_t img = gm / p.out_hw, px = gm - img * p.out_hw;
+                *(uint4*)((uint8_t*)p.out + ((img * p.N + gn) * p.out_hw + px) * 2) = *(const uint4*)h8;
+            }
+            return;
+        }
+    }
+    // plain copy: 16-byte pieces of the output rows
+    constexpr int PPR = BN * OUT_B / 16;  // pieces per row
+    constexpr int EPP = 16 / OUT_B;       // output elements per piece
+#pragma nounroll
+    for (int v = tid; v < CH * PPR; v += NT) {
+        const int r = v / PPR, c = v % PPR;
+        const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c * EPP;
+        if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a piece never straddles N
+        *(uint4*)((uint8_t*)p.out + (gm * p.N + gn0) * OUT_B) = *(const uint4*)(stage + r * OUT_ROW + c * 16);
+    }
+    });
+    }
     TRACE(6);
 }
 
@@ -593,7 +692,7 @@ template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, in
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int MAIN = NS * (BM + BN) * BK;
-    constexpr int EPIB = (BM > 128 ? 64 : BM) * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1);
+    constexpr int EPIB = (BM > 128 ? 64 : BM) * ((EPI == EPI_LOWRANK || BM > 128) ? (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : BN * FT<OUT_T>::bytes + 16);
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 4 * BN * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK>;

@@ -37,6 +37,7 @@ template <> struct FT<SDNQ_F32> {
     static __device__ __forceinline__ float load(const void* p, int64_t i) { return ((const float*)p)[i]; }
     static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
     static __device__ __forceinline__ float round(float v) { return v; }
+    static __device__ __forceinline__ uint32_t bits(float v) { return __float_as_uint(v); }
 };
 template <> struct FT<SDNQ_BF16> {
     typedef uint16_t store_t;
@@ -44,6 +45,7 @@ template <> struct FT<SDNQ_BF16> {
     static __device__ __forceinline__ float load(const void* p, int64_t i) { return bf16_bits_to_f32(((const uint16_t*)p)[i]); }
     static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = f32_to_bf16_bits(v); }
     static __device__ __forceinline__ float round(float v) { return bf16_bits_to_f32(f32_to_bf16_bits(v)); }
+    static __device__ __forceinline__ uint16_t bits(float v) { return f32_to_bf16_bits(v); }
 };
 template <> struct FT<SDNQ_F16> {
     typedef uint16_t store_t;
@@ -51,6 +53,7 @@ template <> struct FT<SDNQ_F16> {
     static __device__ __forceinline__ float load(const void* p, int64_t i) { return f16_bits_to_f32(((const uint16_t*)p)[i]); }
     static __device__ __forceinline__ void store(void* p, int64_t i, float v) { ((uint16_t*)p)[i] = f32_to_f16_bits(v); }
     static __device__ __forceinline__ float round(float v) { return f16_bits_to_f32(f32_to_f16_bits(v)); }
+    static __device__ __forceinline__ uint16_t bits(float v) { return f32_to_f16_bits(v); }
 };
 
 // 16-byte vector of elements -> 8 (16-bit) or 4 (f32) floats
