@@ -7,7 +7,7 @@ arithmetic is the Linear one -- row quantization, int8 / fp8 MFMA scaled matmul 
 float GEMM -- and the ``[M, C_out]`` product is viewed back to NCHW (conv_int8.py:81-88).  The float branch uses this build's
 own GEMM instead of the library convolution the reference calls (``_conv_forward``): same sum, fp32 accumulation.
 
-Not built (raise): groups != 1 (the reference loops ``int_mm`` per group, conv_int8.py:73-79), Conv3d, uint8 / fp16 matmul,
+Not built (raise): groups != 1 (the reference loops ``int_mm`` per group, conv_int8.py:73-79), Conv3d, fp16 matmul,
 Hadamard on conv layers.
 """
 from __future__ import annotations
@@ -96,6 +96,15 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
 @torch.no_grad()
 def quantized_conv_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _conv_matmul_forward(self, input, ops.MM_I8)
+
+
+@torch.no_grad()
+def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    """layers/conv/conv_uint8.py:95-121: unfolded input through the asymmetric-activation int8 matmul."""
+    x2d, fold = _unfold(self, input)
+    if input.numel() / input.shape[2] < 32:
+        return fold(linear._float_forward(self, x2d, linear._state(self)))
+    return fold(linear._uint8_matmul_forward(self, x2d, small_batch_branch=False))
 
 
 @torch.no_grad()

@@ -16,11 +16,11 @@ def get_forward_func(layer_class_name: str, quantized_matmul_dtype: str, use_qua
         from . import conv
         if use_quantized_matmul:
             ent = dtype_dict[quantized_matmul_dtype]
-            if ent["is_integer"] and not ent["is_unsigned"]:
-                return conv.quantized_conv_forward_int8_matmul
+            if ent["is_integer"]:
+                return conv.quantized_conv_forward_uint8_matmul if ent["is_unsigned"] else conv.quantized_conv_forward_int8_matmul
             if not ent["is_integer"] and ent["num_bits"] == 8:
                 return conv.quantized_conv_forward_fp8_matmul
-            raise NotImplementedError(f"conv matmul in {quantized_matmul_dtype} is not built (int8 and fp8 are)")
+            raise NotImplementedError(f"conv matmul in {quantized_matmul_dtype} is not built (int8, uint8 and fp8 are)")
         return conv.quantized_conv_forward
     from . import linear
     if use_quantized_matmul:

@@ -72,7 +72,8 @@ def clear_activation_cache():
 
 
 def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum: bool, want_xrot: bool, prefetch, asymmetric=False):
-    params = (mm, had, want_rowsum, want_xrot, asymmetric)
+    # the stream is part of the key: an entry produced on one stream is not ordered against work on another
+    params = (mm, had, want_rowsum, want_xrot, asymmetric, torch.cuda.current_stream(input.device).cuda_stream if input.is_cuda else -1)
     if CACHE_ACTIVATIONS > 0:
         hit = _act_cache.get(input, params)
         if hit is not None:
@@ -212,15 +213,14 @@ def quantized_linear_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tens
     return _quantized_matmul_forward(self, input, ops.MM_FP8)
 
 
-@torch.no_grad()
-def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = True) -> torch.Tensor:
     """Asymmetric-activation int8 matmul (layers/linear/linear_uint8.py:106-131): activations get a per-row zero point,
     the three cross terms of (x - xzp)(w - wzp) are added in the GEMM epilogue instead of a materialised [M,N] bias."""
     dq = self.sdnq_dequantizer
     st = _state(self)
     k, n = dq.in_features, dq.out_features
     m = input.numel() // input.shape[-1]
-    if m < 32:
+    if m == 0 or (small_batch_branch and m < 32):
         return _float_forward(self, input, st)
     if dq.re_quantize_for_matmul:
         raise NotImplementedError("uint8 matmul with re-quantized (group-wise / sub-byte) weights needs the asymmetric weight "
@@ -239,6 +239,11 @@ def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Te
     y = ops.scaled_mm_lowrank(ops.MM_I8, xq, wq, xs, ws, self.bias, t, st.svd_up, rowsum, zp, input.dtype, a_zp=xzp,
                               w_colsum_scaled=wcs)
     return y.view(*input.shape[:-1], n)
+
+
+@torch.no_grad()
+def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    return _uint8_matmul_forward(self, input)
 
 
 @torch.no_grad()

@@ -289,6 +289,8 @@ CONV_CASES = [
          cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True)),
     dict(name="conv2d_int8_svd16_qmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
          cfg=dict(weights_dtype="int8", use_svd=True, svd_rank=16, use_quantized_matmul_conv=True)),
+    dict(name="conv2d_uint8_uint8mm_qmm_bf16", nd=2, cin=32, cout=48, k=3, conv=dict(padding=1, stride=(1, 2)), xs=[(2, 9, 10)], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", use_quantized_matmul_conv=True)),
     dict(name="conv2d_uint8_int8mm_qmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),
 ]
