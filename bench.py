@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8"])
+    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -67,6 +67,8 @@ def workload_config(name: str):
     if name == "flux_int8_svd":
         return shapes.flux_dev_layer_sequence(), dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
                                                use_quantized_matmul=True), "int8", 4608
+    if name == "sdxl_int8_dequant":  # the reference's DEFAULT mode (use_quantized_matmul=False): dequantize + bf16 matrix-core GEMM per call
+        return shapes.sdxl_unet_layer_sequence(), dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=False), "int8", 16384
     if name == "sdxl_conv_int8":  # the UNet's Conv2d layers through the same int8 matmul (use_quantized_matmul_conv)
         return shapes.sdxl_unet_convs(), dict(weights_dtype="int8", group_size=-1, quant_conv=True, use_quantized_matmul_conv=True), "int8", 16384
     if name == "linear_int8":  # the reference's own micro-benchmark shape (scripts/benchmark_sdnq_inference_matmul.py)
