@@ -637,3 +637,35 @@ def test_long_row_hadamard_rowquant_equals_rotate_then_quantize(k, dt, mm_name, 
     assert np.array_equal(bits_of(xq), bits_of(q2))
     if want_rs:
         assert torch.equal(rs, rs2)
+
+
+def test_end_to_end_transformer_encoder_drop_in(gpu_device):
+    """A whole (tiny, randomly initialised) transformers BERT encoder quantized in place with apply_sdnq_to_module and run on the HIP
+    forwards: every nn.Linear becomes an SDNQLinear, the model still runs through its own code, and the int8 w8a8 output stays
+    close to the float model (quantization error only).  Then the same with fused q/k/v-free options: dequant mode and int4."""
+    transformers = pytest.importorskip("transformers")
+    import sdnq_amd
+    torch.manual_seed(0)
+    cfg = transformers.BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=128,
+                                  max_position_embeddings=128)
+    ids = torch.randint(0, 128, (2, 64), generator=torch.Generator().manual_seed(1)).to(gpu_device)
+
+    def build():
+        torch.manual_seed(0)
+        return transformers.BertModel(cfg).eval().to(torch.bfloat16).to(gpu_device)
+
+    with torch.no_grad():
+        ref = build()(input_ids=ids).last_hidden_state.float()
+    for kwargs, min_cos in ((dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), 0.995),
+                            (dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=False), 0.995),
+                            (dict(weights_dtype="uint4", use_quantized_matmul=True), 0.95),
+                            (dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=64, use_quantized_matmul=True), 0.95)):
+        model = build()
+        model, qcfg = sdnq_amd.apply_sdnq_to_module(model, sdnq_amd.SDNQConfig(minimum_allowed_numel=1024, **kwargs))
+        n_q = sum(1 for m in model.modules() if isinstance(m, sdnq_amd.SDNQLinear))
+        assert n_q >= 2 * 6 and not any(type(m) is torch.nn.Linear and m.weight.numel() >= 65536 for m in model.modules())
+        with torch.no_grad():
+            out = model(input_ids=ids).last_hidden_state.float()
+        assert torch.isfinite(out).all()
+        cos = torch.nn.functional.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+        assert cos >= min_cos, (kwargs, cos)
