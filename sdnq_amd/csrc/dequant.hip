@@ -276,6 +276,77 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const DeqParams p, c
     }
 }
 
+// Few-row linear on an int8 row-wise weight WITH SVD factors (the M < 32 branch of an SVD layer, e.g. FLUX adaLN projections):
+// y = x . W^T + b with W = round(round(q * s) + svd_up . svd_down) exactly as sdnq_hip_dequant forms it (dequantizer.py:79-83),
+// but the rank-R product is done on the matrix cores tile by tile and W never exists in memory.  One workgroup = 32 output
+// channels; its 4 waves split K in blocks of 32.  Per block: D[k][n] = down_t[k][:] . up[n][:] (R/16 MFMAs, operands are
+// 16-byte rows of down_t [K][R] and svd_up [N][R]); lane (n = lane & 31, half = lane >> 5) then owns k = (reg & 3) + 8 (reg >> 2)
+// + 4 half of that tile, decodes the matching 4 x 4 int8 codes of row n, forms W and multiplies by x (f32 copy in LDS).
+// HBM-bound on the codes: N*K bytes (the dequantize + GEMV pair it replaces moves 5 N*K bytes and is VALU-bound on the rank loop).
+template <bool IS_BF16, int MR>
+__global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, const uint16_t* __restrict__ down_t, const void* __restrict__ x,
+                                                         const void* __restrict__ bias, void* __restrict__ out, int64_t M, int64_t ldx) {
+    constexpr int T_ID = IS_BF16 ? SDNQ_BF16 : SDNQ_F16;
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [MR][K]
+    __shared__ float red[4][MR][32];
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = (int)p.K, R = p.rank;
+    for (int i = tid; i < MR * K; i += 256) {
+        const int m = i / K, k = i - m * K;
+        xs[i] = (m < M) ? FT<T_ID>::load(x, (int64_t)m * ldx + k) : 0.0f;
+    }
+    __syncthreads();
+    int64_t gn = (int64_t)blockIdx.x * 32 + nl;
+    const bool n_ok = gn < p.N;
+    if (!n_ok) gn = p.N - 1;
+    const float s = p.scale[gn];
+    const uint16_t* up = (const uint16_t*)p.svd_up + gn * R + hi * 8;
+    const int8_t* wrow = (const int8_t*)p.w + gn * K;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.0f;
+    for (int k0 = wave * 32; k0 < K; k0 += 128) {
+        v16f ud;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ud[e] = 0.0f;
+        const uint16_t* dn = down_t + (int64_t)(k0 + nl) * R + hi * 8;
+        for (int kr = 0; kr < R; kr += 16) {
+            const uint4 fd = *(const uint4*)(dn + kr), fu = *(const uint4*)(up + kr);
+            if constexpr (IS_BF16) ud = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fd), __builtin_bit_cast(v8bf, fu), ud, 0, 0, 0);
+            else ud = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fd), __builtin_bit_cast(v8h, fu), ud, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kb = k0 + 8 * g + 4 * hi;
+            const u32 w4 = *(const u32*)(wrow + kb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float q = (float)(int)(int8_t)(w4 >> (8 * e));
+                float wv = FT<T_ID>::round(q * s);                       // dequantize -> .to(svd dtype)
+                wv = FT<T_ID>::round(wv + ud[4 * g + e]);                // addmm_(svd_up, svd_down): one rounding of the sum
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m] = fmaf(xs[m * K + kb + e], wv, acc[m]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        acc[m] += __shfl_xor(acc[m], 32, 64);
+        if (hi == 0) red[wave][m][nl] = acc[m];
+    }
+    __syncthreads();
+    if (tid < 32 * MR) {
+        const int m = tid / 32, n = tid % 32;
+        const int64_t on = (int64_t)blockIdx.x * 32 + n;
+        if (m < M && on < p.N) {
+            float sum = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+            if (bias) sum += FT<T_ID>::load(bias, on);
+            FT<T_ID>::store(out, (int64_t)m * p.N + on, sum);
+        }
+    }
+}
+
 // t[M][R] = cast( x[M][K] . down[R][K]^T ) on the matrix cores (bf16 / f16): the inner torch.mm of the SVD branch
 // (linear_int8.py:60).  One workgroup = 32 activation rows; its 8 waves split K, each accumulating a 32(n) x 32(m)
 // tile with v_mfma_f32_32x32x16 (A-operand = svd_down rows, B-operand = activation rows, both K-contiguous 16-byte
@@ -467,6 +538,42 @@ extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int6
         return SDNQ_OK;
     }
     return sdnq_hip_linear_float(x, svd_down, nullptr, x_dtype, t, m, rank, k, ldx, stream);
+}
+
+extern "C" int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, const void* x, const void* bias, int dtype,
+                                          void* out, int64_t m, int64_t ldx, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!x || !out || !svd_down_t || !w->svd_up) return SDNQ_ERR_NULL;
+    if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
+    if (w->svd_dtype != dtype) return SDNQ_ERR_DTYPE;
+    if (p.fmt.storage != SDNQ_ST_RAW8 || p.fmt.kind != SDNQ_KIND_INT || p.group_size != p.K || p.P != 1) return SDNQ_ERR_UNSUPPORTED;
+    if (m <= 0 || m > 4 || ldx < p.K || (p.K % 32) != 0 || p.rank <= 0 || (p.rank % 16) != 0) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)svd_down_t % 16) || ((uintptr_t)w->svd_up % 16)) return SDNQ_ERR_ALIGN;
+    const size_t lds = (size_t)(m <= 1 ? 1 : (m <= 2 ? 2 : 4)) * p.K * sizeof(float);
+    if (lds > 150 * 1024) return SDNQ_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((p.N + 31) / 32)), block(256);
+#define SS_LAUNCH(B, MR)                                                                                                     \
+    do {                                                                                                                     \
+        auto kern = skinny_svd_kernel<B, MR>;                                                                                \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+            return SDNQ_ERR_LAUNCH;                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, p, (const uint16_t*)svd_down_t, x, bias, out, m, ldx);                 \
+    } while (0)
+#define SS_DISPATCH(B)            \
+    do {                          \
+        if (m <= 1) SS_LAUNCH(B, 1); \
+        else if (m <= 2) SS_LAUNCH(B, 2); \
+        else SS_LAUNCH(B, 4);     \
+    } while (0)
+    if (dtype == SDNQ_BF16) SS_DISPATCH(true);
+    else SS_DISPATCH(false);
+#undef SS_DISPATCH
+#undef SS_LAUNCH
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
 }
 
 extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, const void* x, const void* bias, int dtype, void* out,

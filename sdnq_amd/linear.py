@@ -90,7 +90,7 @@ def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum
 
 class _State:
     """Per-module cache of kernel-ready tensors, keyed on the identity of the module's parameters."""
-    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "wd", "bias")
+    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "svd_down_t", "wd", "bias")
 
 
 def _key(mod):
@@ -112,6 +112,7 @@ def _state(mod) -> _State:
         st.mm = None
         st.mm_weight = st.mm_scale = st.mm_zp = st.mm_wcs = None
         st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
+        st.svd_down_t = None
         st.wd = None
         mod.__dict__["_sdnq_hip_state"] = st
     return st
@@ -136,6 +137,16 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
         if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
             x2 = x2.contiguous()
         return ops.linear_skinny(st.qw, x2, mod.bias, dq.hadamard_group_size if dq.use_hadamard else 0).view(*input.shape[:-1], n)
+    if (FUSED_SKINNY and m <= 4 and st.svd_up is not None and not dq.use_hadamard and dq.weights_dtype == "int8" and dq.group_size <= 0
+            and dq.kernel_positions == 1 and k % 32 == 0 and st.svd_up.shape[1] % 16 == 0 and input.dtype in (torch.bfloat16, torch.float16)
+            and st.svd_up.dtype == input.dtype and m * k * 4 <= 150 * 1024):
+        # int8 + SVD layer with a few rows: W = round(round(q s) + up.down) is formed on the fly (rank product on the matrix cores)
+        if st.svd_down_t is None:
+            st.svd_down_t = st.svd_down.t().contiguous()  # [K, R]
+        x2 = input.reshape(-1, k)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        return ops.linear_skinny_svd(st.qw, st.svd_down_t, x2, mod.bias).view(*input.shape[:-1], n)
     wd = st.wd
     if wd is None:
         wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)

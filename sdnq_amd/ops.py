@@ -309,6 +309,19 @@ def linear_skinny(qw: QuantWeight, x2d: torch.Tensor, bias, hadamard_group: int 
     return out
 
 
+def linear_skinny_svd(qw: QuantWeight, svd_down_t: torch.Tensor, x2d: torch.Tensor, bias) -> torch.Tensor:
+    """Few-row linear on an int8 row-wise weight with SVD factors; svd_down_t is [K, R] contiguous."""
+    _require_cuda(x2d, bias, svd_down_t)
+    m, k = x2d.shape
+    assert k == qw.k and x2d.stride(1) == 1 and svd_down_t.is_contiguous()
+    if bias is not None and bias.dtype != x2d.dtype:
+        bias = bias.to(x2d.dtype)
+    out = torch.empty((m, qw.n), device=x2d.device, dtype=x2d.dtype)
+    check(_lib.load().sdnq_hip_linear_skinny_svd(ctypes.byref(qw.desc), svd_down_t.data_ptr(), x2d.data_ptr(), _ptr(bias),
+                                                 float_code(x2d.dtype), out.data_ptr(), m, x2d.stride(0), _stream(x2d)), "linear_skinny_svd")
+    return out
+
+
 def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor:
     """t[M,R] = cast(x2d @ svd_down_phys^T); svd_down_phys is physical [R,K]."""
     m, k = x2d.shape
