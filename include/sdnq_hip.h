@@ -213,6 +213,14 @@ int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, con
 int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw, int stride_h,
                     int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, void* out, sdnq_stream_t stream);
 
+/* sdnq_hip_rowquant (no rowsum / rotated copy / prefetch / asymmetric mode) followed by sdnq_hip_scaled_mm (bias: NULL or [N])
+ * in one call: the plain w8a8 Linear of int8_matmul / fp8_matmul (linear_int8.py:75-97, linear_fp8.py:58-78).  Two launches on
+ * `stream`; xq [M][K] and xs [M] are outputs that stay valid (sibling layers reuse them).  hadamard_group as in sdnq_hip_rowquant
+ * (rows longer than 5120 elements are then rotated twice, see there). */
+int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int hadamard_group,
+                         void* xq, float* xs, const void* b, const float* sb, const void* bias, int bias_dtype, void* out,
+                         int out_dtype, int64_t n, sdnq_stream_t stream);
+
 /* the scaled matmul of the conv forwards with the channel-major store fused into the epilogue: out is the conv output
  * [B][N][hw] (NCHW / NCL), rows m = b * hw + pixel -- replaces int_scaled_mm_func(...).view(mm_output_shape) followed by
  * .permute(0, 3, 1, 2).contiguous() (conv_int8.py:71, 81-88).  bias: NULL or [N] of bias_dtype; hw % 8 == 0, m % hw == 0,

@@ -28,3 +28,13 @@ extern "C" int sdnq_hip_device_supported(int ordinal) {
     if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return 0;
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+
+// The whole plain w8a8 Linear in one call: row quantization, then the scaled matmul (two launches on `stream`).  Exists for
+// hosts where the per-call binding cost matters (an eager Python model pays the ctypes marshalling once instead of twice).
+extern "C" int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int hadamard_group,
+                                    void* xq, float* xs, const void* b, const float* sb, const void* bias, int bias_dtype, void* out,
+                                    int out_dtype, int64_t n, sdnq_stream_t stream) {
+    int st = sdnq_hip_rowquant(x, x_dtype, m, k, ldx, mm_dtype, hadamard_group, xq, xs, nullptr, nullptr, nullptr, 0, nullptr, stream);
+    if (st != SDNQ_OK) return st;
+    return sdnq_hip_scaled_mm(mm_dtype, xq, b, xs, sb, bias, bias_dtype, bias ? 1 : 0, 0, out, out_dtype, m, n, k, stream);
+}

@@ -73,7 +73,7 @@ def clear_activation_cache():
 
 def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum: bool, want_xrot: bool, prefetch, asymmetric=False):
     # the stream is part of the key: an entry produced on one stream is not ordered against work on another
-    params = (mm, had, want_rowsum, want_xrot, asymmetric, torch.cuda.current_stream(input.device).cuda_stream if input.is_cuda else -1)
+    params = (mm, had, want_rowsum, want_xrot, asymmetric, ops._stream(input) if input.is_cuda else -1)
     if CACHE_ACTIVATIONS > 0:
         hit = _act_cache.get(input, params)
         if hit is not None:
@@ -93,28 +93,50 @@ class _State:
     __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "svd_down_t", "wd", "bias")
 
 
-def _key(mod):
-    def k(t):
-        return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
-    return (k(mod.weight), k(mod.scale), k(getattr(mod, "zero_point", None)), k(getattr(mod, "svd_up", None)),
-            k(getattr(mod, "svd_down", None)))
+_STATE_FIELDS = ("weight", "scale", "zero_point", "svd_up", "svd_down")
+
+
+def _attr(mod, name):
+    """mod.<name> without nn.Module.__getattr__ (parameters, then buffers, then plain attributes such as None)."""
+    d = mod.__dict__
+    t = d["_parameters"].get(name, d)
+    if t is d:
+        t = d.get(name, d)
+        if t is d:
+            t = getattr(mod, name, None)
+    return t
+
+
+def _signature(mod):
+    out = []
+    for name in _STATE_FIELDS:
+        t = _attr(mod, name)
+        out.append((name, t, None if t is None else t.data_ptr(), None if t is None else t._version))
+    return tuple(out)
 
 
 def _state(mod) -> _State:
+    """Kernel-ready tensors of a module, rebuilt when a parameter object, its storage or its version changes (the check is on the
+    per-forward path of eager models: a few dictionary lookups, no tuple building)."""
     st = mod.__dict__.get("_sdnq_hip_state")
-    key = _key(mod)
-    if st is None or st.key != key:
-        dq = mod.sdnq_dequantizer
-        st = _State()
-        st.key = key
-        st.qw = dq.quant_weight(mod.weight, mod.scale, getattr(mod, "zero_point", None), getattr(mod, "svd_up", None),
-                                getattr(mod, "svd_down", None))
-        st.mm = None
-        st.mm_weight = st.mm_scale = st.mm_zp = st.mm_wcs = None
-        st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
-        st.svd_down_t = None
-        st.wd = None
-        mod.__dict__["_sdnq_hip_state"] = st
+    if st is not None:
+        for name, ref, ptr, ver in st.key:
+            t = _attr(mod, name)
+            if t is not ref or (t is not None and (t.data_ptr() != ptr or t._version != ver)):
+                break
+        else:
+            return st
+    dq = mod.sdnq_dequantizer
+    st = _State()
+    st.key = _signature(mod)
+    st.qw = dq.quant_weight(mod.weight, mod.scale, getattr(mod, "zero_point", None), getattr(mod, "svd_up", None),
+                            getattr(mod, "svd_down", None))
+    st.mm = None
+    st.mm_weight = st.mm_scale = st.mm_zp = st.mm_wcs = None
+    st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
+    st.svd_down_t = None
+    st.wd = None
+    mod.__dict__["_sdnq_hip_state"] = st
     return st
 
 
@@ -202,8 +224,25 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     wq, ws, zp = _prepare_mm_weights(self, st, mm)
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
+    bias = _attr(self, "bias")
+    if not has_svd and zp is None and (had == 0 or k <= 5120):
+        # plain w8a8 layer: on a cache miss the row quantization and the GEMM go through ONE binding call (an eager model is
+        # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers
+        params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
+        hit = _act_cache.get(input, params) if CACHE_ACTIVATIONS > 0 else None
+        if hit is None:
+            x2 = input.reshape(-1, k)
+            if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+                x2 = x2.contiguous()
+            if not x2.is_cuda:
+                raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
+            y, xq, xs = ops.linear_w8a8(mm, x2, wq, ws, bias, input.dtype, had)
+            if CACHE_ACTIVATIONS > 0:
+                _act_cache.put(input, params, (x2, xq, xs, None, None))
+            return y.view(*input.shape[:-1], n)
+        x2, xq, xs, rowsum, xrot = hit
+        return ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype).view(*input.shape[:-1], n)
     x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, wq if PREFETCH_WEIGHTS else None)
-    bias = self.bias
     if has_svd or zp is not None:
         t = None
         if has_svd:  # mm(x, svd_down) of addmm(bias, mm(x, svd_down), svd_up), linear_int8.py:57-62
