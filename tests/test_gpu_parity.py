@@ -699,3 +699,27 @@ def test_skinny_svd_matches_dequant_then_linear(m, dt, qmm, gpu_device):
     assert_close_float(to_f32_numpy(y_fused), ref, tag, (m, tag, qmm, "fused vs oracle"))
     assert_close_float(to_f32_numpy(y_plain), ref, tag, (m, tag, qmm, "plain vs oracle"))
     assert_close_float(to_f32_numpy(y_fused), to_f32_numpy(y_plain), tag, (m, tag, qmm, "fused vs plain"))
+
+
+def test_fp8_matmul_properties_at_sdxl_size(gpu_device):
+    """fp8 scaled matmul at an SDXL ff.proj size: tile independence (row / column slabs of the big problem are bit-identical to
+    the small problems: every output sums its K products in the same order whatever tile it lands in), exact power-of-two scaling,
+    and a sampled block against the oracle within the fp8 tolerance."""
+    m, n, k = 4096, 5120, 640
+    g = torch.Generator().manual_seed(15)
+    a = (torch.randn(m, k, generator=g) * 40).to(torch.float8_e4m3fn).to(gpu_device)
+    b = (torch.randn(n, k, generator=g) * 40).to(torch.float8_e4m3fn).to(gpu_device)
+    sa = (torch.rand(m, generator=g) * 0.02 + 1e-4).to(gpu_device)
+    sb = (torch.rand(n, generator=g) * 0.02 + 1e-4).to(gpu_device)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16).to(gpu_device)
+    full = ops.scaled_mm(ops.MM_FP8, a, b, sa, sb, bias, torch.bfloat16)
+    rows = ops.scaled_mm(ops.MM_FP8, a[1000:1077].contiguous(), b, sa[1000:1077].contiguous(), sb, bias, torch.bfloat16)
+    assert torch.equal(full[1000:1077], rows)
+    cols = ops.scaled_mm(ops.MM_FP8, a, b[640:1280].contiguous(), sa, sb[640:1280].contiguous(), bias[640:1280].contiguous(), torch.bfloat16)
+    assert torch.equal(full[:, 640:1280], cols)
+    dbl = ops.scaled_mm(ops.MM_FP8, a, b, sa * 2, sb, None, torch.float32)
+    base = ops.scaled_mm(ops.MM_FP8, a, b, sa, sb, None, torch.float32)
+    assert torch.equal(dbl, base * 2)
+    ref = O.scaled_mm("fp8", a[:64].view(torch.uint8).cpu().numpy(), b[:256].view(torch.uint8).cpu().numpy(), sa[:64].cpu().numpy(),
+                      sb[:256].cpu().numpy(), bias[:256].float().cpu().numpy(), "bf16")
+    assert_close_float(to_f32_numpy(full[:64, :256]), ref, "bf16", "fp8 sdxl-size block")
