@@ -33,6 +33,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 INT8_MFMA_PEAK_TOPS = 5033.0  # dense: 1024 MAC/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz x 2 (MI355X_MICROARCH.md: i8 = 2x bf16 rate)
 FP8_MFMA_PEAK_TFLOPS = 5033.0
 HBM_PEAK_GBS = 8000.0
@@ -364,7 +365,9 @@ def main():
             ach = gk["ops"] / gk["seconds"] / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s" if mm_name == "int8" else "TFLOP/s",
                                   "frac": round(ach / INT8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                                  "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
+                                  "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]),
+                                  "hbm_achieved_gbps": round(gk["bytes"] / gk["seconds"] / 1e9, 1), "hbm_peak_gbps": HBM_PEAK_GBPS,
+                                  "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
                                   "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3)}
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:

@@ -276,6 +276,106 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const DeqParams p, c
     }
 }
 
+// Fast few-row linear for the two storage formats that matter at M <= 4 (raw 8-bit integers and 4-bit packed integers, signed
+// or unsigned, any group size that is a multiple of 16): the generic kernel above decodes inside its K loop, so a wave has ONE
+// 0.5-1 KiB weight load in flight and runs at 0.7-1.2 TB/s; here the loads of up to four 1024-element chunks of the row are
+// issued before anything is decoded (3-4 KiB in flight per wave, ~20 waves per CU), everything else -- f32(w)*s | fma, rounding
+// to T, optional FWHT un-rotation, fp32 accumulation, wave reduction -- is the same arithmetic in the same order.
+template <int T_ID, int BITS, int MROWS>
+__global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams p, const void* __restrict__ x, const void* __restrict__ bias,
+                                                                 void* __restrict__ out, int64_t M, int64_t ldx, int log2had) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    float acc[MROWS];
+#pragma unroll
+    for (int i = 0; i < MROWS; ++i) acc[i] = 0.0f;
+    const float hscale = log2had ? hadamard_scale(log2had, T_ID) : 1.0f;
+    const uint8_t* wrow = (const uint8_t*)p.w + (BITS == 8 ? n * p.K : n * p.K / 2);
+    const float* srow = p.scale + n * p.G;
+    const float* zrow = p.zp ? p.zp + n * p.G : nullptr;
+    const bool is_signed = p.fmt.kind == SDNQ_KIND_INT;
+    for (int64_t kb = 0; kb < p.K; kb += 4096) {
+        uint4 raw[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // all weight loads of this 4096-element stretch first
+            const int64_t k0 = kb + c * 1024 + (int64_t)lane * 16;
+            raw[c] = make_uint4(0, 0, 0, 0);
+            if (k0 < p.K) {
+                if constexpr (BITS == 8) raw[c] = *(const uint4*)(wrow + k0);
+                else { const uint2 q = *(const uint2*)(wrow + k0 / 2); raw[c].x = q.x; raw[c].y = q.y; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (kb + c * 1024 >= p.K) break;  // wave-uniform
+            const int64_t k0 = kb + c * 1024 + (int64_t)lane * 16;
+            const bool live = k0 < p.K;
+            float w[16];
+            const u32 ww[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int code;
+                if constexpr (BITS == 8) {
+                    const u32 b = (ww[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    code = is_signed ? (int)(int8_t)b : (int)b;
+                } else {
+                    const u32 b = (ww[j >> 3] >> (4 * (j & 7))) & 15u;
+                    code = is_signed ? (int)b - 8 : (int)b;  // packed signed ints are stored as value - min
+                }
+                w[j] = (float)code;
+            }
+            if (live) {
+                const int g = (int)(k0 / p.group_size);  // group_size % 16 == 0: one group per 16-run
+                const float sc = srow[g];
+                if (zrow) {
+                    const float z = zrow[g];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) w[j] = fmaf(w[j], sc, z);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) w[j] = w[j] * sc;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) w[j] = FT<T_ID>::round(w[j]);
+            if (log2had) {
+                wave_hadamard16(w, log2had, hscale);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = FT<T_ID>::round(w[j]);
+            }
+            if (!live) continue;
+#pragma unroll
+            for (int i = 0; i < MROWS; ++i) {
+                const int64_t m = (i < M) ? i : M - 1;
+                float xv[16];
+                if constexpr (T_ID == SDNQ_F32) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Vec16<SDNQ_F32>::unpack(*(const uint4*)((const float*)x + m * ldx + k0 + 4 * q), xv + 4 * q);
+                } else {
+                    Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + m * ldx + k0), xv);
+                    Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + m * ldx + k0 + 8), xv + 8);
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[i] = fmaf(xv[j], w[j], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MROWS; ++i) {
+        float sum = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0 && i < M) {
+            if (bias) sum += FT<T_ID>::load(bias, n);
+            FT<T_ID>::store(out, (int64_t)i * p.N + n, sum);
+        }
+    }
+}
+
 // Few-row linear on an int8 row-wise weight WITH SVD factors (the M < 32 branch of an SVD layer, e.g. FLUX adaLN projections):
 // y = x . W^T + b with W = round(round(q * s) + svd_up . svd_down) exactly as sdnq_hip_dequant forms it (dequantizer.py:79-83),
 // but the rank-R product is done on the matrix cores tile by tile and W never exists in memory.  One workgroup = 32 output
@@ -593,6 +693,33 @@ extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, c
     const int eb = (dtype == SDNQ_F32) ? 4 : 2;
     if (((uintptr_t)x % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
+    {
+        const bool int_fmt = p.fmt.kind == SDNQ_KIND_INT || p.fmt.kind == SDNQ_KIND_UINT;
+        const bool raw8 = p.fmt.storage == SDNQ_ST_RAW8 && int_fmt, pk4 = p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && int_fmt;
+        if ((raw8 || pk4) && m <= 4 && p.P == 1 && (p.group_size % 16) == 0 && (p.K % 16) == 0) {
+            dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
+#define SF_LAUNCH(T, B, MR) hipLaunchKernelGGL((linear_skinny_fast_kernel<T, B, MR>), grid, block, 0, s, p, x, bias, out, m, ldx, log2had)
+#define SF_M(T, B)                       \
+    do {                                 \
+        if (m == 1) SF_LAUNCH(T, B, 1);  \
+        else if (m == 2) SF_LAUNCH(T, B, 2); \
+        else SF_LAUNCH(T, B, 4);         \
+    } while (0)
+#define SF_T(B)                                      \
+    do {                                             \
+        if (dtype == SDNQ_F32) SF_M(SDNQ_F32, B);    \
+        else if (dtype == SDNQ_BF16) SF_M(SDNQ_BF16, B); \
+        else SF_M(SDNQ_F16, B);                      \
+    } while (0)
+            if (raw8) SF_T(8);
+            else SF_T(4);
+#undef SF_T
+#undef SF_M
+#undef SF_LAUNCH
+            SDNQ_CHECK_LAUNCH();
+            return SDNQ_OK;
+        }
+    }
 #define SK_LAUNCH(T, MR)                                                                                      \
     hipLaunchKernelGGL((linear_skinny_kernel<T, MR>), dim3((unsigned)((p.N + 3) / 4), (unsigned)((m + MR - 1) / MR)), \
                        dim3(256), 0, s, p, x, bias, out, m, ldx, log2had)
