@@ -1,8 +1,12 @@
 #!/bin/bash
-# development build of the library with per-workgroup phase timestamps in the GEMM kernel
+# development build of the library with per-workgroup phase timestamps in the GEMM kernel -> build/libsdnq_hip_trace.so
+# (use with SDNQ_HIP_LIB=$PWD/build/libsdnq_hip_trace.so python tools/trace_gemm.py)
 set -euo pipefail
-cd "$(dirname "$0")/../sdnq_amd/csrc"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$ROOT/sdnq_amd/csrc"
+mkdir -p "$ROOT/build"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument -DSDNQ_TRACE"
-for f in api rowquant gemm dequant quantize conv; do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/trace_$f.o & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$(dirname "$0")/../../build/libsdnq_hip_trace.so" /tmp/trace_api.o /tmp/trace_rowquant.o /tmp/trace_gemm.o /tmp/trace_dequant.o /tmp/trace_quantize.o /tmp/trace_conv.o
+OBJS=()
+for f in api rowquant gemm dequant quantize conv; do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/trace_$f.o & OBJS+=(/tmp/trace_$f.o); done; wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$ROOT/build/libsdnq_hip_trace.so" "${OBJS[@]}"
 echo built
