@@ -723,3 +723,29 @@ def test_fp8_matmul_properties_at_sdxl_size(gpu_device):
     ref = O.scaled_mm("fp8", a[:64].view(torch.uint8).cpu().numpy(), b[:256].view(torch.uint8).cpu().numpy(), sa[:64].cpu().numpy(),
                       sb[:256].cpu().numpy(), bias[:256].float().cpu().numpy(), "bf16")
     assert_close_float(to_f32_numpy(full[:64, :256]), ref, "bf16", "fp8 sdxl-size block")
+
+
+def test_weight_cache_switch_is_transparent(gpu_device):
+    """SDNQ_HIP_CACHE_WEIGHTS=0 (re-quantize / unpack on every call, like the reference) gives the same bits as the cached path."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(21)
+    x = torch.randn(64, 512, device=gpu_device, dtype=torch.bfloat16)
+    for kwargs in (dict(weights_dtype="int4", use_quantized_matmul=True), dict(weights_dtype="int6", use_quantized_matmul=True),
+                   dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_quantized_matmul=True),
+                   dict(weights_dtype="uint8", group_size=-1, use_quantized_matmul=True)):
+        lin = torch.nn.Linear(512, 128, bias=True).to(torch.bfloat16).to(gpu_device)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(**kwargs))
+        old = L.CACHE_WEIGHTS
+        try:
+            L.CACHE_WEIGHTS = False
+            mod.__dict__.pop("_sdnq_hip_state", None)
+            a, b = mod(x).clone(), mod(x).clone()
+            assert L._state(mod).mm_weight is None
+            L.CACHE_WEIGHTS = True
+            mod.__dict__.pop("_sdnq_hip_state", None)
+            c, d = mod(x).clone(), mod(x).clone()
+            assert L._state(mod).mm_weight is not None
+        finally:
+            L.CACHE_WEIGHTS = old
+        assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(c, d), kwargs
