@@ -239,8 +239,8 @@ int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int channels, 
                              int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
                              void* xq, float* xs, void* amax_ws, sdnq_stream_t stream);
 
-/* the same few-row linear for int8 row-wise layers WITH SVD factors (w->svd_up [N][R] set): W = round(round(q * s) +
- * svd_up . svd_down) is formed tile by tile with the rank-R product on the matrix cores and never stored (replaces the
+/* the same few-row linear for 8-bit raw / 4-bit packed integer layers (signed or unsigned, row- or group-wise, group % 4 == 0)
+ * WITH SVD factors (w->svd_up [N][R] set): W = round(dequant(q) + svd_up . svd_down) is formed tile by tile with the rank-R product on the matrix cores and never stored (replaces the
  * dequantize incl. addmm_ + F.linear pair of the M < 32 branch, linear_int8.py:102-103 + dequantizer.py:79-83).
  * svd_down_t: [K][R] (the transposed factor, i.e. the reference's stored matmul layout of svd_down), dtype = bf16 / f16
  * = svd dtype; m <= 4, K % 32 == 0, R % 16 == 0; other layouts: SDNQ_ERR_UNSUPPORTED (use dequant + linear_float). */

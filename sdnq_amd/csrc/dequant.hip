@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams
 // 16-byte rows of down_t [K][R] and svd_up [N][R]); lane (n = lane & 31, half = lane >> 5) then owns k = (reg & 3) + 8 (reg >> 2)
 // + 4 half of that tile, decodes the matching 4 x 4 int8 codes of row n, forms W and multiplies by x (f32 copy in LDS).
 // HBM-bound on the codes: N*K bytes (the dequantize + GEMV pair it replaces moves 5 N*K bytes and is VALU-bound on the rank loop).
-template <bool IS_BF16, int MR>
+template <bool IS_BF16, int MR, int BITS>
 __global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, const uint16_t* __restrict__ down_t, const void* __restrict__ x,
                                                          const void* __restrict__ bias, void* __restrict__ out, int64_t M, int64_t ldx) {
     constexpr int T_ID = IS_BF16 ? SDNQ_BF16 : SDNQ_F16;
@@ -400,9 +400,11 @@ __global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, cons
     int64_t gn = (int64_t)blockIdx.x * 32 + nl;
     const bool n_ok = gn < p.N;
     if (!n_ok) gn = p.N - 1;
-    const float s = p.scale[gn];
+    const float* srow = p.scale + gn * p.G;
+    const float* zrow = p.zp ? p.zp + gn * p.G : nullptr;
+    const bool is_signed = p.fmt.kind == SDNQ_KIND_INT;
     const uint16_t* up = (const uint16_t*)p.svd_up + gn * R + hi * 8;
-    const int8_t* wrow = (const int8_t*)p.w + gn * K;
+    const uint8_t* wrow = (const uint8_t*)p.w + (BITS == 8 ? gn * K : gn * K / 2);
     float acc[MR];
 #pragma unroll
     for (int m = 0; m < MR; ++m) acc[m] = 0.0f;
@@ -418,12 +420,18 @@ __global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, cons
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int kb = k0 + 8 * g + 4 * hi;
-            const u32 w4 = *(const u32*)(wrow + kb);
+            const int kb = k0 + 8 * g + 4 * hi;  // 4 consecutive columns: one scale group (group_size % 4 == 0)
+            const float s = srow[kb / p.group_size];
+            const float z = zrow ? zrow[kb / p.group_size] : 0.0f;
+            u32 w4;
+            if constexpr (BITS == 8) w4 = *(const u32*)(wrow + kb);
+            else w4 = *(const uint16_t*)(wrow + kb / 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float q = (float)(int)(int8_t)(w4 >> (8 * e));
-                float wv = FT<T_ID>::round(q * s);                       // dequantize -> .to(svd dtype)
+                float q;
+                if constexpr (BITS == 8) q = is_signed ? (float)(int)(int8_t)(w4 >> (8 * e)) : (float)((w4 >> (8 * e)) & 0xffu);
+                else q = is_signed ? (float)((int)((w4 >> (4 * e)) & 15u) - 8) : (float)((w4 >> (4 * e)) & 15u);  // packed signed: value - min
+                float wv = FT<T_ID>::round(zrow ? fmaf(q, s, z) : q * s);  // dequantize -> .to(svd dtype)
                 wv = FT<T_ID>::round(wv + ud[4 * g + e]);                // addmm_(svd_up, svd_down): one rounding of the sum
 #pragma unroll
                 for (int m = 0; m < MR; ++m) acc[m] = fmaf(xs[m * K + kb + e], wv, acc[m]);
@@ -648,7 +656,9 @@ extern "C" int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_d
     if (!x || !out || !svd_down_t || !w->svd_up) return SDNQ_ERR_NULL;
     if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
     if (w->svd_dtype != dtype) return SDNQ_ERR_DTYPE;
-    if (p.fmt.storage != SDNQ_ST_RAW8 || p.fmt.kind != SDNQ_KIND_INT || p.group_size != p.K || p.P != 1) return SDNQ_ERR_UNSUPPORTED;
+    const bool int_fmt = p.fmt.kind == SDNQ_KIND_INT || p.fmt.kind == SDNQ_KIND_UINT;
+    const bool raw8 = p.fmt.storage == SDNQ_ST_RAW8 && int_fmt, pk4 = p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && int_fmt;
+    if (!(raw8 || pk4) || (p.group_size % 4) != 0 || p.P != 1) return SDNQ_ERR_UNSUPPORTED;
     if (m <= 0 || m > 4 || ldx < p.K || (p.K % 32) != 0 || p.rank <= 0 || (p.rank % 16) != 0) return SDNQ_ERR_SHAPE;
     if (((uintptr_t)svd_down_t % 16) || ((uintptr_t)w->svd_up % 16)) return SDNQ_ERR_ALIGN;
     const size_t lds = (size_t)(m <= 1 ? 1 : (m <= 2 ? 2 : 4)) * p.K * sizeof(float);
@@ -657,7 +667,7 @@ extern "C" int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_d
     dim3 grid((unsigned)((p.N + 31) / 32)), block(256);
 #define SS_LAUNCH(B, MR)                                                                                                     \
     do {                                                                                                                     \
-        auto kern = skinny_svd_kernel<B, MR>;                                                                                \
+        auto kern = raw8 ? skinny_svd_kernel<B, MR, 8> : skinny_svd_kernel<B, MR, 4>;                                        \
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
             return SDNQ_ERR_LAUNCH;                                                                                          \
         hipLaunchKernelGGL(kern, grid, block, lds, s, p, (const uint16_t*)svd_down_t, x, bias, out, m, ldx);                 \

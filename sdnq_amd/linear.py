@@ -159,8 +159,8 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
         if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
             x2 = x2.contiguous()
         return ops.linear_skinny(st.qw, x2, mod.bias, dq.hadamard_group_size if dq.use_hadamard else 0).view(*input.shape[:-1], n)
-    if (FUSED_SKINNY and m <= 4 and st.svd_up is not None and not dq.use_hadamard and dq.weights_dtype == "int8" and dq.group_size <= 0
-            and dq.kernel_positions == 1 and k % 32 == 0 and st.svd_up.shape[1] % 16 == 0 and input.dtype in (torch.bfloat16, torch.float16)
+    if (FUSED_SKINNY and m <= 4 and st.svd_up is not None and not dq.use_hadamard and dq.weights_dtype in ("int8", "uint8", "int4", "uint4")
+            and (dq.group_size <= 0 or dq.group_size % 4 == 0) and dq.kernel_positions == 1 and k % 32 == 0 and st.svd_up.shape[1] % 16 == 0 and input.dtype in (torch.bfloat16, torch.float16)
             and st.svd_up.dtype == input.dtype and m * k * 4 <= 150 * 1024):
         # int8 + SVD layer with a few rows: W = round(round(q s) + up.down) is formed on the fly (rank product on the matrix cores)
         if st.svd_down_t is None:

@@ -674,7 +674,8 @@ def test_end_to_end_transformer_encoder_drop_in(gpu_device):
 @pytest.mark.parametrize("m", [1, 2, 3, 4])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("qmm", [True, False])
-def test_skinny_svd_matches_dequant_then_linear(m, dt, qmm, gpu_device):
+@pytest.mark.parametrize("wdt,gs", [("int8", -1), ("uint4", 32), ("int4", 64), ("uint8", -1)])
+def test_skinny_svd_matches_dequant_then_linear(m, dt, qmm, wdt, gs, gpu_device):
     """int8 + SVD layers with a few rows: the fused kernel (rank product on the matrix cores, W never stored) against the
     dequantize (+ addmm) -> linear pair and the oracle."""
     import sdnq_amd
@@ -683,7 +684,7 @@ def test_skinny_svd_matches_dequant_then_linear(m, dt, qmm, gpu_device):
     torch.manual_seed(13)
     k, n = 384, 200
     lin = torch.nn.Linear(k, n, bias=True).to(dt).to(gpu_device)
-    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype=wdt, group_size=gs, use_svd=True, svd_rank=32,
                                                                    use_quantized_matmul=qmm))
     assert mod.svd_up is not None
     x = torch.randn(m, k, generator=torch.Generator().manual_seed(m)).to(dt).to(gpu_device)
@@ -696,9 +697,9 @@ def test_skinny_svd_matches_dequant_then_linear(m, dt, qmm, gpu_device):
         L.FUSED_SKINNY = True
     tag = "bf16" if dt == torch.bfloat16 else "f16"
     ref = O.forward(oracle_from_module(mod), to_f32_numpy(x), tag)
-    assert_close_float(to_f32_numpy(y_fused), ref, tag, (m, tag, qmm, "fused vs oracle"))
-    assert_close_float(to_f32_numpy(y_plain), ref, tag, (m, tag, qmm, "plain vs oracle"))
-    assert_close_float(to_f32_numpy(y_fused), to_f32_numpy(y_plain), tag, (m, tag, qmm, "fused vs plain"))
+    assert_close_float(to_f32_numpy(y_fused), ref, tag, (m, tag, qmm, wdt, "fused vs oracle"))
+    assert_close_float(to_f32_numpy(y_plain), ref, tag, (m, tag, qmm, wdt, "plain vs oracle"))
+    assert_close_float(to_f32_numpy(y_fused), to_f32_numpy(y_plain), tag, (m, tag, qmm, wdt, "fused vs plain"))
 
 
 def test_fp8_matmul_properties_at_sdxl_size(gpu_device):
