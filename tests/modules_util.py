@@ -1,7 +1,6 @@
 """Build product-path modules (sdnq_amd.SDNQLinear) from golden fixtures or from scratch."""
 import torch
 
-import sdnq_amd
 from sdnq_amd.dequantizer import SDNQDequantizer
 from sdnq_amd.forward import get_forward_func
 from sdnq_amd.layers import SDNQLinear

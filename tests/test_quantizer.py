@@ -6,7 +6,7 @@ import torch
 import sdnq_amd
 from sdnq_amd import quantizer
 from tests.golden_util import Case
-from tests.modules_util import TORCH_DT
+
 
 # cases whose quantization is deterministic given the float weight (no randomized SVD, no float GEMM before rounding)
 EXACT = ["int8_rowwise_noqmm_f32", "int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "fp8_qmm_bf16", "uint4_qmm_bf16",
