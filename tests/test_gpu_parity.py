@@ -750,3 +750,35 @@ def test_weight_cache_switch_is_transparent(gpu_device):
         finally:
             L.CACHE_WEIGHTS = old
         assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(c, d), kwargs
+
+
+def test_zero_weight_row_zero_activation_row_and_big_accumulators(gpu_device):
+    """an all-zero weight row gives scale 0 and y[:, n] == bias[n]; an all-zero activation row gives y[m, :] ==
+    bias; int32 accumulators beyond 2^24 (K = 15360, saturated operands) round to f32 like the reference (RNE) -- bit-exact vs
+    the oracle."""
+    import sdnq_amd
+    torch.manual_seed(31)
+    for kwargs in (dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True), dict(weights_dtype="int4", use_quantized_matmul=True),
+                   dict(weights_dtype="uint4", use_quantized_matmul=True)):
+        lin = torch.nn.Linear(256, 64, bias=True).to(torch.bfloat16)
+        with torch.no_grad():
+            lin.weight[5].zero_()
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin.to(gpu_device), sdnq_amd.SDNQConfig(**kwargs))
+        x = torch.randn(40, 256, device=gpu_device, dtype=torch.bfloat16)
+        x[7].zero_()
+        y = mod(x)
+        assert torch.isfinite(y).all(), kwargs
+        assert torch.equal(y[:, 5], mod.bias[5].expand(40)), kwargs
+        assert torch.equal(y[7], mod.bias), kwargs
+    m, n, k = 64, 64, 15360
+    a = torch.full((m, k), 127, dtype=torch.int8)
+    a[::3] = -128
+    b = torch.full((n, k), 127, dtype=torch.int8)
+    b[::5] = -128
+    b[1, ::2] = 1
+    sa = torch.full((m,), 2.0 ** -20)
+    sb = torch.full((n,), 1.0)
+    y = ops.scaled_mm(ops.MM_I8, a.to(gpu_device), b.to(gpu_device), sa.to(gpu_device), sb.to(gpu_device), None, torch.float32)
+    ref = O.scaled_mm("int8", a.numpy(), b.numpy(), sa.numpy(), sb.numpy(), None, "f32")
+    assert float(np.abs(ref).max()) * 2.0 ** 20 > 2.0 ** 24
+    assert np.array_equal(y.cpu().numpy(), ref)
