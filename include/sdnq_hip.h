@@ -142,6 +142,11 @@ int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* out, int out
  * per-output-row symmetric quantization to the matmul dtype. wq: physical [N][K]; ws: [N] f32. */
 int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, float* ws, sdnq_stream_t stream);
 
+/* asymmetric form for quantized_matmul_dtype "uint8": replaces re_quantize_uint_mm (dequantizer.py:178-187) ->
+ * quantize_uint_mm (quant_utils.py:277-286): scale = (max - min) / 255, zero_point = min + 128 * scale per output row,
+ * wq = int8 codes of (w - zero_point) / scale.  wq: physical [N][K] int8; ws, wzp: [N] f32. */
+int sdnq_hip_requant_asym(const SdnqWeight* w, void* wq, float* ws, float* wzp, sdnq_stream_t stream);
+
 /* ---- a12/a13 (weight half): matmul operand WITHOUT re-quantization ----------------------------
  * replaces the per-call unpack in get_int8_matmul_inputs / get_fp8_matmul_inputs
  * (layers/linear/linear_int8.py:38-50, linear_fp8.py:36-38) for row-wise weights whose codes already fit

@@ -378,7 +378,24 @@ class OracleLinear:
         """re_quantize_matmul (dequantizer.py:204-239): fp32 dequant (no SVD, Hadamard not undone) -> per-row quant.
         Returns (wq [N,K] int8 | e4m3 codes uint8, ws [N])."""
         W = self.dequant_f32_nk()
+        if self.deq["quantized_matmul_dtype"] == "uint8":
+            return rowquant_asym(W)  # re_quantize_uint_mm (dequantizer.py:178-187): (wq int8, ws, zero_point)
         return rowquant(W, self.deq["quantized_matmul_dtype"])[:2]
+
+
+def rowquant_asym(x_f32: np.ndarray):
+    """quantize_uint_mm with matmul_dtype "uint8" -> "int8" range (quant_utils.py:277-286, get_scale_asymmetric :10-19).
+    Returns (q int8 [M,K], scale [M], zero_point [M])."""
+    f = np.float32
+    x = _c(x_f32, f)
+    xmin, xmax = x.min(-1, keepdims=True).astype(f), x.max(-1, keepdims=True).astype(f)
+    scale = ((xmax - xmin).astype(f) / f(255.0)).astype(f)
+    zp = (xmin - f(-128.0) * scale).astype(f)  # zero_point.sub_(scale, alpha=min); 128*scale is exact
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = ((x - zp).astype(f) / scale).astype(f)
+    q = np.clip(np.rint(q), -128, 127)
+    q = np.where(np.isnan(q), 0, q).astype(np.int8)
+    return q, scale.reshape(-1), zp.reshape(-1)
 
 
 def rowquant(x_f32: np.ndarray, matmul_dtype: str):
@@ -547,10 +564,13 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
     K, N = mod.K, mod.N
     M = x2.shape[0]
     f = np.float32
-    assert not d["re_quantize_for_matmul"] and not d["is_packed"], "oracle covers plain uint8 weights for the uint8 matmul"
-    vals, sc, zpv, group = mod._nk_values_scale()
-    wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
-    zp = (zpv + f(128.0) * sc).astype(f)
+    if d["re_quantize_for_matmul"]:  # linear_uint8.py:109-111: int8 codes + per-row scale and zero point, no xor
+        wq, sc, zp = mod.re_quantize_matmul()
+    else:
+        assert not d["is_packed"], "row-wise uint8 is the only weight format that reaches the uint8 matmul without re-quantization"
+        vals, sc, zpv, group = mod._nk_values_scale()
+        wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+        zp = (zpv + f(128.0) * sc).astype(f)
     if d["use_hadamard"]:
         x2 = rotate_hadamard(x2, d["hadamard_group_size"], tag)
     bias = mod.bias
@@ -558,15 +578,8 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
         up, down = mod.svd_nr_rk()
         t = linear_float(round_dtype(x2, mod.svd_tag), down, None, mod.svd_tag)
         bias = lowrank_bias(t, up, None if bias is None else round_dtype(bias, mod.svd_tag), mod.svd_tag)
-    # quantize_uint_mm (quant_utils.py:277-286) with matmul_dtype "int8": get_scale_asymmetric (:10-19)
-    xmin, xmax = x2.min(-1, keepdims=True).astype(f), x2.max(-1, keepdims=True).astype(f)
-    xscale = ((xmax - xmin).astype(f) / f(255.0)).astype(f)
-    xzp = (xmin - f(-128.0) * xscale).astype(f)  # zero_point.sub_(scale, alpha=min)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        q = ((x2 - xzp).astype(f) / xscale).astype(f)
-    q = np.clip(np.rint(q), -128, 127)
-    q = np.where(np.isnan(q), 0, q).astype(np.int8)
-    xs = xscale.reshape(-1)
+    q, xs, xzp = rowquant_asym(x2)  # quantize_uint_mm_input (linear_uint8.py:15-23)
+    xzp = xzp[:, None]
     rowsum = q.astype(np.int32).sum(-1)
     colsum = wq.astype(np.int32).sum(-1)  # sum over K of the weight, per output channel
     zero_bias = ((rowsum.astype(f) * xs).astype(f)[:, None] * zp[None, :]).astype(f)

@@ -26,7 +26,7 @@ EXPORTS = [
     "sdnq_hip_scaled_mm", "sdnq_hip_dequant", "sdnq_hip_requant", "sdnq_hip_unpack_mm", "sdnq_hip_hadamard",
     "sdnq_hip_lowrank_down", "sdnq_hip_scaled_mm_lowrank", "sdnq_hip_linear_float", "sdnq_hip_linear_skinny",
     "sdnq_hip_quantize_weight", "sdnq_hip_im2col", "sdnq_hip_im2col_rowquant", "sdnq_hip_scaled_mm_nchw",
-    "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8",
+    "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
 ]
 
 
@@ -76,6 +76,7 @@ def _declare(lib):
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
     lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
+    lib.sdnq_hip_requant_asym.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, vp]
     lib.sdnq_hip_unpack_mm.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp]
     lib.sdnq_hip_hadamard.argtypes = [vp, i32, i64, i64, i64, i32, vp, i64, vp]
     lib.sdnq_hip_lowrank_down.argtypes = [vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]

@@ -102,25 +102,39 @@ __global__ __launch_bounds__(256) void dequant_kernel(const DeqParams p, void* _
 }
 
 // one wave per weight row: phase 1 amax of the fp32 dequant, phase 2 quantize (recompute, L2-hot)
-template <int MM>
-__global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws) {
+// ASYM = re_quantize_uint_mm (dequantizer.py:178-187): int8 codes of (w - zero_point) / scale with the row's min / max range
+template <int MM, bool ASYM = false>
+__global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws,
+                                                      float* __restrict__ wzp) {
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= p.N) return;
     const int64_t npass = (p.K + 1023) / 1024;
-    float amax = 0.0f;
+    float amax = 0.0f, vmin = 3.4e38f, vmax = -3.4e38f;
     for (int64_t ps = 0; ps < npass; ++ps) {
         const int64_t k0 = ps * 1024 + lane * 16;
         if (k0 < p.K) {
             float v[16];
             dequant16(p, n, k0, v);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) amax = fmaxf(amax, fabsf(v[j]));
+            for (int j = 0; j < 16; ++j) {
+                if constexpr (ASYM) { vmin = fminf(vmin, v[j]); vmax = fmaxf(vmax, v[j]); }
+                else amax = fmaxf(amax, fabsf(v[j]));
+            }
         }
     }
-    amax = wave_max(amax);
-    const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
-    const float scale = amax / qmax;
+    float scale, zpv = 0.0f;
+    if constexpr (ASYM) {
+        vmin = wave_min(vmin);
+        vmax = wave_max(vmax);
+        scale = (vmax - vmin) / 255.0f;   // get_scale_asymmetric (quant_utils.py:10-19) with the int8 range
+        zpv = fmaf(128.0f, scale, vmin);  // zero_point.sub_(scale, alpha=-128); 128*scale is exact
+        if (lane == 0) wzp[n] = zpv;
+    } else {
+        amax = wave_max(amax);
+        const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
+        scale = amax / qmax;
+    }
     if (lane == 0) ws[n] = scale;
     for (int64_t ps = 0; ps < npass; ++ps) {
         const int64_t k0 = ps * 1024 + lane * 16;
@@ -132,7 +146,8 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
             for (int j = 0; j < 16; ++j) {
                 u32 byte;
                 if constexpr (MM == SDNQ_MM_I8) {
-                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[j] / scale);
+                    float q = __builtin_rintf((ASYM ? v[j] - zpv : v[j]) / scale);
+                    if (q != q) q = 0.0f;  // 0/0 of a constant row: NaN.to(int8) is 0 in the reference
                     q = fminf(fmaxf(q, -128.0f), 127.0f);
                     byte = (u32)(int)q & 0xffu;
                 } else {
@@ -576,9 +591,22 @@ extern "C" int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, flo
     p.svd_up = nullptr; p.svd_down = nullptr;  // re_quantize_matmul never receives the SVD factors (linear_int8.py:105)
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
-    if (mm_dtype == SDNQ_MM_I8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws);
-    else if (mm_dtype == SDNQ_MM_FP8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws);
+    if (mm_dtype == SDNQ_MM_I8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws, (float*)nullptr);
+    else if (mm_dtype == SDNQ_MM_FP8) hipLaunchKernelGGL((requant_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws, (float*)nullptr);
     else return SDNQ_ERR_DTYPE;
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_requant_asym(const SdnqWeight* w, void* wq, float* ws, float* wzp, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!wq || !ws || !wzp) return SDNQ_ERR_NULL;
+    if ((uintptr_t)wq % 16) return SDNQ_ERR_ALIGN;
+    p.svd_up = nullptr; p.svd_down = nullptr;  // as sdnq_hip_requant (linear_uint8.py:110)
+    dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
+    hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8, true>), grid, block, 0, (hipStream_t)stream, p, (uint8_t*)wq, ws, wzp);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }

@@ -114,8 +114,12 @@ class SDNQDequantizer:
     def re_quantize_matmul(self, weight, scale, zero_point=None, svd_up=None, svd_down=None, hadamard=None,
                            non_hadamard: bool = True, skip_compile: bool = False):
         """fp32 dequant (Hadamard not undone) -> per-output-row quantization to the matmul dtype.
-        Returns (weight [K,N] with strides (1,K), scale [1,N]) like the reference (dequantizer.py:166-174)."""
+        Returns (weight [K,N] with strides (1,K), scale [1,N]) like the reference (dequantizer.py:166-174); for the uint8
+        matmul dtype also the row zero points [1,N] (re_quantize_uint_mm, dequantizer.py:178-187)."""
         qw = self.quant_weight(weight, scale, zero_point)
+        if self.quantized_matmul_dtype == "uint8":
+            wq, ws, wzp = ops.requant_asym(qw)
+            return wq.t(), ws.view(1, -1), wzp.view(1, -1)
         wq, ws = ops.requant(qw, ops.mm_code(self.quantized_matmul_dtype))
         return wq.t(), ws.view(1, -1)
 

@@ -186,13 +186,17 @@ def quantized_linear_forward(self, input: torch.Tensor) -> torch.Tensor:
     return _float_forward(self, input, _state(self))
 
 
-def _prepare_mm_weights(mod, st: _State, mm: int):
-    """Weight operand of the quantized matmul: (wq [N,K], ws [N], zp [N] | None)."""
+def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
+    """Weight operand of the quantized matmul: (wq [N,K], ws [N], zp [N] | None).  `asymmetric` (the uint8 matmul) only changes
+    the re-quantizer: min / max range and a zero point per output row."""
     dq = mod.sdnq_dequantizer
-    if st.mm == mm and st.mm_weight is not None:
+    key = (mm, asymmetric)
+    if st.mm == key and st.mm_weight is not None:
         return st.mm_weight, st.mm_scale, st.mm_zp
     zp = None
-    if dq.re_quantize_for_matmul:
+    if dq.re_quantize_for_matmul and asymmetric:
+        wq, ws, zp = ops.requant_asym(st.qw)  # linear_uint8.py:109-111
+    elif dq.re_quantize_for_matmul:
         wq, ws = ops.requant(st.qw, mm)  # linear_int8.py:104-107; zero_point folded, none afterwards
     else:
         ws = st.qw.keep[1]  # row-wise scale [N]
@@ -210,7 +214,7 @@ def _prepare_mm_weights(mod, st: _State, mm: int):
             if not ent["is_packed"]:  # plain uint8: zero_point += 128 * scale (linear_int8.py:47-50)
                 zp = torch.add(zp, ws, alpha=128) if zp is not None else ws * 128
     if CACHE_WEIGHTS:
-        st.mm, st.mm_weight, st.mm_scale, st.mm_zp = mm, wq, ws, zp
+        st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, wq, ws, zp, None
     return wq, ws, zp
 
 
@@ -272,10 +276,7 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     m = input.numel() // input.shape[-1]
     if m == 0 or (small_batch_branch and m < 32):
         return _float_forward(self, input, st)
-    if dq.re_quantize_for_matmul:
-        raise NotImplementedError("uint8 matmul with re-quantized (group-wise / sub-byte) weights needs the asymmetric weight "
-                                  "re-quantizer (dequantizer.py:178-187), which is not built; use quantized_matmul_dtype='int8'")
-    wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8)
+    wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)
     wcs = st.mm_wcs
     if wcs is None:  # f32(sum_k wq[n][k]) * ws[n]: static per layer (linear_uint8.py:63 computes it every call)
         wcs = wq.to(torch.int32).sum(dim=1).to(torch.float32).mul_(ws)

@@ -284,6 +284,17 @@ def requant(qw: QuantWeight, mm: int):
     return wq, ws
 
 
+def requant_asym(qw: QuantWeight):
+    """re_quantize_uint_mm (dequantizer.py:178-187): (wq int8 [N,K], ws [N], zero_point [N])."""
+    dev = qw.keep[0].device
+    wq = torch.empty((qw.n, qw.k), device=dev, dtype=torch.int8)
+    ws = torch.empty((qw.n,), device=dev, dtype=torch.float32)
+    wzp = torch.empty((qw.n,), device=dev, dtype=torch.float32)
+    check(_lib.load().sdnq_hip_requant_asym(ctypes.byref(qw.desc), wq.data_ptr(), ws.data_ptr(), wzp.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream), "requant_asym")
+    return wq, ws, wzp
+
+
 def unpack_mm(qw: QuantWeight, mm: int) -> torch.Tensor:
     """Stored codes -> matmul operand [N,K] without re-quantization (linear_int8.py:38-50, linear_fp8.py:36-38)."""
     dev = qw.keep[0].device

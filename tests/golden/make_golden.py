@@ -187,6 +187,13 @@ CASES = [
          cfg=dict(weights_dtype="uint3", use_quantized_matmul=False)),
     dict(name="int8_had64_k192_qmm_bf16", K=192, N=64, Ms=[40], dtype="bf16",
          cfg=dict(weights_dtype="int8", group_size=-1, use_hadamard=True, use_quantized_matmul=True)),
+    dict(name="int8_group64_uint8mm_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int8", quantized_matmul_dtype="uint8", group_size=64, use_quantized_matmul=True)),
+    dict(name="uint4_uint8mm_qmm_bf16", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint4", quantized_matmul_dtype="uint8", use_quantized_matmul=True)),
+    dict(name="int4_svd_had_uint8mm_qmm_f16", K=512, N=64, Ms=[40], dtype="f16",
+         cfg=dict(weights_dtype="int4", quantized_matmul_dtype="uint8", use_svd=True, svd_rank=16, use_hadamard=True,
+                  use_quantized_matmul=True)),
 ]
 
 # Every packed storage dtype gets a dequant-only golden (small).
@@ -291,6 +298,8 @@ CONV_CASES = [
          cfg=dict(weights_dtype="int8", use_svd=True, svd_rank=16, use_quantized_matmul_conv=True)),
     dict(name="conv2d_uint8_uint8mm_qmm_bf16", nd=2, cin=32, cout=48, k=3, conv=dict(padding=1, stride=(1, 2)), xs=[(2, 9, 10)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_int4_g16_uint8mm_qmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(2, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="int4", group_size=16, quantized_matmul_dtype="uint8", use_quantized_matmul_conv=True)),
     dict(name="conv2d_uint8_int8mm_qmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),
 ]

@@ -92,11 +92,15 @@ def test_dequant_and_requant_vs_golden(name, gpu_device):
     else:
         assert np.array_equal(got, ref), name
     if c.has("requant_weight"):
-        wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, zero_point=mod.zero_point)
+        wq, ws, *wzp = dq.re_quantize_matmul(mod.weight, mod.scale, zero_point=mod.zero_point)
         assert tuple(wq.shape) == (c.K, c.N) and wq.stride() == (1, c.K)
         rw = c.raw("requant_weight").reshape(c.K, c.N)
         assert np.array_equal(bits_of(wq.contiguous()), rw.view(np.uint8)), name
         assert np.array_equal(ws.cpu().numpy().reshape(-1), c.raw("requant_scale").reshape(-1)), name
+        assert len(wzp) == int(c.has("requant_zero_point")), name
+        if wzp:  # asymmetric re-quantizer of the uint8 matmul (dequantizer.py:178-187)
+            assert tuple(wzp[0].shape) == (1, c.N)
+            assert np.array_equal(wzp[0].cpu().numpy().reshape(-1), c.raw("requant_zero_point").reshape(-1)), name
 
 
 def test_dequant_every_storage_dtype_bit_exact(gpu_device):
@@ -492,7 +496,7 @@ def test_conv_dequant_and_hip_quantizer_vs_golden(name, gpu_device):
         assert tuple(wd.shape) == tuple(c.info("w_dequant")["shape"])
         assert np.array_equal(to_f32_numpy(wd), c.f32("w_dequant")), (name, "dequant")
     if c.has("requant_weight"):
-        wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, mod.zero_point)
+        wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, mod.zero_point)[:2]
         assert np.array_equal(bits_of(wq.contiguous()), c.raw("requant_weight").view(np.uint8).reshape(bits_of(wq.contiguous()).shape))
         assert np.array_equal(ws.cpu().numpy().reshape(-1), c.raw("requant_scale").reshape(-1))
     from sdnq_amd import quantizer as Q

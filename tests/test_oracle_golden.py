@@ -105,7 +105,8 @@ def test_case_dequant_and_requant(name):
     ref32 = c.f32("w_dequant_f32_nohad").reshape(c.N, c.K)
     got32 = mod.dequantize("f32", hadamard=False)
     if c.has("svd_up"):
-        assert np.all(np.abs(got32 - ref32) <= ulp_bf16(ref32)), name  # addmm in bf16: <= 1 bf16 ulp
+        tol = ulp_bf16(ref32) if c.tag != "f16" else np.maximum(ulp_bf16(ref32), 2.0 ** -24)  # f16 addmm: one subnormal step near 0
+        assert np.all(np.abs(got32 - ref32) <= tol), name  # addmm in bf16: <= 1 bf16 ulp
         assert np.mean(got32 != ref32) < 1e-3
     else:
         assert np.array_equal(got32, ref32), name
@@ -116,9 +117,12 @@ def test_case_dequant_and_requant(name):
     else:
         assert np.array_equal(got, ref), name
     if c.has("requant_weight"):
-        wq, ws = mod.re_quantize_matmul()
+        wq, ws, *wzp = mod.re_quantize_matmul()
         rw = c.raw("requant_weight").reshape(c.K, c.N).T  # logical [K,N] -> [N,K]
         assert np.array_equal(ws, c.raw("requant_scale").reshape(-1)), name
+        assert len(wzp) == int(c.has("requant_zero_point"))
+        if wzp:  # re_quantize_uint_mm (dequantizer.py:178-187)
+            assert np.array_equal(wzp[0], c.raw("requant_zero_point").reshape(-1)), name
         assert np.array_equal(wq.view(np.uint8), rw.view(np.uint8)), name
 
 
@@ -166,7 +170,7 @@ def test_conv_case_dequant_and_forward(name):
         else:
             assert np.array_equal(W, ref), (name, "dequant")
     if c.has("requant_weight"):
-        wq, ws = omod.re_quantize_matmul()
+        wq, ws = omod.re_quantize_matmul()[:2]
         rw = c.raw("requant_weight")  # logical [K, N]
         assert np.array_equal(wq.view(np.uint8), np.ascontiguousarray(rw.T).view(np.uint8)), (name, "requant codes")
         assert np.array_equal(ws, c.raw("requant_scale").reshape(-1)), (name, "requant scale")

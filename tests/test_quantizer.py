@@ -11,7 +11,8 @@ from tests.golden_util import Case
 # cases whose quantization is deterministic given the float weight (no randomized SVD, no float GEMM before rounding)
 EXACT = ["int8_rowwise_noqmm_f32", "int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "fp8_qmm_bf16", "uint4_qmm_bf16",
          "int6_rowwise_packed_qmm_bf16", "uint7_rowwise_packed_qmm_bf16", "uint8_int8mm_qmm_bf16", "uint8_uint8mm_qmm_bf16",
-         "fp4_e2m1_fp8mm_qmm_bf16", "int5_group32_noqmm_bf16", "uint3_noqmm_f16"]
+         "fp4_e2m1_fp8mm_qmm_bf16", "int5_group32_noqmm_bf16", "uint3_noqmm_f16", "int8_group64_uint8mm_qmm_bf16",
+         "uint4_uint8mm_qmm_bf16"]
 
 
 @pytest.mark.parametrize("name", EXACT)
