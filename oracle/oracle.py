@@ -588,3 +588,61 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
     if bias is not None:
         zero_bias = (zero_bias + bias.astype(f)).astype(f)
     return scaled_mm("int8", q, wq, xs, sc, zero_bias, tag)
+
+
+# ---- quantized attention forward ---------------------------------------------------------------
+def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True):
+    """quantize_attn (kernels/triton_atten.py:443-487) for matmul_dtype="int8": K minus its token mean in fp32 (:457-463),
+    then quantize_int_mm per token (quant_utils.py:265-273).  q [Z,H,QN,D], k [Z,KH,KN,D] float32 values.
+    Returns (q_q int8, q_scale [Z,H,QN], k_q int8, k_scale [Z,KH,KN])."""
+    f = np.float32
+    q, k = _c(q, f), _c(k, f)
+    if smooth_k:
+        k = (k - k.mean(axis=2, keepdims=True, dtype=f)).astype(f)
+    d = q.shape[-1]
+    qq, qs, _ = rowquant(q.reshape(-1, d), "int8")
+    kq, ks, _ = rowquant(k.reshape(-1, d), "int8")
+    return qq.reshape(q.shape), qs.reshape(q.shape[:-1]), kq.reshape(k.shape), ks.reshape(k.shape[:-1])
+
+
+def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: bool = False, scale=None, smooth_k: bool = True,
+              block_n: int = 32, out_tag: str | None = None, want_intermediates: bool = False):
+    """sdnq_triton_atten (kernels/triton_atten.py:540-618) in its default configuration (int8 Q.K^T, P.V in the value dtype):
+    the online-softmax loop of sdnq_attn_kernel (:143-335) over key blocks of `block_n`, all queries of a head at once.
+    q/k/v: float32 VALUES of `tag` tensors [Z,H,N,D]; returns float32 values rounded to out_tag (default tag)."""
+    f = np.float32
+    Z, QH, QN, D = q.shape
+    _, KH, KN, _ = k.shape
+    sm_scale = f(D ** -0.5 if scale is None else scale)                       # :512-513
+    log2_sm = f(sm_scale * f(1.4426950408889634))                            # :203
+    qq, qs, kq, ks = attention_quantize(q, k, smooth_k)
+    out = np.empty((Z, QH, QN, D), dtype=f)
+    qidx = np.arange(QN)[:, None]
+    for z in range(Z):
+        for h in range(QH):
+            kh = (h * KH) // QH                                              # :212-213
+            S = qq[z, h].astype(np.int32) @ kq[z, kh].astype(np.int32).T     # exact
+            m = np.full(QN, -np.inf, dtype=f)
+            l = np.ones(QN, dtype=f)
+            acc = np.zeros((QN, D), dtype=f)
+            for n0 in range(0, KN, block_n):
+                n1 = min(n0 + block_n, KN)
+                if is_causal and QN <= n0:
+                    continue
+                s = ((S[:, n0:n1].astype(f) * qs[z, h][:, None]).astype(f) * ks[z, kh][None, n0:n1]).astype(f)
+                s = (s * log2_sm).astype(f)                                  # :278
+                if is_causal:
+                    s = np.where(qidx >= np.arange(n0, n1)[None, :], s, f(-np.inf))  # :287-288
+                m_new = np.maximum(m, s.max(axis=1))
+                with np.errstate(invalid="ignore"):
+                    alpha = np.where(np.isinf(m_new), f(0), np.exp2(m - m_new)).astype(f)   # rows with nothing visible yet
+                    p = np.where(np.isinf(m_new)[:, None], f(0), np.exp2(s - m_new[:, None])).astype(f)
+                l = (l * alpha + p.sum(axis=1, dtype=f)).astype(f)           # :308
+                acc = (acc * alpha[:, None]).astype(f)
+                acc = (acc + round_dtype(p, tag) @ _c(v[z, kh, n0:n1], f)).astype(f)  # p.to(v.dtype); fp32 accumulate (:332-333)
+                m = m_new
+            out[z, h] = acc * (f(1.0) / l)[:, None]                          # :336
+    out = round_dtype(out, out_tag or tag)
+    if want_intermediates:
+        return out, dict(q_q=qq, q_scale=qs, k_q=kq, k_scale=ks)
+    return out

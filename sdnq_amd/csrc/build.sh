@@ -8,10 +8,10 @@ FLAGS="${SDNQ_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unu
 OBJ="$HERE/../../build/obj"
 mkdir -p "$OBJ"
 pids=()
-for f in api rowquant gemm dequant quantize conv; do
+for f in api rowquant gemm dequant quantize conv attention; do
   ( "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" "$OBJ"/api.o "$OBJ"/rowquant.o "$OBJ"/gemm.o "$OBJ"/dequant.o "$OBJ"/quantize.o "$OBJ"/conv.o
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" "$OBJ"/api.o "$OBJ"/rowquant.o "$OBJ"/gemm.o "$OBJ"/dequant.o "$OBJ"/quantize.o "$OBJ"/conv.o "$OBJ"/attention.o
 echo "built $OUT"

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Golden vectors for the quantized attention forward, made by RUNNING the reference's own Triton kernel
+(`sdnq_attn_kernel`, kernels/triton_atten.py:143-335) and its host code (`sdnq_triton_atten`, :540-618) on the CPU through
+Triton's interpreter (TRITON_INTERPRET=1; there is no GPU in the build container).
+
+What this harness has to supply because there is no GPU driver here (nothing of the reference is modified or stored):
+  * the autotuner cannot benchmark without a device, so the kernel is launched with ONE fixed configuration
+    (BLOCK_SIZE_M = BLOCK_SIZE_N = 32, recorded in the fixture's meta; with pv_matmul_dtype=None the result depends on the
+    block size only through fp32 rounding order);
+  * the interpreter does not convert Python floats to scalars, so `sm_scale` is wrapped as an fp32 scalar handle;
+  * the interpreter has no bfloat16 (numpy), so the fixtures are float16; token counts are multiples of 4 because the
+    interpreter's tensor descriptors want 16-byte aligned bases for the per-token fp32 scale vectors.
+Fixtures are DATA only (inputs, the reference's quantized operands, outputs).  Run:  python tests/golden/make_golden_attention.py
+"""
+import json
+import os
+import sys
+import types
+
+os.environ["TRITON_INTERPRET"] = "1"
+os.environ["SDNQ_USE_TORCH_COMPILE"] = "0"
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import triton.language as tl  # noqa: E402
+from triton.runtime.interpreter import TensorHandle  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pkg = types.ModuleType("sdnq")
+pkg.__path__ = ["/root/reference/src/sdnq"]
+sys.modules["sdnq"] = pkg
+from sdnq.kernels import triton_atten as ta  # noqa: E402  (the reference)
+
+BLOCK_M = BLOCK_N = 32
+
+
+class FixedConfig:
+    """Stands in for the autotuner: same kernel function, one fixed tile configuration."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __getitem__(self, grid):
+        def launch(*args, **kw):
+            g = grid({"BLOCK_SIZE_M": BLOCK_M, "BLOCK_SIZE_N": BLOCK_N}) if callable(grid) else grid
+            args = [tl.tensor(TensorHandle(np.array([a], dtype=np.float32), tl.float32), tl.float32) if isinstance(a, float) else a
+                    for a in args]
+            return self.fn[g](*args, BLOCK_SIZE_M=BLOCK_M, BLOCK_SIZE_N=BLOCK_N, **kw)
+        return launch
+
+
+ta.wrap_triton = lambda k: k
+ta.sdnq_attn_kernel = FixedConfig(ta.sdnq_attn_kernel.fn)
+
+CASES = [
+    dict(name="f16_d64_tail", z=1, qh=2, kh=2, qn=40, kn=52, d=64, kw={}),
+    dict(name="f16_d64_causal", z=2, qh=2, kh=2, qn=64, kn=64, d=64, kw=dict(is_causal=True)),
+    dict(name="f16_d64_causal_tail", z=1, qh=1, kh=1, qn=44, kn=44, d=64, kw=dict(is_causal=True)),
+    dict(name="f16_d128_gqa", z=1, qh=4, kh=2, qn=36, kn=68, d=128, kw={}),
+    dict(name="f16_d64_nosmooth_scale", z=1, qh=2, kh=1, qn=36, kn=100, d=64, kw=dict(smooth_k=False, scale=0.2)),
+    dict(name="f16_d64_long", z=1, qh=1, kh=1, qn=132, kn=260, d=64, kw={}),
+]
+
+
+def bits(t):
+    t = t.detach().cpu().contiguous()
+    if t.dtype == torch.float16:
+        return t.view(torch.uint16).numpy().copy(), "f16"
+    return t.numpy().copy(), str(t.dtype).replace("torch.", "")
+
+
+def run(case):
+    g = torch.Generator().manual_seed(sum(map(ord, case["name"])))
+    z, qh, kh, qn, kn, d = (case[k] for k in ("z", "qh", "kh", "qn", "kn", "d"))
+    q = torch.randn(z, qh, qn, d, generator=g)
+    k = torch.randn(z, kh, kn, d, generator=g) + 3.0 * torch.randn(1, kh, 1, d, generator=g)  # channel offsets: what smooth_k removes
+    v = torch.randn(z, kh, kn, d, generator=g)
+    q[..., 5] *= 6.0
+    q, k, v = q.half(), k.half(), v.half()
+    out = ta.sdnq_triton_atten(q, k, v, **case["kw"])
+    q_q, q_s, k_q, k_s, v_q, v_s, _, _ = ta.quantize_attn(q, k, v, smooth_k=case["kw"].get("smooth_k", True))
+    assert v_s is None and v_q.dtype == torch.float16
+    arrays, meta = {}, {"name": case["name"], "dtype": "f16", "shape": dict(z=z, qh=qh, kh=kh, qn=qn, kn=kn, d=d), "kwargs": case["kw"],
+                        "block_m": BLOCK_M, "block_n": BLOCK_N, "tensors": {}}
+    for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s)):
+        arrays[key], tag = bits(t)
+        meta["tensors"][key] = {"dtype": tag, "shape": list(t.shape)}
+    np.savez_compressed(os.path.join(HERE, f"attn_{case['name']}.npz"), **arrays)
+    with open(os.path.join(HERE, f"attn_{case['name']}.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(qh // kh, 1), v.float().repeat_interleave(qh // kh, 1),
+                                                           is_causal=case["kw"].get("is_causal", False), scale=case["kw"].get("scale"))
+    print("wrote attn", case["name"], tuple(out.shape), "max |out - fp32 sdpa| =", float((out.float() - ref).abs().max()))
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:] or None
+    for c in CASES:
+        if only is None or c["name"] in only:
+            run(c)

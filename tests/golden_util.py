@@ -113,3 +113,35 @@ class ConvCase(Case):
             t = self.torch_tensor(key, device=device)
             setattr(mod, key, None if t is None else torch.nn.Parameter(t, requires_grad=False))
         return mod
+
+
+def attn_case_names():
+    return sorted(f[5:-5] for f in os.listdir(GOLD) if f.startswith("attn_") and f.endswith(".json"))
+
+
+class AttnCase:
+    """Quantized-attention fixtures: outputs of the reference's Triton kernel run through Triton's interpreter
+    (tests/golden/make_golden_attention.py)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.meta = json.load(open(os.path.join(GOLD, f"attn_{name}.json")))
+        self.z = np.load(os.path.join(GOLD, f"attn_{name}.npz"))
+        self.tag = self.meta["dtype"]
+        self.kwargs = self.meta["kwargs"]
+
+    def f32(self, key):
+        from oracle import oracle as O
+        tag = self.meta["tensors"][key]["dtype"]
+        return O.from_bits(self.z[key], tag) if tag in ("bf16", "f16") else self.z[key].astype(np.float32)
+
+    def raw(self, key):
+        return self.z[key]
+
+    def torch_tensor(self, key, device=None):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(self.z[key]))
+        view = {"bf16": torch.bfloat16, "f16": torch.float16}.get(self.meta["tensors"][key]["dtype"])
+        if view is not None:
+            t = t.view(view)
+        return t.to(device) if device is not None else t

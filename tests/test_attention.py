@@ -1,0 +1,123 @@
+"""Quantized attention forward: the oracle restatement against fixtures produced by the reference's own
+Triton kernel (run through Triton's interpreter, tests/golden/make_golden_attention.py), and the HIP path against both."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.golden_util import AttnCase, attn_case_names
+
+
+def _quant_agreement(got_q, got_s, ref_q, ref_s, smooth):
+    """int8 codes / scales of Q are bit-exact; K after smooth_k depends on the summation order of the token mean (fp32), so a
+    code may move by one step where x/scale sits on a rounding boundary."""
+    if not smooth:
+        assert np.array_equal(got_q, ref_q) and np.array_equal(got_s, ref_s)
+        return
+    assert np.allclose(got_s, ref_s, rtol=1e-5, atol=0)
+    diff = np.abs(got_q.astype(np.int32) - ref_q.astype(np.int32))
+    assert diff.max() <= 1 and np.mean(diff != 0) < 2e-3
+
+
+@pytest.mark.parametrize("name", attn_case_names())
+def test_oracle_attention_vs_reference_kernel(name):
+    c = AttnCase(name)
+    kw = c.kwargs
+    out, inter = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
+                             smooth_k=kw.get("smooth_k", True), block_n=c.meta["block_n"], want_intermediates=True)
+    assert np.array_equal(inter["q_q"], c.raw("q_q")) and np.array_equal(inter["q_scale"], c.raw("q_scale"))
+    _quant_agreement(inter["k_q"], inter["k_scale"], c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True))
+    ref = c.f32("out")
+    assert out.shape == ref.shape
+    # same arithmetic as the kernel up to exp2 / reduction-order rounding, then one f16 rounding of the output
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    assert err <= 2e-3, (name, err)
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= 5e-4, name
+
+
+def test_oracle_attention_block_size_only_changes_rounding():
+    c = AttnCase("f16_d64_long")
+    a = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, block_n=32)
+    b = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, block_n=128)
+    assert np.abs(a - b).max() / np.abs(a).max() <= 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", attn_case_names())
+def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
+    import torch
+    from sdnq_amd import attention as A
+    c = AttnCase(name)
+    kw = c.kwargs
+    q, k, v = (c.torch_tensor(t, gpu_device) for t in ("q", "k", "v"))
+    qq, qs, kq, ks, vt = A.quantize_attn(q, k, v, smooth_k=kw.get("smooth_k", True))
+    assert np.array_equal(qq.cpu().numpy(), c.raw("q_q")) and np.array_equal(qs.cpu().numpy(), c.raw("q_scale"))
+    _quant_agreement(kq.cpu().numpy(), ks.cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True))
+    kn = k.shape[2]
+    assert torch.equal(vt[..., :kn], v.transpose(2, 3)) and not vt[..., kn:].any()
+    out = A.sdnq_hip_atten(q, k, v, **kw)
+    assert out.dtype == q.dtype and out.shape == q.shape
+    got = out.float().cpu().numpy()
+    for ref, what in ((c.f32("out"), "reference kernel"),
+                      (O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
+                                   smooth_k=kw.get("smooth_k", True)), "oracle")):
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err <= 3e-3, (name, what, err)
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-3, (name, what)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(1, 3, 3, 77, 77, 64, False), (2, 4, 2, 200, 333, 128, False), (1, 2, 2, 130, 130, 64, True)])
+def test_hip_attention_vs_oracle_random(dtype, shape, gpu_device):
+    import torch
+    from sdnq_amd import attention as A
+    z, qh, kh, qn, kn, d, causal = shape
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(qn * 7 + d)
+    q = torch.randn(z, qh, qn, d, generator=g).to(tdt)
+    k = (torch.randn(z, kh, kn, d, generator=g) + 2.0 * torch.randn(1, kh, 1, d, generator=g)).to(tdt)
+    v = torch.randn(z, kh, kn, d, generator=g).to(tdt)
+    out = A.sdnq_hip_atten(q.to(gpu_device), k.to(gpu_device), v.to(gpu_device), is_causal=causal)
+    ref = O.attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), dtype, is_causal=causal)
+    got = out.float().cpu().numpy()
+    lim = 3e-3 if dtype == "f16" else 1.2e-2  # P and the output are rounded to the value dtype
+    assert np.abs(got - ref).max() / np.abs(ref).max() <= lim
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= (1e-3 if dtype == "f16" else 4e-3)
+    # and the quantized result stays close to exact fp32 attention (what the int8 path is an approximation of)
+    exact = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(qh // kh, 1),
+                                                             v.float().repeat_interleave(qh // kh, 1), is_causal=causal).numpy()
+    assert np.linalg.norm(got - exact) / np.linalg.norm(exact) <= 5e-2
+
+
+@pytest.mark.gpu
+def test_hip_attention_full_size_properties(gpu_device):
+    """SDXL self-attention size (4096 tokens, 10 heads of 64): rows of P sum to one, so attention over constant V returns
+    that constant; and the output is invariant to a permutation of the key/value tokens."""
+    import torch
+    from sdnq_amd import attention as A
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(1, 10, 4096, 64, generator=g).bfloat16().to(gpu_device)
+    k = torch.randn(1, 10, 4096, 64, generator=g).bfloat16().to(gpu_device)
+    v = torch.randn(1, 10, 4096, 64, generator=g).bfloat16().to(gpu_device)
+    const = torch.full_like(v, 0.75)
+    out = A.sdnq_hip_atten(q, k, const).float()
+    assert (out - 0.75).abs().max() <= 0.75 * 2 ** -7
+    perm = torch.randperm(4096, generator=g).to(gpu_device)
+    a = A.sdnq_hip_atten(q, k, v).float()
+    b = A.sdnq_hip_atten(q, k[:, :, perm], v[:, :, perm]).float()
+    assert (a - b).norm() / a.norm() <= 4e-3
+    exact = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    assert (a - exact).norm() / exact.norm() <= 5e-2
+
+
+def test_attention_rejects_unbuilt_options():
+    import torch
+    from sdnq_amd import attention as A
+    q = torch.zeros(1, 1, 32, 64, dtype=torch.bfloat16)
+    for kw in (dict(attn_mask=torch.ones(32, 32, dtype=torch.bool)), dict(pv_matmul_dtype="int8"), dict(use_hadamard=True),
+               dict(matmul_dtype="float8_e4m3fn"), dict(return_backward=True)):
+        with pytest.raises(NotImplementedError):
+            A.sdnq_hip_atten(q, q, q, **kw)
+    from sdnq_amd._lib import SdnqHipError
+    with pytest.raises(SdnqHipError):
+        A.sdnq_hip_atten(q, q, q)  # CPU tensors: no fallback
