@@ -19,7 +19,9 @@ _DISABLED = {None, "none", "no", "disabled"}
 
 def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True):
     """quantize_attn (triton_atten.py:443-487) for matmul_dtype="int8", pv_matmul_dtype=None.
-    Returns (q_q int8, q_scale f32 [Z,H,QN], k_q int8, k_scale f32 [Z,KH,KN], v_t [Z,KH,D,KN rounded up to 32])."""
+    Returns (q_q int8 [Z,H,QN,D], q_scale f32 [Z,H,QN], k_q, k_scale f32 [Z,KH,KNp], v_f) with KNp = KN rounded up to 32.
+    k_q [Z,KH,KNp/32,D/32,64,16] int8 and v_f [Z,KH,KNp/32,D/32,2,64,8] are the K / V operands in MFMA-fragment order (see
+    ``unpack_k_fragments`` / ``unpack_v_fragments``); tokens past KN are zero."""
     if not query.is_cuda:
         raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
     z, qh, qn, d = query.shape
@@ -29,15 +31,32 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     knp = (kn + 31) // 32 * 32
     qq = torch.empty((z, qh, qn, d), device=dev, dtype=torch.int8)
     qs = torch.empty((z, qh, qn), device=dev, dtype=torch.float32)
-    kq = torch.empty((z, kh, kn, d), device=dev, dtype=torch.int8)
-    ks = torch.empty((z, kh, kn), device=dev, dtype=torch.float32)
-    vt = torch.empty((z, kh, d, knp), device=dev, dtype=value.dtype)
+    kq = torch.empty((z, kh, knp // 32, d // 32, 64, 16), device=dev, dtype=torch.int8)
+    ks = torch.empty((z, kh, knp), device=dev, dtype=torch.float32)
+    vt = torch.empty((z, kh, knp // 32, d // 32, 2, 64, 8), device=dev, dtype=value.dtype)
     kmean = torch.empty((z, kh, d), device=dev, dtype=torch.float32)
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
                                                 z, qh, kh, qn, kn, d, 1 if smooth_k else 0, qq.data_ptr(), qs.data_ptr(),
                                                 kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), kmean.data_ptr(),
                                                 ops._stream(query)), "attn_prepare")
     return qq, qs, kq, ks, vt
+
+
+_PI = [(n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1) for n in range(32)]  # fragment row <-> key inside a 32-key block
+
+
+def unpack_k_fragments(kq: torch.Tensor) -> torch.Tensor:
+    """Fragment-order K codes [Z,KH,B,D/32,64,16] -> [Z,KH,B*32,D] (lane = g*32 + rho holds bytes [32kk+16g, +16) of key pi(rho))."""
+    z, kh, nb, kk = kq.shape[:4]
+    t = kq.view(z, kh, nb, kk, 2, 32, 16)[:, :, :, :, :, _PI]  # rho -> key order
+    return t.permute(0, 1, 2, 5, 3, 4, 6).reshape(z, kh, nb * 32, kk * 32)
+
+
+def unpack_v_fragments(vf: torch.Tensor) -> torch.Tensor:
+    """Fragment-order V [Z,KH,B,D/32,2,64,8] -> [Z,KH,B*32,D] (lane = g*32 + ql holds keys 16c + 8g + 0..7 of channel 32dd + ql)."""
+    z, kh, nb, kk = vf.shape[:4]
+    t = vf.view(z, kh, nb, kk, 2, 2, 32, 8)  # [.., dd, c, g, ql, j]
+    return t.permute(0, 1, 2, 4, 5, 7, 3, 6).reshape(z, kh, nb * 32, kk * 32)
 
 
 def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype) -> torch.Tensor:

@@ -9,12 +9,15 @@
 // Register layout of the forward kernel (one wave = 32 queries, no LDS, no barriers):
 //   S^T = K.Q^T with K as the first MFMA operand: lane l owns query (l & 31); its 16 accumulator registers are 16 keys of the
 //   32-key block, the other 16 live in lane l ^ 32.  Row statistics are therefore in-lane reductions plus ONE lane exchange.
-//   The K fragment rows are fetched in a permuted order (bits 2 and 3 of the row index swapped) so that registers 8c..8c+7 of
+//   The K fragment rows are taken in a permuted order (bits 2 and 3 of the row index swapped) so that registers 8c..8c+7 of
 //   lane group g hold the CONTIGUOUS keys 16c + 8g .. + 7: exactly the K-slice that lane feeds to PV MFMA c.  P never moves
-//   between lanes and the V^T fragments are plain 16-byte loads.
+//   between lanes.  sdnq_hip_attn_prepare stores quantized K and V already in MFMA-fragment order (1-KiB tiles), so every
+//   fragment load of the loop is one fully coalesced 16-bytes-per-lane access.
 //   O^T = V^T.P^T: query stays on (l & 31), so alpha / 1/l are per-lane scalars.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "../../include/sdnq_hip.h"
 #include "sdnq_dev.h"
@@ -44,21 +47,25 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
     }
 }
 
-// ---- per-token int8 quantization of [rows][d] (d / 8 lanes per row), optional mean subtraction ---------------------------
+// ---- per-token int8 quantization of [heads][n_src][d] (d / 8 lanes per token), optional mean subtraction ------------------
+// The destination has n_dst >= n_src token slots per head (K: rounded up to the 32-key block; the extra tokens get zero codes
+// and a zero scale and are masked in the forward kernel).
 template <int T_ID>
 __global__ __launch_bounds__(256) void attn_quant_kernel(const void* __restrict__ x, const float* __restrict__ mean, int8_t* __restrict__ xq,
-                                                         float* __restrict__ xs, int64_t rows, int64_t rows_per_head, int d) {
+                                                         float* __restrict__ xs, int64_t heads, int64_t n_src, int64_t n_dst, int d,
+                                                         bool frag_major) {
     const int lpr = d / 8;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / lpr;
     const int c8 = (int)(t % lpr) * 8;
-    const bool live = row < rows;
-    const int64_t rr = live ? row : rows - 1;
+    const bool live = row < heads * n_dst;
+    const int64_t head = live ? row / n_dst : 0, n = live ? row % n_dst : 0;
+    const bool real = live && n < n_src;
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::load(x, rr * d + c8 + e);
-    if (mean != nullptr) {
-        const float* mu = mean + (rr / rows_per_head) * d + c8;
+    for (int e = 0; e < 8; ++e) v[e] = real ? FT<T_ID>::load(x, (head * n_src + n) * d + c8 + e) : 0.0f;
+    if (mean != nullptr && real) {
+        const float* mu = mean + head * d + c8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= mu[e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
     }
@@ -76,18 +83,30 @@ __global__ __launch_bounds__(256) void attn_quant_kernel(const void* __restrict_
         o[e >> 2] |= ((u32)(int)q & 0xffu) << (8 * (e & 3));
     }
     if (live) {
-        *(uint2*)(xq + row * d + c8) = make_uint2(o[0], o[1]);
+        if (frag_major) {
+            // K operand in MFMA-fragment order: one 1-KiB tile per (32-key block, 32-channel step), lane (g, rho) holds the 16
+            // bytes [32 kk + 16 g, +16) of key pi(rho) (pi = swap bits 2 and 3, see attn_fwd_kernel) -> every fragment load of
+            // the forward kernel is one fully coalesced 1-KiB access.  n_dst is a multiple of 32.
+            const int kk = c8 >> 5, g = (c8 >> 4) & 1, half = (c8 >> 3) & 1, nl = (int)(n & 31);
+            const int rho = (nl & 0x13) | ((nl & 4) << 1) | ((nl & 8) >> 1);
+            const int64_t tile = (head * (n_dst / 32) + n / 32) * (d / 32) + kk;
+            *(uint2*)(xq + tile * 1024 + (g * 32 + rho) * 16 + half * 8) = make_uint2(o[0], o[1]);
+        } else {
+            *(uint2*)(xq + row * d + c8) = make_uint2(o[0], o[1]);
+        }
         if (c8 == 0) xs[row] = scale;
     }
 }
 
-// ---- V [heads][kn][d] -> V^T [heads][d][knp] (knp = kn rounded up to 32, zero padded) ------------------------------------
+// ---- V [heads][kn][d] -> PV operand in MFMA-fragment order (knp = kn rounded up to 32, zero padded) -----------------------
+// one 1-KiB tile per (32-key block kb, 32-channel block dd, 16-key step c): lane (g, ql) holds the 8 keys
+// kb*32 + 16c + 8g + 0..7 of channel 32dd + ql, i.e. exactly the first operand of PV MFMA (dd, c) of attn_fwd_kernel.
 __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d) {
     __shared__ uint16_t tile[32][128 + 2];
-    const int64_t head = blockIdx.y, key0 = (int64_t)blockIdx.x * 32;
+    const int64_t head = blockIdx.y, kb = blockIdx.x, key0 = kb * 32;
     const uint16_t* src = v + head * kn * d;
-    uint16_t* dst = vt + head * d * knp;
-    const int lpr = d / 8;
+    const int lpr = d / 8, kkn = d / 32;
+    uint16_t* dst = vt + (head * (knp / 32) + kb) * (int64_t)(kkn * 2 * 512);
     for (int t = threadIdx.x; t < 32 * lpr; t += 256) {
         const int kr = t / lpr, c8 = (t % lpr) * 8;
         uint4 val = make_uint4(0, 0, 0, 0);
@@ -97,12 +116,13 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict
         for (int e = 0; e < 8; ++e) tile[kr][c8 + e] = h[e];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < d * 4; t += 256) {
-        const int dd = t / 4, k8 = (t % 4) * 8;
+    for (int t = threadIdx.x; t < kkn * 2 * 64; t += 256) {
+        const int lane = t & 63, c = (t >> 6) & 1, dd = t >> 7;
+        const int dch = 32 * dd + (lane & 31), k8 = 16 * c + 8 * (lane >> 5);
         u32 w[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = (u32)tile[k8 + 2 * e][dd] | ((u32)tile[k8 + 2 * e + 1][dd] << 16);
-        *(uint4*)(dst + (int64_t)dd * knp + key0 + k8) = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int e = 0; e < 4; ++e) w[e] = (u32)tile[k8 + 2 * e][dch] | ((u32)tile[k8 + 2 * e + 1][dch] << 16);
+        *(uint4*)(dst + (int64_t)t * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -114,7 +134,17 @@ struct AttnParams {
     float log2_sm_scale;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+
 // ---- forward: one wave = 32 queries of one head; 4 waves per workgroup -------------------------------------------------
+// The loop is VALU-bound (16 scores per lane and 32-key block against 2 + 4 MFMAs at D = 64), so the score arithmetic is kept
+// to cvt, one packed multiply (k_scale * q_scale * log2(e) * sm_scale folded per key), max3, packed subtract, exp2, packed add
+// and a packed convert; masks exist only in the one block that needs them (key tail / causal diagonal), the running sum stays
+// split over the two lanes of a query until the end, and O is rescaled only when some row maximum of the wave moved.
+// Software pipeline: the K fragments of block kb+1 are already in registers when block kb starts, so S(kb+1) is on the matrix
+// pipe while the VALU works on the scores of kb; V / k_scale of kb+1 and K of kb+2 are in flight meanwhile.
 template <int V_T, int OUT_T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KK = D / 32;  // int8 MFMA K steps of Q.K^T; also the 32-channel blocks of O
@@ -132,97 +162,154 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     v4i qf[KK];
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const v4i*)(qbase + 32 * kk);
-    const float qscale = p.qs[head_lin * p.qn + qrow];
+    // ((acc * q_scale) * k_scale) * log2_sm_scale of triton_atten.py:278 as acc * (k_scale * (q_scale * log2_sm_scale))
+    const float qsl = p.qs[head_lin * p.qn + qrow] * p.log2_sm_scale;
 
     v16f o[KK];
 #pragma unroll
     for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dd][r] = 0.0f;
-    float m_i = -__builtin_inff(), l_i = 1.0f;  // triton_atten.py:231-232
+    float m_i = -__builtin_inff();
+    v2f l2 = {0.0f, 0.0f};  // this lane's half of the row sum (16 of every 32 keys), two partial sums
 
-    const int8_t* kbase = p.kq + kv_lin * p.kn * D + 16 * g;
-    const float* ksbase = p.ks + kv_lin * p.kn;
-    const uint16_t* vbase = p.vt + (kv_lin * D + ql) * p.knp + 8 * g;
-    const int prow = (ql & 0x13) | ((ql & 4) << 1) | ((ql & 8) >> 1);  // K fragment row permutation: swap bits 2 and 3
+    // K and V arrive in MFMA-fragment order (sdnq_hip_attn_prepare): 1-KiB tiles, lane l reads bytes [16 l, 16 l + 16)
+    const int8_t* kbase = p.kq + kv_lin * p.knp * D + lane * 16;
+    const float* ksbase = p.ks + kv_lin * p.knp + 8 * g;
+    const uint16_t* vbase = p.vt + kv_lin * p.knp * D + lane * 8;
 
-    int64_t nkb = (p.kn + 31) / 32;
-    if (CAUSAL) {
-        const int64_t lim = (q0 + 31) / 32 + 1;  // blocks past the last query of this wave are fully masked (triton_atten.py:255)
-        nkb = nkb < lim ? nkb : lim;
-    }
-#pragma nounroll
-    for (int64_t kb = 0; kb < nkb; ++kb) {
-        const int64_t key0 = kb * 32;
-        int64_t kr = key0 + prow;
-        if (kr >= p.kn) kr = p.kn - 1;
-        v4i kf[KK];
+    struct Blk { v4i v[KK][2]; v4f ks[4]; };
+    auto load_k = [&](int64_t kb, v4i (&kf)[KK]) {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + kr * D + 32 * kk);
-        v4i vf[KK][2];
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + (kb * KK + kk) * 1024);
+    };
+    auto load_vs = [&](int64_t kb, Blk& b) {
+        const int64_t key0 = kb * 32;
 #pragma unroll
         for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) vf[dd][c] = *(const v4i*)(vbase + (int64_t)dd * 32 * p.knp + key0 + 16 * c);
-        float ksc[16];
+            for (int c = 0; c < 2; ++c) b.v[dd][c] = *(const v4i*)(vbase + ((kb * KK + dd) * 2 + c) * 512);
+        // registers 8c..8c+7 <-> keys key0 + 16c + 8g + 0..7 (k_scale rows are padded to knp, so this never leaves the row)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int64_t key = key0 + 16 * (r >> 3) + 8 * g + (r & 7);
-            ksc[r] = ksbase[key < p.kn ? key : p.kn - 1];
+        for (int c = 0; c < 2; ++c) {
+            b.ks[2 * c] = *(const v4f*)(ksbase + key0 + 16 * c);
+            b.ks[2 * c + 1] = *(const v4f*)(ksbase + key0 + 16 * c + 4);
         }
+    };
+    auto qk_mfma = [&](const v4i (&kf)[KK]) {
         v16i s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) s = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], s, 0, 0, 0);
-
-        float qk[16];
-        float m_blk = -__builtin_inff();
+        return s;
+    };
+    auto softmax_pv = [&](const v16i& s, const Blk& b, int64_t key0, auto maskedc) {
+        constexpr bool MASKED = decltype(maskedc)::value;
+        // t = acc * k_scale; the per-query factor qsl >= 0 commutes with the row maximum, so it is applied inside the fma that
+        // also subtracts the maximum: p = exp2(t * qsl - m)
+        v2f t[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t key = key0 + 16 * (r >> 3) + 8 * g + (r & 7);
-            float val = (((float)s[r] * qscale) * ksc[r]) * p.log2_sm_scale;  // triton_atten.py:278
-            bool ok = key < p.kn;                                                // :295-296
-            if (CAUSAL) ok = ok && key <= qi;                                    // :287-288
-            qk[r] = ok ? val : -__builtin_inff();
-            m_blk = fmaxf(m_blk, qk[r]);
+        for (int j = 0; j < 8; ++j) {
+            const v4f k4 = b.ks[j >> 1];
+            t[j] = (v2f){(float)s[2 * j], (float)s[2 * j + 1]} * (v2f){k4[2 * (j & 1)], k4[2 * (j & 1) + 1]};
         }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t key = key0 + 16 * (r >> 3) + 8 * g + (r & 7);
+                bool ok = key < p.kn;              // triton_atten.py:295-296
+                if (CAUSAL) ok = ok && key <= qi;  // :287-288
+                if (!ok) t[r >> 1][r & 1] = -__builtin_inff();
+            }
+        }
+        float m_blk = fmaxf(t[0][0], t[0][1]);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) m_blk = fmaxf(fmaxf(m_blk, t[j][0]), t[j][1]);
         m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 32));
-        const float m_new = fmaxf(m_i, m_blk);          // finite from block 0 on: key 0 is valid for every query
+        // an all-zero query row has qsl == 0: its scores are 0 (not 0 * -inf) wherever a key is visible
+        const float m_new = fmaxf(m_i, qsl == 0.0f ? 0.0f : m_blk * qsl);  // finite from block 0 on: key 0 is visible to every query
         const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-        float psum = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            qk[r] = __builtin_amdgcn_exp2f(qk[r] - m_new);
-            psum += qk[r];
-        }
-        psum += __shfl_xor(psum, 32);
-        l_i = fmaf(l_i, alpha, psum);  // :308
         m_i = m_new;
+        v2f psum = {0.0f, 0.0f};
+        const v2f qsl2 = {qsl, qsl}, mneg2 = {-m_new, -m_new};
 #pragma unroll
-        for (int dd = 0; dd < KK; ++dd)
+        for (int j = 0; j < 8; ++j) {
+            t[j] = __builtin_elementwise_fma(t[j], qsl2, mneg2);
+            if constexpr (MASKED) {  // -inf * 0 would be NaN for an all-zero query row
+                if (qsl == 0.0f) t[j] = (v2f){t[j][0] != t[j][0] ? -__builtin_inff() : t[j][0], t[j][1] != t[j][1] ? -__builtin_inff() : t[j][1]};
+            }
+            t[j] = (v2f){__builtin_amdgcn_exp2f(t[j][0]), __builtin_amdgcn_exp2f(t[j][1])};
+            psum += t[j];
+        }
+        l2 = l2 * alpha + psum;  // l_i = fma(l_i, alpha, sum(p)), :308
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+            for (int dd = 0; dd < KK; ++dd) o[dd] *= alpha;
+        }
         // P in the value dtype (p.to(v.dtype), :332), packed as the second MFMA operand: 8 keys per lane group and K step
         v4i pf[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const u32 lo = FT<V_T>::bits(qk[8 * c + 2 * w]), hi = FT<V_T>::bits(qk[8 * c + 2 * w + 1]);
-                pf[c][w] = (int)(lo | (hi << 16));
+                if constexpr (V_T == SDNQ_BF16) pf[c][w] = __builtin_bit_cast(int, __builtin_convertvector(t[4 * c + w], v2bf));
+                else pf[c][w] = __builtin_bit_cast(int, __builtin_convertvector(t[4 * c + w], v2h));
             }
 #pragma unroll
         for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 if constexpr (V_T == SDNQ_BF16)
-                    o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, vf[dd][c]), __builtin_bit_cast(v8bf, pf[c]), o[dd], 0, 0, 0);
+                    o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, b.v[dd][c]), __builtin_bit_cast(v8bf, pf[c]), o[dd], 0, 0, 0);
                 else
-                    o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vf[dd][c]), __builtin_bit_cast(v8h, pf[c]), o[dd], 0, 0, 0);
+                    o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, b.v[dd][c]), __builtin_bit_cast(v8h, pf[c]), o[dd], 0, 0, 0);
             }
+    };
+
+    // blocks [0, n_plain) need no mask; at most ONE more block does (the key tail, or the causal diagonal block key0 == q0)
+    int64_t nkb = (p.kn + 31) / 32, n_plain = p.kn / 32;
+    if (CAUSAL) {
+        const int64_t lim = q0 / 32 + 1;  // blocks past the last query of this wave are fully masked (triton_atten.py:255)
+        nkb = nkb < lim ? nkb : lim;
+        n_plain = n_plain < lim - 1 ? n_plain : lim - 1;
+    }
+    if (n_plain > 0) {
+        const int64_t last = n_plain - 1;
+        v4i kfA[KK], kfB[KK];
+        Blk bA, bB;
+        v16i sA, sB;
+        load_k(0, kfA);
+        load_vs(0, bA);
+        load_k(last < 1 ? last : 1, kfB);
+        sA = qk_mfma(kfA);
+        // two blocks per trip so that the A / B register sets swap roles without moves
+#pragma nounroll
+        for (int64_t kb = 0; kb < n_plain; kb += 2) {
+            // block kb: scores in sA, V / scales in bA; K(kb+1) in kfB
+            sB = qk_mfma(kfB);
+            load_vs(kb + 1 < last ? kb + 1 : last, bB);
+            load_k(kb + 2 < last ? kb + 2 : last, kfA);
+            softmax_pv(sA, bA, kb * 32, std::false_type{});
+            if (kb + 1 >= n_plain) break;
+            // block kb+1: scores in sB, V / scales in bB; K(kb+2) in kfA
+            sA = qk_mfma(kfA);
+            load_vs(kb + 2 < last ? kb + 2 : last, bA);
+            load_k(kb + 3 < last ? kb + 3 : last, kfB);
+            softmax_pv(sB, bB, (kb + 1) * 32, std::false_type{});
+        }
+    }
+    if (n_plain < nkb) {
+        v4i kf[KK];
+        Blk b;
+        load_k(n_plain, kf);
+        load_vs(n_plain, b);
+        const v16i s = qk_mfma(kf);
+        softmax_pv(s, b, n_plain * 32, std::true_type{});
     }
     if (qi >= p.qn) return;
+    float l_i = l2[0] + l2[1];
+    l_i += __shfl_xor(l_i, 32);
     const float inv = 1.0f / l_i;  // acc *= fdiv(1.0, l_i), :336
     char* orow = (char*)p.out + (head_lin * p.qn + qi) * D * FT<OUT_T>::bytes;
 #pragma unroll
@@ -274,15 +361,15 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt) % 16) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int d = (int)head_dim, lpr = d / 8;
-    const int64_t kheads = batch * kv_heads, qrows = batch * q_heads * q_len, krows = kheads * kv_len;
+    const int64_t kheads = batch * kv_heads, qrows = batch * q_heads * q_len;
     const int64_t knp = (kv_len + 31) / 32 * 32;
 #define ATTN_T(T)                                                                                                                  \
     do {                                                                                                                           \
         if (smooth_k) hipLaunchKernelGGL((attn_kmean_kernel<T>), dim3((unsigned)kheads), dim3(256), 0, s, k, kmean, kv_len, d);    \
         hipLaunchKernelGGL((attn_quant_kernel<T>), dim3((unsigned)((qrows * lpr + 255) / 256)), dim3(256), 0, s, q,                \
-                           (const float*)nullptr, (int8_t*)qq, qs, qrows, q_len, d);                                               \
-        hipLaunchKernelGGL((attn_quant_kernel<T>), dim3((unsigned)((krows * lpr + 255) / 256)), dim3(256), 0, s, k,                \
-                           smooth_k ? (const float*)kmean : (const float*)nullptr, (int8_t*)kq, ks, krows, kv_len, d);             \
+                           (const float*)nullptr, (int8_t*)qq, qs, batch * q_heads, q_len, q_len, d, false);                       \
+        hipLaunchKernelGGL((attn_quant_kernel<T>), dim3((unsigned)((kheads * knp * lpr + 255) / 256)), dim3(256), 0, s, k,         \
+                           smooth_k ? (const float*)kmean : (const float*)nullptr, (int8_t*)kq, ks, kheads, kv_len, knp, d, true); \
     } while (0)
     if (dtype == SDNQ_BF16) ATTN_T(SDNQ_BF16);
     else ATTN_T(SDNQ_F16);

@@ -9,7 +9,11 @@ OBJ="$HERE/../../build/obj"
 mkdir -p "$OBJ"
 pids=()
 for f in api rowquant gemm dequant quantize conv attention; do
-  ( "$HIPCC" $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" ) &
+  EXTRA=""
+  # attention.hip: keep the MFMA accumulators in VGPRs (the softmax rescales / reads them with VALU every block; in AGPR form
+  # the compiler moved 80 registers per 32-key block through v_accvgpr_read/write)
+  [ "$f" = attention ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+  ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$OBJ/$f.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

@@ -51,9 +51,10 @@ def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
     q, k, v = (c.torch_tensor(t, gpu_device) for t in ("q", "k", "v"))
     qq, qs, kq, ks, vt = A.quantize_attn(q, k, v, smooth_k=kw.get("smooth_k", True))
     assert np.array_equal(qq.cpu().numpy(), c.raw("q_q")) and np.array_equal(qs.cpu().numpy(), c.raw("q_scale"))
-    _quant_agreement(kq.cpu().numpy(), ks.cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True))
     kn = k.shape[2]
-    assert torch.equal(vt[..., :kn], v.transpose(2, 3)) and not vt[..., kn:].any()
+    k_rows, v_rows = A.unpack_k_fragments(kq), A.unpack_v_fragments(vt)  # MFMA-fragment order -> [Z, KH, KNp, D]
+    _quant_agreement(k_rows[:, :, :kn].cpu().numpy(), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True))
+    assert torch.equal(v_rows[:, :, :kn], v) and not v_rows[:, :, kn:].any() and not k_rows[:, :, kn:].any() and not ks[..., kn:].any()
     out = A.sdnq_hip_atten(q, k, v, **kw)
     assert out.dtype == q.dtype and out.shape == q.shape
     got = out.float().cpu().numpy()
