@@ -258,8 +258,8 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
  * grouped-query head mapping (kv head = h * kv_heads / q_heads, triton_atten.py:212-213).
  * All tensors contiguous [batch][heads][len][head_dim]; head_dim 64 or 128; dtype bf16 / f16.
  *
- * sdnq_hip_attn_prepare <- quantize_attn (triton_atten.py:443-487): kmean [batch*kv_heads][head_dim] f32 (workspace; K minus
- *   its token mean when smooth_k), qq / kq int8 codes + qs / ks f32 per-token scales (quantize_int_mm, quant_utils.py:265-273;
+ * sdnq_hip_attn_prepare <- quantize_attn (triton_atten.py:443-487): kmean [batch*kv_heads][32][head_dim] f32 (workspace for
+ *   the channel sums of 32 token splits; K minus its token mean when smooth_k), qq / kq int8 codes + qs / ks f32 per-token scales (quantize_int_mm, quant_utils.py:265-273;
  *   qs [batch*q_heads][q_len], ks [batch*kv_heads][kv_len rounded up to 32], padding never read as a value),
  *   vt = V transposed to [batch*kv_heads][head_dim][kv_len rounded up to 32] (zero padded) in the value dtype.
  * sdnq_hip_attn_fwd <- sdnq_attn_kernel (triton_atten.py:143-335): out [batch][q_heads][q_len][head_dim] of out_dtype

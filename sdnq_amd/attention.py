@@ -34,7 +34,7 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     kq = torch.empty((z, kh, knp // 32, d // 32, 64, 16), device=dev, dtype=torch.int8)
     ks = torch.empty((z, kh, knp), device=dev, dtype=torch.float32)
     vt = torch.empty((z, kh, knp // 32, d // 32, 2, 64, 8), device=dev, dtype=value.dtype)
-    kmean = torch.empty((z, kh, d), device=dev, dtype=torch.float32)
+    kmean = torch.empty((z, kh, 32, d), device=dev, dtype=torch.float32)  # workspace: channel sums of 32 token splits
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
                                                 z, qh, kh, qn, kn, d, 1 if smooth_k else 0, qq.data_ptr(), qs.data_ptr(),
                                                 kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), kmean.data_ptr(),

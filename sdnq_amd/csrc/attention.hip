@@ -24,15 +24,20 @@
 
 namespace {
 
-// ---- K channel means over the tokens of one (batch, head) ------------------------------------------------------------
+// ---- K channel sums over the tokens of one (batch, head), split over KMEAN_SPLITS workgroups ----------------------------
+// part[head][split][d] = sum of the split's tokens; the consumer adds the splits in a fixed order (deterministic mean).
+constexpr int KMEAN_SPLITS = 32;
+
 template <int T_ID>
-__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, float* __restrict__ mean, int64_t kn, int d) {
+__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, float* __restrict__ part, int64_t kn, int d) {
     __shared__ float red[256 * 8];
     const int lpr = d / 8, rpp = 256 / lpr;  // lanes per token row, rows per pass
     const int tid = threadIdx.x, c8 = (tid % lpr) * 8, r0 = tid / lpr;
-    const char* base = (const char*)k + (int64_t)blockIdx.x * kn * d * FT<T_ID>::bytes;
+    const int64_t head = blockIdx.x / KMEAN_SPLITS, split = blockIdx.x % KMEAN_SPLITS;
+    const int64_t per = (kn + KMEAN_SPLITS - 1) / KMEAN_SPLITS, lo = split * per, hi = lo + per < kn ? lo + per : kn;
+    const char* base = (const char*)k + head * kn * d * FT<T_ID>::bytes;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t r = r0; r < kn; r += rpp) {
+    for (int64_t r = lo + r0; r < hi; r += rpp) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += FT<T_ID>::load(base, r * d + c8 + e);
     }
@@ -43,19 +48,18 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
         float s = 0.0f;
         const int lane_of = tid / 8, e = tid % 8;
         for (int r = 0; r < rpp; ++r) s += red[(r * lpr + lane_of) * 8 + e];
-        mean[(int64_t)blockIdx.x * d + tid] = s / (float)kn;
+        part[(int64_t)blockIdx.x * d + tid] = s;
     }
 }
 
 // ---- per-token int8 quantization of [heads][n_src][d] (d / 8 lanes per token), optional mean subtraction ------------------
 // The destination has n_dst >= n_src token slots per head (K: rounded up to the 32-key block; the extra tokens get zero codes
-// and a zero scale and are masked in the forward kernel).
+// and a zero scale and are masked in the forward kernel).  `mean`: this head's channel means (LDS) or nullptr.
 template <int T_ID>
-__global__ __launch_bounds__(256) void attn_quant_kernel(const void* __restrict__ x, const float* __restrict__ mean, int8_t* __restrict__ xq,
-                                                         float* __restrict__ xs, int64_t heads, int64_t n_src, int64_t n_dst, int d,
-                                                         bool frag_major) {
+__device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, const float* mean, int8_t* __restrict__ xq, float* __restrict__ xs,
+                                                 int64_t heads, int64_t n_src, int64_t n_dst, int d, bool frag_major, int64_t block) {
     const int lpr = d / 8;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t t = block * 256 + threadIdx.x;
     const int64_t row = t / lpr;
     const int c8 = (int)(t % lpr) * 8;
     const bool live = row < heads * n_dst;
@@ -65,9 +69,8 @@ __global__ __launch_bounds__(256) void attn_quant_kernel(const void* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = real ? FT<T_ID>::load(x, (head * n_src + n) * d + c8 + e) : 0.0f;
     if (mean != nullptr && real) {
-        const float* mu = mean + head * d + c8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] -= mu[e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
+        for (int e = 0; e < 8; ++e) v[e] -= mean[c8 + e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
     }
     float amax = 0.0f;
 #pragma unroll
@@ -101,9 +104,9 @@ __global__ __launch_bounds__(256) void attn_quant_kernel(const void* __restrict_
 // ---- V [heads][kn][d] -> PV operand in MFMA-fragment order (knp = kn rounded up to 32, zero padded) -----------------------
 // one 1-KiB tile per (32-key block kb, 32-channel block dd, 16-key step c): lane (g, ql) holds the 8 keys
 // kb*32 + 16c + 8g + 0..7 of channel 32dd + ql, i.e. exactly the first operand of PV MFMA (dd, c) of attn_fwd_kernel.
-__global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d) {
-    __shared__ uint16_t tile[32][128 + 2];
-    const int64_t head = blockIdx.y, kb = blockIdx.x, key0 = kb * 32;
+__device__ __forceinline__ void attn_vt_block(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d,
+                                              int64_t head, int64_t kb, uint16_t (*tile)[128 + 2]) {
+    const int64_t key0 = kb * 32;
     const uint16_t* src = v + head * kn * d;
     const int lpr = d / 8, kkn = d / 32;
     uint16_t* dst = vt + (head * (knp / 32) + kb) * (int64_t)(kkn * 2 * 512);
@@ -123,6 +126,46 @@ __global__ __launch_bounds__(256) void attn_vt_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = (u32)tile[k8 + 2 * e][dch] | ((u32)tile[k8 + 2 * e + 1][dch] << 16);
         *(uint4*)(dst + (int64_t)t * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+struct PrepParams {
+    const void *q, *k, *v;
+    int8_t *qq, *kq;
+    float *qs, *ks;
+    uint16_t* vt;
+    const float* kpart;  // [kheads][KMEAN_SPLITS][d] channel sums (smooth_k) or nullptr
+    int64_t qheads, kheads, qn, kn, knp, nqb, nkb;
+    int d;
+};
+
+// one launch for the three operands: workgroups [0, nqb) quantize Q, [nqb, nqb + nkb) quantize K (a workgroup never straddles
+// heads: knp is a multiple of the 32 / 16 tokens it covers), the rest lay out V
+template <int T_ID>
+__global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
+    __shared__ float smean[128];
+    __shared__ uint16_t tile[32][128 + 2];
+    const int64_t b = blockIdx.x;
+    if (b < p.nqb) {
+        attn_quant_block<T_ID>(p.q, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b);
+    } else if (b < p.nqb + p.nkb) {
+        const int64_t kb = b - p.nqb;
+        const float* mean = nullptr;
+        if (p.kpart != nullptr) {
+            const int64_t head = kb * (256 / (p.d / 8)) / p.knp;
+            if ((int)threadIdx.x < p.d) {
+                const float* pp = p.kpart + head * KMEAN_SPLITS * p.d + threadIdx.x;
+                float s = 0.0f;
+                for (int i = 0; i < KMEAN_SPLITS; ++i) s += pp[i * p.d];
+                smean[threadIdx.x] = s / (float)p.kn;  // k.mean(dim=2), triton_atten.py:459
+            }
+            __syncthreads();
+            mean = smean;
+        }
+        attn_quant_block<T_ID>(p.k, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb);
+    } else {
+        const int64_t vb = b - p.nqb - p.nkb, nb = p.knp / 32;
+        attn_vt_block((const uint16_t*)p.v, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile);
     }
 }
 
@@ -226,7 +269,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         float m_blk = fmaxf(t[0][0], t[0][1]);
 #pragma unroll
         for (int j = 1; j < 8; ++j) m_blk = fmaxf(fmaxf(m_blk, t[j][0]), t[j][1]);
-        m_blk = fmaxf(m_blk, __shfl_xor(m_blk, 32));
+        {   // the other 16 keys of this query live in lane ^ 32: one v_permlane32_swap (VALU) instead of a trip through LDS
+            const u32 mb = __float_as_uint(m_blk);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            m_blk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         // an all-zero query row has qsl == 0: its scores are 0 (not 0 * -inf) wherever a key is visible
         const float m_new = fmaxf(m_i, qsl == 0.0f ? 0.0f : m_blk * qsl);  // finite from block 0 on: key 0 is visible to every query
         const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
@@ -361,21 +408,21 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt) % 16) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int d = (int)head_dim, lpr = d / 8;
-    const int64_t kheads = batch * kv_heads, qrows = batch * q_heads * q_len;
-    const int64_t knp = (kv_len + 31) / 32 * 32;
-#define ATTN_T(T)                                                                                                                  \
-    do {                                                                                                                           \
-        if (smooth_k) hipLaunchKernelGGL((attn_kmean_kernel<T>), dim3((unsigned)kheads), dim3(256), 0, s, k, kmean, kv_len, d);    \
-        hipLaunchKernelGGL((attn_quant_kernel<T>), dim3((unsigned)((qrows * lpr + 255) / 256)), dim3(256), 0, s, q,                \
-                           (const float*)nullptr, (int8_t*)qq, qs, batch * q_heads, q_len, q_len, d, false);                       \
-        hipLaunchKernelGGL((attn_quant_kernel<T>), dim3((unsigned)((kheads * knp * lpr + 255) / 256)), dim3(256), 0, s, k,         \
-                           smooth_k ? (const float*)kmean : (const float*)nullptr, (int8_t*)kq, ks, kheads, kv_len, knp, d, true); \
-    } while (0)
-    if (dtype == SDNQ_BF16) ATTN_T(SDNQ_BF16);
-    else ATTN_T(SDNQ_F16);
-#undef ATTN_T
-    hipLaunchKernelGGL(attn_vt_kernel, dim3((unsigned)(knp / 32), (unsigned)kheads), dim3(256), 0, s, (const uint16_t*)v, (uint16_t*)vt,
-                       kv_len, knp, d);
+    const int64_t kheads = batch * kv_heads;
+    PrepParams p{};
+    p.q = q; p.k = k; p.v = v; p.qq = (int8_t*)qq; p.kq = (int8_t*)kq; p.qs = qs; p.ks = ks; p.vt = (uint16_t*)vt;
+    p.kpart = smooth_k ? kmean : nullptr;
+    p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d;
+    p.nqb = (p.qheads * q_len * lpr + 255) / 256;
+    p.nkb = kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
+    const int64_t blocks = p.nqb + p.nkb + kheads * (p.knp / 32);
+    if (dtype == SDNQ_BF16) {
+        if (smooth_k) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
+        hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    } else {
+        if (smooth_k) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
+        hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    }
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }
