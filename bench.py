@@ -44,7 +44,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant"])
+    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant",
+                            "sdxl_attn_int8", "flux_attn_int8"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,6 +255,127 @@ def cpu_baseline(shape_list, mm_name, budget_s):
             "sample": f"row-quantize + {mm_name} scaled-mm over the step's {len(sample)} distinct GEMM shapes (MxKxN " + ",".join(sample) + f"), {passes} passes, {t_total:.1f}s"}
 
 
+# Q.K^T runs on the int8 matrix pipe and P.V on the bf16 one, half of the operations each: ops / (ops/2/int8 + ops/2/bf16)
+ATTN_MFMA_PEAK_TOPS = round(2.0 / (1.0 / INT8_MFMA_PEAK_TOPS + 1.0 / (INT8_MFMA_PEAK_TOPS / 2.0)), 1)
+
+
+def attention_bench(args, device, distributed, world, rank):
+    """the quantized attention calls of one denoising step (int8 Q.K^T, bf16 P.V), each = prepare
+    (smooth-K, per-token int8 of Q and K, V layout) + forward kernel.  Same timing contract as the Linear workloads."""
+    from sdnq_amd import attention as A
+    from sdnq_amd import shapes
+    calls = shapes.sdxl_unet_attentions() if args.workload == "sdxl_attn_int8" else shapes.flux_dev_attentions()
+    g = torch.Generator(device=device).manual_seed(rank)
+    tensors = {}
+    for (name, h, qn, kn, d, rep) in calls:
+        tensors[name] = tuple(torch.randn(1, h, n, d, device=device, dtype=torch.bfloat16, generator=g) for n in (qn, kn, kn))
+    ops_per_step = shapes.ops_of_attentions(calls)
+    n_calls = sum(c[5] for c in calls)
+
+    def run_step():
+        for (name, h, qn, kn, d, rep) in calls:
+            q, k, v = tensors[name]
+            for _ in range(rep):
+                A.sdnq_hip_atten(q, k, v)
+
+    def capture(fn):
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(side):
+            fn()
+            side.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                fn()
+        torch.cuda.synchronize()
+        return gr, side
+
+    run_step()
+    torch.cuda.synchronize()
+    graph = None if args.no_graph else capture(run_step)[0]
+    step = graph.replay if graph is not None else run_step
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    replicas = world if distributed else 1
+    result = {
+        "metric": f"quantized-attention GOP/s ({args.workload})", "value": round(ops_per_step * args.steps * replicas / elapsed / 1e9, 1),
+        "unit": "GOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8 (Q.K^T) + bf16 (P.V)", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n_calls} attention calls of one denoising step, bs=1 ("
+                               + ", ".join(f"{rep} x {h} heads {qn}x{kn}x{d}" for (_, h, qn, kn, d, rep) in calls) + ")",
+                   "parallelism": f"{world} independent replicas" if distributed else "single GPU",
+                   "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16", "smooth_k": True,
+                   "matmul_dtype": "int8", "pv_matmul_dtype": None, "ops_per_step": ops_per_step},
+        "step_latency_ms": round(ms_per_step, 4),
+    }
+    if rank == 0:
+        # the forward kernel alone (operands prepared once), graph-replayed, HIP events on the launch stream
+        prepared = {name: A.quantize_attn(*tensors[name]) for name in tensors}
+
+        def fwd_only():
+            for (name, h, qn, kn, d, rep) in calls:
+                parts = prepared[name]
+                for _ in range(rep):
+                    A.atten_fwd(*parts, kn, d ** -0.5, False, torch.bfloat16)
+
+        gr, side = capture(fwd_only)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(side):
+            gr.replay()
+            e0.record(side)
+            for _ in range(5):
+                gr.replay()
+            e1.record(side)
+            side.synchronize()
+        sec = e0.elapsed_time(e1) / 5 / 1e3
+        ach = ops_per_step / sec / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": ATTN_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                              "frac": round(ach / ATTN_MFMA_PEAK_TOPS, 4), "traffic": None,
+                              "peak_note": "half of the operations on the int8 matrix pipe, half on the bf16 one",
+                              "kernel": "attn_fwd_kernel", "launches_per_step": n_calls, "avg_launch_us": round(sec / n_calls * 1e6, 3)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline_attention(calls, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline_error"] = repr(e)
+        print(json.dumps(result))
+
+
+def cpu_baseline_attention(calls, budget_s):
+    """The oracle's restatement of the reference attention (numpy) on a bounded sample: 2 heads of 1024 x 1024 tokens."""
+    import numpy as np
+    from oracle import oracle as O
+    d = calls[0][4]
+    rng = np.random.default_rng(0)
+    q, k, v = (O.round_dtype(rng.standard_normal((1, 2, 1024, d)).astype(np.float32), "bf16") for _ in range(3))
+    ops = 4 * 2 * 1024 * 1024 * d
+    O.attention(q, k, v, "bf16")
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s or n == 0:
+        O.attention(q, k, v, "bf16")
+        n += 1
+    sec = time.perf_counter() - t0
+    return {"value": round(ops * n / sec / 1e9, 2), "unit": "GOP/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle (numpy) quantized attention, 2 heads x 1024 x 1024 x {d}, {n} passes, {sec:.1f}s (numpy / BLAS default threading)"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,6 +395,13 @@ def main():
     from sdnq_amd import linear as L
     if not _lib.load().sdnq_hip_device_supported(local_rank):
         raise SystemExit("device is not gfx950: the HIP kernels of this repo target MI355X only")
+
+    if args.workload.endswith("_attn_int8"):
+        attention_bench(args, device, distributed, world, rank)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     shape_list, cfg_kwargs, mm_name, tokens = workload_config(args.workload)
     tp = args.tp and distributed

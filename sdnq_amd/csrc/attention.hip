@@ -16,6 +16,7 @@
 //   O^T = V^T.P^T: query stays on (l & 31), so alpha / 1/l are per-lane scalars.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -137,6 +138,7 @@ struct PrepParams {
     const float* kpart;  // [kheads][KMEAN_SPLITS][d] channel sums (smooth_k) or nullptr
     int64_t qheads, kheads, qn, kn, knp, nqb, nkb;
     int d;
+    bool smooth_inline;  // K means computed inside the K workgroups (short key sequences)
 };
 
 // one launch for the three operands: workgroups [0, nqb) quantize Q, [nqb, nqb + nkb) quantize K (a workgroup never straddles
@@ -144,14 +146,35 @@ struct PrepParams {
 template <int T_ID>
 __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
     __shared__ float smean[128];
-    __shared__ uint16_t tile[32][128 + 2];
+    __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
     const int64_t b = blockIdx.x;
     if (b < p.nqb) {
         attn_quant_block<T_ID>(p.q, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b);
     } else if (b < p.nqb + p.nkb) {
         const int64_t kb = b - p.nqb;
         const float* mean = nullptr;
-        if (p.kpart != nullptr) {
+        if (p.smooth_inline) {
+            // short key sequences (cross-attention onto text tokens): every K workgroup sums its head's channels itself
+            // instead of a separate attn_kmean_kernel launch
+            const int lpr = p.d / 8, rpp = 256 / lpr, tid = threadIdx.x, c8 = (tid % lpr) * 8;
+            const int64_t head = kb * rpp / p.knp;
+            float* red = (float*)&tile[0][0];  // 256 * 8 floats <= sizeof(tile)
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t r = tid / lpr; r < p.kn; r += rpp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += FT<T_ID>::load(p.k, (head * p.kn + r) * p.d + c8 + e);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[e];
+            __syncthreads();
+            if (tid < p.d) {
+                float sum = 0.0f;
+                for (int r = 0; r < rpp; ++r) sum += red[(r * lpr + tid / 8) * 8 + tid % 8];
+                smean[tid] = sum / (float)p.kn;
+            }
+            __syncthreads();
+            mean = smean;
+        } else if (p.kpart != nullptr) {
             const int64_t head = kb * (256 / (p.d / 8)) / p.knp;
             if ((int)threadIdx.x < p.d) {
                 const float* pp = p.kpart + head * KMEAN_SPLITS * p.d + threadIdx.x;
@@ -173,7 +196,7 @@ struct AttnParams {
     const int8_t* qq; const float* qs; const int8_t* kq; const float* ks; const uint16_t* vt;
     void* out;
     int64_t qh, kh, qn, kn, knp;
-    int qblocks;
+    int qblocks, split;
     float log2_sm_scale;
 };
 
@@ -195,8 +218,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int ql = lane & 31, g = lane >> 5;
     const int64_t head_lin = blockIdx.x / p.qblocks;  // z * QH + h
     const int qblk = blockIdx.x % p.qblocks;
-    const int64_t q0 = (int64_t)qblk * 128 + wave * 32;
-    if (q0 >= p.qn) return;  // wave-uniform
+    // split == 1: the 4 waves of a workgroup take 4 query tiles.  split == 2 (few tiles for the 1024 SIMDs of the chip): two query
+    // tiles per workgroup, waves 2t / 2t+1 each take HALF the key blocks of tile t and merge through LDS at the end.
+    const int half = p.split == 2 ? (wave & 1) : 0;
+    const int64_t q0 = p.split == 2 ? (int64_t)qblk * 64 + (wave >> 1) * 32 : (int64_t)qblk * 128 + wave * 32;
+    const bool active = q0 < p.qn;  // wave-uniform
+    if (!active && p.split != 2) return;
     const int64_t z = head_lin / p.qh, h = head_lin % p.qh;
     const int64_t kv_lin = z * p.kh + (h * p.kh) / p.qh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
 
@@ -321,24 +348,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         nkb = nkb < lim ? nkb : lim;
         n_plain = n_plain < lim - 1 ? n_plain : lim - 1;
     }
-    if (n_plain > 0) {
-        const int64_t last = n_plain - 1;
+    // this wave's share: plain blocks [lo, hi); the masked block (if any) goes to the last share
+    int64_t lo = 0, hi = n_plain;
+    bool do_masked = n_plain < nkb;
+    if (p.split == 2) {
+        const int64_t mid = (n_plain + 1) / 2;
+        if (half == 0) { hi = mid; do_masked = false; } else { lo = mid; }
+    }
+    if (!active) { hi = lo; do_masked = false; }
+    if (lo < hi) {
+        const int64_t last = hi - 1;
         v4i kfA[KK], kfB[KK];
         Blk bA, bB;
         v16i sA, sB;
-        load_k(0, kfA);
-        load_vs(0, bA);
-        load_k(last < 1 ? last : 1, kfB);
+        load_k(lo, kfA);
+        load_vs(lo, bA);
+        load_k(lo + 1 < last ? lo + 1 : last, kfB);
         sA = qk_mfma(kfA);
         // two blocks per trip so that the A / B register sets swap roles without moves
 #pragma nounroll
-        for (int64_t kb = 0; kb < n_plain; kb += 2) {
+        for (int64_t kb = lo; kb < hi; kb += 2) {
             // block kb: scores in sA, V / scales in bA; K(kb+1) in kfB
             sB = qk_mfma(kfB);
             load_vs(kb + 1 < last ? kb + 1 : last, bB);
             load_k(kb + 2 < last ? kb + 2 : last, kfA);
             softmax_pv(sA, bA, kb * 32, std::false_type{});
-            if (kb + 1 >= n_plain) break;
+            if (kb + 1 >= hi) break;
             // block kb+1: scores in sB, V / scales in bB; K(kb+2) in kfA
             sA = qk_mfma(kfA);
             load_vs(kb + 2 < last ? kb + 2 : last, bA);
@@ -346,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             softmax_pv(sB, bB, (kb + 1) * 32, std::false_type{});
         }
     }
-    if (n_plain < nkb) {
+    if (do_masked) {
         v4i kf[KK];
         Blk b;
         load_k(n_plain, kf);
@@ -354,8 +389,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         const v16i s = qk_mfma(kf);
         softmax_pv(s, b, n_plain * 32, std::true_type{});
     }
-    if (qi >= p.qn) return;
     float l_i = l2[0] + l2[1];
+    if (p.split == 2) {
+        // merge the two key halves of a query tile: o = o0 * 2^(m0 - m) + o1 * 2^(m1 - m), same for the row sums
+        __shared__ float comb[2][KK * 16 + 2][64];
+        float (*cb)[64] = comb[wave >> 1];
+        if (half == 1 && active) {
+#pragma unroll
+            for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cb[dd * 16 + r][lane] = o[dd][r];
+            cb[KK * 16][lane] = m_i;
+            cb[KK * 16 + 1][lane] = l_i;
+        }
+        __syncthreads();
+        if (half == 1 || !active) return;
+        const float m1 = cb[KK * 16][lane], l1 = cb[KK * 16 + 1][lane];
+        const float m = fmaxf(m_i, m1);  // at least one half saw a visible key
+        const float a0 = __builtin_amdgcn_exp2f(m_i - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+        l_i = l_i * a0 + l1 * a1;
+#pragma unroll
+        for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dd][r] = o[dd][r] * a0 + cb[dd * 16 + r][lane] * a1;
+    }
+    if (qi >= p.qn) return;
     l_i += __shfl_xor(l_i, 32);
     const float inv = 1.0f / l_i;  // acc *= fdiv(1.0, l_i), :336
     char* orow = (char*)p.out + (head_lin * p.qn + qi) * D * FT<OUT_T>::bytes;
@@ -411,16 +469,18 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
     const int64_t kheads = batch * kv_heads;
     PrepParams p{};
     p.q = q; p.k = k; p.v = v; p.qq = (int8_t*)qq; p.kq = (int8_t*)kq; p.qs = qs; p.ks = ks; p.vt = (uint16_t*)vt;
-    p.kpart = smooth_k ? kmean : nullptr;
+    const bool inline_mean = smooth_k && kv_len <= 256;
+    p.smooth_inline = inline_mean;
+    p.kpart = (smooth_k && !inline_mean) ? kmean : nullptr;
     p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d;
     p.nqb = (p.qheads * q_len * lpr + 255) / 256;
     p.nkb = kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
     const int64_t blocks = p.nqb + p.nkb + kheads * (p.knp / 32);
     if (dtype == SDNQ_BF16) {
-        if (smooth_k) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
+        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
         hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else {
-        if (smooth_k) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
+        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
         hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
     SDNQ_CHECK_LAUNCH();
@@ -436,7 +496,11 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     AttnParams p{};
     p.qq = (const int8_t*)qq; p.qs = qs; p.kq = (const int8_t*)kq; p.ks = ks; p.vt = (const uint16_t*)vt; p.out = out;
     p.qh = q_heads; p.kh = kv_heads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32;
-    p.qblocks = (int)((q_len + 127) / 128);
+    // few query tiles for the 1024 SIMDs (e.g. SDXL at batch 1: 1280): split every tile's keys over two waves
+    static const int force_split = [] { const char* e = getenv("SDNQ_HIP_ATTN_SPLIT"); return e ? atoi(e) : 0; }();  // tuning aid
+    const int64_t tiles = batch * q_heads * ((q_len + 31) / 32);
+    p.split = force_split ? force_split : ((tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);  // measured: tools/bench_attention.py
+    p.qblocks = (int)(p.split == 2 ? (q_len + 63) / 64 : (q_len + 127) / 128);
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
     const int64_t blocks = batch * q_heads * p.qblocks;
     hipStream_t s = (hipStream_t)stream;

@@ -155,3 +155,23 @@ def bytes_of(shapes, weight_bits: float = 8.0, act_bytes: int = 2) -> dict:
     w = sum(r * (n * k * weight_bits / 8 + 4 * n + (act_bytes * n if b else 0)) for (_, m, k, n, b, r) in shapes)
     a = sum(r * (act_bytes * m * k + act_bytes * m * n) for (_, m, k, n, b, r) in shapes)
     return {"weights": w, "activations": a}
+
+
+def sdxl_unet_attentions(latent: int = 128, text_tokens: int = 77, head_dim: int = 64):
+    """Attention calls of one SDXL-base UNet step at bs=1: every transformer layer runs one self-attention over its image
+    tokens and one cross-attention onto the text tokens.  Entries: (name, heads, q_len, kv_len, head_dim, repeat)."""
+    out = []
+    for c, tokens, modules, layers in ((640, (latent // 2) ** 2, 5, 2), (1280, (latent // 4) ** 2, 6, 10)):
+        out += [(f"c{c}.attn1", c // head_dim, tokens, tokens, head_dim, modules * layers),
+                (f"c{c}.attn2", c // head_dim, tokens, text_tokens, head_dim, modules * layers)]
+    return out
+
+
+def flux_dev_attentions(img_tokens: int = 4096, txt_tokens: int = 512, d: int = 3072, head_dim: int = 128):
+    """FLUX.1-dev: 19 double-stream + 38 single-stream blocks, each one joint attention over text + image tokens."""
+    return [("joint_attn", d // head_dim, img_tokens + txt_tokens, img_tokens + txt_tokens, head_dim, 19 + 38)]
+
+
+def ops_of_attentions(calls, batch: int = 1) -> int:
+    """2 * QN * KN * D for Q.K^T plus the same for P.V, per head."""
+    return sum(4 * batch * h * qn * kn * d * rep for (_, h, qn, kn, d, rep) in calls)
