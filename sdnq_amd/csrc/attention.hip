@@ -214,7 +214,7 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 template <int V_T, int OUT_T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KK = D / 32;  // int8 MFMA K steps of Q.K^T; also the 32-channel blocks of O
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in SGPRs: block indices stay scalar
     const int ql = lane & 31, g = lane >> 5;
     const int64_t head_lin = blockIdx.x / p.qblocks;  // z * QH + h
     const int qblk = blockIdx.x % p.qblocks;
@@ -249,16 +249,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const uint16_t* vbase = p.vt + kv_lin * p.knp * D + lane * 8;
 
     struct Blk { v4i v[KK][2]; v4f ks[4]; };
-    auto load_k = [&](int64_t kb, v4i (&kf)[KK]) {
+    auto load_k = [&](int kb, v4i (&kf)[KK]) {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + (kb * KK + kk) * 1024);
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + (int64_t)kb * (KK * 1024) + kk * 1024);
     };
-    auto load_vs = [&](int64_t kb, Blk& b) {
-        const int64_t key0 = kb * 32;
+    auto load_vs = [&](int kb, Blk& b) {
+        const int64_t key0 = (int64_t)kb * 32;
 #pragma unroll
         for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) b.v[dd][c] = *(const v4i*)(vbase + ((kb * KK + dd) * 2 + c) * 512);
+            for (int c = 0; c < 2; ++c) b.v[dd][c] = *(const v4i*)(vbase + (int64_t)kb * (KK * 1024) + (dd * 2 + c) * 512);
         // registers 8c..8c+7 <-> keys key0 + 16c + 8g + 0..7 (k_scale rows are padded to knp, so this never leaves the row)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -342,22 +342,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     };
 
     // blocks [0, n_plain) need no mask; at most ONE more block does (the key tail, or the causal diagonal block key0 == q0)
-    int64_t nkb = (p.kn + 31) / 32, n_plain = p.kn / 32;
+    int nkb = (int)((p.kn + 31) / 32), n_plain = (int)(p.kn / 32);
     if (CAUSAL) {
-        const int64_t lim = q0 / 32 + 1;  // blocks past the last query of this wave are fully masked (triton_atten.py:255)
+        const int lim = (int)(q0 / 32) + 1;  // blocks past the last query of this wave are fully masked (triton_atten.py:255)
         nkb = nkb < lim ? nkb : lim;
         n_plain = n_plain < lim - 1 ? n_plain : lim - 1;
     }
     // this wave's share: plain blocks [lo, hi); the masked block (if any) goes to the last share
-    int64_t lo = 0, hi = n_plain;
+    int lo = 0, hi = n_plain;
     bool do_masked = n_plain < nkb;
     if (p.split == 2) {
-        const int64_t mid = (n_plain + 1) / 2;
+        const int mid = (n_plain + 1) / 2;
         if (half == 0) { hi = mid; do_masked = false; } else { lo = mid; }
     }
     if (!active) { hi = lo; do_masked = false; }
     if (lo < hi) {
-        const int64_t last = hi - 1;
+        const int last = hi - 1;
         v4i kfA[KK], kfB[KK];
         Blk bA, bB;
         v16i sA, sB;
@@ -367,18 +367,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         sA = qk_mfma(kfA);
         // two blocks per trip so that the A / B register sets swap roles without moves
 #pragma nounroll
-        for (int64_t kb = lo; kb < hi; kb += 2) {
+        for (int kb = lo; kb < hi; kb += 2) {
             // block kb: scores in sA, V / scales in bA; K(kb+1) in kfB
             sB = qk_mfma(kfB);
             load_vs(kb + 1 < last ? kb + 1 : last, bB);
             load_k(kb + 2 < last ? kb + 2 : last, kfA);
-            softmax_pv(sA, bA, kb * 32, std::false_type{});
+            softmax_pv(sA, bA, (int64_t)kb * 32, std::false_type{});
             if (kb + 1 >= hi) break;
             // block kb+1: scores in sB, V / scales in bB; K(kb+2) in kfA
             sA = qk_mfma(kfA);
             load_vs(kb + 2 < last ? kb + 2 : last, bA);
             load_k(kb + 3 < last ? kb + 3 : last, kfB);
-            softmax_pv(sB, bB, (kb + 1) * 32, std::false_type{});
+            softmax_pv(sB, bB, (int64_t)(kb + 1) * 32, std::false_type{});
         }
     }
     if (do_masked) {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         load_k(n_plain, kf);
         load_vs(n_plain, b);
         const v16i s = qk_mfma(kf);
-        softmax_pv(s, b, n_plain * 32, std::true_type{});
+        softmax_pv(s, b, (int64_t)n_plain * 32, std::true_type{});
     }
     float l_i = l2[0] + l2[1];
     if (p.split == 2) {
