@@ -36,6 +36,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 INT8_MFMA_PEAK_TOPS = 5033.0  # dense: 1024 MAC/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz x 2 (MI355X_MICROARCH.md: i8 = 2x bf16 rate)
 FP8_MFMA_PEAK_TFLOPS = 5033.0
+# measured ceilings of the same instructions in a register-resident loop on this part (tools/mfma_peak.hip,
+# profiles/r01_mfma_peak.txt): the issue rate is the datasheet's (one 32x32x32 i8 MFMA per 32 clocks per SIMD) but the shader
+# clock sits at 2.0-2.3 GHz under matrix load, not 2.4
+INT8_MFMA_MEASURED_TOPS = 4200.0
+BF16_MFMA_MEASURED_TFLOPS = 2300.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -497,7 +502,9 @@ def main():
                                   "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]),
                                   "hbm_achieved_gbps": round(gk["bytes"] / gk["seconds"] / 1e9, 1), "hbm_peak_gbps": HBM_PEAK_GBPS,
                                   "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
-                                  "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3)}
+                                  "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3),
+                                  "peak_measured": INT8_MFMA_MEASURED_TOPS, "frac_of_measured_peak": round(ach / INT8_MFMA_MEASURED_TOPS, 4),
+                                  "peak_measured_source": "profiles/r01_mfma_peak.txt (register-resident MFMA loop, tools/mfma_peak.hip)"}
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:
                 result["cpu_baseline"] = cpu_baseline(shape_list, mm_name, args.cpu_seconds)
