@@ -254,7 +254,9 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
 
 /* ---- quantized attention (forward) ------------------------------------------------------------
  * replaces sdnq_triton_atten (kernels/triton_atten.py:540-618) in its default configuration: matmul_dtype "int8" for
- * Q.K^T, pv_matmul_dtype None (P.V in the value dtype), smooth_k, no attention mask, optional causal masking,
+ * Q.K^T, pv_matmul_dtype None (P.V in the value dtype), smooth_k, optional Hadamard rotation of Q and K (hadamard_group: 0 or a
+ * power of two in [4, head_dim] dividing head_dim; apply_hadamard / rotate_hadamard, triton_atten.py:464-467), no attention mask,
+ * optional causal masking,
  * grouped-query head mapping (kv head = h * kv_heads / q_heads, triton_atten.py:212-213).
  * All tensors contiguous [batch][heads][len][head_dim]; head_dim 64 or 128; dtype bf16 / f16.
  *
@@ -265,8 +267,8 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
  * sdnq_hip_attn_fwd <- sdnq_attn_kernel (triton_atten.py:143-335): out [batch][q_heads][q_len][head_dim] of out_dtype
  *   (the value dtype or f32). */
 int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads,
-                          int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, void* qq, float* qs,
-                          void* kq, float* ks, void* vt, float* kmean, sdnq_stream_t stream);
+                          int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, int hadamard_group,
+                          void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean, sdnq_stream_t stream);
 int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
                       float sm_scale, int is_causal, void* out, int out_dtype, int64_t batch, int64_t q_heads,
                       int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, sdnq_stream_t stream);

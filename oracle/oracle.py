@@ -591,7 +591,7 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
 
 
 # ---- quantized attention forward ---------------------------------------------------------------
-def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True):
+def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True, hadamard_group: int = 0, tag: str = "bf16"):
     """quantize_attn (kernels/triton_atten.py:443-487) for matmul_dtype="int8": K minus its token mean in fp32 (:457-463),
     then quantize_int_mm per token (quant_utils.py:265-273).  q [Z,H,QN,D], k [Z,KH,KN,D] float32 values.
     Returns (q_q int8, q_scale [Z,H,QN], k_q int8, k_scale [Z,KH,KN])."""
@@ -599,6 +599,9 @@ def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True):
     q, k = _c(q, f), _c(k, f)
     if smooth_k:
         k = (k - k.mean(axis=2, keepdims=True, dtype=f)).astype(f)
+    if hadamard_group:  # apply_hadamard(q) / rotate_hadamard(k.to(hadamard.dtype)) in the tensor dtype (:464-467)
+        q = rotate_hadamard(q, hadamard_group, tag)
+        k = rotate_hadamard(round_dtype(k, tag), hadamard_group, tag)
     d = q.shape[-1]
     qq, qs, _ = rowquant(q.reshape(-1, d), "int8")
     kq, ks, _ = rowquant(k.reshape(-1, d), "int8")
@@ -606,7 +609,7 @@ def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True):
 
 
 def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: bool = False, scale=None, smooth_k: bool = True,
-              block_n: int = 32, out_tag: str | None = None, want_intermediates: bool = False):
+              block_n: int = 32, out_tag: str | None = None, want_intermediates: bool = False, hadamard_group: int = 0):
     """sdnq_triton_atten (kernels/triton_atten.py:540-618) in its default configuration (int8 Q.K^T, P.V in the value dtype):
     the online-softmax loop of sdnq_attn_kernel (:143-335) over key blocks of `block_n`, all queries of a head at once.
     q/k/v: float32 VALUES of `tag` tensors [Z,H,N,D]; returns float32 values rounded to out_tag (default tag)."""
@@ -615,7 +618,7 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
     _, KH, KN, _ = k.shape
     sm_scale = f(D ** -0.5 if scale is None else scale)                       # :512-513
     log2_sm = f(sm_scale * f(1.4426950408889634))                            # :203
-    qq, qs, kq, ks = attention_quantize(q, k, smooth_k)
+    qq, qs, kq, ks = attention_quantize(q, k, smooth_k, hadamard_group, tag)
     out = np.empty((Z, QH, QN, D), dtype=f)
     qidx = np.arange(QN)[:, None]
     for z in range(Z):

@@ -2,9 +2,8 @@
 
 Host-side mirror of the reference's ``sdnq_triton_atten`` (kernels/triton_atten.py:540-618): same argument names, same
 defaults.  Built: the default configuration -- int8 Q.K^T (``matmul_dtype="int8"``), P.V in the value dtype
-(``pv_matmul_dtype=None``), ``smooth_k``, optional ``is_causal``, grouped-query heads.  Reference-valid options that are not
-built raise ``NotImplementedError`` naming the gap (attention masks, quantized P.V, Hadamard rotation, fp16 accumulation,
-the backward outputs).
+(``pv_matmul_dtype=None``), ``smooth_k``, optional ``use_hadamard`` and ``is_causal``, grouped-query heads.  Reference-valid options that are not
+built raise ``NotImplementedError`` naming the gap (attention masks, quantized P.V, fp16 accumulation, the backward outputs).
 """
 from __future__ import annotations
 
@@ -17,7 +16,7 @@ from . import _lib, ops
 _DISABLED = {None, "none", "no", "disabled"}
 
 
-def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True):
+def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True, hadamard_group: int = 0):
     """quantize_attn (triton_atten.py:443-487) for matmul_dtype="int8", pv_matmul_dtype=None.
     Returns (q_q int8 [Z,H,QN,D], q_scale f32 [Z,H,QN], k_q, k_scale f32 [Z,KH,KNp], v_f) with KNp = KN rounded up to 32.
     k_q [Z,KH,KNp/32,D/32,64,16] int8 and v_f [Z,KH,KNp/32,D/32,2,64,8] are the K / V operands in MFMA-fragment order (see
@@ -36,7 +35,7 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     vt = torch.empty((z, kh, knp // 32, d // 32, 2, 64, 8), device=dev, dtype=value.dtype)
     kmean = torch.empty((z, kh, 32, d), device=dev, dtype=torch.float32)  # workspace: channel sums of 32 token splits
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
-                                                z, qh, kh, qn, kn, d, 1 if smooth_k else 0, qq.data_ptr(), qs.data_ptr(),
+                                                z, qh, kh, qn, kn, d, 1 if smooth_k else 0, hadamard_group, qq.data_ptr(), qs.data_ptr(),
                                                 kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), kmean.data_ptr(),
                                                 ops._stream(query)), "attn_prepare")
     return qq, qs, kq, ks, vt
@@ -81,8 +80,6 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
         raise NotImplementedError("attention masks are not built for MI355X (is_causal is)")
     if return_backward:
         raise NotImplementedError("the backward outputs (lse) of the quantized attention are not built for MI355X")
-    if use_hadamard:
-        raise NotImplementedError("Hadamard-rotated quantized attention is not built for MI355X")
     if use_fp16_accum:
         raise NotImplementedError("use_fp16_accum is an RDNA work-around; the MI355X kernels accumulate in fp32")
     if matmul_dtype in {"auto", "enabled", "uint8"}:  # triton_atten.py:452-453
@@ -101,5 +98,10 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
     if out_dtype is None:
         out_dtype = query.dtype
     sm_scale = d ** -0.5 if scale is None else scale  # triton_atten.py:512-513
-    qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k)
+    group = 0
+    if use_hadamard:  # triton_atten.py:563-569: group from the (power-of-two) head dim, halved until it divides
+        from .quant_utils import get_hadamard_group_size
+        use_hadamard, group = get_hadamard_group_size(d, min(hadamard_group_size, d))
+        group = group if use_hadamard else 0
+    qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k, hadamard_group=group)
     return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype)

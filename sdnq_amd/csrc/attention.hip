@@ -22,6 +22,7 @@
 
 #include "../../include/sdnq_hip.h"
 #include "sdnq_dev.h"
+#include "hadamard_dev.h"
 
 namespace {
 
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
 // and a zero scale and are masked in the forward kernel).  `mean`: this head's channel means (LDS) or nullptr.
 template <int T_ID>
 __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, const float* mean, int8_t* __restrict__ xq, float* __restrict__ xs,
-                                                 int64_t heads, int64_t n_src, int64_t n_dst, int d, bool frag_major, int64_t block) {
+                                                 int64_t heads, int64_t n_src, int64_t n_dst, int d, bool frag_major, int64_t block,
+                                                 int log2g) {
     const int lpr = d / 8;
     const int64_t t = block * 256 + threadIdx.x;
     const int64_t row = t / lpr;
@@ -72,6 +74,17 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
     if (mean != nullptr && real) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= mean[c8 + e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
+    }
+    if (log2g != 0) {
+        // apply_hadamard(q) / rotate_hadamard(k.to(hadamard.dtype)) (triton_atten.py:464-467): x.view(.., D/g, g) @ H_g in the
+        // tensor dtype; this lane's 8 channels are elements lane*8 + e of the wave, groups of g <= D are aligned segments
+        if (mean != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+        }
+        wave_hadamard(v, log2g, hadamard_scale(log2g, T_ID));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
     }
     float amax = 0.0f;
 #pragma unroll
@@ -137,7 +150,7 @@ struct PrepParams {
     uint16_t* vt;
     const float* kpart;  // [kheads][KMEAN_SPLITS][d] channel sums (smooth_k) or nullptr
     int64_t qheads, kheads, qn, kn, knp, nqb, nkb;
-    int d;
+    int d, log2g;  // log2g: log2 of the Hadamard group (0 = no rotation)
     bool smooth_inline;  // K means computed inside the K workgroups (short key sequences)
 };
 
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
     const int64_t b = blockIdx.x;
     if (b < p.nqb) {
-        attn_quant_block<T_ID>(p.q, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b);
+        attn_quant_block<T_ID>(p.q, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b, p.log2g);
     } else if (b < p.nqb + p.nkb) {
         const int64_t kb = b - p.nqb;
         const float* mean = nullptr;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             __syncthreads();
             mean = smean;
         }
-        attn_quant_block<T_ID>(p.k, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb);
+        attn_quant_block<T_ID>(p.k, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb, p.log2g);
     } else {
         const int64_t vb = b - p.nqb - p.nkb, nb = p.knp / 32;
         attn_vt_block((const uint16_t*)p.v, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile);
@@ -457,12 +470,18 @@ bool shape_ok(int64_t batch, int64_t qh, int64_t kh, int64_t qn, int64_t kn, int
 }  // namespace
 
 extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads,
-                                     int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, void* qq,
-                                     float* qs, void* kq, float* ks, void* vt, float* kmean, sdnq_stream_t stream) {
+                                     int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k,
+                                     int hadamard_group, void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean,
+                                     sdnq_stream_t stream) {
     if (!q || !k || !v || !qq || !qs || !kq || !ks || !vt || (smooth_k && !kmean)) return SDNQ_ERR_NULL;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
     if (head_dim != 64 && head_dim != 128) return SDNQ_ERR_UNSUPPORTED;
     if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_UNSUPPORTED;  // PV runs in the value dtype on the matrix cores
+    int log2g = 0;
+    if (hadamard_group != 0) {
+        if (hadamard_group < 4 || hadamard_group > head_dim || (hadamard_group & (hadamard_group - 1)) || head_dim % hadamard_group) return SDNQ_ERR_SHAPE;
+        while ((1 << log2g) < hadamard_group) ++log2g;
+    }
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt) % 16) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int d = (int)head_dim, lpr = d / 8;
@@ -473,6 +492,7 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
     p.smooth_inline = inline_mean;
     p.kpart = (smooth_k && !inline_mean) ? kmean : nullptr;
     p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d;
+    p.log2g = log2g;
     p.nqb = (p.qheads * q_len * lpr + 255) / 256;
     p.nkb = kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
     const int64_t blocks = p.nqb + p.nkb + kheads * (p.knp / 32);

@@ -59,6 +59,8 @@ CASES = [
     dict(name="f16_d128_gqa", z=1, qh=4, kh=2, qn=36, kn=68, d=128, kw={}),
     dict(name="f16_d64_nosmooth_scale", z=1, qh=2, kh=1, qn=36, kn=100, d=64, kw=dict(smooth_k=False, scale=0.2)),
     dict(name="f16_d64_long", z=1, qh=1, kh=1, qn=132, kn=260, d=64, kw={}),
+    dict(name="f16_d64_hadamard", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(use_hadamard=True)),
+    dict(name="f16_d128_hadamard_g32", z=1, qh=2, kh=1, qn=36, kn=40, d=128, kw=dict(use_hadamard=True, hadamard_group_size=32, is_causal=True)),
 ]
 
 
@@ -78,10 +80,16 @@ def run(case):
     q[..., 5] *= 6.0
     q, k, v = q.half(), k.half(), v.half()
     out = ta.sdnq_triton_atten(q, k, v, **case["kw"])
-    q_q, q_s, k_q, k_s, v_q, v_s, _, _ = ta.quantize_attn(q, k, v, smooth_k=case["kw"].get("smooth_k", True))
+    hadamard, hgroup = None, 0
+    if case["kw"].get("use_hadamard"):  # the group / matrix choice of sdnq_triton_atten (triton_atten.py:563-569)
+        hch = ta.next_power_of_2(d)
+        ok, hgroup = ta.get_hadamard_group_size(hch, min(case["kw"].get("hadamard_group_size", 256), hch))
+        hadamard = ta.get_hadamard(hgroup, dtype=q.dtype, device=q.device) if ok else None
+    q_q, q_s, k_q, k_s, v_q, v_s, used_h, used_g = ta.quantize_attn(q, k, v, smooth_k=case["kw"].get("smooth_k", True), hadamard=hadamard,
+                                                                    hadamard_group_size=hgroup or 256)
     assert v_s is None and v_q.dtype == torch.float16
     arrays, meta = {}, {"name": case["name"], "dtype": "f16", "shape": dict(z=z, qh=qh, kh=kh, qn=qn, kn=kn, d=d), "kwargs": case["kw"],
-                        "block_m": BLOCK_M, "block_n": BLOCK_N, "tensors": {}}
+                        "block_m": BLOCK_M, "block_n": BLOCK_N, "hadamard_group": int(used_g) if used_h else 0, "tensors": {}}
     for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s)):
         arrays[key], tag = bits(t)
         meta["tensors"][key] = {"dtype": tag, "shape": list(t.shape)}

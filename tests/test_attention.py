@@ -7,25 +7,28 @@ from oracle import oracle as O
 from tests.golden_util import AttnCase, attn_case_names
 
 
-def _quant_agreement(got_q, got_s, ref_q, ref_s, smooth):
+def _quant_agreement(got_q, got_s, ref_q, ref_s, inexact, hadamard=False):
     """int8 codes / scales of Q are bit-exact; K after smooth_k depends on the summation order of the token mean (fp32), so a
-    code may move by one step where x/scale sits on a rounding boundary."""
-    if not smooth:
+    code may move by one step where x/scale sits on a rounding boundary.  With a Hadamard rotation the rotated value itself is
+    rounded to the tensor dtype after a differently ordered fp32 sum (FWHT vs matrix product): one dtype ulp on some elements,
+    i.e. a few codes move by one step and a row scale can move by one ulp of the dtype (Hadamard tolerance)."""
+    if not inexact and not hadamard:
         assert np.array_equal(got_q, ref_q) and np.array_equal(got_s, ref_s)
         return
-    assert np.allclose(got_s, ref_s, rtol=1e-5, atol=0)
+    assert np.allclose(got_s, ref_s, rtol=2e-3 if hadamard else 1e-5, atol=0)
     diff = np.abs(got_q.astype(np.int32) - ref_q.astype(np.int32))
-    assert diff.max() <= 1 and np.mean(diff != 0) < 2e-3
+    assert diff.max() <= 1 and np.mean(diff != 0) < (2e-2 if hadamard else 2e-3)
 
 
 @pytest.mark.parametrize("name", attn_case_names())
 def test_oracle_attention_vs_reference_kernel(name):
     c = AttnCase(name)
     kw = c.kwargs
+    hg = c.meta.get("hadamard_group", 0)
     out, inter = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
-                             smooth_k=kw.get("smooth_k", True), block_n=c.meta["block_n"], want_intermediates=True)
-    assert np.array_equal(inter["q_q"], c.raw("q_q")) and np.array_equal(inter["q_scale"], c.raw("q_scale"))
-    _quant_agreement(inter["k_q"], inter["k_scale"], c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True))
+                             smooth_k=kw.get("smooth_k", True), block_n=c.meta["block_n"], want_intermediates=True, hadamard_group=hg)
+    _quant_agreement(inter["q_q"], inter["q_scale"], c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
+    _quant_agreement(inter["k_q"], inter["k_scale"], c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True), hadamard=bool(hg))
     ref = c.f32("out")
     assert out.shape == ref.shape
     # same arithmetic as the kernel up to exp2 / reduction-order rounding, then one f16 rounding of the output
@@ -49,18 +52,20 @@ def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
     c = AttnCase(name)
     kw = c.kwargs
     q, k, v = (c.torch_tensor(t, gpu_device) for t in ("q", "k", "v"))
-    qq, qs, kq, ks, vt = A.quantize_attn(q, k, v, smooth_k=kw.get("smooth_k", True))
-    assert np.array_equal(qq.cpu().numpy(), c.raw("q_q")) and np.array_equal(qs.cpu().numpy(), c.raw("q_scale"))
+    hg = c.meta.get("hadamard_group", 0)
+    qq, qs, kq, ks, vt = A.quantize_attn(q, k, v, smooth_k=kw.get("smooth_k", True), hadamard_group=hg)
+    _quant_agreement(qq.cpu().numpy(), qs.cpu().numpy(), c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
     kn = k.shape[2]
     k_rows, v_rows = A.unpack_k_fragments(kq), A.unpack_v_fragments(vt)  # MFMA-fragment order -> [Z, KH, KNp, D]
-    _quant_agreement(k_rows[:, :, :kn].cpu().numpy(), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True))
+    _quant_agreement(k_rows[:, :, :kn].cpu().numpy(), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True),
+                     hadamard=bool(hg))
     assert torch.equal(v_rows[:, :, :kn], v) and not v_rows[:, :, kn:].any() and not k_rows[:, :, kn:].any() and not ks[..., kn:].any()
     out = A.sdnq_hip_atten(q, k, v, **kw)
     assert out.dtype == q.dtype and out.shape == q.shape
     got = out.float().cpu().numpy()
     for ref, what in ((c.f32("out"), "reference kernel"),
                       (O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
-                                   smooth_k=kw.get("smooth_k", True)), "oracle")):
+                                   smooth_k=kw.get("smooth_k", True), hadamard_group=hg), "oracle")):
         err = np.abs(got - ref).max() / np.abs(ref).max()
         assert err <= 3e-3, (name, what, err)
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-3, (name, what)
@@ -115,7 +120,7 @@ def test_attention_rejects_unbuilt_options():
     import torch
     from sdnq_amd import attention as A
     q = torch.zeros(1, 1, 32, 64, dtype=torch.bfloat16)
-    for kw in (dict(attn_mask=torch.ones(32, 32, dtype=torch.bool)), dict(pv_matmul_dtype="int8"), dict(use_hadamard=True),
+    for kw in (dict(attn_mask=torch.ones(32, 32, dtype=torch.bool)), dict(pv_matmul_dtype="int8"), dict(use_fp16_accum=True),
                dict(matmul_dtype="float8_e4m3fn"), dict(return_backward=True)):
         with pytest.raises(NotImplementedError):
             A.sdnq_hip_atten(q, q, q, **kw)
