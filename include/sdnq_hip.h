@@ -255,7 +255,7 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
 /* ---- quantized attention (forward) ------------------------------------------------------------
  * replaces sdnq_triton_atten (kernels/triton_atten.py:540-618) in its default configuration: matmul_dtype "int8" for
  * Q.K^T, pv_matmul_dtype None (P.V in the value dtype), smooth_k, optional Hadamard rotation of Q and K (hadamard_group: 0 or a
- * power of two in [4, head_dim] dividing head_dim; apply_hadamard / rotate_hadamard, triton_atten.py:464-467), no attention mask,
+ * power of two in [4, head_dim] dividing head_dim; apply_hadamard / rotate_hadamard, triton_atten.py:464-467), optional attention mask,
  * optional causal masking,
  * grouped-query head mapping (kv head = h * kv_heads / q_heads, triton_atten.py:212-213).
  * All tensors contiguous [batch][heads][len][head_dim]; head_dim 64 or 128; dtype bf16 / f16.
@@ -265,12 +265,16 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
  *   qs [batch*q_heads][q_len], ks [batch*kv_heads][kv_len rounded up to 32], padding never read as a value),
  *   vt = V transposed to [batch*kv_heads][head_dim][kv_len rounded up to 32] (zero padded) in the value dtype.
  * sdnq_hip_attn_fwd <- sdnq_attn_kernel (triton_atten.py:143-335): out [batch][q_heads][q_len][head_dim] of out_dtype
- *   (the value dtype or f32). */
+ *   (the value dtype or f32).  mask: NULL, or the attention mask of get_attn_inputs (triton_atten.py:520-527) addressed as
+ *   mask[b * mask_stride_b + h * mask_stride_h + q * mask_stride_q + key] (element strides, 0 where it broadcasts, keys
+ *   contiguous); mask_dtype -1 = int8 / bool (0 = masked out, :290-291), else SdnqFloat = additive mask, added to the base-2
+ *   logits as is (:292-293).  A query with no visible key returns 0 (l_i stays 1, :232). */
 int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads,
                           int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, int hadamard_group,
                           void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean, sdnq_stream_t stream);
 int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
-                      float sm_scale, int is_causal, void* out, int out_dtype, int64_t batch, int64_t q_heads,
+                      float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                      int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, int64_t batch, int64_t q_heads,
                       int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, sdnq_stream_t stream);
 
 #ifdef __cplusplus

@@ -609,10 +609,13 @@ def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True, hada
 
 
 def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: bool = False, scale=None, smooth_k: bool = True,
-              block_n: int = 32, out_tag: str | None = None, want_intermediates: bool = False, hadamard_group: int = 0):
+              block_n: int = 32, out_tag: str | None = None, want_intermediates: bool = False, hadamard_group: int = 0,
+              mask: np.ndarray | None = None):
     """sdnq_triton_atten (kernels/triton_atten.py:540-618) in its default configuration (int8 Q.K^T, P.V in the value dtype):
     the online-softmax loop of sdnq_attn_kernel (:143-335) over key blocks of `block_n`, all queries of a head at once.
-    q/k/v: float32 VALUES of `tag` tensors [Z,H,N,D]; returns float32 values rounded to out_tag (default tag)."""
+    q/k/v: float32 VALUES of `tag` tensors [Z,H,N,D]; returns float32 values rounded to out_tag (default tag).
+    mask: None, a bool / int8 array (0 = masked out, :290-291) or a float array added to the base-2 logits as is (:292-293),
+    broadcastable to [Z,H,QN,KN] after left-padding to 4-D (get_attn_inputs :520-527)."""
     f = np.float32
     Z, QH, QN, D = q.shape
     _, KH, KN, _ = k.shape
@@ -621,6 +624,11 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
     qq, qs, kq, ks = attention_quantize(q, k, smooth_k, hadamard_group, tag)
     out = np.empty((Z, QH, QN, D), dtype=f)
     qidx = np.arange(QN)[:, None]
+    mask_is_bool = False
+    if mask is not None:
+        mask_is_bool = mask.dtype in (np.bool_, np.int8)
+        mask = mask.reshape((1,) * (4 - mask.ndim) + mask.shape)
+        mask = np.broadcast_to(mask != 0 if mask_is_bool else mask.astype(f), (Z, QH, QN, KN))
     for z in range(Z):
         for h in range(QH):
             kh = (h * KH) // QH                                              # :212-213
@@ -636,10 +644,14 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
                 s = (s * log2_sm).astype(f)                                  # :278
                 if is_causal:
                     s = np.where(qidx >= np.arange(n0, n1)[None, :], s, f(-np.inf))  # :287-288
+                if mask is not None:
+                    mb = mask[z, h, :, n0:n1]
+                    s = np.where(mb, s, f(-np.inf)) if mask_is_bool else (s + mb).astype(f)
                 m_new = np.maximum(m, s.max(axis=1))
+                dead = np.isneginf(m_new)  # no visible key so far: alpha = exp2(0), p = exp2(-inf - 0) (:299-301)
                 with np.errstate(invalid="ignore"):
-                    alpha = np.where(np.isinf(m_new), f(0), np.exp2(m - m_new)).astype(f)   # rows with nothing visible yet
-                    p = np.where(np.isinf(m_new)[:, None], f(0), np.exp2(s - m_new[:, None])).astype(f)
+                    alpha = np.where(dead, f(1), np.exp2(m - m_new)).astype(f)
+                    p = np.exp2(s - np.where(dead, f(0), m_new)[:, None]).astype(f)
                 l = (l * alpha + p.sum(axis=1, dtype=f)).astype(f)           # :308
                 acc = (acc * alpha[:, None]).astype(f)
                 acc = (acc + round_dtype(p, tag) @ _c(v[z, kh, n0:n1], f)).astype(f)  # p.to(v.dtype); fp32 accumulate (:332-333)

@@ -2,8 +2,8 @@
 
 Host-side mirror of the reference's ``sdnq_triton_atten`` (kernels/triton_atten.py:540-618): same argument names, same
 defaults.  Built: the default configuration -- int8 Q.K^T (``matmul_dtype="int8"``), P.V in the value dtype
-(``pv_matmul_dtype=None``), ``smooth_k``, optional ``use_hadamard`` and ``is_causal``, grouped-query heads.  Reference-valid options that are not
-built raise ``NotImplementedError`` naming the gap (attention masks, quantized P.V, fp16 accumulation, the backward outputs).
+(``pv_matmul_dtype=None``), ``smooth_k``, optional ``use_hadamard``, ``is_causal`` and ``attn_mask`` (bool or additive), grouped-query heads.  Reference-valid options that are not
+built raise ``NotImplementedError`` naming the gap (quantized P.V, fp16 accumulation, the backward outputs).
 """
 from __future__ import annotations
 
@@ -58,14 +58,39 @@ def unpack_v_fragments(vf: torch.Tensor) -> torch.Tensor:
     return t.permute(0, 1, 2, 4, 5, 7, 3, 6).reshape(z, kh, nb * 32, kk * 32)
 
 
-def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype) -> torch.Tensor:
-    """sdnq_atten_fwd (triton_atten.py:338-385) on the quantized operands of ``quantize_attn``."""
+def prepare_mask(attn_mask: torch.Tensor, qn: int, kn: int) -> torch.Tensor:
+    """The mask normalisation of get_attn_inputs (triton_atten.py:520-527): bool -> int8, left-pad to 4-D, a trailing 1 expands
+    to the key count, contiguous."""
+    if attn_mask.dtype == torch.bool:
+        attn_mask = attn_mask.to(dtype=torch.int8)
+    while attn_mask.ndim < 4:
+        attn_mask = attn_mask.unsqueeze(0)
+    if attn_mask.shape[-1] == 1:
+        attn_mask = attn_mask.expand(-1, -1, -1, kn)
+    attn_mask = attn_mask.contiguous()
+    if attn_mask.shape[-1] != kn or attn_mask.shape[-2] not in (1, qn):
+        raise ValueError(f"attention mask of shape {tuple(attn_mask.shape)} does not match {qn} queries x {kn} keys")
+    if attn_mask.dtype not in (torch.int8, torch.float32, torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"attention mask dtype {attn_mask.dtype} (bool / int8 / float32 / bfloat16 / float16 are built)")
+    return attn_mask
+
+
+def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype,
+              attn_mask: torch.Tensor | None = None) -> torch.Tensor:
+    """sdnq_atten_fwd (triton_atten.py:338-385) on the quantized operands of ``quantize_attn``; ``attn_mask`` as ``prepare_mask``
+    returns it (4-D, contiguous; size-1 dimensions broadcast, triton_atten.py:371-378)."""
     z, qh, qn, d = qq.shape
     kh = kq.shape[1]
     out = torch.empty((z, qh, qn, d), device=qq.device, dtype=out_dtype)
+    mptr, mdt, ms = None, 0, (0, 0, 0)
+    if attn_mask is not None:
+        mptr = attn_mask.data_ptr()
+        mdt = -1 if attn_mask.dtype == torch.int8 else ops.float_code(attn_mask.dtype)
+        ms = tuple(attn_mask.stride(i) if attn_mask.shape[i] != 1 else 0 for i in range(3))
     ops.check(_lib.load().sdnq_hip_attn_fwd(qq.data_ptr(), qs.data_ptr(), kq.data_ptr(), ks.data_ptr(), vt.data_ptr(),
-                                            ops.float_code(vt.dtype), float(sm_scale), 1 if is_causal else 0, out.data_ptr(),
-                                            ops.float_code(out_dtype), z, qh, kh, qn, kn, d, ops._stream(qq)), "attn_fwd")
+                                            ops.float_code(vt.dtype), float(sm_scale), 1 if is_causal else 0, mptr, mdt, *ms,
+                                            out.data_ptr(), ops.float_code(out_dtype), z, qh, kh, qn, kn, d, ops._stream(qq)),
+              "attn_fwd")
     return out
 
 
@@ -76,8 +101,6 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
                    pv_matmul_dtype: str | None = None, do_quantize: bool = True, use_fp16_accum: bool = False,
                    out_dtype: torch.dtype | None = None, return_backward: bool = False) -> torch.Tensor:
     """Drop-in for ``sdnq_triton_atten(query, key, value, ...)`` (triton_atten.py:540-618); [Z, H, N, D] layout."""
-    if attn_mask is not None:
-        raise NotImplementedError("attention masks are not built for MI355X (is_causal is)")
     if return_backward:
         raise NotImplementedError("the backward outputs (lse) of the quantized attention are not built for MI355X")
     if use_fp16_accum:
@@ -104,4 +127,8 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
         use_hadamard, group = get_hadamard_group_size(d, min(hadamard_group_size, d))
         group = group if use_hadamard else 0
     qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k, hadamard_group=group)
-    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype)
+    if attn_mask is not None:
+        if not attn_mask.is_cuda:
+            raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
+        attn_mask = prepare_mask(attn_mask, query.shape[2], key.shape[2])
+    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask)

@@ -211,7 +211,14 @@ struct AttnParams {
     int64_t qh, kh, qn, kn, knp;
     int qblocks, split;
     float log2_sm_scale;
+    const void* mask;  // attention mask [*, *, q, key] (key stride 1) or nullptr
+    int mask_dtype;    // -1: int8 / bool (0 = masked out), else SdnqFloat of an additive mask
+    int64_t ms_z, ms_h, ms_q;  // element strides (0 for broadcast dimensions)
 };
+
+__device__ __forceinline__ float ldf_mask(const void* p, int64_t i, int dt) {
+    return dt == SDNQ_F32 ? ((const float*)p)[i] : (dt == SDNQ_BF16 ? bf16_bits_to_f32(((const uint16_t*)p)[i]) : f16_bits_to_f32(((const uint16_t*)p)[i]));
+}
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
@@ -224,7 +231,7 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 // split over the two lanes of a query until the end, and O is rescaled only when some row maximum of the wave moved.
 // Software pipeline: the K fragments of block kb+1 are already in registers when block kb starts, so S(kb+1) is on the matrix
 // pipe while the VALU works on the scores of kb; V / k_scale of kb+1 and K of kb+2 are in flight meanwhile.
-template <int V_T, int OUT_T, int D, bool CAUSAL>
+template <int V_T, int OUT_T, int D, bool CAUSAL, bool HAS_MASK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KK = D / 32;  // int8 MFMA K steps of Q.K^T; also the 32-channel blocks of O
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in SGPRs: block indices stay scalar
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const bool active = q0 < p.qn;  // wave-uniform
     if (!active && p.split != 2) return;
     const int64_t z = head_lin / p.qh, h = head_lin % p.qh;
+    const int64_t mz = z, mh = h;  // attention-mask batch / head index (strides are 0 where the mask broadcasts)
     const int64_t kv_lin = z * p.kh + (h * p.kh) / p.qh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
 
     const int64_t qi = q0 + ql, qrow = qi < p.qn ? qi : p.qn - 1;
@@ -297,37 +305,70 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             const v4f k4 = b.ks[j >> 1];
             t[j] = (v2f){(float)s[2 * j], (float)s[2 * j + 1]} * (v2f){k4[2 * (j & 1)], k4[2 * (j & 1) + 1]};
         }
+        float alpha;
+        v2f psum = {0.0f, 0.0f};
         if constexpr (MASKED) {
+            // slow path (key tail, causal diagonal, attention mask): fully scaled scores first, then the masks, and the -inf-safe
+            // updates of triton_atten.py:299-301 (a row that has seen no visible key yet keeps m = -inf, alpha = 1, p = 0)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] *= qsl;
+            const char* mrow = nullptr;
+            if constexpr (HAS_MASK) {
+                const int64_t mq = qi < p.qn ? qi : p.qn - 1;
+                mrow = (const char*)p.mask + (mz * p.ms_z + mh * p.ms_h + mq * p.ms_q) * (p.mask_dtype == -1 ? 1 : (p.mask_dtype == SDNQ_F32 ? 4 : 2));
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t key = key0 + 16 * (r >> 3) + 8 * g + (r & 7);
                 bool ok = key < p.kn;              // triton_atten.py:295-296
                 if (CAUSAL) ok = ok && key <= qi;  // :287-288
-                if (!ok) t[r >> 1][r & 1] = -__builtin_inff();
+                float add = 0.0f;
+                if constexpr (HAS_MASK) {
+                    if (ok) {
+                        if (p.mask_dtype == -1) ok = ((const int8_t*)mrow)[key] != 0;                 // :290-291
+                        else add = ldf_mask(mrow, key, p.mask_dtype);                                  // :292-293 (added as is)
+                    }
+                }
+                t[r >> 1][r & 1] = ok ? t[r >> 1][r & 1] + add : -__builtin_inff();
             }
-        }
-        float m_blk = fmaxf(t[0][0], t[0][1]);
+            float m_blk = fmaxf(t[0][0], t[0][1]);
 #pragma unroll
-        for (int j = 1; j < 8; ++j) m_blk = fmaxf(fmaxf(m_blk, t[j][0]), t[j][1]);
-        {   // the other 16 keys of this query live in lane ^ 32: one v_permlane32_swap (VALU) instead of a trip through LDS
-            const u32 mb = __float_as_uint(m_blk);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-            m_blk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-        // an all-zero query row has qsl == 0: its scores are 0 (not 0 * -inf) wherever a key is visible
-        const float m_new = fmaxf(m_i, qsl == 0.0f ? 0.0f : m_blk * qsl);  // finite from block 0 on: key 0 is visible to every query
-        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-        m_i = m_new;
-        v2f psum = {0.0f, 0.0f};
-        const v2f qsl2 = {qsl, qsl}, mneg2 = {-m_new, -m_new};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            t[j] = __builtin_elementwise_fma(t[j], qsl2, mneg2);
-            if constexpr (MASKED) {  // -inf * 0 would be NaN for an all-zero query row
-                if (qsl == 0.0f) t[j] = (v2f){t[j][0] != t[j][0] ? -__builtin_inff() : t[j][0], t[j][1] != t[j][1] ? -__builtin_inff() : t[j][1]};
+            for (int j = 1; j < 8; ++j) m_blk = fmaxf(fmaxf(m_blk, t[j][0]), t[j][1]);
+            {
+                const u32 mb = __float_as_uint(m_blk);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                m_blk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            t[j] = (v2f){__builtin_amdgcn_exp2f(t[j][0]), __builtin_amdgcn_exp2f(t[j][1])};
-            psum += t[j];
+            const float m_new = fmaxf(m_i, m_blk);
+            const bool dead = m_new == -__builtin_inff();
+            alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_i - m_new);
+            m_i = m_new;
+            const float m_use = dead ? 0.0f : m_new;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                t[j] -= m_use;
+                t[j] = (v2f){__builtin_amdgcn_exp2f(t[j][0]), __builtin_amdgcn_exp2f(t[j][1])};
+                psum += t[j];
+            }
+        } else {
+            float m_blk = fmaxf(t[0][0], t[0][1]);
+#pragma unroll
+            for (int j = 1; j < 8; ++j) m_blk = fmaxf(fmaxf(m_blk, t[j][0]), t[j][1]);
+            {   // the other 16 keys of this query live in lane ^ 32: one v_permlane32_swap (VALU) instead of a trip through LDS
+                const u32 mb = __float_as_uint(m_blk);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                m_blk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float m_new = fmaxf(m_i, m_blk * qsl);  // finite: every key of a plain block is visible
+            alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            m_i = m_new;
+            const v2f qsl2 = {qsl, qsl}, mneg2 = {-m_new, -m_new};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                t[j] = __builtin_elementwise_fma(t[j], qsl2, mneg2);
+                t[j] = (v2f){__builtin_amdgcn_exp2f(t[j][0]), __builtin_amdgcn_exp2f(t[j][1])};
+                psum += t[j];
+            }
         }
         l2 = l2 * alpha + psum;  // l_i = fma(l_i, alpha, sum(p)), :308
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
@@ -361,14 +402,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         nkb = nkb < lim ? nkb : lim;
         n_plain = n_plain < lim - 1 ? n_plain : lim - 1;
     }
-    // this wave's share: plain blocks [lo, hi); the masked block (if any) goes to the last share
+    // this wave's share: plain blocks [lo, hi) and slow-path blocks [mlo, mhi) (the one tail / diagonal block goes to the last
+    // share; with an attention mask EVERY block takes the slow path and the halves split them)
+    int mlo = n_plain, mhi = nkb;
+    if (HAS_MASK) { n_plain = 0; mlo = 0; }
     int lo = 0, hi = n_plain;
-    bool do_masked = n_plain < nkb;
     if (p.split == 2) {
         const int mid = (n_plain + 1) / 2;
-        if (half == 0) { hi = mid; do_masked = false; } else { lo = mid; }
+        if (half == 0) hi = mid; else lo = mid;
+        if (HAS_MASK) {
+            const int mm = (nkb + 1) / 2;
+            if (half == 0) mhi = mm; else mlo = mm;
+        } else if (half == 0) {
+            mhi = mlo;
+        }
     }
-    if (!active) { hi = lo; do_masked = false; }
+    if (!active) { hi = lo; mhi = mlo; }
     if (lo < hi) {
         const int last = hi - 1;
         v4i kfA[KK], kfB[KK];
@@ -394,13 +443,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             softmax_pv(sB, bB, (int64_t)(kb + 1) * 32, std::false_type{});
         }
     }
-    if (do_masked) {
+#pragma nounroll
+    for (int kb = mlo; kb < mhi; ++kb) {
         v4i kf[KK];
         Blk b;
-        load_k(n_plain, kf);
-        load_vs(n_plain, b);
+        load_k(kb, kf);
+        load_vs(kb, b);
         const v16i s = qk_mfma(kf);
-        softmax_pv(s, b, (int64_t)n_plain * 32, std::true_type{});
+        softmax_pv(s, b, (int64_t)kb * 32, std::true_type{});
     }
     float l_i = l2[0] + l2[1];
     if (p.split == 2) {
@@ -418,7 +468,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         __syncthreads();
         if (half == 1 || !active) return;
         const float m1 = cb[KK * 16][lane], l1 = cb[KK * 16 + 1][lane];
-        const float m = fmaxf(m_i, m1);  // at least one half saw a visible key
+        float m = fmaxf(m_i, m1);
+        if (m == -__builtin_inff()) m = 0.0f;  // no visible key in either half (attention mask): both weights become 0
         const float a0 = __builtin_amdgcn_exp2f(m_i - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
         l_i = l_i * a0 + l1 * a1;
 #pragma unroll
@@ -428,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
     if (qi >= p.qn) return;
     l_i += __shfl_xor(l_i, 32);
-    const float inv = 1.0f / l_i;  // acc *= fdiv(1.0, l_i), :336
+    const float inv = l_i > 0.0f ? 1.0f / l_i : 0.0f;  // acc *= fdiv(1.0, l_i), :336; a row with no visible key is 0 (l stays 1, acc 0 there)
     char* orow = (char*)p.out + (head_lin * p.qn + qi) * D * FT<OUT_T>::bytes;
 #pragma unroll
     for (int dd = 0; dd < KK; ++dd)
@@ -450,8 +501,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 
 template <int V_T, int OUT_T, int D>
 int launch_fwd(const AttnParams& p, int causal, int64_t blocks, hipStream_t s) {
-    if (causal) hipLaunchKernelGGL((attn_fwd_kernel<V_T, OUT_T, D, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_fwd_kernel<V_T, OUT_T, D, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (p.mask) {
+        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<V_T, OUT_T, D, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<V_T, OUT_T, D, false, true>), grid, block, 0, s, p);
+    } else {
+        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<V_T, OUT_T, D, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<V_T, OUT_T, D, false, false>), grid, block, 0, s, p);
+    }
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }
@@ -508,9 +565,12 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
 }
 
 extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
-                                 float sm_scale, int is_causal, void* out, int out_dtype, int64_t batch, int64_t q_heads,
-                                 int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, sdnq_stream_t stream) {
+                                 float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                                 int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, int64_t batch,
+                                 int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                                 sdnq_stream_t stream) {
     if (!qq || !qs || !kq || !ks || !vt || !out) return SDNQ_ERR_NULL;
+    if (mask && mask_dtype != -1 && mask_dtype != SDNQ_F32 && mask_dtype != SDNQ_BF16 && mask_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
     if (((uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt | (uintptr_t)out) % 16) return SDNQ_ERR_ALIGN;
     AttnParams p{};
@@ -522,6 +582,7 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     p.split = force_split ? force_split : ((tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);  // measured: tools/bench_attention.py
     p.qblocks = (int)(p.split == 2 ? (q_len + 63) / 64 : (q_len + 127) / 128);
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
+    p.mask = mask; p.mask_dtype = mask_dtype; p.ms_z = mask_stride_b; p.ms_h = mask_stride_h; p.ms_q = mask_stride_q;
     const int64_t blocks = batch * q_heads * p.qblocks;
     hipStream_t s = (hipStream_t)stream;
     const int d = (int)head_dim;

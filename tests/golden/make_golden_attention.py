@@ -59,6 +59,9 @@ CASES = [
     dict(name="f16_d128_gqa", z=1, qh=4, kh=2, qn=36, kn=68, d=128, kw={}),
     dict(name="f16_d64_nosmooth_scale", z=1, qh=2, kh=1, qn=36, kn=100, d=64, kw=dict(smooth_k=False, scale=0.2)),
     dict(name="f16_d64_long", z=1, qh=1, kh=1, qn=132, kn=260, d=64, kw={}),
+    dict(name="f16_d64_boolmask", z=2, qh=2, kh=2, qn=40, kn=80, d=64, kw={}, mask=dict(kind="bool", shape=(2, 1, 40, 80), dead_rows=(3, 17))),
+    dict(name="f16_d64_floatmask_2d_causal", z=1, qh=2, kh=1, qn=48, kn=48, d=64, kw=dict(is_causal=True), mask=dict(kind="f16", shape=(48, 48))),
+    dict(name="f16_d128_f32mask_keyonly", z=1, qh=2, kh=2, qn=36, kn=44, d=128, kw={}, mask=dict(kind="f32", shape=(1, 2, 1, 44))),
     dict(name="f16_d64_hadamard", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(use_hadamard=True)),
     dict(name="f16_d128_hadamard_g32", z=1, qh=2, kh=1, qn=36, kn=40, d=128, kw=dict(use_hadamard=True, hadamard_group_size=32, is_causal=True)),
 ]
@@ -68,6 +71,8 @@ def bits(t):
     t = t.detach().cpu().contiguous()
     if t.dtype == torch.float16:
         return t.view(torch.uint16).numpy().copy(), "f16"
+    if t.dtype == torch.bool:
+        return t.view(torch.uint8).numpy().copy(), "bool"
     return t.numpy().copy(), str(t.dtype).replace("torch.", "")
 
 
@@ -79,7 +84,20 @@ def run(case):
     v = torch.randn(z, kh, kn, d, generator=g)
     q[..., 5] *= 6.0
     q, k, v = q.half(), k.half(), v.half()
-    out = ta.sdnq_triton_atten(q, k, v, **case["kw"])
+    mask = None
+    if "mask" in case:
+        ms = case["mask"]
+        if ms["kind"] == "bool":
+            mask = torch.rand(ms["shape"], generator=g) > 0.35
+            for r in ms.get("dead_rows", ()):
+                mask[..., r, :] = False  # queries with no visible key: the reference returns 0 for them
+            mask[..., 32:64] &= torch.rand(ms["shape"][:-1] + (1,), generator=g) > 0.5  # some fully masked 32-key blocks
+        else:
+            mask = torch.randn(ms["shape"], generator=g) * 2.0
+            mask[torch.rand(ms["shape"], generator=g) < 0.2] = float("-inf")
+            mask[..., 0] = 0.5  # every query keeps a visible key
+            mask = mask.to(torch.float16 if ms["kind"] == "f16" else torch.float32)
+    out = ta.sdnq_triton_atten(q, k, v, attn_mask=mask, **case["kw"])
     hadamard, hgroup = None, 0
     if case["kw"].get("use_hadamard"):  # the group / matrix choice of sdnq_triton_atten (triton_atten.py:563-569)
         hch = ta.next_power_of_2(d)
@@ -90,15 +108,18 @@ def run(case):
     assert v_s is None and v_q.dtype == torch.float16
     arrays, meta = {}, {"name": case["name"], "dtype": "f16", "shape": dict(z=z, qh=qh, kh=kh, qn=qn, kn=kn, d=d), "kwargs": case["kw"],
                         "block_m": BLOCK_M, "block_n": BLOCK_N, "hadamard_group": int(used_g) if used_h else 0, "tensors": {}}
-    for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s)):
+    for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s))             + ((("mask", mask),) if mask is not None else ()):
         arrays[key], tag = bits(t)
         meta["tensors"][key] = {"dtype": tag, "shape": list(t.shape)}
     np.savez_compressed(os.path.join(HERE, f"attn_{case['name']}.npz"), **arrays)
     with open(os.path.join(HERE, f"attn_{case['name']}.json"), "w") as f:
         json.dump(meta, f, indent=1)
-    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(qh // kh, 1), v.float().repeat_interleave(qh // kh, 1),
-                                                           is_causal=case["kw"].get("is_causal", False), scale=case["kw"].get("scale"))
-    print("wrote attn", case["name"], tuple(out.shape), "max |out - fp32 sdpa| =", float((out.float() - ref).abs().max()))
+    if mask is None:
+        ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float().repeat_interleave(qh // kh, 1), v.float().repeat_interleave(qh // kh, 1),
+                                                               is_causal=case["kw"].get("is_causal", False), scale=case["kw"].get("scale"))
+        print("wrote attn", case["name"], tuple(out.shape), "max |out - fp32 sdpa| =", float((out.float() - ref).abs().max()))
+    else:
+        print("wrote attn", case["name"], tuple(out.shape), "mask", mask.dtype, tuple(mask.shape), "finite:", bool(torch.isfinite(out.float()).all()))
 
 
 if __name__ == "__main__":

@@ -138,10 +138,19 @@ class AttnCase:
     def raw(self, key):
         return self.z[key]
 
+    def has(self, key):
+        return key in self.meta["tensors"]
+
+    def mask_array(self):
+        """The attention mask as the oracle takes it: bool array, or float32 values of the additive mask; None without one."""
+        if not self.has("mask"):
+            return None
+        return self.z["mask"].astype(np.bool_) if self.meta["tensors"]["mask"]["dtype"] == "bool" else self.f32("mask")
+
     def torch_tensor(self, key, device=None):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(self.z[key]))
-        view = {"bf16": torch.bfloat16, "f16": torch.float16}.get(self.meta["tensors"][key]["dtype"])
+        view = {"bf16": torch.bfloat16, "f16": torch.float16, "bool": torch.bool}.get(self.meta["tensors"][key]["dtype"])
         if view is not None:
             t = t.view(view)
         return t.to(device) if device is not None else t

@@ -26,7 +26,8 @@ def test_oracle_attention_vs_reference_kernel(name):
     kw = c.kwargs
     hg = c.meta.get("hadamard_group", 0)
     out, inter = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
-                             smooth_k=kw.get("smooth_k", True), block_n=c.meta["block_n"], want_intermediates=True, hadamard_group=hg)
+                             smooth_k=kw.get("smooth_k", True), block_n=c.meta["block_n"], want_intermediates=True, hadamard_group=hg,
+                             mask=c.mask_array())
     _quant_agreement(inter["q_q"], inter["q_scale"], c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
     _quant_agreement(inter["k_q"], inter["k_scale"], c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True), hadamard=bool(hg))
     ref = c.f32("out")
@@ -60,12 +61,12 @@ def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
     _quant_agreement(k_rows[:, :, :kn].cpu().numpy(), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True),
                      hadamard=bool(hg))
     assert torch.equal(v_rows[:, :, :kn], v) and not v_rows[:, :, kn:].any() and not k_rows[:, :, kn:].any() and not ks[..., kn:].any()
-    out = A.sdnq_hip_atten(q, k, v, **kw)
+    out = A.sdnq_hip_atten(q, k, v, attn_mask=c.torch_tensor("mask", gpu_device) if c.has("mask") else None, **kw)
     assert out.dtype == q.dtype and out.shape == q.shape
     got = out.float().cpu().numpy()
     for ref, what in ((c.f32("out"), "reference kernel"),
                       (O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
-                                   smooth_k=kw.get("smooth_k", True), hadamard_group=hg), "oracle")):
+                                   smooth_k=kw.get("smooth_k", True), hadamard_group=hg, mask=c.mask_array()), "oracle")):
         err = np.abs(got - ref).max() / np.abs(ref).max()
         assert err <= 3e-3, (name, what, err)
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-3, (name, what)
@@ -96,6 +97,37 @@ def test_hip_attention_vs_oracle_random(dtype, shape, gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["bool", "bf16", "f32"])
+def test_hip_attention_masks_vs_oracle(kind, gpu_device):
+    """Attention masks on the split-key path (2 waves per query tile) and with broadcast dimensions, bf16, against the oracle;
+    queries with no visible key return 0 like the reference."""
+    import torch
+    from sdnq_amd import attention as A
+    z, h, qn, kn, d = 1, 18, 2048, 2100, 64  # 1152 query tiles and kv_len >= 2048: the launcher picks the split-key variant
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(z, h, qn, d, generator=g).bfloat16()
+    k = torch.randn(z, h, kn, d, generator=g).bfloat16()
+    v = torch.randn(z, h, kn, d, generator=g).bfloat16()
+    if kind == "bool":
+        mask = torch.rand(1, 1, qn, kn, generator=g) > 0.5
+        mask[..., 5, :] = False
+        mask[..., :, 64:1100] = False  # whole key blocks masked, including everything one key half sees for some tiles
+    else:
+        mask = torch.randn(h, 1, kn, generator=g) * 3.0
+        mask[torch.rand(h, 1, kn, generator=g) < 0.3] = float("-inf")
+        mask[..., 7] = 0.0
+        mask = mask.to(torch.bfloat16 if kind == "bf16" else torch.float32)
+    out = A.sdnq_hip_atten(q.to(gpu_device), k.to(gpu_device), v.to(gpu_device), attn_mask=mask.to(gpu_device)).float().cpu().numpy()
+    ref = O.attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), "bf16",
+                      mask=mask.numpy() if kind == "bool" else mask.float().numpy())
+    assert np.isfinite(out).all()
+    if kind == "bool":
+        assert not out[:, :, 5].any()
+    assert np.abs(out - ref).max() / np.abs(ref).max() <= 1.2e-2
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= 4e-3
+
+
+@pytest.mark.gpu
 def test_hip_attention_full_size_properties(gpu_device):
     """SDXL self-attention size (4096 tokens, 10 heads of 64): rows of P sum to one, so attention over constant V returns
     that constant; and the output is invariant to a permutation of the key/value tokens."""
@@ -120,7 +152,7 @@ def test_attention_rejects_unbuilt_options():
     import torch
     from sdnq_amd import attention as A
     q = torch.zeros(1, 1, 32, 64, dtype=torch.bfloat16)
-    for kw in (dict(attn_mask=torch.ones(32, 32, dtype=torch.bool)), dict(pv_matmul_dtype="int8"), dict(use_fp16_accum=True),
+    for kw in (dict(pv_matmul_dtype="int8"), dict(use_fp16_accum=True),
                dict(matmul_dtype="float8_e4m3fn"), dict(return_backward=True)):
         with pytest.raises(NotImplementedError):
             A.sdnq_hip_atten(q, q, q, **kw)
