@@ -40,8 +40,10 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
     const char* base = (const char*)k + head * kn * d * FT<T_ID>::bytes;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t r = lo + r0; r < hi; r += rpp) {
+        float v[8];
+        Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)base + r * d + c8), v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += FT<T_ID>::load(base, r * d + c8 + e);
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[e];
@@ -68,9 +70,8 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
     const bool live = row < heads * n_dst;
     const int64_t head = live ? row / n_dst : 0, n = live ? row % n_dst : 0;
     const bool real = live && n < n_src;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = real ? FT<T_ID>::load(x, (head * n_src + n) * d + c8 + e) : 0.0f;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (real) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + (head * n_src + n) * d + c8), v);  // 8 elements per 16-byte load
     if (mean != nullptr && real) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= mean[c8 + e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
@@ -174,8 +175,10 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             float* red = (float*)&tile[0][0];  // 256 * 8 floats <= sizeof(tile)
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int64_t r = tid / lpr; r < p.kn; r += rpp) {
+                float v[8];
+                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)p.k + (head * p.kn + r) * p.d + c8), v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += FT<T_ID>::load(p.k, (head * p.kn + r) * p.d + c8 + e);
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[e];
