@@ -258,7 +258,10 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
  * power of two in [4, head_dim] dividing head_dim; apply_hadamard / rotate_hadamard, triton_atten.py:464-467), optional attention mask,
  * optional causal masking,
  * grouped-query head mapping (kv head = h * kv_heads / q_heads, triton_atten.py:212-213).
- * All tensors contiguous [batch][heads][len][head_dim]; head_dim 64 or 128; dtype bf16 / f16.
+ * Tensors are [batch][heads][len][head_dim] with head_dim contiguous; q / k / v / out may be strided views (x_strides = element
+ * strides {batch, head, token}, each a multiple of 8; NULL = contiguous), e.g. the transposed view of a [batch][len][heads *
+ * head_dim] projection output, which the reference would first copy (`.contiguous()`, triton_atten.py:469-470).  head_dim 64
+ * or 128; dtype bf16 / f16.
  *
  * sdnq_hip_attn_prepare <- quantize_attn (triton_atten.py:443-487): kmean [batch*kv_heads][32][head_dim] f32 (workspace for
  *   the channel sums of 32 token splits; K minus its token mean when smooth_k), qq / kq int8 codes + qs / ks f32 per-token scales (quantize_int_mm, quant_utils.py:265-273;
@@ -271,11 +274,13 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
  *   logits as is (:292-293).  A query with no visible key returns 0 (l_i stays 1, :232). */
 int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads,
                           int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, int hadamard_group,
-                          void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean, sdnq_stream_t stream);
+                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, void* qq, float* qs,
+                          void* kq, float* ks, void* vt, float* kmean, sdnq_stream_t stream);
 int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
                       float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
-                      int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, int64_t batch, int64_t q_heads,
-                      int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, sdnq_stream_t stream);
+                      int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, const int64_t* out_strides,
+                      int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                      sdnq_stream_t stream);
 
 #ifdef __cplusplus
 }

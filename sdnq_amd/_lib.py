@@ -90,8 +90,8 @@ def _declare(lib):
     lib.sdnq_hip_scaled_mm_nchw.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
     lib.sdnq_hip_im2col.argtypes = [vp, i32] + [i32] * 12 + [vp, vp]
     lib.sdnq_hip_im2col_rowquant.argtypes = [vp, i32] + [i32] * 12 + [i32, vp, vp, vp, vp]
-    lib.sdnq_hip_attn_prepare.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [i32, i32, vp, vp, vp, vp, vp, vp, vp]
-    lib.sdnq_hip_attn_fwd.argtypes = [vp, vp, vp, vp, vp, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32] + [i64] * 6 + [vp]
+    lib.sdnq_hip_attn_prepare.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.sdnq_hip_attn_fwd.argtypes = [vp, vp, vp, vp, vp, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp] + [i64] * 6 + [vp]
     for name in EXPORTS:
         if name not in ("sdnq_hip_strerror",):
             getattr(lib, name).restype = c.c_int

@@ -7,13 +7,24 @@ built raise ``NotImplementedError`` naming the gap (quantized P.V, fp16 accumula
 """
 from __future__ import annotations
 
-import ctypes  # noqa: F401  (the binding itself lives in _lib)
+import ctypes
 
 import torch
 
 from . import _lib, ops
 
 _DISABLED = {None, "none", "no", "disabled"}
+
+
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """[Z,H,N,D] views whose head_dim is contiguous and whose other strides keep rows 16-byte aligned are used as they are (the
+    transposed view of a [Z,N,H*D] projection output is the common case); anything else is copied like the reference does."""
+    ok = t.stride(-1) == 1 and all(st % 8 == 0 for st in t.stride()[:-1]) and t.data_ptr() % 16 == 0
+    return t if ok else t.contiguous()
+
+
+def _strides(t: torch.Tensor):
+    return (ctypes.c_int64 * 3)(*t.stride()[:3])
 
 
 def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True, hadamard_group: int = 0):
@@ -25,7 +36,7 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
         raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
     z, qh, qn, d = query.shape
     _, kh, kn, _ = key.shape
-    query, key, value = query.contiguous(), key.contiguous(), value.contiguous()
+    query, key, value = _rows16(query), _rows16(key), _rows16(value)  # strided views are read in place (no .contiguous() copy)
     dev = query.device
     knp = (kn + 31) // 32 * 32
     qq = torch.empty((z, qh, qn, d), device=dev, dtype=torch.int8)
@@ -35,7 +46,8 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     vt = torch.empty((z, kh, knp // 32, d // 32, 2, 64, 8), device=dev, dtype=value.dtype)
     kmean = torch.empty((z, kh, 32, d), device=dev, dtype=torch.float32)  # workspace: channel sums of 32 token splits
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
-                                                z, qh, kh, qn, kn, d, 1 if smooth_k else 0, hadamard_group, qq.data_ptr(), qs.data_ptr(),
+                                                z, qh, kh, qn, kn, d, 1 if smooth_k else 0, hadamard_group, _strides(query), _strides(key),
+                                                _strides(value), qq.data_ptr(), qs.data_ptr(),
                                                 kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), kmean.data_ptr(),
                                                 ops._stream(query)), "attn_prepare")
     return qq, qs, kq, ks, vt
@@ -76,12 +88,15 @@ def prepare_mask(attn_mask: torch.Tensor, qn: int, kn: int) -> torch.Tensor:
 
 
 def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype,
-              attn_mask: torch.Tensor | None = None) -> torch.Tensor:
+              attn_mask: torch.Tensor | None = None, token_major: bool = False) -> torch.Tensor:
     """sdnq_atten_fwd (triton_atten.py:338-385) on the quantized operands of ``quantize_attn``; ``attn_mask`` as ``prepare_mask``
     returns it (4-D, contiguous; size-1 dimensions broadcast, triton_atten.py:371-378)."""
     z, qh, qn, d = qq.shape
     kh = kq.shape[1]
-    out = torch.empty((z, qh, qn, d), device=qq.device, dtype=out_dtype)
+    if token_major:  # memory [Z, N, H, D], returned as its [Z, H, N, D] view: out.transpose(1, 2).reshape(Z, N, H*D) is then free
+        out = torch.empty((z, qn, qh, d), device=qq.device, dtype=out_dtype).transpose(1, 2)
+    else:
+        out = torch.empty((z, qh, qn, d), device=qq.device, dtype=out_dtype)
     mptr, mdt, ms = None, 0, (0, 0, 0)
     if attn_mask is not None:
         mptr = attn_mask.data_ptr()
@@ -89,7 +104,8 @@ def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out
         ms = tuple(attn_mask.stride(i) if attn_mask.shape[i] != 1 else 0 for i in range(3))
     ops.check(_lib.load().sdnq_hip_attn_fwd(qq.data_ptr(), qs.data_ptr(), kq.data_ptr(), ks.data_ptr(), vt.data_ptr(),
                                             ops.float_code(vt.dtype), float(sm_scale), 1 if is_causal else 0, mptr, mdt, *ms,
-                                            out.data_ptr(), ops.float_code(out_dtype), z, qh, kh, qn, kn, d, ops._stream(qq)),
+                                            out.data_ptr(), ops.float_code(out_dtype), _strides(out), z, qh, kh, qn, kn, d,
+                                            ops._stream(qq)),
               "attn_fwd")
     return out
 
@@ -131,4 +147,7 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
         if not attn_mask.is_cuda:
             raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
         attn_mask = prepare_mask(attn_mask, query.shape[2], key.shape[2])
-    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask)
+    # like torch's SDPA, the output takes the memory layout of the query: a [Z,N,H,D]-backed query (the transposed view a
+    # diffusers / transformers attention processor passes) gets a [Z,N,H,D]-backed output
+    token_major = query.shape[1] > 1 and query.shape[2] > 1 and query.stride(2) > query.stride(1) and query.stride(-1) == 1
+    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask, token_major=token_major)

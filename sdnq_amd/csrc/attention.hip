@@ -26,22 +26,28 @@
 
 namespace {
 
+// element strides of a [batch][heads][tokens][head_dim] tensor whose head_dim is contiguous (e.g. the transposed view of a
+// [batch][tokens][heads * head_dim] projection output); `heads` splits a linear batch*heads index
+struct Strides {
+    int64_t b, h, n, heads;
+    __device__ __forceinline__ int64_t at(int64_t head_lin, int64_t tok) const { return (head_lin / heads) * b + (head_lin % heads) * h + tok * n; }
+};
+
 // ---- K channel sums over the tokens of one (batch, head), split over KMEAN_SPLITS workgroups ----------------------------
 // part[head][split][d] = sum of the split's tokens; the consumer adds the splits in a fixed order (deterministic mean).
 constexpr int KMEAN_SPLITS = 32;
 
 template <int T_ID>
-__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, float* __restrict__ part, int64_t kn, int d) {
+__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, const Strides ks, float* __restrict__ part, int64_t kn, int d) {
     __shared__ float red[256 * 8];
     const int lpr = d / 8, rpp = 256 / lpr;  // lanes per token row, rows per pass
     const int tid = threadIdx.x, c8 = (tid % lpr) * 8, r0 = tid / lpr;
     const int64_t head = blockIdx.x / KMEAN_SPLITS, split = blockIdx.x % KMEAN_SPLITS;
     const int64_t per = (kn + KMEAN_SPLITS - 1) / KMEAN_SPLITS, lo = split * per, hi = lo + per < kn ? lo + per : kn;
-    const char* base = (const char*)k + head * kn * d * FT<T_ID>::bytes;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t r = lo + r0; r < hi; r += rpp) {
         float v[8];
-        Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)base + r * d + c8), v);
+        Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)k + ks.at(head, r) + c8), v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
@@ -60,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
 // The destination has n_dst >= n_src token slots per head (K: rounded up to the 32-key block; the extra tokens get zero codes
 // and a zero scale and are masked in the forward kernel).  `mean`: this head's channel means (LDS) or nullptr.
 template <int T_ID>
-__device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, const float* mean, int8_t* __restrict__ xq, float* __restrict__ xs,
+__device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, const Strides xst, const float* mean, int8_t* __restrict__ xq, float* __restrict__ xs,
                                                  int64_t heads, int64_t n_src, int64_t n_dst, int d, bool frag_major, int64_t block,
                                                  int log2g) {
     const int lpr = d / 8;
@@ -71,7 +77,7 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
     const int64_t head = live ? row / n_dst : 0, n = live ? row % n_dst : 0;
     const bool real = live && n < n_src;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (real) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + (head * n_src + n) * d + c8), v);  // 8 elements per 16-byte load
+    if (real) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + xst.at(head, n) + c8), v);  // 8 elements per 16-byte load
     if (mean != nullptr && real) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= mean[c8 + e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
@@ -119,16 +125,15 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
 // ---- V [heads][kn][d] -> PV operand in MFMA-fragment order (knp = kn rounded up to 32, zero padded) -----------------------
 // one 1-KiB tile per (32-key block kb, 32-channel block dd, 16-key step c): lane (g, ql) holds the 8 keys
 // kb*32 + 16c + 8g + 0..7 of channel 32dd + ql, i.e. exactly the first operand of PV MFMA (dd, c) of attn_fwd_kernel.
-__device__ __forceinline__ void attn_vt_block(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d,
+__device__ __forceinline__ void attn_vt_block(const uint16_t* __restrict__ v, const Strides vst, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d,
                                               int64_t head, int64_t kb, uint16_t (*tile)[128 + 2]) {
     const int64_t key0 = kb * 32;
-    const uint16_t* src = v + head * kn * d;
     const int lpr = d / 8, kkn = d / 32;
     uint16_t* dst = vt + (head * (knp / 32) + kb) * (int64_t)(kkn * 2 * 512);
     for (int t = threadIdx.x; t < 32 * lpr; t += 256) {
         const int kr = t / lpr, c8 = (t % lpr) * 8;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (key0 + kr < kn) val = *(const uint4*)(src + (key0 + kr) * d + c8);
+        if (key0 + kr < kn) val = *(const uint4*)(v + vst.at(head, key0 + kr) + c8);
         const uint16_t* h = (const uint16_t*)&val;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[kr][c8 + e] = h[e];
@@ -149,6 +154,7 @@ struct PrepParams {
     int8_t *qq, *kq;
     float *qs, *ks;
     uint16_t* vt;
+    Strides qst, kst, vst;
     const float* kpart;  // [kheads][KMEAN_SPLITS][d] channel sums (smooth_k) or nullptr
     int64_t qheads, kheads, qn, kn, knp, nqb, nkb;
     int d, log2g;  // log2g: log2 of the Hadamard group (0 = no rotation)
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
     const int64_t b = blockIdx.x;
     if (b < p.nqb) {
-        attn_quant_block<T_ID>(p.q, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b, p.log2g);
+        attn_quant_block<T_ID>(p.q, p.qst, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b, p.log2g);
     } else if (b < p.nqb + p.nkb) {
         const int64_t kb = b - p.nqb;
         const float* mean = nullptr;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int64_t r = tid / lpr; r < p.kn; r += rpp) {
                 float v[8];
-                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)p.k + (head * p.kn + r) * p.d + c8), v);
+                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)p.k + p.kst.at(head, r) + c8), v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += v[e];
             }
@@ -201,10 +207,10 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             __syncthreads();
             mean = smean;
         }
-        attn_quant_block<T_ID>(p.k, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb, p.log2g);
+        attn_quant_block<T_ID>(p.k, p.kst, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb, p.log2g);
     } else {
         const int64_t vb = b - p.nqb - p.nkb, nb = p.knp / 32;
-        attn_vt_block((const uint16_t*)p.v, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile);
+        attn_vt_block((const uint16_t*)p.v, p.vst, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile);
     }
 }
 
@@ -214,6 +220,7 @@ struct AttnParams {
     int64_t qh, kh, qn, kn, knp;
     int qblocks, split;
     float log2_sm_scale;
+    Strides ost;       // output strides (elements)
     const void* mask;  // attention mask [*, *, q, key] (key stride 1) or nullptr
     int mask_dtype;    // -1: int8 / bool (0 = masked out), else SdnqFloat of an additive mask
     int64_t ms_z, ms_h, ms_q;  // element strides (0 for broadcast dimensions)
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     if (qi >= p.qn) return;
     l_i += __shfl_xor(l_i, 32);
     const float inv = l_i > 0.0f ? 1.0f / l_i : 0.0f;  // acc *= fdiv(1.0, l_i), :336; a row with no visible key is 0 (l stays 1, acc 0 there)
-    char* orow = (char*)p.out + (head_lin * p.qn + qi) * D * FT<OUT_T>::bytes;
+    char* orow = (char*)p.out + p.ost.at(head_lin, qi) * FT<OUT_T>::bytes;
 #pragma unroll
     for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
@@ -531,7 +538,8 @@ bool shape_ok(int64_t batch, int64_t qh, int64_t kh, int64_t qn, int64_t kn, int
 
 extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads,
                                      int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k,
-                                     int hadamard_group, void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean,
+                                     int hadamard_group, const int64_t* q_strides, const int64_t* k_strides,
+                                     const int64_t* v_strides, void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean,
                                      sdnq_stream_t stream) {
     if (!q || !k || !v || !qq || !qs || !kq || !ks || !vt || (smooth_k && !kmean)) return SDNQ_ERR_NULL;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
@@ -551,16 +559,24 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
     const bool inline_mean = smooth_k && kv_len <= 256;
     p.smooth_inline = inline_mean;
     p.kpart = (smooth_k && !inline_mean) ? kmean : nullptr;
+    auto strides_of = [&](const int64_t* st, int64_t heads, int64_t len, Strides& out) {
+        out.heads = heads;
+        if (st) { out.b = st[0]; out.h = st[1]; out.n = st[2]; } else { out.b = heads * len * head_dim; out.h = len * head_dim; out.n = head_dim; }
+        return out.b % 8 == 0 && out.h % 8 == 0 && out.n % 8 == 0;  // 16-byte rows
+    };
+    if (!strides_of(q_strides, q_heads, q_len, p.qst) || !strides_of(k_strides, kv_heads, kv_len, p.kst) ||
+        !strides_of(v_strides, kv_heads, kv_len, p.vst))
+        return SDNQ_ERR_ALIGN;
     p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d;
     p.log2g = log2g;
     p.nqb = (p.qheads * q_len * lpr + 255) / 256;
     p.nkb = kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
     const int64_t blocks = p.nqb + p.nkb + kheads * (p.knp / 32);
     if (dtype == SDNQ_BF16) {
-        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
+        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d);
         hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else {
-        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, kmean, kv_len, d);
+        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d);
         hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
     SDNQ_CHECK_LAUNCH();
@@ -569,7 +585,8 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
 
 extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
                                  float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
-                                 int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, int64_t batch,
+                                 int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
+                                 const int64_t* out_strides, int64_t batch,
                                  int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
                                  sdnq_stream_t stream) {
     if (!qq || !qs || !kq || !ks || !vt || !out) return SDNQ_ERR_NULL;
@@ -585,6 +602,10 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     p.split = force_split ? force_split : ((tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);  // measured: tools/bench_attention.py
     p.qblocks = (int)(p.split == 2 ? (q_len + 63) / 64 : (q_len + 127) / 128);
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
+    p.ost.heads = q_heads;
+    if (out_strides) { p.ost.b = out_strides[0]; p.ost.h = out_strides[1]; p.ost.n = out_strides[2]; }
+    else { p.ost.b = q_heads * q_len * head_dim; p.ost.h = q_len * head_dim; p.ost.n = head_dim; }
+    if (p.ost.b % 4 || p.ost.h % 4 || p.ost.n % 4) return SDNQ_ERR_ALIGN;
     p.mask = mask; p.mask_dtype = mask_dtype; p.ms_z = mask_stride_b; p.ms_h = mask_stride_h; p.ms_q = mask_stride_q;
     const int64_t blocks = batch * q_heads * p.qblocks;
     hipStream_t s = (hipStream_t)stream;

@@ -128,6 +128,25 @@ def test_hip_attention_masks_vs_oracle(kind, gpu_device):
 
 
 @pytest.mark.gpu
+def test_hip_attention_strided_views_match_contiguous(gpu_device):
+    """q / k / v as the transposed views of [Z, N, H*D] projection outputs (what attention processors pass) are read in place and
+    give bit-identical results to their contiguous copies; the output then has the query's memory layout."""
+    import torch
+    from sdnq_amd import attention as A
+    g = torch.Generator().manual_seed(3)
+    z, h, kh, qn, kn, d = 2, 6, 3, 150, 333, 64
+    q = torch.randn(z, qn, h * d, generator=g).bfloat16().to(gpu_device).view(z, qn, h, d).transpose(1, 2)
+    kv = torch.randn(z, kn, 2 * kh * d, generator=g).bfloat16().to(gpu_device)  # a fused to_kv output: k and v interleaved per token
+    k = kv[..., : kh * d].view(z, kn, kh, d).transpose(1, 2)
+    v = kv[..., kh * d:].view(z, kn, kh, d).transpose(1, 2)
+    assert not q.is_contiguous() and not k.is_contiguous()
+    out = A.sdnq_hip_atten(q, k, v, is_causal=False)
+    ref = A.sdnq_hip_atten(q.contiguous(), k.contiguous(), v.contiguous(), is_causal=False)
+    assert torch.equal(out, ref)
+    assert out.shape == (z, h, qn, d) and out.transpose(1, 2).is_contiguous() and ref.is_contiguous()
+
+
+@pytest.mark.gpu
 def test_hip_attention_full_size_properties(gpu_device):
     """SDXL self-attention size (4096 tokens, 10 heads of 64): rows of P sum to one, so attention over constant V returns
     that constant; and the output is invariant to a permutation of the key/value tokens."""
