@@ -39,6 +39,7 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     query, key, value = _rows16(query), _rows16(key), _rows16(value)  # strided views are read in place (no .contiguous() copy)
     dev = query.device
     knp = (kn + 31) // 32 * 32
+    d_src, d = d, (64 if d <= 64 else 128)  # head dims below 64 / 128 are zero-padded inside the kernels
     qq = torch.empty((z, qh, qn, d), device=dev, dtype=torch.int8)
     qs = torch.empty((z, qh, qn), device=dev, dtype=torch.float32)
     kq = torch.empty((z, kh, knp // 32, d // 32, 64, 16), device=dev, dtype=torch.int8)
@@ -46,7 +47,7 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     vt = torch.empty((z, kh, knp // 32, d // 32, 2, 64, 8), device=dev, dtype=value.dtype)
     kmean = torch.empty((z, kh, 32, d), device=dev, dtype=torch.float32)  # workspace: channel sums of 32 token splits
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
-                                                z, qh, kh, qn, kn, d, 1 if smooth_k else 0, hadamard_group, _strides(query), _strides(key),
+                                                z, qh, kh, qn, kn, d_src, 1 if smooth_k else 0, hadamard_group, _strides(query), _strides(key),
                                                 _strides(value), qq.data_ptr(), qs.data_ptr(),
                                                 kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), kmean.data_ptr(),
                                                 ops._stream(query)), "attn_prepare")
@@ -88,11 +89,12 @@ def prepare_mask(attn_mask: torch.Tensor, qn: int, kn: int) -> torch.Tensor:
 
 
 def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype,
-              attn_mask: torch.Tensor | None = None, token_major: bool = False) -> torch.Tensor:
+              attn_mask: torch.Tensor | None = None, token_major: bool = False, head_dim: int | None = None) -> torch.Tensor:
     """sdnq_atten_fwd (triton_atten.py:338-385) on the quantized operands of ``quantize_attn``; ``attn_mask`` as ``prepare_mask``
     returns it (4-D, contiguous; size-1 dimensions broadcast, triton_atten.py:371-378)."""
     z, qh, qn, d = qq.shape
     kh = kq.shape[1]
+    d = head_dim or d  # qq holds the padded head dim; the output has the tensors' own
     if token_major:  # memory [Z, N, H, D], returned as its [Z, H, N, D] view: out.transpose(1, 2).reshape(Z, N, H*D) is then free
         out = torch.empty((z, qn, qh, d), device=qq.device, dtype=out_dtype).transpose(1, 2)
     else:
@@ -130,8 +132,8 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
     if query.ndim != 4 or key.ndim != 4 or value.ndim != 4:
         raise ValueError("query / key / value must be [batch, heads, tokens, head_dim]")
     d = query.shape[-1]
-    if key.shape[-1] != d or value.shape[-1] != d or d not in (64, 128):
-        raise NotImplementedError("head_dim must be 64 or 128 for query, key and value")
+    if key.shape[-1] != d or value.shape[-1] != d or d % 8 or not 8 <= d <= 128:
+        raise NotImplementedError("query, key and value must share a head_dim that is a multiple of 8 and at most 128")
     if query.dtype not in (torch.bfloat16, torch.float16) or key.dtype != query.dtype or value.dtype != query.dtype:
         raise NotImplementedError("query / key / value must share one of bfloat16 / float16")
     if out_dtype is None:
@@ -140,7 +142,8 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
     group = 0
     if use_hadamard:  # triton_atten.py:563-569: group from the (power-of-two) head dim, halved until it divides
         from .quant_utils import get_hadamard_group_size
-        use_hadamard, group = get_hadamard_group_size(d, min(hadamard_group_size, d))
+        dp = 64 if d <= 64 else 128
+        use_hadamard, group = get_hadamard_group_size(dp, min(hadamard_group_size, dp))
         group = group if use_hadamard else 0
     qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k, hadamard_group=group)
     if attn_mask is not None:
@@ -150,4 +153,4 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
     # like torch's SDPA, the output takes the memory layout of the query: a [Z,N,H,D]-backed query (the transposed view a
     # diffusers / transformers attention processor passes) gets a [Z,N,H,D]-backed output
     token_major = query.shape[1] > 1 and query.shape[2] > 1 and query.stride(2) > query.stride(1) and query.stride(-1) == 1
-    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask, token_major=token_major)
+    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask, token_major=token_major, head_dim=d)

@@ -38,7 +38,8 @@ struct Strides {
 constexpr int KMEAN_SPLITS = 32;
 
 template <int T_ID>
-__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, const Strides ks, float* __restrict__ part, int64_t kn, int d) {
+__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, const Strides ks, float* __restrict__ part, int64_t kn, int d,
+                                                         int d_src) {
     __shared__ float red[256 * 8];
     const int lpr = d / 8, rpp = 256 / lpr;  // lanes per token row, rows per pass
     const int tid = threadIdx.x, c8 = (tid % lpr) * 8, r0 = tid / lpr;
@@ -46,8 +47,8 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
     const int64_t per = (kn + KMEAN_SPLITS - 1) / KMEAN_SPLITS, lo = split * per, hi = lo + per < kn ? lo + per : kn;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t r = lo + r0; r < hi; r += rpp) {
-        float v[8];
-        Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)k + ks.at(head, r) + c8), v);
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c8 < d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)k + ks.at(head, r) + c8), v);  // channels past d_src: zero padding
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
 template <int T_ID>
 __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, const Strides xst, const float* mean, int8_t* __restrict__ xq, float* __restrict__ xs,
                                                  int64_t heads, int64_t n_src, int64_t n_dst, int d, bool frag_major, int64_t block,
-                                                 int log2g) {
+                                                 int log2g, int d_src) {
     const int lpr = d / 8;
     const int64_t t = block * 256 + threadIdx.x;
     const int64_t row = t / lpr;
@@ -77,8 +78,9 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
     const int64_t head = live ? row / n_dst : 0, n = live ? row % n_dst : 0;
     const bool real = live && n < n_src;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (real) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + xst.at(head, n) + c8), v);  // 8 elements per 16-byte load
-    if (mean != nullptr && real) {
+    if (real && c8 < d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + xst.at(head, n) + c8), v);  // 8 elements per 16-byte load; head dims
+    // that are not 64 / 128 are zero-padded to the next one (get_attn_inputs pads to the next power of two, triton_atten.py:514-519)
+    if (mean != nullptr && real && c8 < d_src) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] -= mean[c8 + e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
     }
@@ -126,14 +128,14 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
 // one 1-KiB tile per (32-key block kb, 32-channel block dd, 16-key step c): lane (g, ql) holds the 8 keys
 // kb*32 + 16c + 8g + 0..7 of channel 32dd + ql, i.e. exactly the first operand of PV MFMA (dd, c) of attn_fwd_kernel.
 __device__ __forceinline__ void attn_vt_block(const uint16_t* __restrict__ v, const Strides vst, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d,
-                                              int64_t head, int64_t kb, uint16_t (*tile)[128 + 2]) {
+                                              int64_t head, int64_t kb, uint16_t (*tile)[128 + 2], int d_src) {
     const int64_t key0 = kb * 32;
     const int lpr = d / 8, kkn = d / 32;
     uint16_t* dst = vt + (head * (knp / 32) + kb) * (int64_t)(kkn * 2 * 512);
     for (int t = threadIdx.x; t < 32 * lpr; t += 256) {
         const int kr = t / lpr, c8 = (t % lpr) * 8;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (key0 + kr < kn) val = *(const uint4*)(v + vst.at(head, key0 + kr) + c8);
+        if (key0 + kr < kn && c8 < d_src) val = *(const uint4*)(v + vst.at(head, key0 + kr) + c8);
         const uint16_t* h = (const uint16_t*)&val;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[kr][c8 + e] = h[e];
@@ -157,7 +159,7 @@ struct PrepParams {
     Strides qst, kst, vst;
     const float* kpart;  // [kheads][KMEAN_SPLITS][d] channel sums (smooth_k) or nullptr
     int64_t qheads, kheads, qn, kn, knp, nqb, nkb;
-    int d, log2g;  // log2g: log2 of the Hadamard group (0 = no rotation)
+    int d, d_src, log2g;  // d: head dim padded to 64 / 128, d_src: the tensors' head dim; log2g: log2 of the Hadamard group (0 = none)
     bool smooth_inline;  // K means computed inside the K workgroups (short key sequences)
 };
 
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
     const int64_t b = blockIdx.x;
     if (b < p.nqb) {
-        attn_quant_block<T_ID>(p.q, p.qst, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b, p.log2g);
+        attn_quant_block<T_ID>(p.q, p.qst, nullptr, p.qq, p.qs, p.qheads, p.qn, p.qn, p.d, false, b, p.log2g, p.d_src);
     } else if (b < p.nqb + p.nkb) {
         const int64_t kb = b - p.nqb;
         const float* mean = nullptr;
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             float* red = (float*)&tile[0][0];  // 256 * 8 floats <= sizeof(tile)
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int64_t r = tid / lpr; r < p.kn; r += rpp) {
-                float v[8];
-                Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)p.k + p.kst.at(head, r) + c8), v);
+                float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (c8 < p.d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)p.k + p.kst.at(head, r) + c8), v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += v[e];
             }
@@ -207,10 +209,10 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             __syncthreads();
             mean = smean;
         }
-        attn_quant_block<T_ID>(p.k, p.kst, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb, p.log2g);
+        attn_quant_block<T_ID>(p.k, p.kst, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb, p.log2g, p.d_src);
     } else {
         const int64_t vb = b - p.nqb - p.nkb, nb = p.knp / 32;
-        attn_vt_block((const uint16_t*)p.v, p.vst, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile);
+        attn_vt_block((const uint16_t*)p.v, p.vst, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile, p.d_src);
     }
 }
 
@@ -221,6 +223,7 @@ struct AttnParams {
     int qblocks, split;
     float log2_sm_scale;
     Strides ost;       // output strides (elements)
+    int d_out;         // channels the output tensor has (<= D: padded head dims)
     const void* mask;  // attention mask [*, *, q, key] (key stride 1) or nullptr
     int mask_dtype;    // -1: int8 / bool (0 = masked out), else SdnqFloat of an additive mask
     int64_t ms_z, ms_h, ms_q;  // element strides (0 for broadcast dimensions)
@@ -496,6 +499,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int dcol = 32 * dd + 8 * t + 4 * g;  // registers 4t..4t+3 are 4 consecutive channels
+            if (dcol >= p.d_out) continue;
             float f[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) f[u] = o[dd][4 * t + u] * inv;
@@ -543,8 +547,10 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
                                      sdnq_stream_t stream) {
     if (!q || !k || !v || !qq || !qs || !kq || !ks || !vt || (smooth_k && !kmean)) return SDNQ_ERR_NULL;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
-    if (head_dim != 64 && head_dim != 128) return SDNQ_ERR_UNSUPPORTED;
+    if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
     if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_UNSUPPORTED;  // PV runs in the value dtype on the matrix cores
+    const int64_t head_dim_src = head_dim;
+    head_dim = head_dim <= 64 ? 64 : 128;  // the kernels' head dim; the extra channels are zeros
     int log2g = 0;
     if (hadamard_group != 0) {
         if (hadamard_group < 4 || hadamard_group > head_dim || (hadamard_group & (hadamard_group - 1)) || head_dim % hadamard_group) return SDNQ_ERR_SHAPE;
@@ -561,22 +567,22 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
     p.kpart = (smooth_k && !inline_mean) ? kmean : nullptr;
     auto strides_of = [&](const int64_t* st, int64_t heads, int64_t len, Strides& out) {
         out.heads = heads;
-        if (st) { out.b = st[0]; out.h = st[1]; out.n = st[2]; } else { out.b = heads * len * head_dim; out.h = len * head_dim; out.n = head_dim; }
+        if (st) { out.b = st[0]; out.h = st[1]; out.n = st[2]; } else { out.b = heads * len * head_dim_src; out.h = len * head_dim_src; out.n = head_dim_src; }
         return out.b % 8 == 0 && out.h % 8 == 0 && out.n % 8 == 0;  // 16-byte rows
     };
     if (!strides_of(q_strides, q_heads, q_len, p.qst) || !strides_of(k_strides, kv_heads, kv_len, p.kst) ||
         !strides_of(v_strides, kv_heads, kv_len, p.vst))
         return SDNQ_ERR_ALIGN;
-    p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d;
+    p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d; p.d_src = (int)head_dim_src;
     p.log2g = log2g;
     p.nqb = (p.qheads * q_len * lpr + 255) / 256;
     p.nkb = kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
     const int64_t blocks = p.nqb + p.nkb + kheads * (p.knp / 32);
     if (dtype == SDNQ_BF16) {
-        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d);
+        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d, p.d_src);
         hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     } else {
-        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d);
+        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d, p.d_src);
         hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     }
     SDNQ_CHECK_LAUNCH();
@@ -592,7 +598,10 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     if (!qq || !qs || !kq || !ks || !vt || !out) return SDNQ_ERR_NULL;
     if (mask && mask_dtype != -1 && mask_dtype != SDNQ_F32 && mask_dtype != SDNQ_BF16 && mask_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
-    if (((uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt | (uintptr_t)out) % 16) return SDNQ_ERR_ALIGN;
+    if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
+    const int64_t head_dim_src = head_dim;
+    head_dim = head_dim <= 64 ? 64 : 128;  // as in sdnq_hip_attn_prepare: qq / kq / vt hold the padded head dim
+    if (((uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt | (uintptr_t)out) % 8) return SDNQ_ERR_ALIGN;
     AttnParams p{};
     p.qq = (const int8_t*)qq; p.qs = qs; p.kq = (const int8_t*)kq; p.ks = ks; p.vt = (const uint16_t*)vt; p.out = out;
     p.qh = q_heads; p.kh = kv_heads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32;
@@ -604,7 +613,8 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
     p.ost.heads = q_heads;
     if (out_strides) { p.ost.b = out_strides[0]; p.ost.h = out_strides[1]; p.ost.n = out_strides[2]; }
-    else { p.ost.b = q_heads * q_len * head_dim; p.ost.h = q_len * head_dim; p.ost.n = head_dim; }
+    else { p.ost.b = q_heads * q_len * head_dim_src; p.ost.h = q_len * head_dim_src; p.ost.n = head_dim_src; }
+    p.d_out = (int)head_dim_src;
     if (p.ost.b % 4 || p.ost.h % 4 || p.ost.n % 4) return SDNQ_ERR_ALIGN;
     p.mask = mask; p.mask_dtype = mask_dtype; p.ms_z = mask_stride_b; p.ms_h = mask_stride_h; p.ms_q = mask_stride_q;
     const int64_t blocks = batch * q_heads * p.qblocks;

@@ -62,6 +62,8 @@ CASES = [
     dict(name="f16_d64_boolmask", z=2, qh=2, kh=2, qn=40, kn=80, d=64, kw={}, mask=dict(kind="bool", shape=(2, 1, 40, 80), dead_rows=(3, 17))),
     dict(name="f16_d64_floatmask_2d_causal", z=1, qh=2, kh=1, qn=48, kn=48, d=64, kw=dict(is_causal=True), mask=dict(kind="f16", shape=(48, 48))),
     dict(name="f16_d128_f32mask_keyonly", z=1, qh=2, kh=2, qn=36, kn=44, d=128, kw={}, mask=dict(kind="f32", shape=(1, 2, 1, 44))),
+    dict(name="f16_d40_padded", z=1, qh=2, kh=2, qn=40, kn=56, d=40, kw={}),
+    dict(name="f16_d80_padded_causal", z=1, qh=2, kh=1, qn=36, kn=36, d=80, kw=dict(is_causal=True)),
     dict(name="f16_d64_hadamard", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(use_hadamard=True)),
     dict(name="f16_d128_hadamard_g32", z=1, qh=2, kh=1, qn=36, kn=40, d=128, kw=dict(use_hadamard=True, hadamard_group_size=32, is_causal=True)),
 ]

@@ -55,12 +55,14 @@ def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
     q, k, v = (c.torch_tensor(t, gpu_device) for t in ("q", "k", "v"))
     hg = c.meta.get("hadamard_group", 0)
     qq, qs, kq, ks, vt = A.quantize_attn(q, k, v, smooth_k=kw.get("smooth_k", True), hadamard_group=hg)
-    _quant_agreement(qq.cpu().numpy(), qs.cpu().numpy(), c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
+    d = q.shape[-1]  # head dims below 64 / 128 are zero-padded by the prepare kernel
+    _quant_agreement(qq[..., :d].cpu().numpy(), qs.cpu().numpy(), c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
     kn = k.shape[2]
     k_rows, v_rows = A.unpack_k_fragments(kq), A.unpack_v_fragments(vt)  # MFMA-fragment order -> [Z, KH, KNp, D]
-    _quant_agreement(k_rows[:, :, :kn].cpu().numpy(), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True),
+    _quant_agreement(k_rows[:, :, :kn, :d].cpu().numpy(), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True),
                      hadamard=bool(hg))
-    assert torch.equal(v_rows[:, :, :kn], v) and not v_rows[:, :, kn:].any() and not k_rows[:, :, kn:].any() and not ks[..., kn:].any()
+    assert torch.equal(v_rows[:, :, :kn, :d], v) and not v_rows[:, :, kn:].any() and not k_rows[:, :, kn:].any() and not ks[..., kn:].any()
+    assert not qq[..., d:].any() and not k_rows[..., d:].any() and not v_rows[..., d:].any()
     out = A.sdnq_hip_atten(q, k, v, attn_mask=c.torch_tensor("mask", gpu_device) if c.has("mask") else None, **kw)
     assert out.dtype == q.dtype and out.shape == q.shape
     got = out.float().cpu().numpy()
