@@ -786,3 +786,26 @@ def test_zero_weight_row_zero_activation_row_and_big_accumulators(gpu_device):
     ref = O.scaled_mm("int8", a.numpy(), b.numpy(), sa.numpy(), sb.numpy(), None, "f32")
     assert float(np.abs(ref).max()) * 2.0 ** 20 > 2.0 ** 24
     assert np.array_equal(y.cpu().numpy(), ref)
+
+
+def test_scaled_mm_output_beyond_2_31_elements(gpu_device):
+    """Maximum sizes: an output with more than 2^31 elements (70 001 x 32 768) and an M that is not a multiple of any tile --
+    every index computation must be 64-bit.  Sampled rows / columns are bit-exact vs the oracle; the last element is written."""
+    m, n, k = 70001, 32768, 256
+    g = torch.Generator(device=gpu_device).manual_seed(9)
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8, device=gpu_device, generator=g)
+    b = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=gpu_device, generator=g)
+    sa = torch.rand(m, device=gpu_device, generator=g) * 0.01 + 0.001
+    sb = torch.rand(n, device=gpu_device, generator=g) * 0.01 + 0.001
+    bias = torch.randn(n, device=gpu_device, dtype=torch.bfloat16, generator=g)
+    y = ops.scaled_mm(ops.MM_I8, a, b, sa, sb, bias, torch.bfloat16)
+    assert y.numel() > 2 ** 31
+    rows = torch.tensor([0, 1, 63, 64, 32767, 32768, 65535, 65536, 65537, 69999, 70000], device=gpu_device)
+    cols = torch.tensor([0, 31, 127, 128, 16383, 16384, 32511, 32767], device=gpu_device)
+    ref_rows = O.scaled_mm("int8", a[rows].cpu().numpy(), b.cpu().numpy(), sa[rows].cpu().numpy(), sb.cpu().numpy(), bias.float().cpu().numpy(), "bf16")
+    assert np.array_equal(to_f32_numpy(y[rows]), ref_rows)
+    ref_cols = O.scaled_mm("int8", a[::997].cpu().numpy(), b[cols].cpu().numpy(), sa[::997].cpu().numpy(), sb[cols].cpu().numpy(),
+                           bias[cols].float().cpu().numpy(), "bf16")
+    assert np.array_equal(to_f32_numpy(y[::997][:, cols]), ref_cols)
+    del y
+    torch.cuda.empty_cache()
