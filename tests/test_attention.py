@@ -169,6 +169,29 @@ def test_hip_attention_full_size_properties(gpu_device):
     assert (a - exact).norm() / exact.norm() <= 5e-2
 
 
+@pytest.mark.gpu
+def test_hip_attention_beyond_2_31_elements(gpu_device):
+    """Maximum sizes: q / k / v with more than 2^31 elements each (4 x 32 heads x 131 080 tokens x 128) and a key tail: every index
+    must be 64-bit.  Sampled query tiles of the first and the last (batch, head) against exact fp32 attention of that head."""
+    import torch
+    from sdnq_amd import attention as A
+    z, h, n, d = 4, 32, 131080, 128
+    g = torch.Generator(device=gpu_device).manual_seed(1)
+    q = torch.randn(z, h, n, d, device=gpu_device, dtype=torch.bfloat16, generator=g)
+    k = torch.randn(z, h, n, d, device=gpu_device, dtype=torch.bfloat16, generator=g)
+    v = torch.randn(z, h, n, d, device=gpu_device, dtype=torch.bfloat16, generator=g)
+    assert q.numel() > 2 ** 31
+    out = A.sdnq_hip_atten(q, k, v)
+    for (zi, hi) in ((0, 0), (z - 1, h - 1)):
+        for q0 in (0, 65536, n - 40):
+            qs = q[zi, hi, q0:q0 + 40].float()
+            p = torch.softmax(qs @ k[zi, hi].float().t() * d ** -0.5, dim=-1)
+            exact = p @ v[zi, hi].float()
+            got = out[zi, hi, q0:q0 + 40].float()
+            assert torch.isfinite(got).all()
+            assert (got - exact).norm() / exact.norm() <= 6e-2, (zi, hi, q0)
+
+
 def test_attention_rejects_unbuilt_options():
     import torch
     from sdnq_amd import attention as A
