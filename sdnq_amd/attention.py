@@ -8,6 +8,7 @@ built raise ``NotImplementedError`` naming the gap (quantized P.V, fp16 accumula
 from __future__ import annotations
 
 import ctypes
+import math
 
 import torch
 
@@ -40,12 +41,17 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     dev = query.device
     knp = (kn + 31) // 32 * 32
     d_src, d = d, (64 if d <= 64 else 128)  # head dims below 64 / 128 are zero-padded inside the kernels
-    qq = torch.empty((z, qh, qn, d), device=dev, dtype=torch.int8)
-    qs = torch.empty((z, qh, qn), device=dev, dtype=torch.float32)
-    kq = torch.empty((z, kh, knp // 32, d // 32, 64, 16), device=dev, dtype=torch.int8)
-    ks = torch.empty((z, kh, knp), device=dev, dtype=torch.float32)
-    vt = torch.empty((z, kh, knp // 32, d // 32, 2, 64, 8), device=dev, dtype=value.dtype)
-    kmean = torch.empty((z, kh, 32, d), device=dev, dtype=torch.float32)  # workspace: channel sums of 32 token splits
+    # one allocation for the five operands + the K-mean workspace (an eager host pays per allocation), 256-byte aligned slices
+    shapes = (((z, qh, qn, d), torch.int8), ((z, qh, qn), torch.float32), ((z, kh, knp // 32, d // 32, 64, 16), torch.int8),
+              ((z, kh, knp), torch.float32), ((z, kh, knp // 32, d // 32, 2, 64, 8), value.dtype),
+              ((z, kh, 32, d), torch.float32))  # last: channel sums of 32 token splits
+    sizes = [-(-(math.prod(shp) * dt.itemsize) // 256) * 256 for shp, dt in shapes]
+    pool = torch.empty((sum(sizes),), device=dev, dtype=torch.uint8)
+    parts, off = [], 0
+    for (shp, dt), nbytes in zip(shapes, sizes):
+        parts.append(pool[off:off + math.prod(shp) * dt.itemsize].view(dt).view(shp))
+        off += nbytes
+    qq, qs, kq, ks, vt, kmean = parts
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
                                                 z, qh, kh, qn, kn, d_src, 1 if smooth_k else 0, hadamard_group, _strides(query), _strides(key),
                                                 _strides(value), qq.data_ptr(), qs.data_ptr(),
