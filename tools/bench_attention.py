@@ -46,5 +46,6 @@ for (z, qh, kh, qn, kn, d) in SHAPES:
     tp = timed(lambda: A.quantize_attn(q, k, v))
     tf = timed(lambda: A.atten_fwd(*parts, kn, d ** -0.5, False, dt))
     ts = timed(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v))
+    tc = timed(lambda: A.sdnq_hip_atten(q, k, v))  # what a caller gets: the fused single launch for short key sequences
     print(f"Z={z} H={qh} QN={qn:5d} KN={kn:5d} D={d:3d}: prepare {tp:8.1f} us   fwd {tf:9.1f} us ({ops / tf / 1e6:7.1f} TOP/s)   "
-          f"total {tp + tf:9.1f} us   torch sdpa ({str(dt)[6:]}) {ts:9.1f} us", flush=True)
+          f"sdnq_hip_atten {tc:9.1f} us   torch sdpa ({str(dt)[6:]}) {ts:9.1f} us", flush=True)
