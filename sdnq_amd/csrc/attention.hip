@@ -249,14 +249,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KK = D / 32;  // int8 MFMA K steps of Q.K^T; also the 32-channel blocks of O
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in SGPRs: block indices stay scalar
     const int ql = lane & 31, g = lane >> 5;
-    const int64_t head_lin = blockIdx.x / p.qblocks;  // z * QH + h
-    const int qblk = blockIdx.x % p.qblocks;
-    // split == 1: the 4 waves of a workgroup take 4 query tiles.  split == 2 (few tiles for the 1024 SIMDs of the chip): two query
-    // tiles per workgroup, waves 2t / 2t+1 each take HALF the key blocks of tile t and merge through LDS at the end.
-    const int half = p.split == 2 ? (wave & 1) : 0;
-    const int64_t q0 = p.split == 2 ? (int64_t)qblk * 64 + (wave >> 1) * 32 : (int64_t)qblk * 128 + wave * 32;
+    // workgroup b runs on XCD b % 8 (private L2 each): give every XCD a CONTIGUOUS range of the (head, query block) sequence, so
+    // that the query blocks of one head -- which all stream the same K / V -- share one L2 instead of filling all eight
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int64_t head_lin = bid / p.qblocks;  // z * QH + h
+    const int qblk = bid % p.qblocks;
+    // split == 1: the 4 waves of a workgroup take 4 query tiles.  split == S in {2, 4} (few tiles for the 1024 SIMDs of the chip):
+    // 4 / S query tiles per workgroup, waves S*t .. S*t + S-1 each take 1/S of the key blocks of tile t and merge through LDS.
+    const int part = p.split > 1 ? (wave & (p.split - 1)) : 0;
+    const int wtile = p.split == 4 ? 0 : (p.split == 2 ? wave >> 1 : wave);  // query tile of this wave inside the workgroup
+    const int64_t q0 = ((int64_t)qblk * (4 / p.split) + wtile) * 32;
     const bool active = q0 < p.qn;  // wave-uniform
-    if (!active && p.split != 2) return;
+    if (!active && p.split == 1) return;
     const int64_t z = head_lin / p.qh, h = head_lin % p.qh;
     const int64_t mz = z, mh = h;  // attention-mask batch / head index (strides are 0 where the mask broadcasts)
     const int64_t kv_lin = z * p.kh + (h * p.kh) / p.qh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
@@ -420,13 +428,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     int mlo = n_plain, mhi = nkb;
     if (HAS_MASK) { n_plain = 0; mlo = 0; }
     int lo = 0, hi = n_plain;
-    if (p.split == 2) {
-        const int mid = (n_plain + 1) / 2;
-        if (half == 0) hi = mid; else lo = mid;
+    if (p.split > 1) {
+        const int per = (n_plain + p.split - 1) / p.split;  // plain blocks per part
+        lo = part * per < n_plain ? part * per : n_plain;
+        hi = lo + per < n_plain ? lo + per : n_plain;
         if (HAS_MASK) {
-            const int mm = (nkb + 1) / 2;
-            if (half == 0) mhi = mm; else mlo = mm;
-        } else if (half == 0) {
+            const int mper = (nkb + p.split - 1) / p.split;
+            mlo = part * mper < nkb ? part * mper : nkb;
+            mhi = mlo + mper < nkb ? mlo + mper : nkb;
+        } else if (part != p.split - 1) {
             mhi = mlo;
         }
     }
@@ -466,11 +476,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         softmax_pv(s, b, (int64_t)kb * 32, std::true_type{});
     }
     float l_i = l2[0] + l2[1];
-    if (p.split == 2) {
-        // merge the two key halves of a query tile: o = o0 * 2^(m0 - m) + o1 * 2^(m1 - m), same for the row sums
-        __shared__ float comb[2][KK * 16 + 2][64];
-        float (*cb)[64] = comb[wave >> 1];
-        if (half == 1 && active) {
+    if (p.split > 1) {
+        // merge the key parts of a query tile: o = sum_i o_i * 2^(m_i - m), same for the row sums
+        __shared__ float comb[3][KK * 16 + 2][64];  // split 2: one slot per tile (2 tiles); split 4: three slots of the one tile
+        if (part != 0 && active) {
+            float (*cb)[64] = comb[p.split == 2 ? wtile : part - 1];
 #pragma unroll
             for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
@@ -479,16 +489,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             cb[KK * 16 + 1][lane] = l_i;
         }
         __syncthreads();
-        if (half == 1 || !active) return;
-        const float m1 = cb[KK * 16][lane], l1 = cb[KK * 16 + 1][lane];
-        float m = fmaxf(m_i, m1);
-        if (m == -__builtin_inff()) m = 0.0f;  // no visible key in either half (attention mask): both weights become 0
-        const float a0 = __builtin_amdgcn_exp2f(m_i - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
-        l_i = l_i * a0 + l1 * a1;
+        if (part != 0 || !active) return;
+#pragma nounroll
+        for (int i = 1; i < p.split; ++i) {
+            float (*cb)[64] = comb[p.split == 2 ? wtile : i - 1];
+            const float m1 = cb[KK * 16][lane], l1 = cb[KK * 16 + 1][lane];
+            float m = fmaxf(m_i, m1);
+            if (m == -__builtin_inff()) m = 0.0f;  // no visible key in either part (attention mask): both weights become 0
+            const float a0 = __builtin_amdgcn_exp2f(m_i - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+            l_i = l_i * a0 + l1 * a1;
 #pragma unroll
-        for (int dd = 0; dd < KK; ++dd)
+            for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dd][r] = o[dd][r] * a0 + cb[dd * 16 + r][lane] * a1;
+                for (int r = 0; r < 16; ++r) o[dd][r] = o[dd][r] * a0 + cb[dd * 16 + r][lane] * a1;
+            m_i = fmaxf(m_i, m1);
+        }
     }
     if (qi >= p.qn) return;
     l_i += __shfl_xor(l_i, 32);
@@ -609,7 +624,9 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     static const int force_split = [] { const char* e = getenv("SDNQ_HIP_ATTN_SPLIT"); return e ? atoi(e) : 0; }();  // tuning aid
     const int64_t tiles = batch * q_heads * ((q_len + 31) / 32);
     p.split = force_split ? force_split : ((tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);  // measured: tools/bench_attention.py
-    p.qblocks = (int)(p.split == 2 ? (q_len + 63) / 64 : (q_len + 127) / 128);
+    if (p.split != 1 && p.split != 2 && p.split != 4) return SDNQ_ERR_SHAPE;
+    const int tiles_per_wg = 4 / p.split;
+    p.qblocks = (int)((q_len + 32 * tiles_per_wg - 1) / (32 * tiles_per_wg));
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
     p.ost.heads = q_heads;
     if (out_strides) { p.ost.b = out_strides[0]; p.ost.h = out_strides[1]; p.ost.n = out_strides[2]; }
