@@ -221,6 +221,7 @@ struct AttnParams {
     void* out;
     int64_t qh, kh, qn, kn, knp;
     int qblocks, split;
+    int shared_kv;  // the 4 waves of a workgroup (4 query tiles of one head) stream K / V through LDS once instead of 4 times
     float log2_sm_scale;
     Strides ost;       // output strides (elements)
     int d_out;         // channels the output tensor has (<= D: padded head dims)
@@ -232,6 +233,9 @@ struct AttnParams {
 __device__ __forceinline__ float ldf_mask(const void* p, int64_t i, int dt) {
     return dt == SDNQ_F32 ? ((const float*)p)[i] : (dt == SDNQ_BF16 ? bf16_bits_to_f32(((const uint16_t*)p)[i]) : f16_bits_to_f32(((const uint16_t*)p)[i]));
 }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int wtile = p.split == 4 ? 0 : (p.split == 2 ? wave >> 1 : wave);  // query tile of this wave inside the workgroup
     const int64_t q0 = ((int64_t)qblk * (4 / p.split) + wtile) * 32;
     const bool active = q0 < p.qn;  // wave-uniform
-    if (!active && p.split == 1) return;
+    if (!active && p.split == 1 && !p.shared_kv) return;  // (shared K / V: every wave is needed for the loads and barriers)
     const int64_t z = head_lin / p.qh, h = head_lin % p.qh;
     const int64_t mz = z, mh = h;  // attention-mask batch / head index (strides are 0 where the mask broadcasts)
     const int64_t kv_lin = z * p.kh + (h * p.kh) / p.qh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
@@ -405,10 +409,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 if constexpr (V_T == SDNQ_BF16) pf[c][w] = __builtin_bit_cast(int, __builtin_convertvector(t[4 * c + w], v2bf));
                 else pf[c][w] = __builtin_bit_cast(int, __builtin_convertvector(t[4 * c + w], v2h));
             }
+        // key step outermost: consecutive MFMAs write different accumulators (back-to-back MFMAs on one accumulator wait for each
+        // other's latency)
 #pragma unroll
-        for (int dd = 0; dd < KK; ++dd)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int dd = 0; dd < KK; ++dd) {
                 if constexpr (V_T == SDNQ_BF16)
                     o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, b.v[dd][c]), __builtin_bit_cast(v8bf, pf[c]), o[dd], 0, 0, 0);
                 else
@@ -440,7 +446,67 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             mhi = mlo;
         }
     }
+    // ---- shared K / V (split == 1, no masks): the workgroup's 4 waves work on 4 query tiles of ONE head, so every key block is
+    // fetched from L2 once per workgroup -- LDS-DMA into a double-buffered stage of two blocks -- and read from LDS by all four.
+    // Per CU the loop otherwise pulls ~25 B/clk from L2, the same per-CU fill plateau the GEMM kernels hit (a timing-only build
+    // whose loads all hit one block in L1 was 22 % faster).
+    constexpr int STG_K = 2 * KK * 1024, STG_V = 4 * KK * 1024, STG_BYTES = STG_K + STG_V + 256;
+    constexpr int COMB_BYTES = 3 * (KK * 16 + 2) * 64 * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STG_BYTES > COMB_BYTES ? 2 * STG_BYTES : COMB_BYTES];
+    if (!CAUSAL && !HAS_MASK && p.shared_kv) {
+        const int n_st = n_plain / 2;  // full two-block stages; the same for every wave (no causal limit)
+        const uint8_t* gk = (const uint8_t*)p.kq + kv_lin * p.knp * D + lane * 16;
+        const uint8_t* gv = (const uint8_t*)p.vt + kv_lin * p.knp * D * 2 + lane * 16;
+        const uint8_t* gs = (const uint8_t*)(p.ks + kv_lin * p.knp) + lane * 4;
+        auto dma_stage = [&](int st, int buf) {
+            uint8_t* dst = smem + buf * STG_BYTES;
+#pragma unroll
+            for (int i = 0; i < 6 * KK / 4; ++i) {  // 1-KiB tiles w, w + 4, ...: first the 2 KK tiles of K, then the 4 KK of V
+                const int tile = wave + 4 * i;
+                const uint8_t* src = tile < 2 * KK ? gk + (int64_t)st * STG_K + tile * 1024 : gv + (int64_t)st * STG_V + (tile - 2 * KK) * 1024;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + tile * 1024), 16, 0, 0);
+            }
+            if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(gs + (int64_t)st * 256), (lptr_t)(dst + STG_K + STG_V), 4, 0, 0);  // 64 k_scales
+        };
+        auto lds_block = [&](int buf, int blk, v4i (&kf)[KK], Blk& b) {
+            const uint8_t* base = smem + buf * STG_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(base + (blk * KK + kk) * 1024 + lane * 16);
+#pragma unroll
+            for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) b.v[dd][c] = *(const v4i*)(base + STG_K + ((blk * KK + dd) * 2 + c) * 1024 + lane * 16);
+            const float* ksl = (const float*)(base + STG_K + STG_V) + blk * 32 + 8 * g;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                b.ks[2 * c] = *(const v4f*)(ksl + 16 * c);
+                b.ks[2 * c + 1] = *(const v4f*)(ksl + 16 * c + 4);
+            }
+        };
+        if (n_st > 0) {
+            dma_stage(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#pragma nounroll
+            for (int st = 0; st < n_st; ++st) {
+                if (st + 1 < n_st) dma_stage(st + 1, (st + 1) & 1);
+                if (active) {
+                    v4i kf0[KK], kf1[KK];
+                    Blk b0, b1;
+                    lds_block(st & 1, 0, kf0, b0);
+                    lds_block(st & 1, 1, kf1, b1);
+                    const v16i s0 = qk_mfma(kf0), s1 = qk_mfma(kf1);
+                    softmax_pv(s0, b0, (int64_t)st * 64, std::false_type{});
+                    softmax_pv(s1, b1, (int64_t)st * 64 + 32, std::false_type{});
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage st + 1 has landed
+                __syncthreads();                                   // ... everybody's has, and everybody is done reading stage st
+            }
+            lo = 2 * n_st;  // an odd last plain block and the key tail go through the per-wave code below
+        }
+    }
     if (!active) { hi = lo; mhi = mlo; }
+    if (p.shared_kv && !active) return;
     if (lo < hi) {
         const int last = hi - 1;
         v4i kfA[KK], kfB[KK];
@@ -478,7 +544,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     float l_i = l2[0] + l2[1];
     if (p.split > 1) {
         // merge the key parts of a query tile: o = sum_i o_i * 2^(m_i - m), same for the row sums
-        __shared__ float comb[3][KK * 16 + 2][64];  // split 2: one slot per tile (2 tiles); split 4: three slots of the one tile
+        float (*comb)[KK * 16 + 2][64] = (float (*)[KK * 16 + 2][64])smem;  // split 2: one slot per tile (2 tiles); split 4: three slots of the one tile
         if (part != 0 && active) {
             float (*cb)[64] = comb[p.split == 2 ? wtile : part - 1];
 #pragma unroll
@@ -623,8 +689,13 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     // few query tiles for the 1024 SIMDs (e.g. SDXL at batch 1: 1280): split every tile's keys over two waves
     static const int force_split = [] { const char* e = getenv("SDNQ_HIP_ATTN_SPLIT"); return e ? atoi(e) : 0; }();  // tuning aid
     const int64_t tiles = batch * q_heads * ((q_len + 31) / 32);
-    p.split = force_split ? force_split : ((tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);  // measured: tools/bench_attention.py
+    // measured (tools/bench_attention.py): splitting pays at head_dim 64 (SDXL 10 x 4096^2: 90 -> 78 us); at head_dim 128 the
+    // unsplit kernel with K / V shared through LDS is faster (FLUX 24 x 4608^2: 333 -> 309 us), at 64 sharing does not pay
+    const bool want_shared = head_dim == 128 && kv_len >= 2048 && !is_causal && !mask;
+    p.split = force_split ? force_split : ((!want_shared && tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);
     if (p.split != 1 && p.split != 2 && p.split != 4) return SDNQ_ERR_SHAPE;
+    static const int force_shared = [] { const char* e = getenv("SDNQ_HIP_ATTN_SHARED"); return e ? atoi(e) : -1; }();  // tuning aid
+    p.shared_kv = (p.split == 1 && !is_causal && !mask && kv_len >= 64) ? (force_shared < 0 ? (want_shared ? 1 : 0) : force_shared) : 0;
     const int tiles_per_wg = 4 / p.split;
     p.qblocks = (int)((q_len + 32 * tiles_per_wg - 1) / (32 * tiles_per_wg));
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
