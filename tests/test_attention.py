@@ -130,6 +130,29 @@ def test_hip_attention_masks_vs_oracle(kind, gpu_device):
 
 
 @pytest.mark.gpu
+def test_hip_attention_ragged_shape_sweep(gpu_device):
+    """Edge shapes: single query / single key, lengths one below / above the 32-wide blocks, causal with q_len != kv_len, grouped
+    heads down to one KV head, f32 output -- every combination against the oracle."""
+    import itertools
+    import torch
+    from sdnq_amd import attention as A
+    g = torch.Generator().manual_seed(77)
+    n = 0
+    for qn, kn, d, causal, (qh, kh) in itertools.product((1, 31, 33, 100), (1, 5, 32, 63, 65, 129), (64, 128), (False, True), ((4, 1), (3, 3))):
+        q = torch.randn(1, qh, qn, d, generator=g).half()
+        k = (torch.randn(1, kh, kn, d, generator=g) + 1.0).half()
+        v = torch.randn(1, kh, kn, d, generator=g).half()
+        out = A.sdnq_hip_atten(q.to(gpu_device), k.to(gpu_device), v.to(gpu_device), is_causal=causal, out_dtype=torch.float32)
+        assert out.dtype == torch.float32
+        ref = O.attention(q.float().numpy(), k.float().numpy(), v.float().numpy(), "f16", is_causal=causal, out_tag="f32")
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), (qn, kn, d, causal, qh, kh)
+        assert np.abs(got - ref).max() <= 3e-3 * max(np.abs(ref).max(), 1e-3), (qn, kn, d, causal, qh, kh)
+        n += 1
+    assert n == 192
+
+
+@pytest.mark.gpu
 def test_hip_attention_strided_views_match_contiguous(gpu_device):
     """q / k / v as the transposed views of [Z, N, H*D] projection outputs (what attention processors pass) are read in place and
     give bit-identical results to their contiguous copies; the output then has the query's memory layout."""
