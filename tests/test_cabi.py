@@ -55,3 +55,27 @@ def test_argument_validation_without_gpu():
     assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -1                                   # uint without zero_point
     w.kind, w.bits, w.storage = 0, 9, 0
     assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -2                                   # 9 bits in uint8 words
+
+
+def test_attention_argument_validation_without_gpu():
+    """The attention entry points validate before launching as well."""
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(8192)
+    p = ctypes.addressof(buf)
+    p += (-p) % 16
+    prep = lib.sdnq_hip_attn_prepare
+    ok_tail = (None, None, None, p, p, p, p, p, p, None)  # strides (contiguous), qq, qs, kq, ks, vt, kmean, stream
+    assert prep(None, p, p, 1, 1, 2, 2, 8, 8, 64, 1, 0, *ok_tail) == -1                       # NULL query
+    assert prep(p, p, p, 0, 1, 2, 2, 8, 8, 64, 1, 0, *ok_tail) == -5                          # float32 inputs: not built
+    assert prep(p, p, p, 1, 1, 3, 2, 8, 8, 64, 1, 0, *ok_tail) == -3                          # q_heads % kv_heads
+    assert prep(p, p, p, 1, 1, 2, 2, 8, 8, 136, 1, 0, *ok_tail) == -5                         # head_dim > 128
+    assert prep(p, p, p, 1, 1, 2, 2, 8, 8, 60, 1, 0, *ok_tail) == -5                          # head_dim % 8
+    assert prep(p, p, p, 1, 1, 2, 2, 8, 8, 64, 1, 48, *ok_tail) == -3                         # Hadamard group not a power of two
+    assert prep(p + 2, p, p, 1, 1, 2, 2, 8, 8, 64, 1, 0, *ok_tail) == -4                      # alignment
+    bad = (ctypes.c_int64 * 3)(1024, 516, 68)                                                 # token stride not a multiple of 8
+    assert prep(p, p, p, 1, 1, 2, 2, 8, 8, 64, 1, 0, bad, None, None, p, p, p, p, p, p, None) == -4
+    fwd = lib.sdnq_hip_attn_fwd
+    assert fwd(p, p, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, None, 1, None, 1, 2, 2, 8, 8, 64, None) == -1    # NULL out
+    assert fwd(p, p, p, p, p, 1, 0.125, 0, p, 5, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -2          # mask dtype
+    assert fwd(p, p, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 0, 64, None) == -3       # kv_len 0
+    assert fwd(p, p, p, p, p, 0, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -2       # f32 value operand
