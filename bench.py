@@ -50,7 +50,7 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant",
-                            "sdxl_attn_int8", "flux_attn_int8"])
+                            "sdxl_attn_int8", "flux_attn_int8", "sdxl_unet_all"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -363,6 +363,95 @@ def attention_bench(args, device, distributed, world, rank):
         print(json.dumps(result))
 
 
+def unet_all_bench(args, device, distributed, world, rank):
+    """Every quantizable operation of one SDXL-UNet denoising step at bs=1 in ONE hipGraph: the 741 Linear layers (int8 w8a8), the
+    49 Conv2d layers as int8 GEMMs and the 140 attention calls (int8 Q.K^T) -- the three workloads sdxl_int8, sdxl_conv_int8 and
+    sdxl_attn_int8 back to back.  Reported beside the headline, not instead of it."""
+    from sdnq_amd import attention as A
+    from sdnq_amd import shapes
+    lin_cfg = dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    linears = build_layers(shapes.sdxl_unet_layer_sequence(), lin_cfg, device, seed=rank)
+    convs = build_conv_layers(shapes.sdxl_unet_convs(), dict(weights_dtype="int8", group_size=-1, quant_conv=True, use_quantized_matmul_conv=True),
+                              device, seed=rank)
+    calls = shapes.sdxl_unet_attentions()
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    qkv = {name: tuple(torch.randn(1, h, n, d, device=device, dtype=torch.bfloat16, generator=g) for n in (qn, kn, kn))
+           for (name, h, qn, kn, d, rep) in calls}
+    ops = {"linear": sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in linears),
+           "conv": sum(2 * m * k * n + m * n for (_, _, _, m, k, n, _) in convs), "attention": shapes.ops_of_attentions(calls)}
+
+    def attn_step():
+        for (name, h, qn, kn, d, rep) in calls:
+            for _ in range(rep):
+                A.sdnq_hip_atten(*qkv[name])
+
+    parts = {"linear": lambda: run_step(linears), "conv": lambda: run_step(convs), "attention": attn_step}
+
+    def full_step():
+        for fn in parts.values():
+            fn()
+
+    def capture(fn):
+        side = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(side):
+            fn()
+            side.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                fn()
+        torch.cuda.synchronize()
+        return gr
+
+    for _ in range(2):
+        full_step()
+    torch.cuda.synchronize()
+    graph = capture(full_step)
+    for _ in range(args.warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    if distributed:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    total_ops = sum(ops.values())
+    replicas = world if distributed else 1
+    result = {"metric": "quantized-op GOP/s (SDXL UNet step: Linear + Conv2d + attention, bs=1)",
+              "value": round(total_ops * args.steps * replicas / elapsed / 1e9, 1), "unit": "GOP/s", "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": "i8 (+ bf16 P.V)", "data": "synthetic",
+              "config": {"workload": f"sdxl_unet_all: {len(linears)} Linear + {len(convs)} Conv2d + {sum(c[5] for c in calls)} attention calls of one "
+                                     "denoising step, bs=1, one hipGraph", "parallelism": f"{world} independent replicas" if distributed else "single GPU",
+                         "launch": "hipGraph replay", "activations": "bf16", "ops_per_step": total_ops, "ops_by_part": ops},
+              "step_latency_ms": round(ms, 4)}
+    if rank == 0:
+        part_ms = {}
+        for name, fn in parts.items():  # each part alone, graph-replayed, HIP events
+            gr = capture(fn)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gr.replay()
+            e0.record()
+            for _ in range(5):
+                gr.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            part_ms[name] = round(e0.elapsed_time(e1) / 5, 4)
+        result["parts_ms"] = part_ms
+        print(json.dumps(result))
+
+
 def cpu_baseline_attention(calls, budget_s):
     """The oracle's restatement of the reference attention (numpy) on a bounded sample: 2 heads of 1024 x 1024 tokens."""
     import numpy as np
@@ -401,6 +490,12 @@ def main():
     if not _lib.load().sdnq_hip_device_supported(local_rank):
         raise SystemExit("device is not gfx950: the HIP kernels of this repo target MI355X only")
 
+    if args.workload == "sdxl_unet_all":
+        unet_all_bench(args, device, distributed, world, rank)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload.endswith("_attn_int8"):
         attention_bench(args, device, distributed, world, rank)
         if distributed:
