@@ -150,6 +150,10 @@ CASES = [
     # name, K, N, Ms, dtype, config kwargs
     dict(name="int8_rowwise_noqmm_f32", K=256, N=64, Ms=[4, 40], dtype="f32",
          cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=False)),
+    dict(name="int8_rowwise_noqmm_bf16", K=512, N=256, Ms=[48, 200], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=False)),
+    dict(name="int8_rowwise_noqmm_f16_nobias", K=320, N=136, Ms=[130], dtype="f16", bias=False,
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=False)),
     dict(name="int8_rowwise_qmm_bf16", K=512, N=256, Ms=[4, 48, 77], dtype="bf16",
          cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)),
     dict(name="int8_rowwise_qmm_f16_nobias", K=256, N=64, Ms=[33], dtype="f16", bias=False,
