@@ -43,8 +43,8 @@ class _ActivationCache:
     recycled for a different tensor while the entry is alive.
     """
 
-    def __init__(self, size: int):
-        self.size = size
+    def __init__(self, size: int | None = None):
+        self.size = size   # None: the module-level CACHE_ACTIVATIONS, read at use time (the switch can be flipped after import)
         self.entries = []  # most recent last: (tensor, version, params, result)
 
     def get(self, t: torch.Tensor, params):
@@ -57,14 +57,15 @@ class _ActivationCache:
 
     def put(self, t: torch.Tensor, params, result):
         self.entries.append((t, t._version, params, result))
-        if len(self.entries) > self.size:
+        cap = max(CACHE_ACTIVATIONS, 0) if self.size is None else self.size
+        while len(self.entries) > cap:
             self.entries.pop(0)
 
     def clear(self):
         self.entries.clear()
 
 
-_act_cache = _ActivationCache(CACHE_ACTIVATIONS)
+_act_cache = _ActivationCache()
 
 
 def clear_activation_cache():
