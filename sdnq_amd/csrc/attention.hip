@@ -384,10 +384,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
                 const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
                 m_blk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            const float m_new = fmaxf(m_i, m_blk * qsl);  // finite: every key of a plain block is visible
-            alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-            m_i = m_new;
-            const v2f qsl2 = {qsl, qsl}, mneg2 = {-m_new, -m_new};
+            // lazy reference maximum: m_i follows the row maximum only when it grew by more than 2^8 for some query of the wave
+            // (first block: from -inf).  Otherwise p = 2^(s - m_i) <= 2^8 -- harmless in fp32 sums and in the bf16 / f16 P operand
+            // -- and alpha = 1: no exp2, no rescale of O.  o / l is the same quotient either way (the reference rescales every
+            // block, triton_atten.py:303-309; only fp32 rounding order differs).
+            const float m_cand = m_blk * qsl;  // finite: every key of a plain block is visible
+            alpha = 1.0f;
+            if (__builtin_amdgcn_ballot_w64(m_cand > m_i + 8.0f) != 0) {
+                const float m_new = fmaxf(m_i, m_cand);
+                alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+                m_i = m_new;
+            }
+            const v2f qsl2 = {qsl, qsl}, mneg2 = {-m_i, -m_i};
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 t[j] = __builtin_elementwise_fma(t[j], qsl2, mneg2);
