@@ -34,6 +34,12 @@ struct Im2colParams {
 // A is accumulated as the bit pattern of a non-negative float with atomicMax (zeroed by the host).  Workgroup = 32 groups of 8
 // consecutive pixels (one 16-byte load per channel, 512 contiguous bytes per wave-half) x 8 channel lanes; blockIdx.y splits the
 // channels so that small images still fill the chip; partial maxima are combined in LDS, one atomic per pixel per workgroup.
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned int* __restrict__ p, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) *(uint4*)(p + i) = make_uint4(0, 0, 0, 0);
+    else for (int64_t j = i; j < n; ++j) p[j] = 0;
+}
+
 template <int T_ID>
 __global__ __launch_bounds__(256) void conv_pixel_amax_kernel(const void* __restrict__ x, int64_t pixels, int channels, int64_t total,
                                                               int cpb, unsigned int* __restrict__ amap) {
@@ -214,8 +220,10 @@ extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int
     hipStream_t s = (hipStream_t)stream;
     const int64_t pixels = (int64_t)height * width, total = (int64_t)batch * pixels;
     if (pixels % 8) return SDNQ_ERR_UNSUPPORTED;  // the channel-amax pass reads 8 pixels per 16-byte load
-    if ((uintptr_t)x % 16) return SDNQ_ERR_ALIGN;
-    if (hipMemsetAsync(amax_ws, 0, sizeof(unsigned int) * total, s) != hipSuccess) return SDNQ_ERR_LAUNCH;
+    if ((uintptr_t)x % 16 || (uintptr_t)amax_ws % 16) return SDNQ_ERR_ALIGN;
+    // zero the amax map with a plain kernel: hipMemsetAsync goes through the runtime's generic fill kernel (4.6 us per call
+    // in the SDXL conv step, profiles/r01_bench_sdxl_conv_kernel_stats.csv)
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, (unsigned int*)amax_ws, total);
     const float qmax = (mm_dtype == SDNQ_MM_I8) ? 127.0f : 448.0f;
     const unsigned mb = (unsigned)((p.M + 63) / 64);
     const int ct = (P <= 9) ? 32 : 16;
