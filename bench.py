@@ -57,6 +57,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--fuse-projections", action="store_true",
                    help="variant: q/k/v (and cross-attention k/v) projections fused into one layer each, like diffusers' fuse_projections()")
+    p.add_argument("--no-link-projections", action="store_true",
+                   help="do not link attention projections that share their input (sdnq_amd.accelerate links them by default)")
     p.add_argument("--layers-scale", type=float, default=1.0, help="debug: fraction of each layer's repeat count")
     return p.parse_args()
 
@@ -164,6 +166,23 @@ def fuse_shared_input_layers(layers):
     return out
 
 
+def link_shared_input_layers(layers):
+    """What sdnq_amd.accelerate(model) does to a diffusers model (loader.link_projections): the attention projections of one block
+    that consume the SAME tensor (self-attention to_q / to_k / to_v, cross-attention to_k / to_v) become a ProjectionGroup -- the
+    modules and their outputs stay what they were, the first one called runs one scaled matmul for all of them."""
+    import sdnq_amd
+    n, i = 0, 0
+    is_proj = lambda nm: any(t in nm for t in (".to_q", ".to_k", ".to_v"))  # noqa: E731
+    while i < len(layers):
+        j = i + 1
+        while j < len(layers) and layers[j][2] is layers[i][2] and j - i < 3 and is_proj(layers[i][0]) and is_proj(layers[j][0]):
+            j += 1
+        if j - i > 1 and sdnq_amd.link_layers([l[1] for l in layers[i:j]]):
+            n += 1
+        i = j
+    return n
+
+
 def run_step(layers):
     """One pass over every layer.  The activation-quantization cache is emptied first: within a step a tensor consumed by
     several layers is quantized once (sdnq_amd/linear.py:_ActivationCache), but nothing is carried across steps."""
@@ -180,12 +199,24 @@ def time_gemm_kernel(layers, mm_name, device):
     from sdnq_amd import linear as L
     from sdnq_amd import ops
     mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
-    calls, total_ops, total_bytes = [], 0, 0
+    calls, total_ops, total_bytes, seen_groups = [], 0, 0, set()
     for (_, mod, x, m, k, n, has_bias) in layers:
         if m < 32 or not hasattr(mod, "sdnq_dequantizer"):
             continue
         dq = mod.sdnq_dequantizer
         if dq.svd_rank and getattr(mod, "svd_up", None) is not None:
+            continue
+        group = mod.__dict__.get("_sdnq_group") if L.LINK_PROJECTIONS else None
+        if group is not None:  # linked projections: ONE launch for the members, exactly as in the step
+            if id(group) in seen_groups:
+                continue
+            seen_groups.add(id(group))
+            group._operands(mm)
+            xq, xs, _, _ = ops.rowquant(x, mm, 0)
+            g = len(group.mods)
+            calls.append((xq, group.wq, xs, group.ws, group.bias, g))
+            total_ops += g * (2 * m * k * n + (m * n if has_bias else 0))
+            total_bytes += m * k + g * (n * k + 2 * m * n + 4 * n + (2 * n if has_bias else 0)) + 4 * m
             continue
         st = L._state(mod)
         wq, ws, zp = L._prepare_mm_weights(mod, st, mm)
@@ -193,15 +224,18 @@ def time_gemm_kernel(layers, mm_name, device):
             from sdnq_amd import conv as C
             x = C._unfold(mod, x)[0]
         xq, xs, _, _ = ops.rowquant(x, mm, dq.hadamard_group_size if dq.use_hadamard else 0)
-        calls.append((xq, wq, xs, ws, mod.bias))
+        calls.append((xq, wq, xs, ws, mod.bias, 1))
         total_ops += 2 * m * k * n + (m * n if has_bias else 0)
         total_bytes += m * k + n * k + 2 * m * n + 4 * (m + n) + (2 * n if has_bias else 0)  # xq + Wq + y(bf16) + xs + ws + bias
     if not calls:
         return None
 
     def launch_all():
-        for (xq, wq, xs, ws, bias) in calls:
-            ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
+        for (xq, wq, xs, ws, bias, g) in calls:
+            if g == 1:
+                ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
+            else:
+                ops.scaled_mm_multi(mm, xq, wq, xs, ws, bias, torch.bfloat16, g)
     launch_all()
     torch.cuda.synchronize()
     s = torch.cuda.Stream(device=device)
@@ -513,6 +547,9 @@ def main():
                               tp_world=world if tp else 1, seed=0 if tp else rank)
     if args.fuse_projections and not is_conv and not tp:
         layers = fuse_shared_input_layers(layers)
+    linked = 0
+    if not args.no_link_projections and not args.fuse_projections and not is_conv and not tp:
+        linked = link_shared_input_layers(layers)
     ops_per_step = sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in layers)
 
     # eager warm-up (builds the per-module weight caches), then capture the whole step
@@ -572,6 +609,7 @@ def main():
                    "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16",
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
                    "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
+                   "linked_projection_groups": linked,
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
         "step_latency_ms": round(ms_per_step, 4),

@@ -131,6 +131,15 @@ int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* 
                        const void* bias, int bias_dtype, int bias_ndim, int64_t ld_bias, void* out,
                        int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
+/* the same scaled matmul over the STACKED weights of layers that consume one activation (to_q / to_k / to_v of an attention block),
+ * each layer's columns stored in its own contiguous tensor: b [n_outs * seg_n][K], sb / bias [n_outs * seg_n], outs[i] is
+ * [M][seg_n] (seg_n % 8 == 0, n_outs <= 4, n == n_outs * seg_n).  One launch and one pass over the quantized activation instead
+ * of n_outs; every output element is the value sdnq_hip_scaled_mm gives for its layer (int_scaled_mm_func per layer,
+ * kernel_wrappers.py:193-204). */
+int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                             int bias_dtype, void* const* outs, int n_outs, int64_t seg_n, int out_dtype, int64_t m, int64_t n,
+                             int64_t k, sdnq_stream_t stream);
+
 /* ---- a4/a5/a6: dequantize ---------------------------------------------------------------------
  * replaces SDNQDequantizer.__call__ -> dequantize_weight (dequantizer.py:135-162, 389-429):
  * unpack -> f32(w)*scale | fma(f32(w),scale,zp) -> [+ svd_up@svd_down in svd dtype] -> cast ->

@@ -69,7 +69,17 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int group_m;  // m-strips per rasterization group
     int swz;      // LDS chunk swizzle mask (7; 0 only for experiments)
+    // several output tensors (linked projections: one GEMM over the stacked weights of to_q / to_k / to_v, each layer's output in
+    // its own [M][seg_n] tensor): channel n goes to out_seg[n / seg_n]; seg_n % 8 == 0, so a 16-byte piece never straddles tensors
+    void* out_seg[4];
+    int64_t seg_n;  // 0: single output p.out
 };
+
+__device__ __forceinline__ uint8_t* out_piece(const GemmParams& p, int64_t gm, int64_t gn0, int out_b) {
+    if (p.seg_n == 0) return (uint8_t*)p.out + (gm * p.N + gn0) * out_b;
+    const int64_t seg = gn0 / p.seg_n;
+    return (uint8_t*)p.out_seg[seg] + (gm * p.seg_n + (gn0 - seg * p.seg_n)) * out_b;
+}
 
 template <int MM> struct MmaTraits;
 template <> struct MmaTraits<SDNQ_MM_I8> {
@@ -586,7 +596,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 o[4 * h + e] = res;
             }
         }
-        uint8_t* dst = (uint8_t*)p.out + (gm * p.N + gn0) * OUT_B;
+        uint8_t* dst = out_piece(p, gm, gn0, OUT_B);
         if constexpr (OUT_T == SDNQ_F32) {
             *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
             *(uint4*)(dst + 16) = Vec16<SDNQ_F32>::pack(o + 4);
@@ -681,7 +691,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int r = v / PPR, c = v % PPR;
         const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c * EPP;
         if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a piece never straddles N
-        *(uint4*)((uint8_t*)p.out + (gm * p.N + gn0) * OUT_B) = *(const uint4*)(stage + r * OUT_ROW + c * 16);
+        *(uint4*)out_piece(p, gm, gn0, OUT_B) = *(const uint4*)(stage + r * OUT_ROW + c * 16);
     }
     });
     }
@@ -820,6 +830,26 @@ extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, co
     hipStream_t s = (hipStream_t)stream;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, bias_ndim, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, bias_ndim, out_dtype, s);
+}
+
+extern "C" int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                        int bias_dtype, void* const* outs, int n_outs, int64_t seg_n, int out_dtype, int64_t m,
+                                        int64_t n, int64_t k, sdnq_stream_t stream) {
+    if (!outs || n_outs < 1 || n_outs > 4) return SDNQ_ERR_SHAPE;
+    for (int i = 0; i < n_outs; ++i)
+        if (!outs[i] || (uintptr_t)outs[i] % 16) return outs[i] ? SDNQ_ERR_ALIGN : SDNQ_ERR_NULL;
+    if (seg_n <= 0 || seg_n % 8 || seg_n * n_outs != n) return SDNQ_ERR_SHAPE;
+    int st = check_common(mm_dtype, a, b, sa, sb, outs[0], out_dtype, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (bias && (bias_dtype < 0 || bias_dtype > 2)) return SDNQ_ERR_DTYPE;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = outs[0];
+    for (int i = 0; i < n_outs; ++i) p.out_seg[i] = outs[i];
+    p.seg_n = seg_n;
+    p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias ? bias_dtype : out_dtype;
+    hipStream_t s = (hipStream_t)stream;
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);
 }
 
 extern "C" int sdnq_hip_scaled_mm_nchw(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,

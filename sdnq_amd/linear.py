@@ -219,6 +219,56 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
     return wq, ws, zp
 
 
+class ProjectionGroup:
+    """Layers of one attention block that consume the SAME tensor (to_q / to_k / to_v of self-attention, to_k / to_v of
+    cross-attention) and have equal shapes and a row-wise direct-matmul configuration (``loader._fusable``).  The first member
+    called with a tensor runs ONE scaled matmul over the stacked weights (``sdnq_hip_scaled_mm_multi``: one launch and one pass
+    over the quantized activation instead of one per layer) writing each member's output into its own contiguous tensor; the
+    other members, called with the very same tensor object, just pick theirs up.  Every output element is bit-identical to what
+    the member computes alone (each output channel keeps its own scale and bias).  The stacked operand is a copy of the members'
+    weights (the members themselves, their parameters and the state_dict are untouched)."""
+
+    def __init__(self, mods):
+        self.mods = list(mods)
+        self.sig = None   # member state keys the stacked operands were built from
+        self.wq = self.ws = self.bias = None
+        self.last = None  # (input tensor, its version, stream, outputs, indices not handed out yet)
+
+    def _operands(self, mm):
+        states = [_state(m) for m in self.mods]
+        sig = tuple(id(st) for st in states) + tuple(st.key for st in states) + (mm,)
+        if sig != self.sig:
+            parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
+            if any(zp is not None for (_, _, zp) in parts):
+                return False
+            self.wq = torch.cat([wq.reshape(wq.shape[0], -1) for (wq, _, _) in parts], dim=0).contiguous()
+            self.ws = torch.cat([ws.reshape(-1) for (_, ws, _) in parts], dim=0).contiguous()
+            biases = [_attr(m, "bias") for m in self.mods]
+            self.bias = None if biases[0] is None else torch.cat(biases, dim=0).contiguous()
+            self.sig, self.last = sig, None
+        return True
+
+    def forward(self, mod, input: torch.Tensor, mm: int):
+        idx = next(i for i, m in enumerate(self.mods) if m is mod)
+        stream = ops._stream(input)
+        last = self.last
+        if last is None or last[0] is not input or last[1] != input._version or last[2] != stream or idx not in last[4]:
+            if not self._operands(mm):
+                return None
+            dq = mod.sdnq_dequantizer
+            x2, xq, xs, _, _ = _rowquant_cached(input, dq.in_features, mm, 0, False, False, None)
+            outs = ops.scaled_mm_multi(mm, xq, self.wq, xs, self.ws, self.bias, input.dtype, len(self.mods))
+            last = self.last = (input, input._version, stream, outs, set(range(len(self.mods))))
+        y = last[3][idx].view(*input.shape[:-1], mod.sdnq_dequantizer.out_features)
+        last[4].discard(idx)
+        if not last[4]:
+            self.last = None  # every member has its output: hold on to nothing (the input and the outputs belong to the host again)
+        return y
+
+
+LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
+
+
 def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_branch: bool = True) -> torch.Tensor:
     dq = self.sdnq_dequantizer
     st = _state(self)
@@ -226,6 +276,11 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     m = input.numel() // input.shape[-1]
     if m == 0 or (small_batch_branch and m < 32):  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
         return _float_forward(self, input, st)
+    group = self.__dict__.get("_sdnq_group")
+    if group is not None and LINK_PROJECTIONS and input.is_cuda:
+        y = group.forward(self, input, mm)
+        if y is not None:
+            return y
     wq, ws, zp = _prepare_mm_weights(self, st, mm)
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None

@@ -52,6 +52,43 @@ def accelerate(model: torch.nn.Module) -> int:
             module.sdnq_dequantizer = dq
             module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
             module.__dict__.pop("_sdnq_hip_state", None)
+            module.__dict__.pop("_sdnq_group", None)
+            count += 1
+    from . import linear
+    if linear.LINK_PROJECTIONS:
+        link_projections(model)
+    return count
+
+
+@torch.no_grad()
+def link_layers(mods) -> bool:
+    """Make `mods` (layers that consume the same tensor) a ``linear.ProjectionGroup`` if their configuration allows it."""
+    from .linear import ProjectionGroup
+    mods = list(mods)
+    if len(mods) < 2 or len(mods) > 4 or not _fusable(mods):
+        return False
+    d0 = mods[0].sdnq_dequantizer
+    if any(m.sdnq_dequantizer.out_features != d0.out_features for m in mods) or d0.out_features % 8:
+        return False
+    group = ProjectionGroup(mods)
+    for m in mods:
+        m.__dict__["_sdnq_group"] = group
+    return True
+
+
+@torch.no_grad()
+def link_projections(model: torch.nn.Module) -> int:
+    """For every attention block of ``model``: ``to_q / to_k / to_v`` (self-attention, when they have equal shapes) or ``to_k /
+    to_v`` (cross-attention) become one ``ProjectionGroup`` -- transparent to the host model: the modules, their names, parameters
+    and outputs stay what they were, but the three (two) GEMMs of a shared input run as one launch.  Returns the number of groups."""
+    count = 0
+    for module in model.modules():
+        q, k, v = (getattr(module, a, None) for a in ("to_q", "to_k", "to_v"))
+        if k is None or v is None or k is v:
+            continue
+        if q is not None and link_layers([q, k, v]):
+            count += 1
+        elif link_layers([k, v]):
             count += 1
     return count
 

@@ -206,6 +206,22 @@ def scaled_mm(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, 
     return out
 
 
+def scaled_mm_multi(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype,
+                    n_outs: int):
+    """One scaled matmul over the stacked weights of `n_outs` layers, each layer's output in its own contiguous [M, N / n_outs]
+    tensor (sdnq_hip_scaled_mm_multi)."""
+    _require_cuda(a, b_phys)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    seg = n // n_outs
+    outs = [torch.empty((m, seg), device=a.device, dtype=out_dtype) for _ in range(n_outs)]
+    ptrs = (ctypes.c_void_p * n_outs)(*[o.data_ptr() for o in outs])
+    check(_lib.load().sdnq_hip_scaled_mm_multi(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                               float_code(bias.dtype) if bias is not None else 0, ptrs, n_outs, seg, float_code(out_dtype),
+                                               m, n, k, _stream(a)), "scaled_mm_multi")
+    return outs
+
+
 def linear_w8a8(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype, hadamard_group: int = 0):
     """rowquant + scaled_mm through ONE binding call (two launches) -> (out [M,N], xq [M,K], xs [M,1])."""
     m, k = x2d.shape

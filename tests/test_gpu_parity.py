@@ -809,3 +809,65 @@ def test_scaled_mm_output_beyond_2_31_elements(gpu_device):
     assert np.array_equal(to_f32_numpy(y[::997][:, cols]), ref_cols)
     del y
     torch.cuda.empty_cache()
+
+
+def test_linked_projections_are_transparent(gpu_device):
+    """sdnq_amd.link_projections / accelerate: to_q / to_k / to_v of an attention block run as ONE scaled matmul over the stacked
+    weights (sdnq_hip_scaled_mm_multi) when they are called with the same tensor; every member returns its own contiguous tensor,
+    bit-identical to what it computes alone, whatever the call order; a different tensor, a modified tensor and a small batch take
+    the ordinary paths."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+
+    class Attn(torch.nn.Module):
+        def __init__(self, c, cross, bias):
+            super().__init__()
+            self.to_q = torch.nn.Linear(c, c, bias=bias)
+            self.to_k = torch.nn.Linear(cross or c, c, bias=bias)
+            self.to_v = torch.nn.Linear(cross or c, c, bias=bias)
+
+    torch.manual_seed(13)
+    for mmd, cross, bias in (("int8", 0, True), ("float8_e4m3fn", 0, False), ("int8", 256, False)):
+        wd = "int8" if mmd == "int8" else "float8_e4m3fn"
+        blk = Attn(320, cross, bias).to(torch.bfloat16).to(gpu_device)
+        cfg = sdnq_amd.SDNQConfig(weights_dtype=wd, quantized_matmul_dtype=mmd, group_size=-1, use_quantized_matmul=True)
+        for name in ("to_q", "to_k", "to_v"):
+            setattr(blk, name, sdnq_amd.sdnq_quantize_layer(getattr(blk, name), cfg)[0])
+        mods = [blk.to_q, blk.to_k, blk.to_v]
+        x = torch.randn(2, 75, 320, device=gpu_device, dtype=torch.bfloat16)
+        xt = torch.randn(2, 77, cross or 320, device=gpu_device, dtype=torch.bfloat16)
+        inputs = [x, xt if cross else x, xt if cross else x]
+        alone = [m(i).clone() for m, i in zip(mods, inputs)]
+        assert sdnq_amd.accelerate(blk) == 3
+        group = blk.to_k.__dict__["_sdnq_group"]
+        assert len(group.mods) == (2 if cross else 3) and (("_sdnq_group" in blk.to_q.__dict__) == (not cross))
+        for order in ((0, 1, 2), (2, 0, 1)):
+            L.clear_activation_cache()
+            group.last = None
+            outs = {i: mods[i](inputs[i]) for i in order}
+            for i in range(3):
+                assert torch.equal(outs[i], alone[i]) and outs[i].is_contiguous(), (mmd, cross, i)
+            assert outs[1].data_ptr() != outs[2].data_ptr()
+            assert group.last is None  # every member was served: nothing is kept alive
+            a = mods[1](inputs[1])
+            assert group.last is not None and group.last[0] is inputs[1]
+            held = group.last[3][-1].data_ptr()
+            assert mods[2](inputs[2]).data_ptr() == held and torch.equal(a, alone[1])  # the same launch serves the sibling
+            if not cross:
+                mods[0](inputs[0])
+            assert group.last is None
+        x2 = torch.randn_like(inputs[1])
+        assert torch.equal(mods[1](x2), (lambda g: (g.__setattr__("last", None), L.clear_activation_cache(), mods[1](x2))[2])(group))
+        keep = inputs[1].clone()
+        inputs[1].mul_(0.5)  # version bump: the stored outputs no longer belong to this tensor
+        old = L.LINK_PROJECTIONS
+        try:
+            got = mods[1](inputs[1])
+            L.LINK_PROJECTIONS = False
+            L.clear_activation_cache()
+            assert torch.equal(got, mods[1](inputs[1]))
+        finally:
+            L.LINK_PROJECTIONS = old
+        inputs[1].copy_(keep)
+        small = torch.randn(5, cross or 320, device=gpu_device, dtype=torch.bfloat16)
+        assert mods[1](small).shape == (5, 320)  # M < 32: dequant + float GEMM branch, untouched
