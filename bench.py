@@ -621,13 +621,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
         traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm_traffic.json")
+        pmc_name = "r01_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
         if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             # (tools/pmc_shapes.py + tools/pmc_traffic.py; counters cannot be read inside this process)
             with open(pmc) as f:
                 traffic = round(json.load(f)["_all_gemm_kernel"]["hbm_bytes_per_launch"])
-            traffic_src = "profiles/r01_pmc_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)"
+            traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)"
         if gk:
             ach = gk["ops"] / gk["seconds"] / 1e12
             result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s" if mm_name == "int8" else "TFLOP/s",
