@@ -83,13 +83,15 @@ def link_projections(model: torch.nn.Module) -> int:
     and outputs stay what they were, but the three (two) GEMMs of a shared input run as one launch.  Returns the number of groups."""
     count = 0
     for module in model.modules():
-        q, k, v = (getattr(module, a, None) for a in ("to_q", "to_k", "to_v"))
-        if k is None or v is None or k is v:
-            continue
-        if q is not None and link_layers([q, k, v]):
-            count += 1
-        elif link_layers([k, v]):
-            count += 1
+        # diffusers' Attention: to_q / to_k / to_v, and add_q_proj / add_k_proj / add_v_proj of the joint (SD3 / FLUX) blocks
+        for names in (("to_q", "to_k", "to_v"), ("add_q_proj", "add_k_proj", "add_v_proj")):
+            q, k, v = (getattr(module, a, None) for a in names)
+            if k is None or v is None or k is v:
+                continue
+            if q is not None and link_layers([q, k, v]):
+                count += 1
+            elif link_layers([k, v]):
+                count += 1
     return count
 
 
