@@ -75,3 +75,45 @@ def test_fuse_projections_layout_on_cpu():
         assert torch.equal(f.weight[:, 96 * i:96 * (i + 1)], part.weight) and torch.equal(f.scale[:, 96 * i:96 * (i + 1)], part.scale)
         assert torch.equal(f.bias[96 * i:96 * (i + 1)], part.bias)
     assert tuple(b.to_kv.weight.shape) == (128, 192) and b.to_kv.bias is None
+
+
+def test_link_projections_wiring():
+    """loader.link_projections: which layers of an attention block become one ProjectionGroup (host logic only, no kernels)."""
+    import torch
+    import sdnq_amd
+
+    class Attn(torch.nn.Module):
+        def __init__(self, c, cross):
+            super().__init__()
+            self.to_q = torch.nn.Linear(c, c, bias=False)
+            self.to_k = torch.nn.Linear(cross or c, c, bias=False)
+            self.to_v = torch.nn.Linear(cross or c, c, bias=False)
+
+    def quantized(blk, **cfg):
+        for name in ("to_q", "to_k", "to_v"):
+            setattr(blk, name, sdnq_amd.sdnq_quantize_layer(getattr(blk, name).to(torch.bfloat16), sdnq_amd.SDNQConfig(**cfg))[0])
+        return blk
+
+    row = dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    blk = quantized(Attn(64, 0), **row)
+    assert sdnq_amd.link_projections(blk) == 1
+    g = blk.to_q.__dict__["_sdnq_group"]
+    assert g is blk.to_k.__dict__["_sdnq_group"] is blk.to_v.__dict__["_sdnq_group"] and len(g.mods) == 3
+    cross = quantized(Attn(64, 96), **row)
+    assert sdnq_amd.link_projections(cross) == 1
+    assert "_sdnq_group" not in cross.to_q.__dict__ and len(cross.to_k.__dict__["_sdnq_group"].mods) == 2
+    # group-wise sub-byte weights are re-quantized per layer, a dequantize-mode layer has no quantized matmul: not linked
+    assert sdnq_amd.link_projections(quantized(Attn(64, 0), weights_dtype="uint4", use_quantized_matmul=True)) == 0
+    assert sdnq_amd.link_projections(quantized(Attn(64, 0), weights_dtype="int8", group_size=-1, use_quantized_matmul=False)) == 0
+    # accelerate() re-links from scratch and honours the switch
+    from sdnq_amd import linear as L
+    old = L.LINK_PROJECTIONS
+    try:
+        L.LINK_PROJECTIONS = False
+        sdnq_amd.accelerate(blk)
+        assert "_sdnq_group" not in blk.to_q.__dict__
+        L.LINK_PROJECTIONS = True
+        sdnq_amd.accelerate(blk)
+        assert len(blk.to_q.__dict__["_sdnq_group"].mods) == 3
+    finally:
+        L.LINK_PROJECTIONS = old
