@@ -405,6 +405,7 @@ def unet_all_bench(args, device, distributed, world, rank):
     from sdnq_amd import shapes
     lin_cfg = dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
     linears = build_layers(shapes.sdxl_unet_layer_sequence(), lin_cfg, device, seed=rank)
+    linked = 0 if args.no_link_projections else link_shared_input_layers(linears)  # as sdnq_amd.accelerate(model) does
     convs = build_conv_layers(shapes.sdxl_unet_convs(), dict(weights_dtype="int8", group_size=-1, quant_conv=True, use_quantized_matmul_conv=True),
                               device, seed=rank)
     calls = shapes.sdxl_unet_attentions()
@@ -468,7 +469,8 @@ def unet_all_bench(args, device, distributed, world, rank):
               "dtype": "i8 (+ bf16 P.V)", "data": "synthetic",
               "config": {"workload": f"sdxl_unet_all: {len(linears)} Linear + {len(convs)} Conv2d + {sum(c[5] for c in calls)} attention calls of one "
                                      "denoising step, bs=1, one hipGraph", "parallelism": f"{world} independent replicas" if distributed else "single GPU",
-                         "launch": "hipGraph replay", "activations": "bf16", "ops_per_step": total_ops, "ops_by_part": ops},
+                         "launch": "hipGraph replay", "activations": "bf16", "linked_projection_groups": linked, "ops_per_step": total_ops,
+                         "ops_by_part": ops},
               "step_latency_ms": round(ms, 4)}
     if rank == 0:
         part_ms = {}
