@@ -827,6 +827,7 @@ def test_linked_projections_are_transparent(gpu_device):
             self.to_v = torch.nn.Linear(cross or c, c, bias=bias)
 
     torch.manual_seed(13)
+    L.LINK_PROJECTIONS = True  # the test is about the linked path whatever SDNQ_HIP_LINK_PROJECTIONS says (restored below per case)
     for mmd, cross, bias in (("int8", 0, True), ("float8_e4m3fn", 0, False), ("int8", 256, False)):
         wd = "int8" if mmd == "int8" else "float8_e4m3fn"
         blk = Attn(320, cross, bias).to(torch.bfloat16).to(gpu_device)
@@ -860,14 +861,14 @@ def test_linked_projections_are_transparent(gpu_device):
         assert torch.equal(mods[1](x2), (lambda g: (g.__setattr__("last", None), L.clear_activation_cache(), mods[1](x2))[2])(group))
         keep = inputs[1].clone()
         inputs[1].mul_(0.5)  # version bump: the stored outputs no longer belong to this tensor
-        old = L.LINK_PROJECTIONS
         try:
             got = mods[1](inputs[1])
             L.LINK_PROJECTIONS = False
             L.clear_activation_cache()
             assert torch.equal(got, mods[1](inputs[1]))
         finally:
-            L.LINK_PROJECTIONS = old
+            L.LINK_PROJECTIONS = True
         inputs[1].copy_(keep)
         small = torch.randn(5, cross or 320, device=gpu_device, dtype=torch.bfloat16)
         assert mods[1](small).shape == (5, 320)  # M < 32: dequant + float GEMM branch, untouched
+    L.LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
