@@ -207,6 +207,7 @@ def time_gemm_kernel(layers, mm_name, device):
         if dq.svd_rank and getattr(mod, "svd_up", None) is not None:
             continue
         group = mod.__dict__.get("_sdnq_group") if L.LINK_PROJECTIONS else None
+        group = group[0] if group is not None else None
         if group is not None:  # linked projections: ONE launch for the members, exactly as in the step
             if id(group) in seen_groups:
                 continue

@@ -230,36 +230,43 @@ class ProjectionGroup:
 
     def __init__(self, mods):
         self.mods = list(mods)
-        self.sig = None   # member state keys the stacked operands were built from
+        self.sig = None   # (matmul dtype, the members' weight / scale objects and versions the stacked operands were built from)
         self.wq = self.ws = self.bias = None
         self.last = None  # (input tensor, its version, stream, outputs, indices not handed out yet)
 
     def _operands(self, mm):
+        # per-compute check on the eager path: the members' weight / scale objects and versions (a changed parameter rebuilds the
+        # stacked operands); the full per-module signature is only evaluated when something changed
+        refs = self.sig
+        if refs is not None and refs[0] == mm:
+            for m, (w, wv, sc, sv) in zip(self.mods, refs[1]):
+                if _attr(m, "weight") is not w or w._version != wv or _attr(m, "scale") is not sc or sc._version != sv:
+                    break
+            else:
+                return self.wq is not None
         states = [_state(m) for m in self.mods]
-        sig = tuple(id(st) for st in states) + tuple(st.key for st in states) + (mm,)
-        if sig != self.sig:
-            parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
-            if any(zp is not None for (_, _, zp) in parts):
-                return False
-            self.wq = torch.cat([wq.reshape(wq.shape[0], -1) for (wq, _, _) in parts], dim=0).contiguous()
-            self.ws = torch.cat([ws.reshape(-1) for (_, ws, _) in parts], dim=0).contiguous()
-            biases = [_attr(m, "bias") for m in self.mods]
-            self.bias = None if biases[0] is None else torch.cat(biases, dim=0).contiguous()
-            self.sig, self.last = sig, None
+        parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
+        self.sig = (mm, [(_attr(m, "weight"), _attr(m, "weight")._version, _attr(m, "scale"), _attr(m, "scale")._version) for m in self.mods])
+        self.last = None
+        if any(zp is not None for (_, _, zp) in parts):
+            self.wq = None
+            return False
+        self.wq = torch.cat([wq.reshape(wq.shape[0], -1) for (wq, _, _) in parts], dim=0).contiguous()
+        self.ws = torch.cat([ws.reshape(-1) for (_, ws, _) in parts], dim=0).contiguous()
+        biases = [_attr(m, "bias") for m in self.mods]
+        self.bias = None if biases[0] is None else torch.cat(biases, dim=0).contiguous()
         return True
 
-    def forward(self, mod, input: torch.Tensor, mm: int):
-        idx = next(i for i, m in enumerate(self.mods) if m is mod)
+    def forward(self, mod, idx: int, input: torch.Tensor, mm: int):
         stream = ops._stream(input)
         last = self.last
         if last is None or last[0] is not input or last[1] != input._version or last[2] != stream or idx not in last[4]:
             if not self._operands(mm):
                 return None
-            dq = mod.sdnq_dequantizer
-            x2, xq, xs, _, _ = _rowquant_cached(input, dq.in_features, mm, 0, False, False, None)
+            x2, xq, xs, _, _ = _rowquant_cached(input, input.shape[-1], mm, 0, False, False, None)
             outs = ops.scaled_mm_multi(mm, xq, self.wq, xs, self.ws, self.bias, input.dtype, len(self.mods))
             last = self.last = (input, input._version, stream, outs, set(range(len(self.mods))))
-        y = last[3][idx].view(*input.shape[:-1], mod.sdnq_dequantizer.out_features)
+        y = last[3][idx].view(*input.shape[:-1], -1)
         last[4].discard(idx)
         if not last[4]:
             self.last = None  # every member has its output: hold on to nothing (the input and the outputs belong to the host again)
@@ -278,7 +285,7 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
         return _float_forward(self, input, st)
     group = self.__dict__.get("_sdnq_group")
     if group is not None and LINK_PROJECTIONS and input.is_cuda:
-        y = group.forward(self, input, mm)
+        y = group[0].forward(self, group[1], input, mm)
         if y is not None:
             return y
     wq, ws, zp = _prepare_mm_weights(self, st, mm)

@@ -71,8 +71,8 @@ def link_layers(mods) -> bool:
     if any(m.sdnq_dequantizer.out_features != d0.out_features for m in mods) or d0.out_features % 8:
         return False
     group = ProjectionGroup(mods)
-    for m in mods:
-        m.__dict__["_sdnq_group"] = group
+    for i, m in enumerate(mods):
+        m.__dict__["_sdnq_group"] = (group, i)
     return True
 
 

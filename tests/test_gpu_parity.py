@@ -840,7 +840,7 @@ def test_linked_projections_are_transparent(gpu_device):
         inputs = [x, xt if cross else x, xt if cross else x]
         alone = [m(i).clone() for m, i in zip(mods, inputs)]
         assert sdnq_amd.accelerate(blk) == 3
-        group = blk.to_k.__dict__["_sdnq_group"]
+        group = blk.to_k.__dict__["_sdnq_group"][0]
         assert len(group.mods) == (2 if cross else 3) and (("_sdnq_group" in blk.to_q.__dict__) == (not cross))
         for order in ((0, 1, 2), (2, 0, 1)):
             L.clear_activation_cache()

@@ -97,11 +97,11 @@ def test_link_projections_wiring():
     row = dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
     blk = quantized(Attn(64, 0), **row)
     assert sdnq_amd.link_projections(blk) == 1
-    g = blk.to_q.__dict__["_sdnq_group"]
-    assert g is blk.to_k.__dict__["_sdnq_group"] is blk.to_v.__dict__["_sdnq_group"] and len(g.mods) == 3
+    g = blk.to_q.__dict__["_sdnq_group"][0]
+    assert g is blk.to_k.__dict__["_sdnq_group"][0] is blk.to_v.__dict__["_sdnq_group"][0] and len(g.mods) == 3
     cross = quantized(Attn(64, 96), **row)
     assert sdnq_amd.link_projections(cross) == 1
-    assert "_sdnq_group" not in cross.to_q.__dict__ and len(cross.to_k.__dict__["_sdnq_group"].mods) == 2
+    assert "_sdnq_group" not in cross.to_q.__dict__ and len(cross.to_k.__dict__["_sdnq_group"][0].mods) == 2
     # group-wise sub-byte weights are re-quantized per layer, a dequantize-mode layer has no quantized matmul: not linked
     assert sdnq_amd.link_projections(quantized(Attn(64, 0), weights_dtype="uint4", use_quantized_matmul=True)) == 0
     assert sdnq_amd.link_projections(quantized(Attn(64, 0), weights_dtype="int8", group_size=-1, use_quantized_matmul=False)) == 0
@@ -114,6 +114,6 @@ def test_link_projections_wiring():
         assert "_sdnq_group" not in blk.to_q.__dict__
         L.LINK_PROJECTIONS = True
         sdnq_amd.accelerate(blk)
-        assert len(blk.to_q.__dict__["_sdnq_group"].mods) == 3
+        assert len(blk.to_q.__dict__["_sdnq_group"][0].mods) == 3
     finally:
         L.LINK_PROJECTIONS = old
