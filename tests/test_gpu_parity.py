@@ -871,4 +871,10 @@ def test_linked_projections_are_transparent(gpu_device):
         inputs[1].copy_(keep)
         small = torch.randn(5, cross or 320, device=gpu_device, dtype=torch.bfloat16)
         assert mods[1](small).shape == (5, 320)  # M < 32: dequant + float GEMM branch, untouched
+        if mmd == "int8" and not bias:
+            with torch.no_grad():
+                mods[2].weight.neg_()  # a member's weight changes in place (version bump): the stacked operands are rebuilt
+            L.clear_activation_cache()
+            k_again = mods[1](inputs[1])
+            assert torch.equal(mods[2](inputs[2]), -alone[2]) and torch.equal(k_again, alone[1])
     L.LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
