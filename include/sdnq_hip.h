@@ -140,6 +140,12 @@ int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void* b, const f
                              int bias_dtype, void* const* outs, int n_outs, int64_t seg_n, int out_dtype, int64_t m, int64_t n,
                              int64_t k, sdnq_stream_t stream);
 
+/* the float GEMM of sdnq_hip_linear_float over the STACKED dequantized weights of layers that consume one activation, each
+ * layer's columns in its own contiguous tensor (the dequantize + F.linear mode of linked attention projections, layers/linear/
+ * forward.py:25-26 per layer): wd [n_outs * seg_n][K], bias NULL or [n_outs * seg_n], outs[i] [M][seg_n]; M > 32. */
+int sdnq_hip_linear_float_multi(const void* x, const void* wd, const void* bias, int dtype, void* const* outs, int n_outs,
+                                int64_t seg_n, int64_t m, int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream);
+
 /* ---- a4/a5/a6: dequantize ---------------------------------------------------------------------
  * replaces SDNQDequantizer.__call__ -> dequantize_weight (dequantizer.py:135-162, 389-429):
  * unpack -> f32(w)*scale | fma(f32(w),scale,zp) -> [+ svd_up@svd_down in svd dtype] -> cast ->

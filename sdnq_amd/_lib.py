@@ -27,7 +27,7 @@ EXPORTS = [
     "sdnq_hip_lowrank_down", "sdnq_hip_scaled_mm_lowrank", "sdnq_hip_linear_float", "sdnq_hip_linear_skinny",
     "sdnq_hip_quantize_weight", "sdnq_hip_im2col", "sdnq_hip_im2col_rowquant", "sdnq_hip_scaled_mm_nchw",
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
-    "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi",
+    "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
 ]
 
 
@@ -88,6 +88,7 @@ def _declare(lib):
     lib.sdnq_hip_linear_skinny_svd.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, i32, vp, i64, i64, vp]
     lib.sdnq_hip_linear_w8a8.argtypes = [i32, vp, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.sdnq_hip_scaled_mm_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_linear_float_multi.argtypes = [vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, i64, vp]
     lib.sdnq_hip_scaled_mm_nchw.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
     lib.sdnq_hip_im2col.argtypes = [vp, i32] + [i32] * 12 + [vp, vp]
     lib.sdnq_hip_im2col_rowquant.argtypes = [vp, i32] + [i32] * 12 + [i32, vp, vp, vp, vp]

@@ -634,7 +634,7 @@ extern "C" int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, s
 }
 
 int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,
-                    int64_t ldx, hipStream_t s);  // gemm.hip
+                    int64_t ldx, hipStream_t s, void* const* outs = nullptr, int n_outs = 0, int64_t seg_n = 0);  // gemm.hip
 
 extern "C" int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
                                      int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {

@@ -802,16 +802,33 @@ extern "C" int sdnq_hip_debug_trace(unsigned long long* host, int n_words) {
 
 // internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`
 int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,
-                    int64_t ldx, hipStream_t s) {
+                    int64_t ldx, hipStream_t s, void* const* outs = nullptr, int n_outs = 0, int64_t seg_n = 0) {
     const int eb = (dtype == SDNQ_F32) ? 4 : 2;
     GemmParams p{};
     p.a = (const uint8_t*)x; p.b = (const uint8_t*)w; p.bias = bias; p.out = out;
+    if (outs) {  // several output tensors, one per stacked layer (sdnq_hip_linear_float_multi)
+        for (int i = 0; i < n_outs; ++i) p.out_seg[i] = outs[i];
+        p.seg_n = seg_n;
+    }
     p.M = m; p.N = n; p.K = k * eb; p.lda = ldx * eb; p.ldb = k * eb; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = dtype;
 #define FG(MMV, T) (bias ? launch_tiles<MMV, T, EPI_BIAS1D>(p, s) : launch_tiles<MMV, T, EPI_NONE>(p, s))
     if (dtype == SDNQ_BF16) return FG(MM_BF16, SDNQ_BF16);
     if (dtype == SDNQ_F16) return FG(MM_F16, SDNQ_F16);
     return FG(MM_F32, SDNQ_F32);
 #undef FG
+}
+
+extern "C" int sdnq_hip_linear_float_multi(const void* x, const void* wd, const void* bias, int dtype, void* const* outs, int n_outs,
+                                           int64_t seg_n, int64_t m, int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {
+    if (!x || !wd || !outs) return SDNQ_ERR_NULL;
+    if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
+    if (n_outs < 1 || n_outs > 4 || seg_n <= 0 || seg_n % 8 || seg_n * n_outs != n) return SDNQ_ERR_SHAPE;
+    const int eb = (dtype == SDNQ_F32) ? 4 : 2;
+    if (m <= 32 || k <= 0 || ldx < k || ((k * eb) % 16) != 0) return SDNQ_ERR_SHAPE;  // few rows: the per-layer path
+    if (((uintptr_t)x % 16) || ((uintptr_t)wd % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
+    for (int i = 0; i < n_outs; ++i)
+        if (!outs[i] || (uintptr_t)outs[i] % 16) return outs[i] ? SDNQ_ERR_ALIGN : SDNQ_ERR_NULL;
+    return sdnq_float_gemm(x, wd, bias, dtype, outs[0], m, n, k, ldx, (hipStream_t)stream, outs, n_outs, seg_n);
 }
 
 extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,

@@ -170,6 +170,9 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
         if x2.stride(-1) != 1:
             x2 = x2.contiguous()
         return ops.linear_skinny_svd(st.qw, st.svd_down_t, x2, mod.bias).view(*input.shape[:-1], n)
+    group = mod.__dict__.get("_sdnq_group")
+    if group is not None and group[0].float_mode and LINK_PROJECTIONS and m > 32 and input.is_cuda and st.wd is None and n % 8 == 0:
+        return group[0].forward_float(mod, group[1], input)
     wd = st.wd
     if wd is None:
         wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)
@@ -228,8 +231,9 @@ class ProjectionGroup:
     the member computes alone (each output channel keeps its own scale and bias).  The stacked operand is a copy of the members'
     weights (the members themselves, their parameters and the state_dict are untouched)."""
 
-    def __init__(self, mods):
+    def __init__(self, mods, float_mode: bool = False):
         self.mods = list(mods)
+        self.float_mode = float_mode  # members run dequantize + F.linear (use_quantized_matmul=False) instead of the quantized matmul
         self.sig = None   # (matmul dtype, the members' weight / scale objects and versions the stacked operands were built from)
         self.wq = self.ws = self.bias = None
         self.last = None  # (input tensor, its version, stream, outputs, indices not handed out yet)
@@ -273,6 +277,33 @@ class ProjectionGroup:
         return y
 
 
+    def forward_float(self, mod, idx: int, input: torch.Tensor):
+        """The dequantize + F.linear mode (use_quantized_matmul=False, M > 32): every member is dequantized into its slab of ONE
+        [sum N][K] buffer (as many dequantize launches as before), then one float GEMM writes the members' outputs."""
+        stream = ops._stream(input)
+        last = self.last
+        if last is None or last[0] is not input or last[1] != input._version or last[2] != stream or idx not in last[4]:
+            dq = mod.sdnq_dequantizer
+            k, n = dq.in_features, dq.out_features
+            x2 = input.reshape(-1, k)
+            if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+                x2 = x2.contiguous()
+            g = len(self.mods)
+            wd = torch.empty((g * n, k), device=input.device, dtype=input.dtype)
+            for i, m in enumerate(self.mods):
+                d = m.sdnq_dequantizer
+                ops.dequant(_state(m).qw, input.dtype, d.hadamard_group_size if d.use_hadamard else 0, out=wd[i * n:(i + 1) * n])
+            biases = [_attr(m, "bias") for m in self.mods]
+            bias = None if biases[0] is None else torch.cat(biases, dim=0)
+            outs = ops.linear_float_multi(x2, wd, bias, g)
+            last = self.last = (input, input._version, stream, outs, set(range(g)))
+        y = last[3][idx].view(*input.shape[:-1], -1)
+        last[4].discard(idx)
+        if not last[4]:
+            self.last = None
+        return y
+
+
 LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
 
 
@@ -284,7 +315,7 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     if m == 0 or (small_batch_branch and m < 32):  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
         return _float_forward(self, input, st)
     group = self.__dict__.get("_sdnq_group")
-    if group is not None and LINK_PROJECTIONS and input.is_cuda:
+    if group is not None and not group[0].float_mode and LINK_PROJECTIONS and input.is_cuda:
         y = group[0].forward(self, group[1], input, mm)
         if y is not None:
             return y

@@ -65,12 +65,15 @@ def link_layers(mods) -> bool:
     """Make `mods` (layers that consume the same tensor) a ``linear.ProjectionGroup`` if their configuration allows it."""
     from .linear import ProjectionGroup
     mods = list(mods)
-    if len(mods) < 2 or len(mods) > 4 or not _fusable(mods):
+    if len(mods) < 2 or len(mods) > 4:
+        return False
+    float_mode = _float_linkable(mods)
+    if not float_mode and not _fusable(mods):
         return False
     d0 = mods[0].sdnq_dequantizer
     if any(m.sdnq_dequantizer.out_features != d0.out_features for m in mods) or d0.out_features % 8:
         return False
-    group = ProjectionGroup(mods)
+    group = ProjectionGroup(mods, float_mode=float_mode)
     for i, m in enumerate(mods):
         m.__dict__["_sdnq_group"] = (group, i)
     return True
@@ -93,6 +96,18 @@ def link_projections(model: torch.nn.Module) -> int:
             elif link_layers([k, v]):
                 count += 1
     return count
+
+
+def _float_linkable(mods) -> bool:
+    """Layers in the dequantize + F.linear mode (use_quantized_matmul=False) of equal in_features and result dtype: any weight
+    format works, the members are dequantized side by side and share one float GEMM."""
+    dqs = [getattr(m, "sdnq_dequantizer", None) for m in mods]
+    if any(d is None for d in dqs) or not all(is_hot_path_linear(m) for m in mods):
+        return False
+    d0 = dqs[0]
+    if any(d.use_quantized_matmul or d.in_features != d0.in_features or d.result_dtype != d0.result_dtype for d in dqs):
+        return False
+    return len({m.bias is None for m in mods}) == 1
 
 
 def _fusable(mods) -> bool:

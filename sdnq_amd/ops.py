@@ -222,6 +222,19 @@ def scaled_mm_multi(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Te
     return outs
 
 
+def linear_float_multi(x2d: torch.Tensor, wd: torch.Tensor, bias, n_outs: int):
+    """F.linear over the stacked dequantized weights of `n_outs` layers, one contiguous output per layer (M > 32)."""
+    _require_cuda(x2d, wd)
+    m, k = x2d.shape
+    n = wd.shape[0]
+    seg = n // n_outs
+    outs = [torch.empty((m, seg), device=x2d.device, dtype=x2d.dtype) for _ in range(n_outs)]
+    ptrs = (ctypes.c_void_p * n_outs)(*[o.data_ptr() for o in outs])
+    check(_lib.load().sdnq_hip_linear_float_multi(x2d.data_ptr(), wd.data_ptr(), _ptr(bias), float_code(x2d.dtype), ptrs, n_outs, seg,
+                                                  m, n, k, x2d.stride(0), _stream(x2d)), "linear_float_multi")
+    return outs
+
+
 def linear_w8a8(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype, hadamard_group: int = 0):
     """rowquant + scaled_mm through ONE binding call (two launches) -> (out [M,N], xq [M,K], xs [M,1])."""
     m, k = x2d.shape
@@ -277,9 +290,10 @@ def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, 
     return out
 
 
-def dequant(qw: QuantWeight, out_dtype: torch.dtype, hadamard_group: int = 0, use_svd: bool = True) -> torch.Tensor:
+def dequant(qw: QuantWeight, out_dtype: torch.dtype, hadamard_group: int = 0, use_svd: bool = True, out: torch.Tensor | None = None) -> torch.Tensor:
     dev = qw.keep[0].device
-    out = torch.empty((qw.n, qw.k), device=dev, dtype=out_dtype)
+    if out is None:
+        out = torch.empty((qw.n, qw.k), device=dev, dtype=out_dtype)
     d = qw.desc
     if not use_svd and d.svd_up:
         d = SdnqWeight.from_buffer_copy(bytes(d))

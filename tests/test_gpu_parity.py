@@ -878,3 +878,42 @@ def test_linked_projections_are_transparent(gpu_device):
             k_again = mods[1](inputs[1])
             assert torch.equal(mods[2](inputs[2]), -alone[2]) and torch.equal(k_again, alone[1])
     L.LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
+
+
+def test_linked_projections_float_mode(gpu_device):
+    """use_quantized_matmul=False (the reference's default): linked to_q / to_k / to_v are dequantized side by side into one buffer
+    and share ONE float GEMM (sdnq_hip_linear_float_multi); the weights fed to it are the members' dequantized weights bit for bit,
+    so each output equals the member's own dequantize + F.linear up to the fp32 accumulation order of a different tile choice."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+
+    class Attn(torch.nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            self.to_q, self.to_k, self.to_v = (torch.nn.Linear(c, c, bias=True) for _ in range(3))
+
+    torch.manual_seed(3)
+    old = L.LINK_PROJECTIONS
+    try:
+        for wd, dt in (("int8", torch.bfloat16), ("uint4", torch.float16), ("int6", torch.bfloat16)):
+            blk = Attn(256).to(dt).to(gpu_device)
+            for name in ("to_q", "to_k", "to_v"):
+                setattr(blk, name, sdnq_amd.sdnq_quantize_layer(getattr(blk, name), sdnq_amd.SDNQConfig(weights_dtype=wd, use_quantized_matmul=False))[0])
+            mods = [blk.to_q, blk.to_k, blk.to_v]
+            x = torch.randn(3, 50, 256, device=gpu_device, dtype=dt)
+            L.LINK_PROJECTIONS = False
+            alone = [m(x).clone() for m in mods]
+            L.LINK_PROJECTIONS = True
+            assert sdnq_amd.link_projections(blk) == 1 and blk.to_q.__dict__["_sdnq_group"][0].float_mode
+            outs = [m(x) for m in mods]
+            group = blk.to_q.__dict__["_sdnq_group"][0]
+            assert group.last is None
+            ulp = 2.0 ** (-8 if dt == torch.bfloat16 else -11)
+            for o, a in zip(outs, alone):
+                assert o.shape == a.shape and o.is_contiguous()
+                assert (o.float() - a.float()).abs().max() <= 2 * ulp * a.float().abs().max(), wd
+                assert (o != a).float().mean() < 0.05, wd
+            small = torch.randn(4, 256, device=gpu_device, dtype=dt)
+            assert torch.equal(mods[0](small), (lambda: (setattr(L, "LINK_PROJECTIONS", False), mods[0](small), setattr(L, "LINK_PROJECTIONS", True))[1])())
+    finally:
+        L.LINK_PROJECTIONS = old

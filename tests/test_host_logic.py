@@ -102,9 +102,12 @@ def test_link_projections_wiring():
     cross = quantized(Attn(64, 96), **row)
     assert sdnq_amd.link_projections(cross) == 1
     assert "_sdnq_group" not in cross.to_q.__dict__ and len(cross.to_k.__dict__["_sdnq_group"][0].mods) == 2
-    # group-wise sub-byte weights are re-quantized per layer, a dequantize-mode layer has no quantized matmul: not linked
+    # group-wise sub-byte weights with a quantized matmul are re-quantized per layer: not linked
     assert sdnq_amd.link_projections(quantized(Attn(64, 0), weights_dtype="uint4", use_quantized_matmul=True)) == 0
-    assert sdnq_amd.link_projections(quantized(Attn(64, 0), weights_dtype="int8", group_size=-1, use_quantized_matmul=False)) == 0
+    # dequantize-mode layers (the reference's default) link in float mode, whatever the weight format
+    deq = quantized(Attn(64, 0), weights_dtype="uint4", use_quantized_matmul=False)
+    assert sdnq_amd.link_projections(deq) == 1 and deq.to_q.__dict__["_sdnq_group"][0].float_mode
+    assert not blk.to_q.__dict__["_sdnq_group"][0].float_mode
     # accelerate() re-links from scratch and honours the switch
     from sdnq_amd import linear as L
     old = L.LINK_PROJECTIONS
