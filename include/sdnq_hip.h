@@ -140,6 +140,33 @@ int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void* b, const f
                              int bias_dtype, void* const* outs, int n_outs, int64_t seg_n, int out_dtype, int64_t m, int64_t n,
                              int64_t k, sdnq_stream_t stream);
 
+/* ---- grouped scaled matmul: many layers that consume ONE activation, no stacked weight copy ------------------------------
+ * The same arithmetic as sdnq_hip_scaled_mm, per layer (int_scaled_mm_func per layer, kernel_wrappers.py:193-204), for layers
+ * whose inputs are the very same tensor: to_q / to_k / to_v of a self-attention block, or every cross-attention to_k / to_v of a
+ * UNet step (all 140 of SDXL read the one encoder_hidden_states).  One launch, one pass over the quantized activation, and the
+ * weights are read where the layers' own parameters live: the output channels of all layers are cut into UNITS of `unit_n`
+ * channels (unit_n divides every layer's N; unit_n % 64 == 0) and `units` -- a DEVICE-resident table, one entry per unit, built
+ * once per group -- says where each unit's weight rows, scales and bias are.
+ * Output: ONE buffer `out` of M * (n_units * unit_n) elements; the layer that starts at channel n_start and has n_seg channels
+ * owns the contiguous [M][n_seg] matrix at element offset M * n_start.
+ * bias_dtype < 0: no layer has a bias (SdnqGemmUnit.bias ignored), else every layer has one of that dtype. */
+typedef struct SdnqGemmUnit {
+    const void* b;     /* weight rows [unit_n][K] of this unit (physical [N][K] layout, K contiguous) */
+    const float* sb;   /* [unit_n] weight scales */
+    const void* bias;  /* [unit_n] bias elements or NULL */
+    int64_t n_start;   /* first output channel of the LAYER this unit belongs to, in the concatenated channel order */
+    int32_t n_seg;     /* channels of that layer */
+    int32_t n_loc;     /* first channel of this unit inside its layer */
+} SdnqGemmUnit;
+int sdnq_hip_scaled_mm_grouped(int mm_dtype, const void* a, const float* sa, const SdnqGemmUnit* units, int64_t n_units,
+                               int64_t unit_n, int bias_dtype, void* out, int out_dtype, int64_t m, int64_t k,
+                               sdnq_stream_t stream);
+
+/* Tuning hook (development / benchmarking only, process-wide): force the GEMM tile configuration of every following scaled
+ * matmul launch (ids: sdnq_amd/csrc/gemm.hip, launch_tiles); < 0 restores the built-in shape heuristics.  Never needed for
+ * correct results -- every configuration produces identical outputs. */
+void sdnq_hip_set_tile_override(int tile_id);
+
 /* the float GEMM of sdnq_hip_linear_float over the STACKED dequantized weights of layers that consume one activation, each
  * layer's columns in its own contiguous tensor (the dequantize + F.linear mode of linked attention projections, layers/linear/
  * forward.py:25-26 per layer): wd [n_outs * seg_n][K], bias NULL or [n_outs * seg_n], outs[i] [M][seg_n]; M > 32. */

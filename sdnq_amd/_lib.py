@@ -28,6 +28,7 @@ EXPORTS = [
     "sdnq_hip_quantize_weight", "sdnq_hip_im2col", "sdnq_hip_im2col_rowquant", "sdnq_hip_scaled_mm_nchw",
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
+    "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override",
 ]
 
 
@@ -40,6 +41,12 @@ class SdnqWeight(ctypes.Structure):
         ("exponent", ctypes.c_int32), ("mantissa", ctypes.c_int32), ("native_float", ctypes.c_int32),
         ("positions", ctypes.c_int32),
     ]
+
+
+class SdnqGemmUnit(ctypes.Structure):
+    """One unit of output channels of a grouped scaled matmul (include/sdnq_hip.h); the table lives in DEVICE memory."""
+    _fields_ = [("b", ctypes.c_void_p), ("sb", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("n_start", ctypes.c_int64),
+                ("n_seg", ctypes.c_int32), ("n_loc", ctypes.c_int32)]
 
 
 class SdnqHipError(RuntimeError):
@@ -88,6 +95,9 @@ def _declare(lib):
     lib.sdnq_hip_linear_skinny_svd.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, i32, vp, i64, i64, vp]
     lib.sdnq_hip_linear_w8a8.argtypes = [i32, vp, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.sdnq_hip_scaled_mm_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_set_tile_override.argtypes = [i32]
+    lib.sdnq_hip_set_tile_override.restype = None
+    lib.sdnq_hip_scaled_mm_grouped.argtypes = [i32, vp, vp, vp, i64, i64, i32, vp, i32, i64, i64, vp]
     lib.sdnq_hip_linear_float_multi.argtypes = [vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, i64, vp]
     lib.sdnq_hip_scaled_mm_nchw.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
     lib.sdnq_hip_im2col.argtypes = [vp, i32] + [i32] * 12 + [vp, vp]
@@ -95,7 +105,7 @@ def _declare(lib):
     lib.sdnq_hip_attn_prepare.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.sdnq_hip_attn_fwd.argtypes = [vp, vp, vp, vp, vp, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp] + [i64] * 6 + [vp]
     for name in EXPORTS:
-        if name not in ("sdnq_hip_strerror",):
+        if name not in ("sdnq_hip_strerror", "sdnq_hip_set_tile_override"):
             getattr(lib, name).restype = c.c_int
 
 

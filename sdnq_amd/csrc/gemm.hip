@@ -73,10 +73,26 @@ struct GemmParams {
     // its own [M][seg_n] tensor): channel n goes to out_seg[n / seg_n]; seg_n % 8 == 0, so a 16-byte piece never straddles tensors
     void* out_seg[4];
     int64_t seg_n;  // 0: single output p.out
+    // grouped launch (sdnq_hip_scaled_mm_grouped): the output channels are cut into units of unit_n channels, each with its own
+    // weight rows / scales / bias (the layers' own parameters, no stacked copy); BN divides unit_n, so a tile lies inside one unit
+    const SdnqGemmUnit* units;  // device table or null
+    int64_t unit_n;
 };
 
-__device__ __forceinline__ uint8_t* out_piece(const GemmParams& p, int64_t gm, int64_t gn0, int out_b) {
-    if (p.seg_n == 0) return (uint8_t*)p.out + (gm * p.N + gn0) * out_b;
+// Where one workgroup's BN output channels live: weight rows, per-channel vectors and the output matrix they belong to.
+struct TileView {
+    const uint8_t* b;      // weight row of the tile's first channel
+    const float* sb;       // its scale
+    const void* bias;      // 1-D bias vector the tile indexes with bias0 + i
+    int64_t bias0;
+    uint8_t* out;          // &out_matrix[0][first channel of the tile]
+    int64_t out_ld;        // channels per row of that matrix
+    int64_t n_lim;         // valid channels from the tile's first one (may exceed BN)
+};
+
+// address of output row gm, channel `c` of the tile (global channel gn0 = n0 + c)
+__device__ __forceinline__ uint8_t* out_piece(const GemmParams& p, const TileView& tv, int64_t gm, int64_t gn0, int c, int out_b) {
+    if (p.seg_n == 0) return tv.out + (gm * tv.out_ld + c) * out_b;
     const int64_t seg = gn0 / p.seg_n;
     return (uint8_t*)p.out_seg[seg] + (gm * p.seg_n + (gn0 - seg * p.seg_n)) * out_b;
 }
@@ -210,7 +226,13 @@ template <> struct FragOps<SDNQ_MM_FP8> {
 //            ks run, the fragments of sub-step ks+1 (or of the next stage, right after the barrier) are already being
 //            read into the other of two fragment sets, so neither the LDS latency nor the two waves of a SIMD reading
 //            LDS in lock-step after every barrier leave the matrix pipe idle.
-enum { LD_DMA = 0, LD_PIPE = 2 };
+//   LD_PP  : the LD_DMA ring driven PING-PONG by the two halves of an 8-wave workgroup (waves 0-3 / 4-7: wave w and wave w+4
+//            sit on the same SIMD).  Each half alternates a LOAD phase (all LDS->register fragment reads of one K stage, its
+//            share of the LDS-DMA issue for the stage NS-1 ahead, counted vmcnt) with an MFMA phase (the stage's matrix
+//            instructions back to back at raised priority), the second half running one phase behind the first, one raw
+//            s_barrier per phase: while one wave of a SIMD feeds the matrix pipe, its partner does the issue-heavy work
+//            (an LDS-DMA costs its wave ~60-180 issue cycles) that in the lock-step schedules above leaves the pipe idle.
+enum { LD_DMA = 0, LD_PIPE = 2, LD_PP = 3 };
 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
@@ -264,6 +286,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     }
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const int K = (int)p.K;
+    TileView tv;
+    if (p.units != nullptr) {  // grouped launch: this tile lies inside ONE unit of one layer (BN divides unit_n); wave-uniform loads
+        const int64_t u = n0 / p.unit_n, d = n0 - u * p.unit_n;
+        const SdnqGemmUnit un = p.units[u];
+        tv.b = (const uint8_t*)un.b + d * p.ldb;
+        tv.sb = un.sb + d;
+        tv.bias = un.bias;
+        tv.bias0 = d;
+        tv.out_ld = un.n_seg;
+        tv.out = (uint8_t*)p.out + (p.M * un.n_start + un.n_loc + d) * OUT_B;
+        tv.n_lim = p.unit_n - d;
+    } else {
+        tv.b = p.b + n0 * p.ldb;
+        tv.sb = p.sb + n0;
+        tv.bias = p.bias;
+        tv.bias0 = n0;
+        tv.out_ld = p.N;
+        tv.out = (uint8_t*)p.out + n0 * OUT_B;
+        tv.n_lim = p.N - n0;
+    }
 
     // ---- LDS-DMA assignment: piece = 8 tile rows x 128 B; lane l -> row l/8, physical chunk l%8 ----------------
     // wave w owns A pieces w, w+NW, ... and B pieces w, w+NW, ...; the source chunk is the swizzle-inverse of the
@@ -277,10 +319,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int piece = (isA ? i : i - A_PIECES) * NW + wave;
         const int r = piece * RPP + r8;
         const int c = chunk_of(r);
-        int64_t g = (isA ? m0 : n0) + r;
-        const int64_t lim = isA ? p.M : p.N;
-        if (g >= lim) g = lim - 1;  // clamp: rows past the edge are computed on valid memory and never stored
-        src[i] = (isA ? p.a + g * p.lda : p.b + g * p.ldb) + c * 16;
+        // clamp: rows past the edge are computed on valid memory and never stored
+        if (isA) {
+            int64_t g = m0 + r;
+            if (g >= p.M) g = p.M - 1;
+            src[i] = p.a + g * p.lda + c * 16;
+        } else {
+            const int64_t g = r < tv.n_lim ? r : tv.n_lim - 1;
+            src[i] = tv.b + g * p.ldb + c * 16;
+        }
     }
     // logical K offset (bytes) of this lane's chunk: the swizzle only depends on (piece*8 + r8) >> 1, and piece*8 is a
     // multiple of 8, so the chunk is the same for every piece of an operand up to the parity of piece*4 -- NW is even,
@@ -321,10 +368,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // per-output-channel epilogue vectors -> LDS once per workgroup (after the DMA prologue so its load latency hides
     // under it; visible after the first barrier of the K loop)
     for (int i = tid; i < BN; i += NT) {
-        int64_t gn = n0 + i;
-        if (gn >= p.N) gn = p.N - 1;
-        if constexpr (!is_float_mm<MM>) s_sb[i] = p.sb[gn];
-        if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = p.bias ? ldf_rt(p.bias, gn, p.bias_dtype) : 0.0f;
+        const int64_t li = i < tv.n_lim ? i : tv.n_lim - 1;  // channel inside the tile, clamped to the last valid one
+        const int64_t gn = n0 + li;
+        if constexpr (!is_float_mm<MM>) s_sb[i] = tv.sb[li];
+        if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = tv.bias ? ldf_rt(tv.bias, tv.bias0 + li, p.bias_dtype) : 0.0f;
         if constexpr (EPI == EPI_LOWRANK) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
     }
 
@@ -400,6 +447,59 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 mma_set(std::integral_constant<int, cur>{});
             });
         }
+    } else if constexpr (LD == LD_PP) {
+        static_assert(NW == 8, "ping-pong schedule: two halves of four waves");
+        typedef typename FragOps<MM>::frag_t frag_t;
+        constexpr int KS = BK / MT::KB;
+        constexpr int INFLIGHT = (AHEAD - 1) * PPW;  // DMA pieces of the younger stages that may stay in flight at a wait
+        frag_t fa[KS][TM], fb[KS][TN];
+        const int half = __builtin_amdgcn_readfirstlane(wave >> 2);
+        // Time is cut into slots by workgroup-wide barriers.  Half 0 runs LOAD(j) in slot 2j and MFMA(j) in slot 2j+1, half 1
+        // LOAD(j) in slot 2j+1 and MFMA(j) in slot 2j+2.
+        //   RAW: stage j is first read in slot 2j; every wave waits for ITS pieces of stage j (counted vmcnt) before the barrier
+        //        that ends slot 2j-1 (half 0: end of MFMA(j-1); half 1: end of LOAD(j-1)).
+        //   WAR: the DMA for stage j+AHEAD overwrites the ring slot of stage j-1; it is issued in LOAD(j) (slots 2j / 2j+1), after
+        //        the barrier that ends slot 2j-1, by which time both halves have finished reading stage j-1 (lgkmcnt(0) before
+        //        the barrier that ends a LOAD phase).
+        wait_vmcnt<INFLIGHT>();  // own pieces of stage 0 (stages 1..AHEAD-1 stay in flight)
+        __builtin_amdgcn_s_barrier();
+        if (half == 1) __builtin_amdgcn_s_barrier();  // the stagger: half 1 sits out slot 0
+#pragma nounroll
+        for (int kt = 0; kt < nk; ++kt) {
+            // ---- LOAD(kt)
+            issue(kt + AHEAD);
+            {
+                const uint8_t* sA = lds + slot_c * STAGE_BYTES;
+                const uint8_t* sB = sA + BM * BK;
+                slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template load<BK>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
+                }
+            }
+            if (half == 1) wait_vmcnt<INFLIGHT>();  // own pieces of stage kt+1, read by half 0 in the next slot
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA(kt)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j]);
+            __builtin_amdgcn_s_setprio(0);
+            if (half == 0) wait_vmcnt<INFLIGHT>();  // own pieces of stage kt+1, read by this half right after the barrier
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (half == 0) __builtin_amdgcn_s_barrier();  // matches half 1's extra barrier at the start
     } else if constexpr (LD == LD_DMA) {
         // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
         // single raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs.
@@ -518,7 +618,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int v = tid; v < CH * G8; v += NT) {
         const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
         const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c8;
-        if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a group of 8 never straddles N
+        if (gm >= p.M || c8 >= tv.n_lim) continue;  // N % 8 == 0: a group of 8 never straddles N
         const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
         float zsum = 0.0f, azp = 0.0f;
         if constexpr (EPI == EPI_LOWRANK) {
@@ -596,7 +696,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 o[4 * h + e] = res;
             }
         }
-        uint8_t* dst = out_piece(p, gm, gn0, OUT_B);
+        uint8_t* dst = out_piece(p, tv, gm, gn0, c8, OUT_B);
         if constexpr (OUT_T == SDNQ_F32) {
             *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
             *(uint4*)(dst + 16) = Vec16<SDNQ_F32>::pack(o + 4);
@@ -690,8 +790,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int v = tid; v < CH * PPR; v += NT) {
         const int r = v / PPR, c = v % PPR;
         const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c * EPP;
-        if (gm >= p.M || gn0 >= p.N) continue;  // N % 8 == 0: a piece never straddles N
-        *(uint4*)out_piece(p, gm, gn0, OUT_B) = *(const uint4*)(stage + r * OUT_ROW + c * 16);
+        if (gm >= p.M || c * EPP >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
+        *(uint4*)out_piece(p, tv, gm, gn0, c * EPP, OUT_B) = *(const uint4*)(stage + r * OUT_ROW + c * 16);
     }
     });
     }
@@ -733,14 +833,39 @@ int launch_one(GemmParams p, hipStream_t s) {
 // Tile choice. The chip has 256 CUs and the LDS-DMA latency is ~1 us, so what matters for diffusion-size GEMMs
 // (1-30 GOP, a few hundred tiles) is (a) enough workgroups to touch every CU and (b) as many bytes in flight per CU
 // as the 160 KB LDS allows: every configuration uses a ring deep enough to fill most of the LDS of its CU.
+// Tile override for tuning sweeps: environment SDNQ_HIP_TILE at first use, or sdnq_hip_set_tile_override() at run time.
+std::atomic<int> g_forced_tile{-2};
+inline int forced_tile() {
+    int f = g_forced_tile.load(std::memory_order_relaxed);
+    if (f == -2) {
+        const char* e = getenv("SDNQ_HIP_TILE");
+        f = e ? atoi(e) : -1;
+        g_forced_tile.store(f, std::memory_order_relaxed);
+    }
+    return f;
+}
+
+// the ping-pong configurations exist for the quantized matmuls with the plain epilogues and 16-bit outputs (the model paths)
+template <int MM, int OUT_T, int EPI> constexpr bool PP_OK = !is_float_mm<MM> && EPI <= EPI_BIAS1D && OUT_T != SDNQ_F32;
+
 template <int MM, int OUT_T, int EPI>
 int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    static const int force = [] { const char* e = getenv("SDNQ_HIP_TILE"); return e ? atoi(e) : -1; }();  // tuning aid
+    const int force = forced_tile();  // tuning aid
     if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
     if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
     if (force == 3) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
+    if constexpr (PP_OK<MM, OUT_T, EPI>) {
+        if (force == 4) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PP, 64>(p, s);
+        if (force == 5) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PP, 64>(p, s);
+        if (force == 6) return launch_one<MM, OUT_T, EPI, 128, 256, 64, 64, 4, LD_PP, 64>(p, s);
+        if (force == 7) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PP, 128>(p, s);
+        if (force == 8) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4, LD_PP, 64>(p, s);
+        if (force == 9) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_PP, 128>(p, s);
+        if (force == 10) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4, LD_PIPE, 64>(p, s);
+        if (force == 11) return launch_one<MM, OUT_T, EPI, 128, 256, 64, 64, 3, LD_PP, 64>(p, s);
+    }
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt). Every kernel launch starts with cold
     // L2s (data comes from MALL/HBM at ~2 us loaded latency) and the L2->LDS fill rate per CU is ~30 B/clk, so:
     //  * large problems: 256x256 tiles (8 waves of 128x64, 64-byte K stages, 4-deep ring) -- twice the MACs per byte
@@ -751,12 +876,21 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     // Deeper rings for the 64x128 tiles (5-6 stages, one workgroup per CU) measured 5-30 % slower than 3 stages x 2 workgroups.
     // Software-pipelined fragment reads (LD_PIPE) measured +3..9 % on the 256x256 tiles and +8 % on the 64x64 ones, -1.5 % on
     // the SDXL step for the 64x128 tiles (one MFMA per sub-step leaves nothing to hide behind), so those keep LD_DMA.
-    if (tiles(256, 256) >= 200) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    auto fits = [&](int bn) { return p.units == nullptr || (p.unit_n % bn) == 0; };  // grouped launch: a tile stays inside one unit
+    if (tiles(256, 256) >= 200 && fits(256)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
     //  * tall problems that cannot fill the chip with 256x256 tiles (conv GEMMs 16384 x 320 x 2880..8640, 4096 x 5120 x 640):
     //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
-    if (p.M >= 2048 && tiles(256, 128) >= 150) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
-    if (p.M > 128) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
+    if (p.M >= 2048 && tiles(256, 128) >= 150 && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
+    if (p.M > 128 && fits(128)) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
+}
+
+// development override SDNQ_HIP_TILE with a grouped launch: refuse tiles that do not divide the unit
+inline bool force_tile_unfit(const GemmParams& p) {
+    const int force = forced_tile();
+    if (force < 0 || p.units == nullptr) return false;
+    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256};
+    return force < (int)(sizeof(bn_of) / sizeof(int)) ? (p.unit_n % bn_of[force]) != 0 : false;
 }
 
 template <int MM, int EPI>
@@ -790,6 +924,8 @@ int check_common(int mm_dtype, const void* a, const void* b, const float* sa, co
 }
 
 }  // namespace
+
+extern "C" void sdnq_hip_set_tile_override(int tile_id) { g_forced_tile.store(tile_id < 0 ? -1 : tile_id, std::memory_order_relaxed); }
 
 #ifdef SDNQ_TRACE
 extern "C" int sdnq_hip_debug_trace(unsigned long long* host, int n_words) {
@@ -865,6 +1001,24 @@ extern "C" int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void*
     p.seg_n = seg_n;
     p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias ? bias_dtype : out_dtype;
     hipStream_t s = (hipStream_t)stream;
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);
+}
+
+extern "C" int sdnq_hip_scaled_mm_grouped(int mm_dtype, const void* a, const float* sa, const SdnqGemmUnit* units, int64_t n_units,
+                                          int64_t unit_n, int bias_dtype, void* out, int out_dtype, int64_t m, int64_t k,
+                                          sdnq_stream_t stream) {
+    if (!units) return SDNQ_ERR_NULL;
+    if (n_units <= 0 || unit_n <= 0 || (unit_n % 64) != 0) return SDNQ_ERR_SHAPE;  // the smallest tile is 64 channels wide
+    // `units` is device memory: its b / sb pointers cannot be checked here; check_common sees a / sa / out and the shapes
+    int st = check_common(mm_dtype, a, a, sa, sa, out, out_dtype, m, n_units * unit_n, k);
+    if (st != SDNQ_OK) return st;
+    if (bias_dtype > 2) return SDNQ_ERR_DTYPE;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.sa = sa; p.out = out; p.units = units; p.unit_n = unit_n;
+    p.M = m; p.N = n_units * unit_n; p.K = k; p.bias_ndim = bias_dtype >= 0 ? 1 : 0; p.bias_dtype = bias_dtype >= 0 ? bias_dtype : out_dtype;
+    hipStream_t s = (hipStream_t)stream;
+    if (force_tile_unfit(p)) return SDNQ_ERR_SHAPE;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);
 }

@@ -222,6 +222,75 @@ def scaled_mm_multi(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Te
     return outs
 
 
+class GemmGroup:
+    """Device-resident unit table of a grouped scaled matmul (sdnq_hip_scaled_mm_grouped): the output channels of several layers
+    that consume ONE activation, cut into units of `unit_n` channels that point at the layers' own weight / scale / bias tensors
+    (no stacked copy).  `members`: [(wq [N_i, K] int8 | fp8 physical, ws [N_i] f32, bias [N_i] | None)], all with one K."""
+
+    def __init__(self, members):
+        import math
+        import numpy as np
+        ns = [int(w.shape[0]) for (w, _, _) in members]
+        unit = 0
+        for n in ns:
+            unit = math.gcd(unit, n)
+        if unit % 64:
+            raise _lib.SdnqHipError(f"grouped matmul needs layer widths with a common divisor that is a multiple of 64 (got {ns})")
+        while unit > 2048 and unit % 128 == 0:  # keep units tile-sized multiples; any divisor of the gcd works
+            unit //= 2
+        has_bias = members[0][2] is not None
+        if any((b is not None) != has_bias for (_, _, b) in members):
+            raise _lib.SdnqHipError("grouped matmul: either every layer has a bias or none has")
+        self.k = int(members[0][0].shape[1])
+        self.keep = []  # the tensors the table points into
+        rows = []
+        n_start = 0
+        for (w, ws, bias) in members:
+            _require_cuda(w, ws, bias)
+            n = int(w.shape[0])
+            if w.shape[1] != self.k or not w.is_contiguous() or w.element_size() != 1:
+                raise _lib.SdnqHipError("grouped matmul: weights must be contiguous [N, K] 1-byte operands of one K")
+            ws = ws.reshape(-1)
+            if ws.dtype != torch.float32 or not ws.is_contiguous() or ws.numel() != n:
+                raise _lib.SdnqHipError("grouped matmul: scales must be contiguous float32 [N]")
+            if bias is not None:
+                bias = bias.contiguous()
+                if bias.dtype != members[0][2].dtype:
+                    raise _lib.SdnqHipError("grouped matmul: one bias dtype per group")
+            self.keep.append((w, ws, bias))
+            for loc in range(0, n, unit):
+                rows.append((w.data_ptr() + loc * self.k, ws.data_ptr() + 4 * loc,
+                             0 if bias is None else bias.data_ptr() + loc * bias.element_size(), n_start, n, loc))
+            n_start += n
+        dt = np.dtype([("b", "<u8"), ("sb", "<u8"), ("bias", "<u8"), ("n_start", "<i8"), ("n_seg", "<i4"), ("n_loc", "<i4")])
+        assert dt.itemsize == ctypes.sizeof(_lib.SdnqGemmUnit)
+        table = np.array(rows, dtype=dt)
+        self.device = members[0][0].device
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(self.device)
+        self.n_units, self.unit_n, self.n_total = len(rows), unit, n_start
+        self.widths = ns
+        self.bias_dtype = float_code(members[0][2].dtype) if has_bias else -1
+        self.mm_torch = members[0][0].dtype
+
+
+def scaled_mm_grouped(mm: int, a: torch.Tensor, sa: torch.Tensor, group: GemmGroup, out_dtype: torch.dtype):
+    """One launch for every layer of `group` on the shared quantized activation a [M, K]; returns one contiguous [M, N_i] tensor
+    per layer (views of ONE allocation), each bit-identical to scaled_mm on that layer alone."""
+    _require_cuda(a, sa)
+    m, k = a.shape
+    if k != group.k:
+        raise _lib.SdnqHipError(f"grouped matmul: activation has K={k}, the group K={group.k}")
+    out = torch.empty((m * group.n_total,), device=a.device, dtype=out_dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_grouped(mm, a.data_ptr(), sa.data_ptr(), group.table.data_ptr(), group.n_units, group.unit_n,
+                                                 group.bias_dtype, out.data_ptr(), float_code(out_dtype), m, k, _stream(a)),
+          "scaled_mm_grouped")
+    outs, start = [], 0
+    for n in group.widths:
+        outs.append(out[m * start:m * (start + n)].view(m, n))
+        start += n
+    return outs
+
+
 def linear_float_multi(x2d: torch.Tensor, wd: torch.Tensor, bias, n_outs: int):
     """F.linear over the stacked dequantized weights of `n_outs` layers, one contiguous output per layer (M > 32)."""
     _require_cuda(x2d, wd)
