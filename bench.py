@@ -167,20 +167,17 @@ def fuse_shared_input_layers(layers):
 
 
 def link_shared_input_layers(layers):
-    """What sdnq_amd.accelerate(model) does to a diffusers model (loader.link_projections): the attention projections of one block
-    that consume the SAME tensor (self-attention to_q / to_k / to_v, cross-attention to_k / to_v) become a ProjectionGroup -- the
-    modules and their outputs stay what they were, the first one called runs one scaled matmul for all of them."""
+    """What sdnq_amd.accelerate(model) does to a diffusers model (loader.link_projections): the attention projections that consume
+    the SAME tensor become a ProjectionGroup -- to_q / to_k / to_v of each self-attention block, and ALL cross-attention to_k /
+    to_v of the model (every one of them reads the one encoder_hidden_states tensor) as one model-wide group.  The modules and
+    their outputs stay what they were; the first member called in a step runs one grouped scaled matmul for all of them."""
     import sdnq_amd
-    n, i = 0, 0
     is_proj = lambda nm: any(t in nm for t in (".to_q", ".to_k", ".to_v"))  # noqa: E731
-    while i < len(layers):
-        j = i + 1
-        while j < len(layers) and layers[j][2] is layers[i][2] and j - i < 3 and is_proj(layers[i][0]) and is_proj(layers[j][0]):
-            j += 1
-        if j - i > 1 and sdnq_amd.link_layers([l[1] for l in layers[i:j]]):
-            n += 1
-        i = j
-    return n
+    by_input = {}
+    for l in layers:
+        if is_proj(l[0]):
+            by_input.setdefault(id(l[2]), []).append(l[1])
+    return sum(1 for mods in by_input.values() if len(mods) > 1 and sdnq_amd.link_layers(mods))
 
 
 def run_step(layers):
@@ -212,12 +209,15 @@ def time_gemm_kernel(layers, mm_name, device):
             if id(group) in seen_groups:
                 continue
             seen_groups.add(id(group))
-            group._operands(mm)
+            if not group._operands(mm):
+                raise RuntimeError("linked group without a unit table")
             xq, xs, _, _ = ops.rowquant(x, mm, 0)
-            g = len(group.mods)
-            calls.append((xq, group.wq, xs, group.ws, group.bias, g))
-            total_ops += g * (2 * m * k * n + (m * n if has_bias else 0))
-            total_bytes += m * k + g * (n * k + 2 * m * n + 4 * n + (2 * n if has_bias else 0)) + 4 * m
+            calls.append((xq, group.gemm, xs, None, None, len(group.mods)))
+            for gm in group.mods:
+                gn, gb = gm.sdnq_dequantizer.out_features, gm.bias is not None
+                total_ops += 2 * m * k * gn + (m * gn if gb else 0)
+                total_bytes += gn * k + 2 * m * gn + 4 * gn + (2 * gn if gb else 0)
+            total_bytes += m * k + 4 * m
             continue
         st = L._state(mod)
         wq, ws, zp = L._prepare_mm_weights(mod, st, mm)
@@ -236,7 +236,7 @@ def time_gemm_kernel(layers, mm_name, device):
             if g == 1:
                 ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
             else:
-                ops.scaled_mm_multi(mm, xq, wq, xs, ws, bias, torch.bfloat16, g)
+                ops.scaled_mm_grouped(mm, xq, xs, wq, torch.bfloat16)
     launch_all()
     torch.cuda.synchronize()
     s = torch.cuda.Stream(device=device)

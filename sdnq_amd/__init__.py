@@ -10,6 +10,7 @@ from .dequantizer import SDNQDequantizer
 from .forward import get_forward_func
 from .kernel_wrappers import fp8_scaled_mm_func, int_scaled_mm_func
 from .layers import SDNQLayer, SDNQLinear, get_sdnq_wrapper_class
+from .linear import invalidate
 from .loader import accelerate, apply_sdnq_options_to_model, fuse_projections, link_layers, link_projections
 from .quantizer import (QuantizationMethod, SDNQConfig, apply_sdnq_to_module, sdnq_post_load_quant, sdnq_quantize_layer,
                         sdnq_quantize_layer_weight)
@@ -19,6 +20,6 @@ __version__ = sdnq_version
 __all__ = [
     "QuantizationMethod", "SDNQConfig", "SDNQDequantizer", "SDNQLayer", "SDNQLinear", "accelerate", "fuse_projections", "link_layers", "link_projections",
     "apply_sdnq_options_to_model", "apply_sdnq_to_module", "dtype_dict", "fp8_scaled_mm_func", "get_forward_func",
-    "get_sdnq_wrapper_class", "int_scaled_mm_func", "sdnq_post_load_quant", "sdnq_quantize_layer",
+    "get_sdnq_wrapper_class", "int_scaled_mm_func", "invalidate", "sdnq_post_load_quant", "sdnq_quantize_layer",
     "sdnq_quantize_layer_weight",
 ]

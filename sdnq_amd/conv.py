@@ -90,7 +90,7 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
                 return y.view(b, -1, wo) if nd == 1 else y.view(b, -1, ho, wo)
             return _folder(self, nd, b, ho, wo)(ops.scaled_mm(mm, xq, wq, xs, ws, self.bias, input.dtype))
     x2d, fold = _unfold(self, input)
-    return fold(linear._quantized_matmul_forward(self, x2d, mm, small_batch_branch=False))
+    return fold(linear._quantized_matmul_forward(self, x2d, mm, small_batch_branch=False, cache_input=False))
 
 
 @torch.no_grad()
@@ -104,7 +104,7 @@ def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tens
     x2d, fold = _unfold(self, input)
     if input.numel() / input.shape[2] < 32:
         return fold(linear._float_forward(self, x2d, linear._state(self)))
-    return fold(linear._uint8_matmul_forward(self, x2d, small_batch_branch=False))
+    return fold(linear._uint8_matmul_forward(self, x2d, small_batch_branch=False, cache_input=False))
 
 
 @torch.no_grad()

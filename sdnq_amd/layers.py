@@ -36,6 +36,9 @@ class SDNQLayer(torch.nn.Module):
             self.weight = torch.nn.Parameter(w, requires_grad=True)
             del self.sdnq_dequantizer, self.scale, self.zero_point, self.svd_up, self.svd_down
             self.__dict__.pop("_sdnq_hip_state", None)
+            group = self.__dict__.pop("_sdnq_group", None)
+            if group is not None:  # linked siblings (attention projections sharing this layer's input) run alone from now on
+                group[0].dissolve()
         self.__class__ = self.original_class
         del self.original_class, self.forward_func
         return self

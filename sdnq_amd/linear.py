@@ -32,50 +32,102 @@ FUSED_SKINNY = os.environ.get("SDNQ_HIP_FUSED_SKINNY", "1").lower() not in {"0",
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
 
 
+CACHE_ACTIVATION_BYTES = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATION_MB", "256")) << 20  # bound on what the entries pin
+
+
+def tensor_key(t: torch.Tensor):
+    """What must be unchanged for a stored result to still belong to `t`: storage address, view geometry and the version counter.
+    Inference tensors (torch.inference_mode) do not track versions: None -- callers then skip every identity-keyed reuse."""
+    if t.is_inference():
+        return None
+    return (t.data_ptr(), t.storage_offset(), t.shape, t.stride(), t._version)
+
+
+def _param_version(t: torch.Tensor) -> int:
+    return -1 if t.is_inference() else t._version
+
+
 class _ActivationCache:
     """Quantized activations keyed on the identity of the input tensor.
 
     In a transformer block several Linear layers consume the SAME tensor object (attn.to_q / to_k / to_v all get
     `hidden_states`; every cross-attention to_k / to_v gets the same `encoder_hidden_states`).  The reference
     re-quantizes it for each of them (linear_int8.py:64); the result is identical every time, so this build keeps the
-    last few (xq, xs, ...) tuples and reuses them when the very same tensor object (unchanged `_version`) comes back
-    with the same quantization parameters.  Entries hold a strong reference to their input, so its storage cannot be
-    recycled for a different tensor while the entry is alive.
+    last few (xq, xs, ...) tuples and reuses them when the very same tensor object comes back unchanged -- same storage
+    address, offset, shape, strides and `_version` (``tensor_key``) -- with the same quantization parameters.  Entries hold
+    a strong reference to their input, so its storage cannot be recycled for a different tensor while the entry is alive;
+    they are bounded by count (SDNQ_HIP_CACHE_ACTIVATIONS) and by the bytes they pin (SDNQ_HIP_CACHE_ACTIVATION_MB).
+    Writers that bypass autograd's version counter (raw-pointer kernels of another library) must call
+    ``sdnq_amd.invalidate(tensor)``; inference tensors (no version counter) are never cached.
     """
 
-    def __init__(self, size: int | None = None):
+    def __init__(self, size: int | None = None, max_bytes: int | None = None):
         self.size = size   # None: the module-level CACHE_ACTIVATIONS, read at use time (the switch can be flipped after import)
-        self.entries = []  # most recent last: (tensor, version, params, result)
+        self.max_bytes = max_bytes
+        self.entries = []  # most recent last: (tensor, key, params, result, pinned bytes)
 
     def get(self, t: torch.Tensor, params):
+        key = tensor_key(t)
+        if key is None:
+            return None
         for i in range(len(self.entries) - 1, -1, -1):
             e = self.entries[i]
-            if e[0] is t and e[1] == t._version and e[2] == params:
+            if e[0] is t and e[1] == key and e[2] == params:
                 self.entries.append(self.entries.pop(i))
                 return e[3]
         return None
 
     def put(self, t: torch.Tensor, params, result):
-        self.entries.append((t, t._version, params, result))
+        key = tensor_key(t)
+        if key is None:
+            return
+        nbytes = t.numel() * t.element_size() + sum(r.numel() * r.element_size() for r in result if isinstance(r, torch.Tensor) and r is not t)
+        self.entries.append((t, key, params, result, nbytes))
         cap = max(CACHE_ACTIVATIONS, 0) if self.size is None else self.size
-        while len(self.entries) > cap:
+        lim = CACHE_ACTIVATION_BYTES if self.max_bytes is None else self.max_bytes
+        while len(self.entries) > cap or (len(self.entries) > 1 and sum(e[4] for e in self.entries) > lim):
             self.entries.pop(0)
+
+    def invalidate(self, t: torch.Tensor | None = None):
+        """Drop the entries of `t` (every entry whose input shares t's storage), or everything."""
+        if t is None:
+            self.entries.clear()
+            return
+        base = t.untyped_storage().data_ptr() if t.numel() else None
+        self.entries = [e for e in self.entries if e[0] is not t and (base is None or e[0].untyped_storage().data_ptr() != base)]
 
     def clear(self):
         self.entries.clear()
 
 
 _act_cache = _ActivationCache()
+_groups = []  # weak references to the live SharedInputGroups (invalidate() reaches their pending outputs)
 
 
 def clear_activation_cache():
     _act_cache.clear()
 
 
-def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum: bool, want_xrot: bool, prefetch, asymmetric=False):
+def invalidate(tensor: torch.Tensor | None = None):
+    """Forget everything derived from `tensor` (its quantized copy, outputs of linked projections computed from it but not yet
+    handed out); with no argument, from every tensor.  Needed only when a tensor's contents were changed WITHOUT bumping its
+    autograd version counter, e.g. by another library's raw-pointer kernel."""
+    _act_cache.invalidate(tensor)
+    for ref in list(_groups):
+        g = ref()
+        if g is None:
+            _groups.remove(ref)
+        elif g.last is not None and (tensor is None or g.last[0] is tensor
+                                     or (tensor.numel() and g.last[0].untyped_storage().data_ptr() == tensor.untyped_storage().data_ptr())):
+            g.last = None
+
+
+def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum: bool, want_xrot: bool, prefetch, asymmetric=False,
+                     cache: bool = True):
     # the stream is part of the key: an entry produced on one stream is not ordered against work on another
     params = (mm, had, want_rowsum, want_xrot, asymmetric, ops._stream(input) if input.is_cuda else -1)
-    if CACHE_ACTIVATIONS > 0:
+    cache = cache and CACHE_ACTIVATIONS > 0
+    if cache:
         hit = _act_cache.get(input, params)
         if hit is not None:
             return hit
@@ -84,7 +136,7 @@ def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum
         x2 = x2.contiguous()
     res = ops.rowquant(x2, mm, had, want_rowsum=want_rowsum, want_xrot=want_xrot, prefetch=prefetch, asymmetric=asymmetric)
     res = (x2,) + tuple(res)
-    if CACHE_ACTIVATIONS > 0:
+    if cache:
         _act_cache.put(input, params, res)
     return res
 
@@ -112,7 +164,7 @@ def _signature(mod):
     out = []
     for name in _STATE_FIELDS:
         t = _attr(mod, name)
-        out.append((name, t, None if t is None else t.data_ptr(), None if t is None else t._version))
+        out.append((name, t, None if t is None else t.data_ptr(), None if t is None else _param_version(t)))
     return tuple(out)
 
 
@@ -123,7 +175,7 @@ def _state(mod) -> _State:
     if st is not None:
         for name, ref, ptr, ver in st.key:
             t = _attr(mod, name)
-            if t is not ref or (t is not None and (t.data_ptr() != ptr or t._version != ver)):
+            if t is not ref or (t is not None and (t.data_ptr() != ptr or _param_version(t) != ver)):
                 break
         else:
             return st
@@ -172,7 +224,9 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
         return ops.linear_skinny_svd(st.qw, st.svd_down_t, x2, mod.bias).view(*input.shape[:-1], n)
     group = mod.__dict__.get("_sdnq_group")
     if group is not None and group[0].float_mode and LINK_PROJECTIONS and m > 32 and input.is_cuda and st.wd is None and n % 8 == 0:
-        return group[0].forward_float(mod, group[1], input)
+        y = group[0].forward_float(mod, group[1], input)
+        if y is not None:
+            return y
     wd = st.wd
     if wd is None:
         wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)
@@ -223,91 +277,148 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
 
 
 class ProjectionGroup:
-    """Layers of one attention block that consume the SAME tensor (to_q / to_k / to_v of self-attention, to_k / to_v of
-    cross-attention) and have equal shapes and a row-wise direct-matmul configuration (``loader._fusable``).  The first member
-    called with a tensor runs ONE scaled matmul over the stacked weights (``sdnq_hip_scaled_mm_multi``: one launch and one pass
-    over the quantized activation instead of one per layer) writing each member's output into its own contiguous tensor; the
-    other members, called with the very same tensor object, just pick theirs up.  Every output element is bit-identical to what
-    the member computes alone (each output channel keeps its own scale and bias).  The stacked operand is a copy of the members'
-    weights (the members themselves, their parameters and the state_dict are untouched)."""
+    """Layers that consume the SAME tensor: to_q / to_k / to_v of a self-attention block, or every cross-attention to_k / to_v of
+    a model (all of them read the one ``encoder_hidden_states``), with a row-wise direct-matmul configuration
+    (``loader._fusable``).  The first member called with a tensor runs ONE grouped scaled matmul
+    (``sdnq_hip_scaled_mm_grouped``: one launch and one pass over the quantized activation instead of one per layer; the weights
+    are read where the members' own parameters live -- no stacked copy) and writes each member's output into its own contiguous
+    [M, N] matrix; the other members, called with the very same unchanged tensor object, just pick theirs up.  Every output
+    element is bit-identical to what the member computes alone (each output channel keeps its own scale and bias).
+
+    The grouping is a guess about the host's call pattern, checked at run time: results are only handed to a member that is
+    called with the identical tensor object in an unchanged state (``tensor_key``) on the same stream, and a group whose
+    members turn out NOT to share their input (two recomputes in a row that left outputs unclaimed) dissolves itself -- the
+    members then run alone, as if never linked.  Inference tensors (no version counter) are never served from a group."""
 
     def __init__(self, mods, float_mode: bool = False):
+        import weakref
         self.mods = list(mods)
         self.float_mode = float_mode  # members run dequantize + F.linear (use_quantized_matmul=False) instead of the quantized matmul
-        self.sig = None   # (matmul dtype, the members' weight / scale objects and versions the stacked operands were built from)
-        self.wq = self.ws = self.bias = None
-        self.last = None  # (input tensor, its version, stream, outputs, indices not handed out yet)
+        self.sig = None    # what the unit table was built from: matmul dtype + every member's operand identity / storage / version
+        self.gemm = None   # ops.GemmGroup
+        self.last = None   # (input tensor, its key, stream, outputs, indices not handed out yet)
+        self.wasted = 0    # consecutive computes whose outputs were not all claimed
+        _groups.append(weakref.ref(self))
 
-    def _operands(self, mm):
-        # per-compute check on the eager path: the members' weight / scale objects and versions (a changed parameter rebuilds the
-        # stacked operands); the full per-module signature is only evaluated when something changed
-        refs = self.sig
-        if refs is not None and refs[0] == mm:
-            for m, (w, wv, sc, sv) in zip(self.mods, refs[1]):
-                if _attr(m, "weight") is not w or w._version != wv or _attr(m, "scale") is not sc or sc._version != sv:
-                    break
-            else:
-                return self.wq is not None
-        states = [_state(m) for m in self.mods]
-        parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
-        self.sig = (mm, [(_attr(m, "weight"), _attr(m, "weight")._version, _attr(m, "scale"), _attr(m, "scale")._version) for m in self.mods])
+    def dissolve(self):
+        for m in self.mods:
+            if m.__dict__.get("_sdnq_group", (None,))[0] is self:
+                m.__dict__.pop("_sdnq_group", None)
         self.last = None
-        if any(zp is not None for (_, _, zp) in parts):
-            self.wq = None
+        self.gemm = None
+
+    def _member_sig(self, m):
+        out = []
+        for name in ("weight", "scale", "bias"):
+            t = _attr(m, name)
+            out.append(None if t is None else (t, t.data_ptr(), _param_version(t), t.device))
+        return out
+
+    def _sig_current(self, mm) -> bool:
+        sig = self.sig
+        if sig is None or sig[0] != mm:
             return False
-        self.wq = torch.cat([wq.reshape(wq.shape[0], -1) for (wq, _, _) in parts], dim=0).contiguous()
-        self.ws = torch.cat([ws.reshape(-1) for (_, ws, _) in parts], dim=0).contiguous()
-        biases = [_attr(m, "bias") for m in self.mods]
-        self.bias = None if biases[0] is None else torch.cat(biases, dim=0).contiguous()
+        for m, ref in zip(self.mods, sig[1]):
+            for name, r in zip(("weight", "scale", "bias"), ref):
+                t = _attr(m, name)
+                if r is None:
+                    if t is not None:
+                        return False
+                elif t is not r[0] or t.data_ptr() != r[1] or _param_version(t) != r[2] or t.device != r[3]:
+                    return False
         return True
 
-    def forward(self, mod, idx: int, input: torch.Tensor, mm: int):
-        stream = ops._stream(input)
+    def _operands(self, mm):
+        # per-compute check on the eager path: identity, storage address, version and device of every member's weight, scale and
+        # bias (a changed, moved or offloaded parameter rebuilds the unit table)
+        if self._sig_current(mm):
+            return self.gemm is not None
+        states = [_state(m) for m in self.mods]
+        parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
+        self.sig = (mm, [self._member_sig(m) for m in self.mods])
+        self.last = None
+        self.gemm = None
+        if any(zp is not None for (_, _, zp) in parts) or len({w.device for (w, _, _) in parts}) != 1:
+            return False
+        members = []
+        for m, (wq, ws, _) in zip(self.mods, parts):
+            members.append((wq.reshape(wq.shape[0], -1), ws.reshape(-1), _attr(m, "bias")))
+        try:
+            self.gemm = ops.GemmGroup(members)
+        except ops._lib.SdnqHipError:
+            return False
+        return True
+
+    def _claim(self, idx: int, input: torch.Tensor, key, stream):
+        """The stored output of member idx if `input` is the tensor the stored outputs were computed from, else None."""
         last = self.last
-        if last is None or last[0] is not input or last[1] != input._version or last[2] != stream or idx not in last[4]:
-            if not self._operands(mm):
-                return None
-            x2, xq, xs, _, _ = _rowquant_cached(input, input.shape[-1], mm, 0, False, False, None)
-            outs = ops.scaled_mm_multi(mm, xq, self.wq, xs, self.ws, self.bias, input.dtype, len(self.mods))
-            last = self.last = (input, input._version, stream, outs, set(range(len(self.mods))))
+        if last is None or last[0] is not input or last[1] != key or last[2] != stream or idx not in last[4]:
+            return None
         y = last[3][idx].view(*input.shape[:-1], -1)
         last[4].discard(idx)
         if not last[4]:
             self.last = None  # every member has its output: hold on to nothing (the input and the outputs belong to the host again)
+            self.wasted = 0
         return y
 
+    def _begin_compute(self) -> bool:
+        """Account for outputs nobody claimed; False once the group has dissolved itself."""
+        if self.last is not None and self.last[4]:
+            self.wasted += 1
+            if self.wasted >= 2:
+                self.dissolve()
+                return False
+        return True
+
+    def forward(self, mod, idx: int, input: torch.Tensor, mm: int):
+        key = tensor_key(input)
+        if key is None:
+            return None  # inference tensor: no way to tell whether it changed between the members' calls
+        stream = ops._stream(input)
+        y = self._claim(idx, input, key, stream)
+        if y is not None:
+            return y
+        if not self._begin_compute() or not self._operands(mm):
+            return None
+        x2, xq, xs, _, _ = _rowquant_cached(input, input.shape[-1], mm, 0, False, False, None)
+        outs = ops.scaled_mm_grouped(mm, xq, xs, self.gemm, input.dtype)
+        self.last = (input, key, stream, outs, set(range(len(self.mods))))
+        return self._claim(idx, input, key, stream)
 
     def forward_float(self, mod, idx: int, input: torch.Tensor):
         """The dequantize + F.linear mode (use_quantized_matmul=False, M > 32): every member is dequantized into its slab of ONE
         [sum N][K] buffer (as many dequantize launches as before), then one float GEMM writes the members' outputs."""
+        key = tensor_key(input)
+        if key is None:
+            return None
         stream = ops._stream(input)
-        last = self.last
-        if last is None or last[0] is not input or last[1] != input._version or last[2] != stream or idx not in last[4]:
-            dq = mod.sdnq_dequantizer
-            k, n = dq.in_features, dq.out_features
-            x2 = input.reshape(-1, k)
-            if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
-                x2 = x2.contiguous()
-            g = len(self.mods)
-            wd = torch.empty((g * n, k), device=input.device, dtype=input.dtype)
-            for i, m in enumerate(self.mods):
-                d = m.sdnq_dequantizer
-                ops.dequant(_state(m).qw, input.dtype, d.hadamard_group_size if d.use_hadamard else 0, out=wd[i * n:(i + 1) * n])
-            biases = [_attr(m, "bias") for m in self.mods]
-            bias = None if biases[0] is None else torch.cat(biases, dim=0)
-            outs = ops.linear_float_multi(x2, wd, bias, g)
-            last = self.last = (input, input._version, stream, outs, set(range(g)))
-        y = last[3][idx].view(*input.shape[:-1], -1)
-        last[4].discard(idx)
-        if not last[4]:
-            self.last = None
-        return y
+        y = self._claim(idx, input, key, stream)
+        if y is not None:
+            return y
+        if not self._begin_compute():
+            return None
+        dq = mod.sdnq_dequantizer
+        k, n = dq.in_features, dq.out_features
+        x2 = input.reshape(-1, k)
+        if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+            x2 = x2.contiguous()
+        g = len(self.mods)
+        wd = torch.empty((g * n, k), device=input.device, dtype=input.dtype)
+        for i, m in enumerate(self.mods):
+            d = m.sdnq_dequantizer
+            ops.dequant(_state(m).qw, input.dtype, d.hadamard_group_size if d.use_hadamard else 0, out=wd[i * n:(i + 1) * n])
+        biases = [_attr(m, "bias") for m in self.mods]
+        bias = None if biases[0] is None else torch.cat(biases, dim=0)
+        outs = ops.linear_float_multi(x2, wd, bias, g)
+        self.last = (input, key, stream, outs, set(range(g)))
+        return self._claim(idx, input, key, stream)
 
 
 LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
 
 
-def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_branch: bool = True) -> torch.Tensor:
+def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_branch: bool = True, cache_input: bool = True) -> torch.Tensor:
+    """cache_input=False: `input` is a temporary of the caller (a freshly unfolded conv input) that no other layer can ever see."""
     dq = self.sdnq_dequantizer
     st = _state(self)
     k, n = dq.in_features, dq.out_features
@@ -327,7 +438,8 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
         # plain w8a8 layer: on a cache miss the row quantization and the GEMM go through ONE binding call (an eager model is
         # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers
         params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
-        hit = _act_cache.get(input, params) if CACHE_ACTIVATIONS > 0 else None
+        use_cache = cache_input and CACHE_ACTIVATIONS > 0
+        hit = _act_cache.get(input, params) if use_cache else None
         if hit is None:
             x2 = input.reshape(-1, k)
             if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
@@ -335,12 +447,13 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
             if not x2.is_cuda:
                 raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
             y, xq, xs = ops.linear_w8a8(mm, x2, wq, ws, bias, input.dtype, had)
-            if CACHE_ACTIVATIONS > 0:
+            if use_cache:
                 _act_cache.put(input, params, (x2, xq, xs, None, None))
             return y.view(*input.shape[:-1], n)
         x2, xq, xs, rowsum, xrot = hit
         return ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype).view(*input.shape[:-1], n)
-    x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, wq if PREFETCH_WEIGHTS else None)
+    x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, wq if PREFETCH_WEIGHTS else None,
+                                                cache=cache_input)
     if has_svd or zp is not None:
         t = None
         if has_svd:  # mm(x, svd_down) of addmm(bias, mm(x, svd_down), svd_up), linear_int8.py:57-62
@@ -361,7 +474,7 @@ def quantized_linear_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tens
     return _quantized_matmul_forward(self, input, ops.MM_FP8)
 
 
-def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = True) -> torch.Tensor:
+def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = True, cache_input: bool = True) -> torch.Tensor:
     """Asymmetric-activation int8 matmul (layers/linear/linear_uint8.py:106-131): activations get a per-row zero point,
     the three cross terms of (x - xzp)(w - wzp) are added in the GEMM epilogue instead of a materialised [M,N] bias."""
     dq = self.sdnq_dequantizer
@@ -379,7 +492,7 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
     x2, xq, xs, rowsum, xrot, xzp = _rowquant_cached(input, k, ops.MM_I8, had, zp is not None, has_svd,
-                                                     wq if PREFETCH_WEIGHTS else None, asymmetric=True)
+                                                     wq if PREFETCH_WEIGHTS else None, asymmetric=True, cache=cache_input)
     t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
     y = ops.scaled_mm_lowrank(ops.MM_I8, xq, wq, xs, ws, self.bias, t, st.svd_up, rowsum, zp, input.dtype, a_zp=xzp,
                               w_colsum_scaled=wcs)

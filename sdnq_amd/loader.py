@@ -41,6 +41,20 @@ def is_hot_path_conv(module: torch.nn.Module) -> bool:
             and getattr(dq, "quantized_matmul_dtype", "int8") in ("int8", "uint8", "fp8", "float8_e4m3fn"))
 
 
+def _unlink(module: torch.nn.Module):
+    """Take `module` out of its ProjectionGroup; the group dissolves (its other members run alone again)."""
+    g = module.__dict__.pop("_sdnq_group", None)
+    if g is not None:
+        g[0].dissolve()
+
+
+def _clear_step_state(_module=None, _args=None):
+    """forward-pre-hook of the root model: nothing derived from activations outlives a step (quantized copies of the previous
+    step's inputs, outputs of linked projections nobody claimed)."""
+    from . import linear
+    linear.invalidate(None)
+
+
 @torch.no_grad()
 def accelerate(model: torch.nn.Module) -> int:
     """Route every quantized Linear (and Conv1d / Conv2d with groups = 1) of ``model`` through the HIP forwards.
@@ -52,49 +66,92 @@ def accelerate(model: torch.nn.Module) -> int:
             module.sdnq_dequantizer = dq
             module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
             module.__dict__.pop("_sdnq_hip_state", None)
-            module.__dict__.pop("_sdnq_group", None)
+            _unlink(module)
             count += 1
     from . import linear
     if linear.LINK_PROJECTIONS:
         link_projections(model)
+    if count and not getattr(model, "_sdnq_hip_step_hook", None):
+        model._sdnq_hip_step_hook = model.register_forward_pre_hook(_clear_step_state)
     return count
 
 
 @torch.no_grad()
 def link_layers(mods) -> bool:
-    """Make `mods` (layers that consume the same tensor) a ``linear.ProjectionGroup`` if their configuration allows it."""
+    """Make `mods` (layers that consume the same tensor) a ``linear.ProjectionGroup`` if their configuration allows it: any number
+    of row-wise direct-matmul layers of one input size whose widths share a divisor that is a multiple of 64 (one grouped launch,
+    no weight copy), or up to four equally shaped layers in the dequantize + F.linear mode (one float GEMM)."""
     from .linear import ProjectionGroup
     mods = list(mods)
-    if len(mods) < 2 or len(mods) > 4:
+    if len(mods) < 2:
         return False
     float_mode = _float_linkable(mods)
     if not float_mode and not _fusable(mods):
         return False
     d0 = mods[0].sdnq_dequantizer
-    if any(m.sdnq_dequantizer.out_features != d0.out_features for m in mods) or d0.out_features % 8:
-        return False
+    if float_mode:
+        if len(mods) > 4 or any(m.sdnq_dequantizer.out_features != d0.out_features for m in mods) or d0.out_features % 8:
+            return False
+    else:
+        import math
+        unit = 0
+        for m in mods:
+            unit = math.gcd(unit, m.sdnq_dequantizer.out_features)
+        if unit % 64:
+            return False
+    for m in mods:
+        _unlink(m)
     group = ProjectionGroup(mods, float_mode=float_mode)
     for i, m in enumerate(mods):
         m.__dict__["_sdnq_group"] = (group, i)
     return True
 
 
+def _is_cross_attention(module, q, k) -> bool:
+    """diffusers' Attention says so itself (is_cross_attention / cross_attention_dim); otherwise a key projection that reads a
+    different width than the query projection can only be fed another tensor."""
+    flag = getattr(module, "is_cross_attention", None)
+    if flag is not None:
+        return bool(flag)
+    if getattr(module, "cross_attention_dim", None) is not None:
+        return True
+    return q is None or getattr(q, "in_features", None) != getattr(k, "in_features", None)
+
+
 @torch.no_grad()
 def link_projections(model: torch.nn.Module) -> int:
-    """For every attention block of ``model``: ``to_q / to_k / to_v`` (self-attention, when they have equal shapes) or ``to_k /
-    to_v`` (cross-attention) become one ``ProjectionGroup`` -- transparent to the host model: the modules, their names, parameters
-    and outputs stay what they were, but the three (two) GEMMs of a shared input run as one launch.  Returns the number of groups."""
+    """Link the attention projections of ``model`` that consume one tensor -- transparent to the host model: the modules, their
+    names, parameters and outputs stay what they were.
+
+    * self-attention blocks: ``to_q / to_k / to_v`` (and ``add_q_proj / add_k_proj / add_v_proj`` of the joint SD3 / FLUX blocks)
+      become one ProjectionGroup: three GEMMs of a shared input run as one launch;
+    * cross-attention blocks: ``to_q`` reads the image tokens and stays alone; ``to_k / to_v`` of EVERY cross-attention block with
+      the same input width and configuration go into ONE model-wide group -- a UNet hands the same ``encoder_hidden_states``
+      tensor to all of them (140 projections in SDXL), so the first one called in a step computes all of them in one launch.
+    Whether the members really receive one tensor is checked at run time (``ProjectionGroup``): a group whose guess is wrong
+    dissolves itself.  Returns the number of groups."""
     count = 0
+    cross = {}  # (in_features, configuration) -> [to_k, to_v, to_k, to_v, ...] in module order
     for module in model.modules():
-        # diffusers' Attention: to_q / to_k / to_v, and add_q_proj / add_k_proj / add_v_proj of the joint (SD3 / FLUX) blocks
         for names in (("to_q", "to_k", "to_v"), ("add_q_proj", "add_k_proj", "add_v_proj")):
             q, k, v = (getattr(module, a, None) for a in names)
-            if k is None or v is None or k is v:
+            if k is None or v is None or k is v or not is_hot_path_linear(k) or not is_hot_path_linear(v):
+                continue
+            if names[0] == "to_q" and _is_cross_attention(module, q, k):
+                dk = k.sdnq_dequantizer
+                key = (dk.in_features, dk.weights_dtype, dk.quantized_matmul_dtype, dk.use_quantized_matmul, dk.result_dtype, k.bias is None)
+                cross.setdefault(key, []).extend([k, v])
                 continue
             if q is not None and link_layers([q, k, v]):
                 count += 1
             elif link_layers([k, v]):
                 count += 1
+    for mods in cross.values():
+        if link_layers(mods):
+            count += 1
+        else:  # e.g. the dequantize + F.linear mode (at most four equal layers per group): per-block pairs
+            for i in range(0, len(mods), 2):
+                count += bool(link_layers(mods[i:i + 2]))
     return count
 
 
@@ -200,6 +257,7 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
             dq.quantized_matmul_dtype = quantized_matmul_dtype
         module.forward_func = get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul)
         module.__dict__.pop("_sdnq_hip_state", None)
+        _unlink(module)  # the layer's layout / forward may have changed: its group (if any) dissolves, siblings run alone
     return model
 
 

@@ -812,8 +812,8 @@ def test_scaled_mm_output_beyond_2_31_elements(gpu_device):
 
 
 def test_linked_projections_are_transparent(gpu_device):
-    """sdnq_amd.link_projections / accelerate: to_q / to_k / to_v of an attention block run as ONE scaled matmul over the stacked
-    weights (sdnq_hip_scaled_mm_multi) when they are called with the same tensor; every member returns its own contiguous tensor,
+    """sdnq_amd.link_projections / accelerate: to_q / to_k / to_v of an attention block run as ONE grouped scaled matmul
+    (sdnq_hip_scaled_mm_grouped, reading the members' own weights) when they are called with the same tensor; every member returns its own contiguous tensor,
     bit-identical to what it computes alone, whatever the call order; a different tensor, a modified tensor and a small batch take
     the ordinary paths."""
     import sdnq_amd
@@ -859,6 +859,7 @@ def test_linked_projections_are_transparent(gpu_device):
             assert group.last is None
         x2 = torch.randn_like(inputs[1])
         assert torch.equal(mods[1](x2), (lambda g: (g.__setattr__("last", None), L.clear_activation_cache(), mods[1](x2))[2])(group))
+        group.last, group.wasted = None, 0  # (unclaimed outputs count against the group: see test_linked_group_dissolves_...)
         keep = inputs[1].clone()
         inputs[1].mul_(0.5)  # version bump: the stored outputs no longer belong to this tensor
         try:
@@ -869,6 +870,7 @@ def test_linked_projections_are_transparent(gpu_device):
         finally:
             L.LINK_PROJECTIONS = True
         inputs[1].copy_(keep)
+        group.last, group.wasted = None, 0
         small = torch.randn(5, cross or 320, device=gpu_device, dtype=torch.bfloat16)
         assert mods[1](small).shape == (5, 320)  # M < 32: dequant + float GEMM branch, untouched
         if mmd == "int8" and not bias:
@@ -877,6 +879,7 @@ def test_linked_projections_are_transparent(gpu_device):
             L.clear_activation_cache()
             k_again = mods[1](inputs[1])
             assert torch.equal(mods[2](inputs[2]), -alone[2]) and torch.equal(k_again, alone[1])
+            assert "_sdnq_group" in mods[1].__dict__  # still linked
     L.LINK_PROJECTIONS = os.environ.get("SDNQ_HIP_LINK_PROJECTIONS", "1").lower() not in {"0", "false", "no"}
 
 
@@ -917,3 +920,109 @@ def test_linked_projections_float_mode(gpu_device):
             assert torch.equal(mods[0](small), (lambda: (setattr(L, "LINK_PROJECTIONS", False), mods[0](small), setattr(L, "LINK_PROJECTIONS", True))[1])())
     finally:
         L.LINK_PROJECTIONS = old
+
+
+def _attn_block(c, cross, bias, gpu_device, cfg):
+    import sdnq_amd
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_q = torch.nn.Linear(c, c, bias=bias)
+            self.to_k = torch.nn.Linear(cross or c, c, bias=bias)
+            self.to_v = torch.nn.Linear(cross or c, c, bias=bias)
+
+    blk = Attn().to(torch.bfloat16).to(gpu_device)
+    for name in ("to_q", "to_k", "to_v"):
+        setattr(blk, name, sdnq_amd.sdnq_quantize_layer(getattr(blk, name), cfg)[0])
+    return blk
+
+
+def test_model_wide_cross_attention_group(gpu_device):
+    """Every cross-attention to_k / to_v of a model reads the one encoder_hidden_states tensor: accelerate() puts them -- layers of
+    DIFFERENT widths included -- into ONE ProjectionGroup; the first one called in a step computes all of them in one grouped launch
+    and every member's output is bit-identical to the layer computed alone.  Nothing is carried into the next step."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(21)
+    cfg = sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    model = torch.nn.ModuleList([_attn_block(c, 512, False, gpu_device, cfg) for c in (320, 640, 320, 640, 1280)])
+    text = torch.randn(1, 77, 512, device=gpu_device, dtype=torch.bfloat16)
+    old = L.LINK_PROJECTIONS
+    try:
+        L.LINK_PROJECTIONS = False
+        sdnq_amd.accelerate(model)
+        alone = [(b.to_k(text).clone(), b.to_v(text).clone()) for b in model]
+        L.LINK_PROJECTIONS = True
+        assert sdnq_amd.accelerate(model) == 15
+        group = model[0].to_k.__dict__["_sdnq_group"][0]
+        assert len(group.mods) == 10 and all(b.to_v.__dict__["_sdnq_group"][0] is group for b in model)
+        assert all("_sdnq_group" not in b.to_q.__dict__ for b in model)
+        for step in range(2):
+            L.invalidate()
+            for i, b in enumerate(model):
+                kk, vv = b.to_k(text), b.to_v(text)
+                assert torch.equal(kk, alone[i][0]) and torch.equal(vv, alone[i][1]) and kk.is_contiguous()
+                assert (group.last is None) == (i == len(model) - 1)
+            assert group.wasted == 0 and group.gemm.unit_n == 320 and group.gemm.n_total == 2 * (320 + 640 + 320 + 640 + 1280)
+    finally:
+        L.LINK_PROJECTIONS = old
+
+
+def test_linked_group_dissolves_when_members_do_not_share_their_input(gpu_device):
+    """A q / k / v group whose to_q is fed a different tensor than to_k / to_v (a cross-attention block that looked like
+    self-attention): results stay correct from the first call, and after two computes that left outputs unclaimed the group
+    dissolves itself -- no work is wasted from then on."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(22)
+    cfg = sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    blk = _attn_block(320, 0, True, gpu_device, cfg)
+    h = torch.randn(1, 64, 320, device=gpu_device, dtype=torch.bfloat16)
+    e = torch.randn(1, 64, 320, device=gpu_device, dtype=torch.bfloat16)
+    old = L.LINK_PROJECTIONS
+    try:
+        L.LINK_PROJECTIONS = False
+        want = (blk.to_q(h).clone(), blk.to_k(e).clone(), blk.to_v(e).clone())
+        L.LINK_PROJECTIONS = True
+        assert sdnq_amd.link_projections(blk) == 1
+        for it in range(3):
+            got = (blk.to_q(h), blk.to_k(e), blk.to_v(e))
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+        assert all("_sdnq_group" not in m.__dict__ for m in (blk.to_q, blk.to_k, blk.to_v))
+    finally:
+        L.LINK_PROJECTIONS = old
+
+
+def test_forward_under_inference_mode_and_invalidate(gpu_device):
+    """torch.inference_mode(): inference tensors have no version counter -- the forwards must work (ComfyUI runs models that
+    way) and simply skip every identity-keyed reuse.  sdnq_amd.invalidate(t) drops what was derived from a tensor that a
+    raw-pointer writer changed behind autograd's back."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(23)
+    cfg = sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    blk = _attn_block(320, 0, False, gpu_device, cfg)
+    sdnq_amd.accelerate(blk)
+    x = torch.randn(2, 40, 320, device=gpu_device, dtype=torch.bfloat16)
+    want = [m(x).clone() for m in (blk.to_q, blk.to_k, blk.to_v)]
+    with torch.inference_mode():
+        xi = x.clone()
+        assert xi.is_inference()
+        got = [m(xi) for m in (blk.to_q, blk.to_k, blk.to_v)]
+        xi.mul_(2.0)  # in place, untracked
+        got2 = blk.to_k(xi)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert torch.equal(got2, blk.to_k(x * 2.0))
+    # out-of-band write: same tensor object, same version, different contents (x.data has its own version counter)
+    L.invalidate()
+    blk.to_q(x)  # the group computed k and v from x as well and holds them for the siblings
+    v0 = x._version
+    x.data.mul_(0.5)
+    assert x._version == v0
+    L.invalidate(x)
+    got_k = blk.to_k(x)
+    L.invalidate()
+    assert torch.equal(got_k, blk.to_k(x.clone()))

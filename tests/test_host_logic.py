@@ -47,6 +47,23 @@ def test_activation_cache_identity_version_and_lru():
     assert c.get(b, p) is None and c.get(a, p) == "qa2" and c.get(d, p) == "qd"
     c.clear()
     assert c.get(a, p) is None
+    # key = storage address + view geometry + version; invalidate() drops everything that aliases a tensor's storage
+    base = torch.zeros(8, 8)
+    v1, v2 = base[:4], base[4:]
+    c.put(v1, p, "v1"), c.put(v2, p, "v2")
+    assert c.get(v1, p) == "v1" and c.get(v2, p) == "v2"
+    c.invalidate(base)
+    assert c.get(v1, p) is None and c.get(v2, p) is None
+    # byte bound: an entry that pins more than the limit evicts the older ones (the newest always stays)
+    small = _ActivationCache(8, max_bytes=1024)
+    big = torch.zeros(1024)
+    small.put(a, p, ("x",)), small.put(big, p, ("y",))
+    assert small.get(a, p) is None and small.get(big, p) == ("y",)
+    # inference tensors carry no version counter: never cached, never an error
+    with torch.inference_mode():
+        t = torch.zeros(4, 8)
+        c.put(t, p, "no")
+        assert c.get(t, p) is None
 
 
 def test_fuse_projections_layout_on_cpu():
