@@ -57,19 +57,49 @@ _lock = threading.Lock()
 _lib = None
 
 
-def sources_newer_than_lib() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    hdr = os.path.join(_HERE, "..", "include", "sdnq_hip.h")
-    files = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))] + [hdr]
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
+_SRCS = ("api", "rowquant", "gemm", "dequant", "quantize", "conv", "attention")
+_FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
+
+
+def source_hash() -> str:
+    """SHA-256 over every HIP source, header and compiler flag, computed exactly as sdnq_amd/csrc/build.sh does: the library that
+    is loaded is the one built from the sources in the tree iff this equals the contents of ``libsdnq_hip.so.srchash``."""
+    import hashlib
+    hdrs = sorted(f for f in os.listdir(_CSRC) if f.endswith(".h"))
+    h = hashlib.sha256()
+    for f in hdrs:
+        h.update(open(os.path.join(_CSRC, f), "rb").read())
+    h.update(open(os.path.join(_HERE, "..", "include", "sdnq_hip.h"), "rb").read())
+    hdr_hash = h.hexdigest()
+    flags = os.environ.get("SDNQ_EXTRA_FLAGS", "") + _FLAGS
+    parts = ""
+    for f in _SRCS:
+        extra = "-mllvm -amdgpu-mfma-vgpr-form" if f == "attention" else ""
+        g = hashlib.sha256((f"{hdr_hash} {flags} {extra}\n").encode())
+        g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())
+        parts += f" {f}:{g.hexdigest()}"
+    return hashlib.sha256((parts + "\n").encode()).hexdigest()
+
+
+def lib_is_current() -> bool:
+    try:
+        return os.path.exists(LIB_PATH) and open(LIB_PATH + ".srchash").read().strip() == source_hash()
+    except OSError:
+        return False
+
+
+def sources_newer_than_lib() -> bool:  # kept for callers of the old name
+    return not lib_is_current()
 
 
 def build(force: bool = False) -> str:
-    """Compile every HIP source for gfx950 into sdnq_amd/libsdnq_hip.so (no GPU needed)."""
-    if force or sources_newer_than_lib():
-        subprocess.run(["bash", os.path.join(_CSRC, "build.sh"), LIB_PATH], check=True)
+    """Compile every HIP source for gfx950 into sdnq_amd/libsdnq_hip.so (no GPU needed).  Content-addressed: nothing is rebuilt
+    when the library's recorded source hash equals the hash of the tree; `force` recompiles every object."""
+    if force or not lib_is_current():
+        env = dict(os.environ, FORCE="1") if force else None
+        subprocess.run(["bash", os.path.join(_CSRC, "build.sh"), LIB_PATH], check=True, env=env)
+        if not lib_is_current():
+            raise SdnqHipError("libsdnq_hip.so was built but its source hash does not match the tree (build.sh / _lib.source_hash out of sync)")
     return LIB_PATH
 
 

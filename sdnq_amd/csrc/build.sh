@@ -1,5 +1,8 @@
 #!/bin/bash
 # Build the C-ABI shared library for gfx950 (MI355X). hipcc cross-compiles without a GPU.
+# Content-addressed: every object is keyed on the SHA-256 of its source, every header and the compiler flags, the library on the
+# hashes of its objects (written next to it as <lib>.srchash) -- what is loaded can be checked against what is in the tree
+# (sdnq_amd/_lib.py: source_hash()), independent of file times.  FORCE=1 recompiles everything.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/../libsdnq_hip.so}"
@@ -7,15 +10,24 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="${SDNQ_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
 OBJ="$HERE/../../build/obj"
 mkdir -p "$OBJ"
+SRCS="api rowquant gemm dequant quantize conv attention"
+HDR_HASH=$(cat "$HERE"/*.h "$HERE/../../include/sdnq_hip.h" | sha256sum | cut -d' ' -f1)
 pids=()
-for f in api rowquant gemm dequant quantize conv attention; do
+ALL=""
+for f in $SRCS; do
   EXTRA=""
   # attention.hip: keep the MFMA accumulators in VGPRs (the softmax rescales / reads them with VALU every block; in AGPR form
   # the compiler moved 80 registers per 32-key block through v_accvgpr_read/write)
   [ "$f" = attention ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
-  ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$OBJ/$f.o" ) &
+  H=$( (echo "$HDR_HASH $FLAGS $EXTRA"; cat "$HERE/$f.hip") | sha256sum | cut -d' ' -f1)
+  ALL="$ALL $f:$H"
+  if [ "${FORCE:-0}" != 1 ] && [ -f "$OBJ/$f.o" ] && [ "$(cat "$OBJ/$f.hash" 2>/dev/null)" = "$H" ]; then continue; fi
+  ( "$HIPCC" $FLAGS $EXTRA -c "$HERE/$f.hip" -o "$OBJ/$f.o" && echo "$H" > "$OBJ/$f.hash" ) &
   pids+=($!)
 done
-for p in "${pids[@]}"; do wait "$p"; done
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" "$OBJ"/api.o "$OBJ"/rowquant.o "$OBJ"/gemm.o "$OBJ"/dequant.o "$OBJ"/quantize.o "$OBJ"/conv.o "$OBJ"/attention.o
-echo "built $OUT"
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS $OBJ/$f.o"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" $OBJS
+echo "$ALL" | sha256sum | cut -d' ' -f1 > "$OUT.srchash"
+echo "built $OUT ($(cat "$OUT.srchash" | cut -c1-12))"

@@ -90,6 +90,26 @@ struct TileView {
     int64_t n_lim;         // valid channels from the tile's first one (may exceed BN)
 };
 
+// the 16-byte store of a finished output piece.  SDNQ_STORE_MODE (lab builds): 1 non-temporal, 2 write-through (sc1), 3 sc0 sc1
+// Default 1: the outputs are written once and not read again by this kernel; non-temporal stores measured -2..-9 % on the
+// output-heavy GEMMs (1024 x 10240 x 1280: 24.9 -> 22.6 us, 4096 x 5120 x 640: 31.3 -> 28.9 us) and never slower (tools/micro/gemm_lab.hip).
+#ifndef SDNQ_STORE_MODE
+#define SDNQ_STORE_MODE 1
+#endif
+__device__ __forceinline__ void store16(void* dst, const uint4& v) {
+#if SDNQ_STORE_MODE == 1
+    __builtin_nontemporal_store((v4i){(int)v.x, (int)v.y, (int)v.z, (int)v.w}, (v4i*)dst);
+#elif SDNQ_STORE_MODE == 2
+    const v4i w = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+#elif SDNQ_STORE_MODE == 3
+    const v4i w = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+#else
+    *(uint4*)dst = v;
+#endif
+}
+
 // address of output row gm, channel `c` of the tile (global channel gn0 = n0 + c)
 __device__ __forceinline__ uint8_t* out_piece(const GemmParams& p, const TileView& tv, int64_t gm, int64_t gn0, int c, int out_b) {
     if (p.seg_n == 0) return tv.out + (gm * tv.out_ld + c) * out_b;
@@ -241,8 +261,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPP = 1024 / BK;   // tile rows per 1-KiB DMA piece (8 for 128-byte rows, 16 for 64-byte rows)
     constexpr int LPR = BK / 16;     // lanes (16-byte chunks) per row
-    constexpr int A_PIECES = BM / RPP / NW, B_PIECES = BN / RPP / NW, PPW = A_PIECES + B_PIECES;  // DMA pieces per wave per stage
-    static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split evenly into DMA pieces");
+    // DMA pieces per wave per stage.  Tiles whose A and B rows both split evenly over the waves keep separate A / B piece lists;
+    // other tiles (BN = 160, 320: the shapes that cut N = 10240 / 5120 into exactly 256 / 512 workgroups) deal the pieces of the
+    // combined [A rows | B rows] stage round-robin to the waves (JOINT): the last piece slot of a wave may be empty, and the
+    // counted vmcnt of such a wave is one piece per stage lower.
+    constexpr bool JOINT = (BM % (RPP * NW) != 0) || (BN % (RPP * NW) != 0);
+    constexpr int A_TOT = BM / RPP, TOT = (BM + BN) / RPP;
+    constexpr int A_PIECES = JOINT ? 0 : BM / RPP / NW, B_PIECES = JOINT ? 0 : BN / RPP / NW;
+    constexpr int PPW = JOINT ? (TOT + NW - 1) / NW : A_PIECES + B_PIECES;
+    constexpr int REM = JOINT ? TOT % NW : 0;  // JOINT: waves below REM own PPW pieces, the others PPW - 1 (0: all own PPW)
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % 16 == 0, "tile rows must split into DMA pieces");
     static_assert(BK == 64 || BK == 128, "stage rows are 64 or 128 bytes");
     static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
     constexpr int STAGE_BYTES = (BM + BN) * BK;
@@ -313,10 +341,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     const uint8_t* src[PPW];
     const int r8 = lane / LPR;  // row of this lane inside a DMA piece
     auto chunk_of = [&](int r) { return BK == 128 ? ((lane & 7) ^ ((r >> 1) & p.swz)) : ((lane & 3) ^ ((r >> 2) & (p.swz & 3))); };
+    const bool full = REM == 0 || wave < REM;  // wave-uniform: this wave owns PPW pieces (else PPW - 1)
+    // (operand, piece inside the operand) of this wave's piece slot i
+    auto piece_of = [&](int i, bool& isA) {
+        if constexpr (JOINT) {
+            int pc = i * NW + wave;
+            if (pc >= TOT) pc = TOT - 1;  // the empty slot of a wave with PPW - 1 pieces: never issued
+            isA = pc < A_TOT;
+            return isA ? pc : pc - A_TOT;
+        } else {
+            isA = i < A_PIECES;
+            return (isA ? i : i - A_PIECES) * NW + wave;
+        }
+    };
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const bool isA = i < A_PIECES;
-        const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+        bool isA;
+        const int piece = piece_of(i, isA);
         const int r = piece * RPP + r8;
         const int c = chunk_of(r);
         // clamp: rows past the edge are computed on valid memory and never stored
@@ -333,8 +374,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // multiple of 8, so the chunk is the same for every piece of an operand up to the parity of piece*4 -- NW is even,
     // hence (piece*8 >> 1) & 7 alternates with `piece & 1`; it is recomputed (2 VALU) instead of stored.
     auto kofs = [&](int i) {
-        const bool isA = i < A_PIECES;
-        const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+        bool isA;
+        const int piece = piece_of(i, isA);
         return chunk_of(piece * RPP + r8) << 4;
     };
     int slot_i = 0;  // ring slot the next issued stage goes to
@@ -344,8 +385,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
-            const bool isA = i < A_PIECES;
-            const int piece = (isA ? i : i - A_PIECES) * NW + wave;
+            if (JOINT && i == PPW - 1 && !full) break;  // this wave's last slot is empty
+            bool isA;
+            const int piece = piece_of(i, isA);
             uint8_t* dst = stage + (isA ? 0 : BM * BK) + piece * 1024;
             // chunks past K (K % 16 == 0) and whole stages past the end of K come from a 16-byte zero constant
             const uint8_t* s = (k0 + kofs(i) < K) ? src[i] + k0 : (const uint8_t*)&g_zero16;
@@ -361,6 +403,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 
     const int nk = (K + BK - 1) / BK;
     constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed (LD_DMA)
+    // counted wait: everything but this wave's pieces of the AHEAD - 1 youngest stages has landed
+    auto wait_ahead = [&]() {
+        if (JOINT && !full) wait_vmcnt<(AHEAD - 1) * (PPW - (REM != 0 ? 1 : 0))>();
+        else wait_vmcnt<(AHEAD - 1) * PPW>();
+    };
 #pragma nounroll
     for (int s = 0; s < AHEAD; ++s) issue(s);
     TRACE(1);
@@ -422,7 +469,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[st][i], fa[st][j]);
         };
         // stage 0 landed for every wave -> top up the ring (slot NS-1) -> first fragment set
-        wait_vmcnt<(AHEAD - 1) * PPW>();
+        wait_ahead();
         __builtin_amdgcn_s_barrier();
         issue(AHEAD);
         load_set(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -437,7 +484,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     // flight), this wave's own LDS reads of the finished stage must have completed (its slot is about
                     // to be refilled), one barrier, refill, and the first fragments of the next stage start flowing
                     // while the last MFMAs of this one run.
-                    wait_vmcnt<(AHEAD - 1) * PPW>();
+                    wait_ahead();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     issue(kt + u + 1 + AHEAD);
@@ -451,7 +498,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         static_assert(NW == 8, "ping-pong schedule: two halves of four waves");
         typedef typename FragOps<MM>::frag_t frag_t;
         constexpr int KS = BK / MT::KB;
-        constexpr int INFLIGHT = (AHEAD - 1) * PPW;  // DMA pieces of the younger stages that may stay in flight at a wait
         frag_t fa[KS][TM], fb[KS][TN];
         const int half = __builtin_amdgcn_readfirstlane(wave >> 2);
         // Time is cut into slots by workgroup-wide barriers.  Half 0 runs LOAD(j) in slot 2j and MFMA(j) in slot 2j+1, half 1
@@ -461,7 +507,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         //   WAR: the DMA for stage j+AHEAD overwrites the ring slot of stage j-1; it is issued in LOAD(j) (slots 2j / 2j+1), after
         //        the barrier that ends slot 2j-1, by which time both halves have finished reading stage j-1 (lgkmcnt(0) before
         //        the barrier that ends a LOAD phase).
-        wait_vmcnt<INFLIGHT>();  // own pieces of stage 0 (stages 1..AHEAD-1 stay in flight)
+        wait_ahead();  // own pieces of stage 0 (stages 1..AHEAD-1 stay in flight)
         __builtin_amdgcn_s_barrier();
         if (half == 1) __builtin_amdgcn_s_barrier();  // the stagger: half 1 sits out slot 0
 #pragma nounroll
@@ -480,7 +526,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
                 }
             }
-            if (half == 1) wait_vmcnt<INFLIGHT>();  // own pieces of stage kt+1, read by half 0 in the next slot
+            if (half == 1) wait_ahead();  // own pieces of stage kt+1, read by half 0 in the next slot
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -494,7 +540,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                     for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j]);
             __builtin_amdgcn_s_setprio(0);
-            if (half == 0) wait_vmcnt<INFLIGHT>();  // own pieces of stage kt+1, read by this half right after the barrier
+            if (half == 0) wait_ahead();  // own pieces of stage kt+1, read by this half right after the barrier
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -505,7 +551,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         // single raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs.
 #pragma nounroll
         for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<(AHEAD - 1) * PPW>();
+            wait_ahead();
             __builtin_amdgcn_s_barrier();
             if (kt == 0) TRACE(2);
             issue(kt + AHEAD);
@@ -698,10 +744,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
         uint8_t* dst = out_piece(p, tv, gm, gn0, c8, OUT_B);
         if constexpr (OUT_T == SDNQ_F32) {
-            *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
-            *(uint4*)(dst + 16) = Vec16<SDNQ_F32>::pack(o + 4);
+            store16(dst, Vec16<SDNQ_F32>::pack(o));
+            store16(dst + 16, Vec16<SDNQ_F32>::pack(o + 4));
         } else {
-            *(uint4*)dst = Vec16<OUT_T>::pack(o);
+            store16(dst, Vec16<OUT_T>::pack(o));
         }
     }
     });
@@ -791,7 +837,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int r = v / PPR, c = v % PPR;
         const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c * EPP;
         if (gm >= p.M || c * EPP >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
-        *(uint4*)out_piece(p, tv, gm, gn0, c * EPP, OUT_B) = *(const uint4*)(stage + r * OUT_ROW + c * 16);
+        store16(out_piece(p, tv, gm, gn0, c * EPP, OUT_B), *(const uint4*)(stage + r * OUT_ROW + c * 16));
     }
     });
     }
@@ -803,7 +849,7 @@ int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int MAIN = NS * (BM + BN) * BK;
     constexpr int EPIB = (BM > 128 ? 64 : BM) * ((EPI == EPI_LOWRANK || BM > 128) ? (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : BN * FT<OUT_T>::bytes + 16);
-    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + 4 * BN * 4;
+    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + (EPI == EPI_LOWRANK ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK>;
     static std::atomic<bool> attr_set{false};
@@ -865,6 +911,12 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 9) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_PP, 128>(p, s);
         if (force == 10) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 4, LD_PIPE, 64>(p, s);
         if (force == 11) return launch_one<MM, OUT_T, EPI, 128, 256, 64, 64, 3, LD_PP, 64>(p, s);
+        if (force == 12) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 4, LD_PIPE, 64>(p, s);
+        if (force == 13) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_PIPE, 64>(p, s);
+        if (force == 14) return launch_one<MM, OUT_T, EPI, 128, 320, 32, 160, 3, LD_PIPE, 64>(p, s);
+        if (force == 15) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 4, LD_DMA, 64>(p, s);
+        if (force == 16) return launch_one<MM, OUT_T, EPI, 128, 320, 32, 160, 4, LD_PIPE, 64>(p, s);
+        if (force == 17) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
     }
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt). Every kernel launch starts with cold
     // L2s (data comes from MALL/HBM at ~2 us loaded latency) and the L2->LDS fill rate per CU is ~30 B/clk, so:
@@ -877,10 +929,22 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     // Software-pipelined fragment reads (LD_PIPE) measured +3..9 % on the 256x256 tiles and +8 % on the 64x64 ones, -1.5 % on
     // the SDXL step for the 64x128 tiles (one MFMA per sub-step leaves nothing to hide behind), so those keep LD_DMA.
     auto fits = [&](int bn) { return p.units == nullptr || (p.unit_n % bn) == 0; };  // grouped launch: a tile stays inside one unit
-    if (tiles(256, 256) >= 200 && fits(256)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    // (round 2, tools/micro/gemm_lab.hip + tools/sweep_gemm.py, profiles/r02_gemm_tile_sweep.txt) short-K problems do not amortise
+    // the 256x256 tile's prologue / epilogue: 4096 x 5120 x 640 ran 39 us on it vs 29 us on 256x128
+    if (tiles(256, 256) >= 200 && p.K >= 2048 && fits(256)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
     //  * tall problems that cannot fill the chip with 256x256 tiles (conv GEMMs 16384 x 320 x 2880..8640, 4096 x 5120 x 640):
     //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
     if (p.M >= 2048 && tiles(256, 128) >= 150 && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
+    if constexpr (PP_OK<MM, OUT_T, EPI>) {
+        //  * wide-N, few-row problems (the GEGLU projection 1024 x 10240 x 1280): 256x160 tiles cut N = 10240 into exactly 256
+        //    workgroups of 8 waves (wave tile 32x160), 43 % of the LDS-fill bytes of 64x128 tiles: 27.6 -> 22.4 us
+        if ((p.N % 160) == 0 && tiles(256, 160) >= 192 && tiles(256, 160) <= 512 && fits(160))
+            return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_PIPE, 64>(p, s);
+        //  * one round of 128x128 tiles (160..256 of them) with enough K to matter (1024 x 3840 x 1280: 13.4 -> 11.1 us,
+        //    4096 x 640 x 2560: 16.2 -> 15.4 us): two thirds of the LDS-fill bytes per CU of 64x128 tiles
+        if (tiles(128, 128) >= 160 && tiles(128, 128) <= 256 && p.K >= 1024 && fits(128))
+            return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+    }
     if (p.M > 128 && fits(128)) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
 }
@@ -889,7 +953,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
 inline bool force_tile_unfit(const GemmParams& p) {
     const int force = forced_tile();
     if (force < 0 || p.units == nullptr) return false;
-    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256};
+    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128};
     return force < (int)(sizeof(bn_of) / sizeof(int)) ? (p.unit_n % bn_of[force]) != 0 : false;
 }
 
@@ -925,6 +989,7 @@ int check_common(int mm_dtype, const void* a, const void* b, const float* sa, co
 
 }  // namespace
 
+#ifndef SDNQ_LAB  // tools/micro/gemm_lab.hip includes this file for the kernel template only
 extern "C" void sdnq_hip_set_tile_override(int tile_id) { g_forced_tile.store(tile_id < 0 ? -1 : tile_id, std::memory_order_relaxed); }
 
 #ifdef SDNQ_TRACE
@@ -1064,3 +1129,4 @@ extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const voi
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, EPI_LOWRANK, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, EPI_LOWRANK, out_dtype, s);
 }
+#endif  // SDNQ_LAB

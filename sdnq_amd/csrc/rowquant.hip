@@ -18,27 +18,37 @@
 
 namespace {
 
+// 8 consecutive elements of a row as floats; lanes past the end of the row (`ok` false) get zeros.  The load itself is
+// UNCONDITIONAL (a lane past the end re-reads the start of its row): a load under `if (ok)` makes the compiler close every
+// pass with its own s_waitcnt vmcnt(0), so the passes of a row were fetched one HBM round trip after the other (round 1:
+// 12.2 us for 1024 x 5120 rows, 8.9 us with the loads in flight together).
+template <int T_ID>
+__device__ __forceinline__ void load8_raw(const void* row, int64_t idx, bool ok, uint4& a, uint4& b) {
+    const int64_t i = ok ? idx : 0;
+    if constexpr (T_ID == SDNQ_F32) {
+        a = *(const uint4*)((const float*)row + i);
+        b = *(const uint4*)((const float*)row + i + 4);
+    } else {
+        a = *(const uint4*)((const uint16_t*)row + i);
+        b = a;
+    }
+}
+template <int T_ID>
+__device__ __forceinline__ void unpack8(const uint4& a, const uint4& b, bool ok, float (&v)[8]) {
+    if constexpr (T_ID == SDNQ_F32) {
+        Vec16<SDNQ_F32>::unpack(a, v);
+        Vec16<SDNQ_F32>::unpack(b, v + 4);
+    } else {
+        Vec16<T_ID>::unpack(a, v);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] : 0.0f;
+}
 template <int T_ID>
 __device__ __forceinline__ void load8(const void* row, int64_t idx, bool ok, float (&v)[8]) {
-    if constexpr (T_ID == SDNQ_F32) {
-        if (ok) {
-            const uint4 a = *(const uint4*)((const float*)row + idx);
-            const uint4 b = *(const uint4*)((const float*)row + idx + 4);
-            Vec16<SDNQ_F32>::unpack(a, v);
-            Vec16<SDNQ_F32>::unpack(b, v + 4);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-        }
-    } else {
-        if (ok) {
-            const uint4 a = *(const uint4*)((const uint16_t*)row + idx);
-            Vec16<T_ID>::unpack(a, v);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.0f;
-        }
-    }
+    uint4 a, b;
+    load8_raw<T_ID>(row, idx, ok, a, b);
+    unpack8<T_ID>(a, b, ok, v);
 }
 
 template <int T_ID>
@@ -111,10 +121,15 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
 
     if constexpr (NP > 0) {
         float v[NP][8];
+        {
+            uint4 ra[NP], rb[NP];  // every pass of the row in flight before the first use
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int64_t idx = (int64_t)p * 512 + lane * 8;
-            load8<T_ID>(row, idx, idx < K, v[p]);
+            for (int p = 0; p < NP; ++p) {
+                const int64_t idx = (int64_t)p * 512 + lane * 8;
+                load8_raw<T_ID>(row, idx, idx < K, ra[p], rb[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) unpack8<T_ID>(ra[p], rb[p], (int64_t)p * 512 + lane * 8 < K, v[p]);
         }
         const bool asym = xzp != nullptr;  // asymmetric int8 activations of the uint8 matmul (linear_uint8.py:15-23)
         float amax = 0.0f, vmin = 3.4e38f, vmax = -3.4e38f;
@@ -158,8 +173,9 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
         }
     } else {
         const int64_t npass = (K + 511) / 512;
-        // ---- phase 1: row amax (after rotation + rounding to the activation dtype)
-        float amax = 0.0f;
+        const bool asym = xzp != nullptr;
+        // ---- phase 1: row amax / min / max (after rotation + rounding to the activation dtype)
+        float amax = 0.0f, vmin = 3.4e38f, vmax = -3.4e38f;
         for (int64_t p = 0; p < npass; ++p) {
             const int64_t idx = p * 512 + lane * 8;
             float v[8];
@@ -173,10 +189,22 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 if (xrot != nullptr && idx < K) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+            for (int e = 0; e < 8; ++e) {
+                amax = fmaxf(amax, fabsf(v[e]));
+                if (idx < K) { vmin = fminf(vmin, v[e]); vmax = fmaxf(vmax, v[e]); }
+            }
         }
-        amax = wave_max(amax);
-        const float scale = amax / qmax;
+        float scale, zpv = 0.0f;
+        if (asym) {  // quantize_uint_mm_input, as in the register-resident path above
+            vmin = wave_min(vmin);
+            vmax = wave_max(vmax);
+            scale = (vmax - vmin) / 255.0f;
+            zpv = fmaf(128.0f, scale, vmin);
+            if (lane == 0) xzp[m] = zpv;
+        } else {
+            amax = wave_max(amax);
+            scale = amax / qmax;
+        }
         if (lane == 0) xs[m] = scale;
         // ---- phase 2: quantize
         for (int64_t p = 0; p < npass; ++p) {
@@ -193,8 +221,9 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                     for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
                 }
             }
-            const uint2 w = quant8<MM>(v, scale, isum);
-            if (ok) *(uint2*)(qrow + idx) = w;
+            int isum_p = 0;
+            const uint2 w = quant8<MM>(v, scale, isum_p, zpv, asym);
+            if (ok) { *(uint2*)(qrow + idx) = w; isum += isum_p; }
         }
     }
     if (rowsum != nullptr) {
@@ -236,7 +265,7 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
                                  int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
                                  const void* prefetch, int64_t prefetch_bytes, float* xzp, sdnq_stream_t stream) {
     if (!x || !xq || !xs) return SDNQ_ERR_NULL;
-    if (xzp && (mm_dtype != SDNQ_MM_I8 || k > 5120)) return SDNQ_ERR_UNSUPPORTED;  // asymmetric: int8 only, register-resident rows
+    if (xzp && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;  // asymmetric activations exist for the int8 operand only
     if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
     if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
     if (x_dtype < 0 || x_dtype > 2) return SDNQ_ERR_DTYPE;

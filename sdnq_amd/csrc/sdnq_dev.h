@@ -133,20 +133,34 @@ __device__ __forceinline__ float e5m2_to_f32(uint8_t b) {  // == fp16 with the l
 }
 
 // ---- reductions -------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v) {
+// All-lane reductions of a wave as xor butterflies.  The exchanges for lane ^ 1, 2, 4, 8 are DPP row operations of the VALU,
+// lane ^ 16 is ds_swizzle (bit mode), lane ^ 32 one v_permlane32_swap: no ds_bpermute round trips through the LDS crossbar
+// (six of them per reduction made up a noticeable part of the ~5 us a row-quantization launch lives).
+__device__ __forceinline__ int lane_xor_i32(int x, const int mask) {  // value of x in lane (lane ^ mask); mask is a constant power of two <= 16
+    switch (mask) {
+        case 1: return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        case 2: return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+        case 4:  // lane ^ 7 (row_half_mirror) then ^ 3 (quad_perm [3,2,1,0])
+            return __builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
+        case 8: return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+        default: return __builtin_amdgcn_ds_swizzle(x, 0x401F);                    // 16: bit mode, xor 0x10
+    }
+}
+template <typename OP>
+__device__ __forceinline__ int wave_allreduce_i32(int x, OP op) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    for (int m = 1; m <= 16; m <<= 1) x = op(x, lane_xor_i32(x, m));
+    const auto sw = __builtin_amdgcn_permlane32_swap((u32)x, (u32)x, false, false);  // {own half's value, other half's value}
+    return op((int)sw[0], (int)sw[1]);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    return __int_as_float(wave_allreduce_i32(__float_as_int(v), [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); }));
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    return __int_as_float(wave_allreduce_i32(__float_as_int(v), [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); }));
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    return wave_allreduce_i32(v, [](int a, int b) { return a + b; });
 }
 
 // Host-side launch helpers implemented per translation unit.

@@ -188,6 +188,45 @@ def test_rowquant_bit_exact_vs_oracle(m, k, dt, gpu_device):
             assert np.array_equal(rs.cpu().numpy(), rowsum)
 
 
+def test_rowquant_rounding_ties_and_near_ties(gpu_device):
+    """Rows built so that MANY quotients x / scale are exact rounding ties (k + 0.5 -> half to even) or sit one ulp beside one:
+    the codes must be the reference's bit for bit (any shortcut around the IEEE division would show here first)."""
+    rng = np.random.default_rng(7)
+    rows = []
+    for amax in (127.0, 254.0, 63.5, 190.5, 381.0):  # scale = amax / 127 = 1, 2, 0.5, 1.5, 3
+        s = amax / 127.0
+        halves = (rng.integers(-126, 126, size=1280) + 0.5) * s  # exact ties in f32
+        halves[0] = amax
+        rows.append(halves)
+        near = halves.copy().astype(np.float32)
+        near[1:] = np.nextafter(near[1:], np.float32(np.inf) * np.sign(rng.standard_normal(1279)).astype(np.float32))  # one ulp off a tie
+        rows.append(near)
+    x = torch.from_numpy(np.stack(rows).astype(np.float32))
+    for asym in (False, True):
+        if asym:
+            got = ops.rowquant(x.to(gpu_device), ops.MM_I8, asymmetric=True)
+            q, s_, zp = O.rowquant_asym(x.numpy())
+            assert np.array_equal(got[4].cpu().numpy(), zp)
+        else:
+            got = ops.rowquant(x.to(gpu_device), ops.MM_I8, want_rowsum=True)
+            q, s_, rowsum = O.rowquant(x.numpy(), "int8")
+            assert np.array_equal(got[2].cpu().numpy(), rowsum)
+        assert np.array_equal(bits_of(got[0]), q.view(np.uint8)), asym
+        assert np.array_equal(got[1].cpu().numpy().reshape(-1), s_)
+
+
+def test_asymmetric_rowquant_long_rows(gpu_device):
+    """uint8-matmul activations (quantize_uint_mm_input) at FLUX row lengths: K = 12288 and 15360 (ff.out / proj_out) used to be
+    refused beyond 5120 elements; the LDS-resident kernel has no such limit."""
+    for k in (12288, 15360, 5128):
+        g = torch.Generator().manual_seed(k)
+        x = (torch.randn(33, k, generator=g) * 2 + 0.3).to(torch.bfloat16)
+        xq, xs, rs, _, xzp = ops.rowquant(x.to(gpu_device), ops.MM_I8, want_rowsum=True, asymmetric=True)
+        q, s_, zp = O.rowquant_asym(x.float().numpy())
+        assert np.array_equal(bits_of(xq), q.view(np.uint8)) and np.array_equal(xs.cpu().numpy().reshape(-1), s_)
+        assert np.array_equal(xzp.cpu().numpy(), zp) and np.array_equal(rs.cpu().numpy(), q.astype(np.int32).sum(-1))
+
+
 @pytest.mark.parametrize("g_size", [4, 8, 16, 32, 64, 128, 256, 512])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 def test_hadamard_vs_oracle(g_size, dt, gpu_device):

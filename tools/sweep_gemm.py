@@ -14,12 +14,15 @@ from sdnq_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 mm = ops.MM_FP8 if (len(sys.argv) > 1 and sys.argv[1] == "fp8") else ops.MM_I8
 which = sys.argv[2] if len(sys.argv) > 2 else "sdxl"
-ids = [int(v) for v in sys.argv[3].split("=")[1].split(",")] if len(sys.argv) > 3 else list(range(12))
+ids = [int(v) for v in sys.argv[3].split("=")[1].split(",")] if len(sys.argv) > 3 else list(range(17))
 SDXL = [(4096, 640, 640), (4096, 1920, 640), (4096, 5120, 640), (4096, 640, 2560), (1024, 1280, 1280), (1024, 3840, 1280),
         (1024, 10240, 1280), (1024, 1280, 5120), (77, 1280, 2048)]
 BIG = [(8192, 8192, 8192), (16384, 8192, 4096)]
 FLUX = [(4608, 3072, 3072), (4608, 9216, 3072), (4608, 12288, 3072), (4608, 3072, 15360), (512, 3072, 3072)]
-shapes = {"sdxl": SDXL, "big": BIG, "flux": FLUX, "all": SDXL + BIG + FLUX}[which]
+if os.environ.get("SHAPES"):  # SHAPES="m,n,k;m,n,k"
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
+else:
+    shapes = {"sdxl": SDXL, "big": BIG, "flux": FLUX, "all": SDXL + BIG + FLUX}[which]
 lib = _lib.load()
 
 
@@ -45,7 +48,7 @@ def timed(fn, reps):
 
 print(f"# {'int8' if mm == ops.MM_I8 else 'fp8'} scaled-mm, bf16 out, bias; us per launch (graph replay, incl. ~1.6 us boundary) / TOP/s; '!' = output differs")
 print("# ids: 0 256x256 pipe | 1 64x128 dma | 2 64x64 pipe | 3 256x128 pipe | 4 256x256 PP | 5 256x128 PP ns3 | 6 128x256 PP ns4 | "
-      "7 128x128 PP bk128 ns3 | 8 128x128 PP bk64 ns4 | 9 64x128 PP | 10 128x128 pipe | 11 128x256 PP ns3")
+      "7 128x128 PP bk128 ns3 | 8 128x128 PP bk64 ns4 | 9 64x128 PP | 10 128x128 pipe | 11 128x256 PP ns3 | 12 256x160 pipe ns4 | 13 256x160 pipe ns3 | 14 128x320 pipe ns3 | 15 256x160 dma ns4 | 16 128x320 pipe ns4")
 for (m, n, k) in shapes:
     x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
     if mm == ops.MM_I8:
