@@ -54,7 +54,7 @@ def parse():
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--fuse-projections", action="store_true",
                    help="variant: q/k/v (and cross-attention k/v) projections fused into one layer each, like diffusers' fuse_projections()")
     p.add_argument("--no-link-projections", action="store_true",
@@ -118,11 +118,12 @@ def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=
             if has_bias:
                 lin.bias.copy_(torch.randn(n, device=device, generator=g) * 0.1)
         cfg = sdnq_amd.SDNQConfig(**cfg_kwargs)
-        if tp_world > 1:
-            from sdnq_amd.parallel import column_shard_linear
-            mod = column_shard_linear(lin, cfg, tp_rank, tp_world)
-        else:
-            mod, _ = sdnq_amd.sdnq_quantize_layer(lin, cfg)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, cfg)
+        if tp_world > 1 and m >= 32:
+            # tensor parallel: every rank holds the same quantized "checkpoint" layer and takes its slab of output channels
+            # (views of the stored tensors, sdnq_amd.parallel.column_shard_module); M = 1 embedding layers stay replicated
+            from sdnq_amd.parallel import column_shard_module
+            mod = column_shard_module(mod, tp_rank, tp_world)
         layers.append((name, mod, x, m, k, n, has_bias))
     return layers
 
@@ -293,6 +294,86 @@ def cpu_baseline(shape_list, mm_name, budget_s):
     sample = [f"{m}x{k}x{n}" for (m, k, n, b) in seen]
     return {"value": round(done_ops / t_total / 1e9, 2), "unit": "GOP/s", "cores": cores, "kind": "port",
             "sample": f"row-quantize + {mm_name} scaled-mm over the step's {len(sample)} distinct GEMM shapes (MxKxN " + ",".join(sample) + f"), {passes} passes, {t_total:.1f}s"}
+
+
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_cfg1(budget_s: float = 12.0):
+    """SURVEY 8(d) / BASELINE configs[0]: ONE 4096 x 4096 Linear, int8 row-wise, use_quantized_matmul=False, fp32 -- the
+    reference's CPU-eager path is dequantize (f32(w) * scale) + fp32 matmul -- timed on this box's host cores at M in {1, 64, 4096},
+    with every core and with one core.  Two restatements of that path:
+      * "port": the C + OpenMP oracle (oracle/sdnq_oracle.c: orc_dequant_f32 + orc_linear_float), the checker of the parity tests;
+      * "torch_eager": the same two steps as the torch CPU ops the reference's eager path issues (w.to(f32).mul(scale), F.linear).
+    Bounded: a case that would exceed its share of the budget is timed on a slice of the rows and says so."""
+    import numpy as np
+    from oracle import oracle as O
+    L = O.lib()
+    n = k = 4096
+    rng = np.random.default_rng(0)
+    w = rng.integers(-127, 128, size=(n, k)).astype(np.float32)  # int8 values as the oracle's dequantizer takes them
+    sc = (rng.random(n, dtype=np.float32) * 0.01 + 1e-4).astype(np.float32)
+    bias = rng.standard_normal(n, dtype=np.float32)
+    all_cores = L.orc_num_threads()
+    share = budget_s / 10.0
+    out = {"layer": "4096x4096 int8 row-wise, use_quantized_matmul=False, fp32 (dequantize + fp32 matmul per call)",
+           "cpu_model": _cpu_model(), "host_cores": os.cpu_count(), "torch_version": torch.__version__, "port": {}, "torch_eager": {}}
+
+    def timed(fn, rows_done, rows_total):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        reps = 1
+        while dt < 0.05 and reps < 64:  # short cases: repeat for a stable figure
+            t0 = time.perf_counter()
+            for _ in range(reps * 2):
+                fn()
+            dt = (time.perf_counter() - t0) / (reps * 2)
+            reps *= 2
+            if dt * reps > share:
+                break
+        return dt * rows_total / rows_done
+
+    W = np.empty((n, k), dtype=np.float32)
+    for threads, tname in ((all_cores, "all_cores"), (1, "one_core")):
+        L.orc_set_num_threads(threads)
+        t_deq = timed(lambda: L.orc_dequant_f32(O._p(w), O._p(sc), None, n, k, k, O._p(W)), 1, 1)
+        for m in (1, 64, 4096):
+            rows = m if (threads > 1 or m <= 64) else 64  # one core, M = 4096: a 64-row slice of the matmul, scaled
+            x = rng.standard_normal((rows, k), dtype=np.float32)
+            y = np.empty((rows, n), dtype=np.float32)
+            t_mm = timed(lambda: L.orc_linear_float(O._p(x), O._p(W), O._p(bias), rows, n, k, 0, O._p(y)), rows, m)
+            out["port"][f"M{m}_{tname}"] = {"ms": round((t_deq + t_mm) * 1e3, 3), "dequant_ms": round(t_deq * 1e3, 3), "matmul_ms": round(t_mm * 1e3, 3),
+                                           "threads": threads, "rows_timed": rows}
+    L.orc_set_num_threads(all_cores)
+    wt = torch.from_numpy(w).to(torch.int8)
+    st = torch.from_numpy(sc).reshape(n, 1)
+    bt = torch.from_numpy(bias)
+    old_threads = torch.get_num_threads()
+    try:
+        for threads, tname in ((old_threads, "all_cores"), (1, "one_core")):
+            torch.set_num_threads(threads)
+            for m in (1, 64, 4096):
+                rows = m if (threads > 1 or m <= 64) else 256
+                x = torch.randn(rows, k)
+                t_deq = timed(lambda: wt.to(torch.float32).mul_(st), 1, 1)
+                Wt = wt.to(torch.float32).mul_(st)
+                t_mm = timed(lambda: torch.nn.functional.linear(x, Wt, bt), rows, m)
+                out["torch_eager"][f"M{m}_{tname}"] = {"ms": round((t_deq + t_mm) * 1e3, 3), "dequant_ms": round(t_deq * 1e3, 3),
+                                                      "matmul_ms": round(t_mm * 1e3, 3), "threads": threads, "rows_timed": rows}
+    finally:
+        torch.set_num_threads(old_threads)
+    ops = 2 * 4096 * n * k
+    out["value_gops_M4096_all_cores_port"] = round(ops / (out["port"]["M4096_all_cores"]["ms"] / 1e3) / 1e9, 2)
+    out["value_gops_M4096_all_cores_torch_eager"] = round(ops / (out["torch_eager"]["M4096_all_cores"]["ms"] / 1e3) / 1e9, 2)
+    return out
 
 
 # Q.K^T runs on the int8 matrix pipe and P.V on the bf16 one, half of the operations each: ops / (ops/2/int8 + ops/2/bf16)
@@ -614,6 +695,9 @@ def main():
                    "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
                    "linked_projection_groups": linked,
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
+        **({"tp": {"ranks": world, "rank_devices": [f"cuda:{r}" for r in range(world)], "rccl_version": list(torch.cuda.nccl.version()),
+                   "sharded_layers": sum(1 for l in layers if type(l[1]).__name__ == "ColumnShardedLinear"),
+                   "collective": "all_gather_into_tensor of [M, N/W] bf16 per layer + one transposing copy"}} if tp else {}),
         "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
         "step_latency_ms": round(ms_per_step, 4),
     }
@@ -645,6 +729,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:
                 result["cpu_baseline"] = cpu_baseline(shape_list, mm_name, args.cpu_seconds)
+                if args.workload == "sdxl_int8":  # the reference's own CPU-runnable case (BASELINE configs[0])
+                    result["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1(args.cpu_seconds)
+                    result["cpu_baseline"]["cpu_model"] = result["cpu_baseline"]["cfg1"]["cpu_model"]
+                    result["cpu_baseline"]["torch_version"] = torch.__version__
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline_error"] = repr(e)
         print(json.dumps(result))

@@ -13,10 +13,19 @@ One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm.  The 
 t ~ 2*M*N/W / 153 GB/s + launch latency -- at SDXL bs=1 sizes that is longer than the sharded GEMM itself, which is
 why the default multi-GPU mode of bench.py is independent replicas and TP is opt-in.
 
-Slicing happens on the FLOAT weight before quantization (N/W must stay a multiple of 16, utils.py:96-97), so every
-shard is an ordinary SDNQLinear with the reference's state_dict layout; quantizing per shard is numerically identical
-to slicing a quantized full layer because all quantization statistics are per output row (Hadamard rotates along K;
-the SVD split is the one exception: it is computed per shard, which changes the low-rank factors but not the contract).
+``column_shard_module`` slices an ALREADY QUANTIZED layer (a loaded checkpoint): rank r takes rows [a, b) of the stored weight
+-- a contiguous slab of the physical [N][K] buffer in every storage format (the transposed matmul layout, plain [N, K] /
+[N, G, g], the packed sub-byte codecs, which hold whole rows) -- and the matching slices of scale / zero_point / bias /
+svd_up; svd_down (shared by all channels) is replicated.  The slab's tensors are VIEWS of the full layer's parameters (no
+copy) and the slab is an ordinary SDNQLinear with the reference's state_dict layout, so its output is bit-identical to columns
+[a, b) of the unsharded layer for every format: all quantization statistics, the re-quantization and the low-rank term are
+per output row (N / W stays a multiple of 16, utils.py:96-97).  ``column_shard_linear`` (slice a FLOAT layer, then quantize the
+slab) is kept for building sharded models from float checkpoints; with SVD it derives per-shard factors, the module slicer does not.
+
+Why the gather is not "in place": RCCL collectives move one contiguous buffer per rank, and rank r's columns of a row-major
+[M, N] matrix are M strided pieces, so the gathered [W, M, N/W] buffer needs one transposing copy (fused here into a single
+strided copy kernel).  A copy-free variant needs the GEMM epilogue to store straight into every peer's [M, N] buffer over xGMI
+(IPC-mapped peer memory): not built.
 """
 from __future__ import annotations
 
@@ -65,6 +74,81 @@ class ColumnShardedLinear(torch.nn.Module):
             g3 = gathered.view(self.world, m, wmax)
             out = torch.cat([g3[r, :, : b - a] for r, (a, b) in enumerate(self.bounds)], dim=-1)
         return out.view(*lead, self.n_total)
+
+
+def _slab_of_rows(t: torch.Tensor, n: int, a: int, b: int, what: str) -> torch.Tensor:
+    """Rows [a, b) of a per-output-channel tensor whose FIRST dimension covers the N channels in order, possibly several
+    storage rows per channel (packed codecs: [N * K / G, words] or 1-D [N * K * bits / 8])."""
+    rows = t.shape[0]
+    if rows % n:
+        raise ValueError(f"{what}: first dimension {rows} is not a multiple of N={n}")
+    per = rows // n
+    return t[a * per:b * per]
+
+
+@torch.no_grad()
+def shard_quantized_module(mod: torch.nn.Module, a: int, b: int) -> torch.nn.Module:
+    """SDNQLinear holding output channels [a, b) of the quantized layer `mod`, its tensors being views of mod's parameters."""
+    from .dequantizer import SDNQDequantizer
+    from .forward import get_forward_func
+    from .layers import SDNQLinear
+    from .loader import _DQ_FIELDS, adopt_dequantizer
+    dq0 = adopt_dequantizer(mod.sdnq_dequantizer)
+    if dq0.layer_class_name not in ("Linear", "SDNQLinear") or dq0.use_codebook:
+        raise NotImplementedError("column sharding is built for quantized Linear layers")
+    n, k = dq0.out_features, dq0.in_features
+    if not (0 <= a < b <= n) or a % 16 or (b - a) % 16:
+        raise ValueError(f"channel range [{a}, {b}) of N={n} must be 16-aligned")
+    w = mod.weight
+    transposed = dq0.weight_is_transposed
+    if transposed:  # logical [K, N], strides (1, K) (or contiguous [K, N] straight from safetensors): columns = channels
+        if tuple(w.shape) != (k, n):
+            raise ValueError(f"transposed weight must be [K, N] = ({k}, {n}), got {tuple(w.shape)}")
+        w_s = w[:, a:b]
+    else:
+        w_s = _slab_of_rows(w, n, a, b, "weight")
+
+    def per_channel(t, what):
+        if t is None:
+            return None
+        if t.shape[0] == n:
+            return t[a:b]
+        if t.shape[-1] == n:  # [1, N] of the transposed layout
+            return t[..., a:b]
+        return _slab_of_rows(t, n, a, b, what)
+
+    scale = per_channel(mod.scale, "scale")
+    zp = per_channel(getattr(mod, "zero_point", None), "zero_point")
+    svd_up, svd_down = getattr(mod, "svd_up", None), getattr(mod, "svd_down", None)
+    if svd_up is not None:  # [R, N] / [K, R] with use_quantized_matmul (quantizer.py:164-167), else [N, R] / [R, K]
+        svd_up = svd_up[:, a:b] if dq0.use_quantized_matmul else svd_up[a:b]
+    bias = None if mod.bias is None else mod.bias[a:b]
+    fields = {f: getattr(dq0, f) for f in _DQ_FIELDS}
+    dq = SDNQDequantizer(**fields)
+    dq.original_shape = torch.Size((b - a, *dq0.original_shape[1:]))
+    dq.original_stride = list(torch.empty(dq.original_shape, device="meta").stride())
+    if dq0.result_shape is not None:
+        dq.result_shape = torch.Size((b - a, *dq0.result_shape[1:]))
+    qs = list(dq0.quantized_weight_shape)
+    qs[1 if transposed else 0] = b - a
+    dq.quantized_weight_shape = torch.Size(qs)
+    skeleton = torch.nn.Linear(8, 8, bias=False)
+    skeleton.in_features, skeleton.out_features = k, b - a
+    skeleton.sdnq_dequantizer = dq
+    slab = SDNQLinear(skeleton, get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul))
+    P = lambda t: None if t is None else torch.nn.Parameter(t, requires_grad=False)  # noqa: E731
+    slab.weight, slab.scale, slab.zero_point = P(w_s), P(scale), P(zp)
+    slab.svd_up, slab.svd_down, slab.bias = P(svd_up), P(svd_down), P(bias)
+    return slab
+
+
+@torch.no_grad()
+def column_shard_module(mod: torch.nn.Module, rank: int, world: int, group=None) -> ColumnShardedLinear:
+    """Tensor-parallel shard of a PRE-QUANTIZED SDNQLinear (checkpoint layout untouched): this rank's slab (views of mod's
+    parameters) + the RCCL all-gather of the outputs.  Bit-identical to `mod` for every storage format."""
+    n = int(mod.sdnq_dequantizer.original_shape[0])
+    a, b = shard_bounds(n, rank, world)
+    return ColumnShardedLinear(shard_quantized_module(mod, a, b), n, rank, world, group)
 
 
 @torch.no_grad()

@@ -1065,3 +1065,69 @@ def test_forward_under_inference_mode_and_invalidate(gpu_device):
     got_k = blk.to_k(x)
     L.invalidate()
     assert torch.equal(got_k, blk.to_k(x.clone()))
+
+
+def test_flux_size_int8_svd_layer_vs_oracle(gpu_device):
+    """BASELINE configs[4] geometry at FULL size: FLUX.1-dev proj_mlp 4608 x 3072 -> 12288, int8 row-wise + SVD rank 32 + bias,
+    int8 MFMA with the low-rank term in the GEMM epilogue (EPI_LOWRANK on the 256x256 tile with its 64-row staging chunks --
+    round 1 only checked this epilogue at K = 512, N = 256).  Every row against the oracle: the int8 product is exact, the
+    rank-32 term is a bf16 addmm (<= 1 bf16 ulp of the [M, N] bias by summation order), so the usual 2-ulp output bound."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(31)
+    m, k, n = 4608, 3072, 12288
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+    with torch.no_grad():
+        lin.weight.mul_(0.5)
+        lin.weight[:, :40] += torch.randn(n, 1, device=gpu_device).to(torch.bfloat16) * 0.3  # a low-rank component worth extracting
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32,
+                                                                   use_quantized_matmul=True))
+    assert mod.svd_up is not None and mod.sdnq_dequantizer.svd_rank == 32 and not mod.sdnq_dequantizer.re_quantize_for_matmul
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(32)).to(torch.bfloat16)
+    x[:, 11] *= 20
+    x[77] = 0  # an all-zero activation row: y = bias2d there
+    xg = x.to(gpu_device)
+    y = mod(xg)
+    assert torch.equal(mod(xg[2048:2304].contiguous()), y[2048:2304])  # row-slab independence, bit for bit
+    ref = O.forward(oracle_from_module(mod), x.float().numpy(), "bf16")
+    assert_close_float(to_f32_numpy(y), ref, "bf16", "flux-size int8+svd32")
+    assert float((to_f32_numpy(y) != ref).mean()) < 0.02  # the bulk is bit-identical; the rest are bf16 addmm order effects
+
+
+def test_uint8_zero_point_plus_svd_at_tall_tile_size(gpu_device):
+    """Zero-point term AND low-rank term together in the epilogue of a 256-row tile: uint8 row-wise weights (zero_point kept,
+    linear_int8.py:45-50, 65-69) + SVD rank 32 at M = 4096, N = 1280, K = 1024 (256x128 tiles), against the oracle on all rows."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(33)
+    m, k, n = 4096, 1024, 1280
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+    with torch.no_grad():
+        lin.weight.add_(0.01)  # asymmetric rows: a real zero point
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="uint8", group_size=-1, use_svd=True, svd_rank=32,
+                                                                   use_quantized_matmul=True, quantized_matmul_dtype="int8"))
+    dq = mod.sdnq_dequantizer
+    assert mod.svd_up is not None and mod.zero_point is not None and dq.quantized_matmul_dtype == "int8" and not dq.re_quantize_for_matmul
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(34)).to(torch.bfloat16)
+    y = mod(x.to(gpu_device))
+    ref = O.forward(oracle_from_module(mod), x.float().numpy(), "bf16")
+    assert_close_float(to_f32_numpy(y), ref, "bf16", "uint8 zero point + svd32, 256-row tiles")
+
+
+def test_sdxl_size_fp8_layer_vs_oracle(gpu_device):
+    """BASELINE configs[2] at full layer size: SDXL GEGLU projection 4096 x 640 -> 5120, fp8 e4m3 weights and activations, fp8 MFMA,
+    every row against the oracle with the fp8 bound stated in DESIGN.md (2 bf16 ulp of the output scale; the block-scaled MFMA's
+    accumulation order differs from the oracle's sequential fp32 sum)."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(35)
+    m, k, n = 4096, 640, 5120
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1,
+                                                                   use_quantized_matmul=True))
+    assert mod.forward_func.__name__ == "quantized_linear_forward_fp8_matmul"
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(36)).to(torch.bfloat16)
+    x[:, 3] *= 15
+    y = mod(x.to(gpu_device))
+    ref = O.forward(oracle_from_module(mod), x.float().numpy(), "bf16")
+    assert_close_float(to_f32_numpy(y), ref, "bf16", "sdxl-size fp8")

@@ -84,3 +84,105 @@ def test_column_sharded_linear_world2_gloo(n):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+# ---- pre-quantized modules: column_shard_module / shard_quantized_module -----------------------------------------------------
+_SHARD_CFGS = [
+    dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True),
+    dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True, use_svd=True, svd_rank=8),
+    dict(weights_dtype="int8", use_quantized_matmul=False, use_svd=True, svd_rank=8),
+    dict(weights_dtype="int4", use_quantized_matmul=True, use_hadamard=True, hadamard_group_size=64),
+    dict(weights_dtype="uint4", use_quantized_matmul=False),
+    dict(weights_dtype="int6", group_size=-1, use_quantized_matmul=True),
+    dict(weights_dtype="uint3", use_quantized_matmul=False),
+    dict(weights_dtype="uint8", group_size=-1, use_quantized_matmul=True, quantized_matmul_dtype="int8"),
+    dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_quantized_matmul=True),
+]
+
+
+@pytest.mark.parametrize("cfg", _SHARD_CFGS, ids=lambda c: "-".join(f"{k[:6]}={v}" for k, v in c.items()))
+def test_shard_quantized_module_slices_every_storage_format(cfg):
+    """The slabs of a quantized layer are views of its parameters that tile them exactly: concatenating the slabs' weight / scale /
+    zero_point / svd_up / bias along the channel axis gives the layer's own tensors back, svd_down is shared, and the slab's
+    dequantizer describes a (b - a) x K layer of the same format."""
+    import sdnq_amd
+    from sdnq_amd.parallel import shard_quantized_module
+    torch.manual_seed(0)
+    n, k, world = 96, 128, 3
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(**cfg))
+    dq = mod.sdnq_dequantizer
+    parts = [shard_quantized_module(mod, *shard_bounds(n, r, world)) for r in range(world)]
+    wdim = 1 if dq.weight_is_transposed else 0
+    assert torch.equal(torch.cat([p.weight for p in parts], wdim).view(torch.uint8) if parts[0].weight.dtype == torch.float8_e4m3fn
+                       else torch.cat([p.weight for p in parts], wdim), mod.weight.view(torch.uint8) if mod.weight.dtype == torch.float8_e4m3fn else mod.weight)
+    sdim = -1 if (dq.weight_is_transposed and mod.scale.shape[0] != n) else 0
+    assert torch.equal(torch.cat([p.scale for p in parts], sdim), mod.scale)
+    if getattr(mod, "zero_point", None) is not None:
+        assert torch.equal(torch.cat([p.zero_point for p in parts], sdim), mod.zero_point)
+    assert torch.equal(torch.cat([p.bias for p in parts], 0), mod.bias)
+    if getattr(mod, "svd_up", None) is not None:
+        assert torch.equal(torch.cat([p.svd_up for p in parts], 1 if dq.use_quantized_matmul else 0), mod.svd_up)
+        assert all(p.svd_down.data_ptr() == mod.svd_down.data_ptr() for p in parts)
+    for p, r in zip(parts, range(world)):
+        a, b = shard_bounds(n, r, world)
+        d = p.sdnq_dequantizer
+        assert d.out_features == b - a and d.in_features == k and d.weights_dtype == dq.weights_dtype
+        assert d.weight_is_transposed == dq.weight_is_transposed and d.re_quantize_for_matmul == dq.re_quantize_for_matmul
+        assert p.weight.untyped_storage().data_ptr() == mod.weight.untyped_storage().data_ptr()  # a view, not a copy
+        assert p.forward_func is mod.forward_func
+    with pytest.raises(ValueError):
+        shard_quantized_module(mod, 8, 40)  # not 16-aligned
+
+
+class _OracleForward(torch.nn.Module):
+    """Runs a quantized slab through the CPU oracle (the checker standing in for the HIP forward in the gloo test)."""
+
+    def __init__(self, slab):
+        super().__init__()
+        from tests.modules_util import oracle_from_module
+        self.om = oracle_from_module(slab)
+
+    def forward(self, x):
+        from oracle import oracle as O
+        y = O.forward(self.om, x.float().numpy(), "bf16")
+        return torch.from_numpy(y).to(torch.bfloat16)
+
+
+def _worker_module(rank, world, port, cfg, q):
+    import sdnq_amd
+    from sdnq_amd.parallel import column_shard_module
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(128, 96, bias=True).to(torch.bfloat16)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(**cfg))  # every rank holds the same "checkpoint"
+        x = torch.randn(3, 40, 128).to(torch.bfloat16)
+        sharded = column_shard_module(mod, rank, world)
+        sharded.local = _OracleForward(sharded.local)
+        y = sharded(x)
+        full = _OracleForward(mod)(x)
+        q.put((rank, bool(torch.equal(y, full)) and tuple(y.shape) == (3, 40, 96)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [_SHARD_CFGS[1], _SHARD_CFGS[3]], ids=["int8-svd-qmm", "int4-hadamard"])
+def test_column_shard_module_world2_gloo(cfg):
+    """World-size-2 gloo run of the pre-quantized-module path: both ranks hold the same quantized layer, take their slab
+    (96 channels -> 48 + 48), compute it (oracle standing in for the HIP forward) and all-gather: bit-identical to the full layer."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_module, args=(r, 2, port, cfg, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(2))
+    assert results == {0: True, 1: True}
