@@ -11,6 +11,7 @@ from .forward import get_forward_func
 from .kernel_wrappers import fp8_scaled_mm_func, int_scaled_mm_func
 from .layers import SDNQLayer, SDNQLinear, get_sdnq_wrapper_class
 from .linear import invalidate
+from . import torch_ops  # registers the sdnq_hip::* operators with torch.library
 from .loader import accelerate, apply_sdnq_options_to_model, fuse_projections, link_layers, link_projections
 from .quantizer import (QuantizationMethod, SDNQConfig, apply_sdnq_to_module, sdnq_post_load_quant, sdnq_quantize_layer,
                         sdnq_quantize_layer_weight)

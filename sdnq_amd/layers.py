@@ -22,6 +22,9 @@ class SDNQLayer(torch.nn.Module):
                 setattr(self, key, value)
         self.original_class = original_layer.__class__
         self.forward_func = forward_func
+        if _traceable(self):
+            from . import torch_ops
+            torch_ops.layer_handle(self)
 
     @property
     def dtype(self) -> torch.dtype:
@@ -44,11 +47,21 @@ class SDNQLayer(torch.nn.Module):
         return self
 
     def forward(self, *args, **kwargs) -> torch.Tensor:
+        if torch.compiler.is_compiling() and len(args) == 1 and not kwargs:
+            # under torch.compile: ONE opaque operator per layer (sdnq_amd/torch_ops.py) instead of a graph break at the ctypes calls
+            handle = getattr(self, "_sdnq_hip_handle", None)
+            if handle is not None:
+                return torch.ops.sdnq_hip.layer_forward(args[0], handle)
         return self.forward_func(self, *args, **kwargs)
 
     def __repr__(self) -> str:
         return (f"{self.__class__.__name__}(original_class={self.original_class} forward_func={self.forward_func} "
                 f"sdnq_dequantizer={getattr(self, 'sdnq_dequantizer', None)})")
+
+
+def _traceable(layer) -> bool:
+    dq = layer.__dict__.get("sdnq_dequantizer")
+    return dq is not None and dq.layer_class_name in ("Linear", "SDNQLinear")
 
 
 class SDNQLinear(SDNQLayer, torch.nn.Linear):

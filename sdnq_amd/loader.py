@@ -67,6 +67,9 @@ def accelerate(model: torch.nn.Module) -> int:
             module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
             module.__dict__.pop("_sdnq_hip_state", None)
             _unlink(module)
+            if is_hot_path_linear(module):
+                from . import torch_ops
+                torch_ops.layer_handle(module)  # torch.compile: the layer traces as one sdnq_hip::layer_forward op
             count += 1
     from . import linear
     if linear.LINK_PROJECTIONS:
