@@ -140,6 +140,24 @@ int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void* b, const f
                              int bias_dtype, void* const* outs, int n_outs, int64_t seg_n, int out_dtype, int64_t m, int64_t n,
                              int64_t k, sdnq_stream_t stream);
 
+/* ---- a3/a4 fused: dequantize + float GEMM in one launch (the reference's DEFAULT mode, M > 32) -------------------------------
+ * replaces SDNQDequantizer.__call__ -> dequantize_symmetric / dequantize_asymmetric (dequantizer.py:52-84, 20-48) followed by
+ * torch.nn.functional.linear (layers/linear/forward.py:25-26) for ROW-WISE 8-bit weights (int8: zero_point NULL; uint8: zero_point
+ * [N]): the weight stays 1 byte per element in HBM and LDS, every lane converts its weight row's codes to the activation dtype
+ * between LDS and the matrix core -- W[n][k] = cast(f32(w) * scale[n]) resp. cast(fma(f32(w), scale[n], zero_point[n])), the very
+ * value sdnq_hip_dequant produces -- and out = cast(x . W^T + bias) with fp32 accumulation.
+ * x [M][K] bf16 / f16 (row stride ldx), w [N][K] int8 / uint8, scale / zero_point [N] f32, bias [N] of x_dtype or NULL,
+ * out [M][N] of x_dtype.  K % 16 == 0, N % 8 == 0. */
+int sdnq_hip_linear_w8a16(const void* x, int x_dtype, const void* w, const float* scale, const float* zero_point, const void* bias,
+                          void* out, int64_t m, int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream);
+
+/* the same fused dequantize + float GEMM for SEVERAL signed-int8 row-wise layers that consume one activation (linked attention
+ * projections in the dequantize + F.linear mode), through the unit table of sdnq_hip_scaled_mm_grouped below (SdnqGemmUnit.b =
+ * int8 weight rows, .sb = their scales, .bias of x_dtype): one launch, each layer's output its own [M][n_seg] matrix inside `out`. */
+struct SdnqGemmUnit;
+int sdnq_hip_linear_w8a16_grouped(const void* x, int x_dtype, const struct SdnqGemmUnit* units, int64_t n_units, int64_t unit_n,
+                                  int has_bias, void* out, int64_t m, int64_t k, int64_t ldx, sdnq_stream_t stream);
+
 /* ---- grouped scaled matmul: many layers that consume ONE activation, no stacked weight copy ------------------------------
  * The same arithmetic as sdnq_hip_scaled_mm, per layer (int_scaled_mm_func per layer, kernel_wrappers.py:193-204), for layers
  * whose inputs are the very same tensor: to_q / to_k / to_v of a self-attention block, or every cross-attention to_k / to_v of a

@@ -28,7 +28,7 @@ EXPORTS = [
     "sdnq_hip_quantize_weight", "sdnq_hip_im2col", "sdnq_hip_im2col_rowquant", "sdnq_hip_scaled_mm_nchw",
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
-    "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override",
+    "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
 ]
 
 
@@ -125,6 +125,8 @@ def _declare(lib):
     lib.sdnq_hip_linear_skinny_svd.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, i32, vp, i64, i64, vp]
     lib.sdnq_hip_linear_w8a8.argtypes = [i32, vp, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.sdnq_hip_scaled_mm_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_linear_w8a16_grouped.argtypes = [vp, i32, vp, i64, i64, i32, vp, i64, i64, i64, vp]
+    lib.sdnq_hip_linear_w8a16.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
     lib.sdnq_hip_set_tile_override.argtypes = [i32]
     lib.sdnq_hip_set_tile_override.restype = None
     lib.sdnq_hip_scaled_mm_grouped.argtypes = [i32, vp, vp, vp, i64, i64, i32, vp, i32, i64, i64, vp]

@@ -154,7 +154,18 @@ template <int MM> struct FloatMma {
 template <> struct MmaTraits<MM_BF16> : FloatMma<MM_BF16> {};
 template <> struct MmaTraits<MM_F16> : FloatMma<MM_F16> {};
 template <> struct MmaTraits<MM_F32> : FloatMma<MM_F32> {};
+// Fused dequantize + float GEMM (the reference's DEFAULT mode, use_quantized_matmul=False: dequantize_symmetric / _asymmetric
+// then F.linear, dequantizer.py:52-84 + layers/linear/forward.py:25-26) for row-wise 8-bit weights: the B operand stays int8 /
+// uint8 in HBM and in LDS (HALF the bytes of a dequantized bf16 copy, and no dequantize launch, no [N][K] float matrix in HBM);
+// every lane turns the 8 codes of its weight row into the 8 bf16 / f16 values of its MFMA fragment between LDS and the matrix
+// core -- W = cast(fma(u, s, c)) with u the byte, c = -128 s (signed) or the zero point (unsigned): bit for bit the value
+// sdnq_hip_dequant writes -- and the activations are the plain 16-bit operand.  A stage row is BK bytes of A and BK / 2 of B.
+enum { MM_W8BF16 = 5, MM_W8F16 = 6 };
+template <> struct MmaTraits<MM_W8BF16> : FloatMma<MM_W8BF16> {};
+template <> struct MmaTraits<MM_W8F16> : FloatMma<MM_W8F16> {};
 template <int MM> constexpr bool is_float_mm = (MM >= MM_BF16);
+template <int MM> constexpr bool is_w8a16 = (MM == MM_W8BF16 || MM == MM_W8F16);
+struct WRow { float s, c; };  // scale and additive constant of this lane's weight row (MM_W8*)
 
 // LDS byte offset of 16-byte chunk c (0..7) of tile row r; rows are 128 B, chunk XOR-swizzled.
 // LDS byte offset of 16-byte chunk c of tile row r, XOR-swizzled so that the 16 lanes of a ds_read_b128 group (16
@@ -200,12 +211,36 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
 
 // One MFMA operand fragment (the K-contiguous bytes of tile row `r` this lane feeds to K sub-step `ks`) and the MFMA on it.
 template <int MM> struct FragOps {
-    typedef v4i frag_t;
+    typedef v4i frag_t;   // activation-side fragment
+    typedef typename std::conditional<is_w8a16<MM>, v2i, v4i>::type fragb_t;  // weight-side fragment as read from LDS
     template <int BK> static __device__ __forceinline__ frag_t load(const uint8_t* s, int r, int ks, int fgrp, int swz) {
         return *(const v4i*)(s + lds_off<BK>(r, ks * 2 + fgrp, swz));
     }
-    static __device__ __forceinline__ void mma(typename MmaTraits<MM>::acc_t& c, const frag_t& w, const frag_t& x) {
-        if constexpr (MM == SDNQ_MM_I8) {
+    template <int BKW> static __device__ __forceinline__ fragb_t loadb(const uint8_t* s, int r, int ks, int fgrp, int swz) {
+        if constexpr (is_w8a16<MM>) return *(const v2i*)(s + lds_off<BKW>(r, ks, swz) + fgrp * 8);  // 8 codes = the lane's 8 k values
+        else return *(const v4i*)(s + lds_off<BKW>(r, ks * 2 + fgrp, swz));
+    }
+    // 8 stored bytes -> the 8 16-bit values of the MFMA fragment: v_cvt_f32_ubyteN (the byte extracts below) + fma + packed
+    // convert, ~22 VALU per fragment
+    static __device__ __forceinline__ v4i dequant8(const v2i& raw, const WRow& wr, u32 flip) {
+        const u32 w0 = (u32)raw[0] ^ flip, w1 = (u32)raw[1] ^ flip;  // flip = 0x80808080 for signed codes: u = w + 128
+        float f[8];
+        f[0] = fmaf((float)(w0 & 0xffu), wr.s, wr.c); f[1] = fmaf((float)((w0 >> 8) & 0xffu), wr.s, wr.c);
+        f[2] = fmaf((float)((w0 >> 16) & 0xffu), wr.s, wr.c); f[3] = fmaf((float)(w0 >> 24), wr.s, wr.c);
+        f[4] = fmaf((float)(w1 & 0xffu), wr.s, wr.c); f[5] = fmaf((float)((w1 >> 8) & 0xffu), wr.s, wr.c);
+        f[6] = fmaf((float)((w1 >> 16) & 0xffu), wr.s, wr.c); f[7] = fmaf((float)(w1 >> 24), wr.s, wr.c);
+        const uint4 pk = (MM == MM_W8BF16) ? Vec16<SDNQ_BF16>::pack(f) : Vec16<SDNQ_F16>::pack(f);
+        return (v4i){(int)pk.x, (int)pk.y, (int)pk.z, (int)pk.w};
+    }
+    static __device__ __forceinline__ void mma(typename MmaTraits<MM>::acc_t& c, const fragb_t& wb, const frag_t& x, const WRow& wr, u32 flip) {
+        v4i w;
+        if constexpr (is_w8a16<MM>) w = dequant8(wb, wr, flip);
+        else w = wb;
+        if constexpr (MM == MM_W8BF16) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, x), c, 0, 0, 0);
+        } else if constexpr (MM == MM_W8F16) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, x), c, 0, 0, 0);
+        } else if constexpr (MM == SDNQ_MM_I8) {
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, x, c, 0, 0, 0);
         } else if constexpr (MM == MM_BF16) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, x), c, 0, 0, 0);
@@ -220,12 +255,16 @@ template <int MM> struct FragOps {
 };
 template <> struct FragOps<SDNQ_MM_FP8> {
     typedef v8i frag_t;
+    typedef v8i fragb_t;
     template <int BK> static __device__ __forceinline__ frag_t load(const uint8_t* s, int r, int ks, int fgrp, int swz) {
         const v4i lo = *(const v4i*)(s + lds_off<BK>(r, ks * 4 + fgrp * 2, swz));
         const v4i hi = *(const v4i*)(s + lds_off<BK>(r, ks * 4 + fgrp * 2 + 1, swz));
         return (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
-    static __device__ __forceinline__ void mma(v16f& c, const frag_t& w, const frag_t& x) {
+    template <int BK> static __device__ __forceinline__ fragb_t loadb(const uint8_t* s, int r, int ks, int fgrp, int swz) {
+        return load<BK>(s, r, ks, fgrp, swz);
+    }
+    static __device__ __forceinline__ void mma(v16f& c, const frag_t& w, const frag_t& x, const WRow&, u32) {
         c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
 };
@@ -261,19 +300,23 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RPP = 1024 / BK;   // tile rows per 1-KiB DMA piece (8 for 128-byte rows, 16 for 64-byte rows)
     constexpr int LPR = BK / 16;     // lanes (16-byte chunks) per row
+    // the weight operand of the fused dequantize GEMM holds one byte per K element where the activations hold two
+    constexpr int BKW = is_w8a16<MM> ? BK / 2 : BK;  // bytes per stage row of B
+    constexpr int RPP_B = 1024 / BKW, LPR_B = BKW / 16;
     // DMA pieces per wave per stage.  Tiles whose A and B rows both split evenly over the waves keep separate A / B piece lists;
     // other tiles (BN = 160, 320: the shapes that cut N = 10240 / 5120 into exactly 256 / 512 workgroups) deal the pieces of the
     // combined [A rows | B rows] stage round-robin to the waves (JOINT): the last piece slot of a wave may be empty, and the
     // counted vmcnt of such a wave is one piece per stage lower.
-    constexpr bool JOINT = (BM % (RPP * NW) != 0) || (BN % (RPP * NW) != 0);
+    constexpr bool JOINT = (BM % (RPP * NW) != 0) || (BN % (RPP_B * NW) != 0);
+    static_assert(!is_w8a16<MM> || (BK == 128 && !JOINT), "fused dequantize GEMM: 128-byte activation rows / 64-byte weight rows, even piece split");
     constexpr int A_TOT = BM / RPP, TOT = (BM + BN) / RPP;
-    constexpr int A_PIECES = JOINT ? 0 : BM / RPP / NW, B_PIECES = JOINT ? 0 : BN / RPP / NW;
+    constexpr int A_PIECES = JOINT ? 0 : BM / RPP / NW, B_PIECES = JOINT ? 0 : BN / RPP_B / NW;
     constexpr int PPW = JOINT ? (TOT + NW - 1) / NW : A_PIECES + B_PIECES;
     constexpr int REM = JOINT ? TOT % NW : 0;  // JOINT: waves below REM own PPW pieces, the others PPW - 1 (0: all own PPW)
     static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % 16 == 0, "tile rows must split into DMA pieces");
     static_assert(BK == 64 || BK == 128, "stage rows are 64 or 128 bytes");
     static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
-    constexpr int STAGE_BYTES = (BM + BN) * BK;
+    constexpr int STAGE_BYTES = BM * BK + BN * BKW;
     constexpr int LDS_STAGES = NS;
     constexpr int OUT_B = FT<OUT_T>::bytes;
     constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // the tile leaves in ECH chunks of CH rows (LDS budget)
@@ -339,8 +382,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // wave w owns A pieces w, w+NW, ... and B pieces w, w+NW, ...; the source chunk is the swizzle-inverse of the
     // physical chunk so that LDS stays lane-linear (base + lane*16) as the DMA requires.
     const uint8_t* src[PPW];
-    const int r8 = lane / LPR;  // row of this lane inside a DMA piece
-    auto chunk_of = [&](int r) { return BK == 128 ? ((lane & 7) ^ ((r >> 1) & p.swz)) : ((lane & 3) ^ ((r >> 2) & (p.swz & 3))); };
+    // row of this lane inside a DMA piece and the (swizzle-inverse) 16-byte chunk it fetches, per operand geometry
+    auto r8_of = [&](bool isA) { return lane / (isA ? LPR : LPR_B); };
+    auto chunk_of = [&](int r, bool isA) {
+        return (isA ? BK : BKW) == 128 ? ((lane & 7) ^ ((r >> 1) & p.swz)) : ((lane & 3) ^ ((r >> 2) & (p.swz & 3)));
+    };
     const bool full = REM == 0 || wave < REM;  // wave-uniform: this wave owns PPW pieces (else PPW - 1)
     // (operand, piece inside the operand) of this wave's piece slot i
     auto piece_of = [&](int i, bool& isA) {
@@ -358,8 +404,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int i = 0; i < PPW; ++i) {
         bool isA;
         const int piece = piece_of(i, isA);
-        const int r = piece * RPP + r8;
-        const int c = chunk_of(r);
+        const int r = piece * (isA ? RPP : RPP_B) + r8_of(isA);
+        const int c = chunk_of(r, isA);
         // clamp: rows past the edge are computed on valid memory and never stored
         if (isA) {
             int64_t g = m0 + r;
@@ -376,11 +422,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     auto kofs = [&](int i) {
         bool isA;
         const int piece = piece_of(i, isA);
-        return chunk_of(piece * RPP + r8) << 4;
+        return chunk_of(piece * (isA ? RPP : RPP_B) + r8_of(isA), isA) << 4;
     };
     int slot_i = 0;  // ring slot the next issued stage goes to
+    const int K_B = is_w8a16<MM> ? K / 2 : K;  // bytes of a B row
     auto issue = [&](int kt) {
-        const int k0 = kt * BK;
         uint8_t* stage = lds + slot_i * STAGE_BYTES;
         slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
 #pragma unroll
@@ -390,7 +436,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             const int piece = piece_of(i, isA);
             uint8_t* dst = stage + (isA ? 0 : BM * BK) + piece * 1024;
             // chunks past K (K % 16 == 0) and whole stages past the end of K come from a 16-byte zero constant
-            const uint8_t* s = (k0 + kofs(i) < K) ? src[i] + k0 : (const uint8_t*)&g_zero16;
+            const int k0 = kt * (isA ? BK : BKW);
+            const uint8_t* s = (k0 + kofs(i) < (isA ? K : K_B)) ? src[i] + k0 : (const uint8_t*)&g_zero16;
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
         }
     };
@@ -417,12 +464,28 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int i = tid; i < BN; i += NT) {
         const int64_t li = i < tv.n_lim ? i : tv.n_lim - 1;  // channel inside the tile, clamped to the last valid one
         const int64_t gn = n0 + li;
-        if constexpr (!is_float_mm<MM>) s_sb[i] = tv.sb[li];
+        if constexpr (!is_float_mm<MM> || is_w8a16<MM>) s_sb[i] = tv.sb[li];
+        if constexpr (is_w8a16<MM>) s_zp[i] = p.zp ? p.zp[gn] : -128.0f * tv.sb[li];  // additive constant of the row's dequantization
         if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = tv.bias ? ldf_rt(tv.bias, tv.bias0 + li, p.bias_dtype) : 0.0f;
         if constexpr (EPI == EPI_LOWRANK) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
     }
 
     const int frow = lane & 31, fgrp = lane >> 5;
+    // fused dequantize GEMM: scale and additive constant of the TN weight rows this lane converts (one row per 32-channel block)
+    // They come through the LDS vectors filled above, NOT straight from global memory: the first use of a global load inside
+    // the K loop makes the compiler put an s_waitcnt vmcnt(0) there, which drains the LDS-DMA ring every stage (measured: the
+    // whole fused step 23.3 ms instead of ...: the K loop ran one HBM round trip per stage).
+    WRow wrow[TN];
+    u32 wflip = 0;
+    if constexpr (is_w8a16<MM>) {
+        wflip = p.zp ? 0u : 0x80808080u;  // signed codes: u = w + 128, c = -128 s;  unsigned: c = zero point
+        __syncthreads();  // s_sb / s_zp written by other threads (also waits for the prologue DMAs: once, before the loop)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            wrow[i].s = s_sb[wn * WN + i * 32 + frow];
+            wrow[i].c = s_zp[wn * WN + i * 32 + frow];
+        }
+    }
     int slot_c = 0;  // ring slot being consumed
     auto compute = [&]() {
         const uint8_t* sA = lds + slot_c * STAGE_BYTES;
@@ -431,27 +494,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         constexpr int KS = BK / MT::KB;
         static_assert(KS >= 1, "stage row shorter than one MFMA K step");
         // all fragment reads of the stage are issued before the first MFMA, so LDS latency overlaps the matrix pipe
-        typename FragOps<MM>::frag_t fa[KS][TM], fb[KS][TN];
+        typename FragOps<MM>::frag_t fa[KS][TM];
+        typename FragOps<MM>::fragb_t fb[KS][TN];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template load<BK>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j]);
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j], wrow[i], wflip);
     };
 
     if constexpr (LD == LD_PIPE) {
         typedef typename FragOps<MM>::frag_t frag_t;
         constexpr int KS = BK / MT::KB;
         constexpr int U = (KS & 1) ? 2 : 1;  // stages per loop trip, so that the fragment-set parity is static
-        frag_t fa[2][TM], fb[2][TN];
+        frag_t fa[2][TM];
+        typename FragOps<MM>::fragb_t fb[2][TN];
         auto load_set = [&](int slot, auto ksc, auto setc) {
             constexpr int ks = decltype(ksc)::value, st = decltype(setc)::value;
             const uint8_t* sA = lds + slot * STAGE_BYTES;
@@ -459,14 +524,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
             for (int j = 0; j < TM; ++j) fa[st][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template load<BK>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
         };
         auto mma_set = [&](auto setc) {
             constexpr int st = decltype(setc)::value;
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[st][i], fa[st][j]);
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[st][i], fa[st][j], wrow[i], wflip);
         };
         // stage 0 landed for every wave -> top up the ring (slot NS-1) -> first fragment set
         wait_ahead();
@@ -498,7 +563,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         static_assert(NW == 8, "ping-pong schedule: two halves of four waves");
         typedef typename FragOps<MM>::frag_t frag_t;
         constexpr int KS = BK / MT::KB;
-        frag_t fa[KS][TM], fb[KS][TN];
+        frag_t fa[KS][TM];
+        typename FragOps<MM>::fragb_t fb[KS][TN];
         const int half = __builtin_amdgcn_readfirstlane(wave >> 2);
         // Time is cut into slots by workgroup-wide barriers.  Half 0 runs LOAD(j) in slot 2j and MFMA(j) in slot 2j+1, half 1
         // LOAD(j) in slot 2j+1 and MFMA(j) in slot 2j+2.
@@ -521,7 +587,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template load<BK>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
 #pragma unroll
                     for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
                 }
@@ -538,7 +604,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j]);
+                    for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j], wrow[i], wflip);
             __builtin_amdgcn_s_setprio(0);
             if (half == 0) wait_ahead();  // own pieces of stage kt+1, read by this half right after the barrier
             __builtin_amdgcn_sched_barrier(0);
@@ -847,9 +913,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB>
 int launch_one(GemmParams p, hipStream_t s) {
     constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int MAIN = NS * (BM + BN) * BK;
+    constexpr int MAIN = NS * (BM * BK + BN * (is_w8a16<MM> ? BK / 2 : BK));
     constexpr int EPIB = (BM > 128 ? 64 : BM) * ((EPI == EPI_LOWRANK || BM > 128) ? (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : BN * FT<OUT_T>::bytes + 16);
-    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + (EPI == EPI_LOWRANK ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
+    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + ((EPI == EPI_LOWRANK || is_w8a16<MM>) ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK>;
     static std::atomic<bool> attr_set{false};
@@ -859,7 +925,7 @@ int launch_one(GemmParams p, hipStream_t s) {
         attr_set.store(true, std::memory_order_release);
     }
     if (p.lda == 0) p.lda = p.K;
-    if (p.ldb == 0) p.ldb = p.K;
+    if (p.ldb == 0) p.ldb = is_w8a16<MM> ? p.K / 2 : p.K;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = (int)((p.N + BN - 1) / BN);
     {
@@ -1017,6 +1083,56 @@ int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, v
     if (dtype == SDNQ_F16) return FG(MM_F16, SDNQ_F16);
     return FG(MM_F32, SDNQ_F32);
 #undef FG
+}
+
+// tile choice of the fused dequantize GEMM: wave tiles with two activation sub-tiles per weight sub-tile (the 22-VALU conversion of
+// a weight fragment is shared by two MFMAs), 128-byte activation rows / 64-byte weight rows per stage
+template <int MM, int OUT_T, int EPI>
+int launch_tiles_w8(const GemmParams& p, hipStream_t s) {
+    auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    // measured (tools/sweep_w8a16.py, profiles/r02_w8a16_sweep.txt): what matters is how many MFMAs share one converted weight
+    // fragment -- 128x128 tiles of four waves with 128x32 wave tiles (one conversion per FOUR MFMAs) beat every 64-row wave tile
+    // once there are enough tiles (4096^3: 178 us vs 211-224; 1024 x 10240 x 1280: 47 vs 50-54); 64x128 tiles (conversion per two
+    // MFMAs) for the small problems, where tiles are few
+    const int force = forced_tile();  // tuning / test aid: 0 256x128, 1 64x128, 2 128x128 (64x32 waves), 3 64x64, 4 128x128 (128x32 waves)
+    const bool fit128 = p.units == nullptr || (p.unit_n % 128) == 0;
+    if (force == 0 && fit128) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 128>(p, s);
+    if (force == 2 && fit128) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+    if (force == 3 || (force < 0 && p.M <= 64) || !fit128) return launch_one<MM, OUT_T, EPI, 64, 64, 64, 32, 4, LD_DMA, 128>(p, s);
+    if (force == 4 || (force < 0 && tiles(128, 128) >= 160)) return launch_one<MM, OUT_T, EPI, 128, 128, 128, 32, 3, LD_DMA, 128>(p, s);
+    return launch_one<MM, OUT_T, EPI, 64, 128, 64, 32, 3, LD_DMA, 128>(p, s);
+}
+
+extern "C" int sdnq_hip_linear_w8a16(const void* x, int x_dtype, const void* w, const float* scale, const float* zero_point,
+                                     const void* bias, void* out, int64_t m, int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {
+    if (!x || !w || !scale || !out) return SDNQ_ERR_NULL;
+    if (x_dtype != SDNQ_BF16 && x_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
+    if (m <= 0 || n <= 0 || k <= 0 || (k % 16) != 0 || (n % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)x % 16) || ((uintptr_t)w % 16) || ((uintptr_t)out % 16) || ((ldx * 2) % 16)) return SDNQ_ERR_ALIGN;
+    GemmParams p{};
+    p.a = (const uint8_t*)x; p.b = (const uint8_t*)w; p.sb = scale; p.zp = zero_point; p.bias = bias; p.out = out;
+    p.M = m; p.N = n; p.K = k * 2; p.lda = ldx * 2; p.ldb = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = x_dtype;
+    hipStream_t s = (hipStream_t)stream;
+#define W8(MMV, T) (bias ? launch_tiles_w8<MMV, T, EPI_BIAS1D>(p, s) : launch_tiles_w8<MMV, T, EPI_NONE>(p, s))
+    if (x_dtype == SDNQ_BF16) return W8(MM_W8BF16, SDNQ_BF16);
+    return W8(MM_W8F16, SDNQ_F16);
+#undef W8
+}
+
+extern "C" int sdnq_hip_linear_w8a16_grouped(const void* x, int x_dtype, const SdnqGemmUnit* units, int64_t n_units, int64_t unit_n,
+                                             int has_bias, void* out, int64_t m, int64_t k, int64_t ldx, sdnq_stream_t stream) {
+    if (!x || !units || !out) return SDNQ_ERR_NULL;
+    if (x_dtype != SDNQ_BF16 && x_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
+    if (m <= 0 || n_units <= 0 || unit_n <= 0 || (unit_n % 64) != 0 || k <= 0 || (k % 16) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)x % 16) || ((uintptr_t)out % 16) || ((ldx * 2) % 16)) return SDNQ_ERR_ALIGN;
+    GemmParams p{};
+    p.a = (const uint8_t*)x; p.out = out; p.units = units; p.unit_n = unit_n;
+    p.M = m; p.N = n_units * unit_n; p.K = k * 2; p.lda = ldx * 2; p.ldb = k; p.bias_ndim = has_bias ? 1 : 0; p.bias_dtype = x_dtype;
+    hipStream_t s = (hipStream_t)stream;
+#define W8(MMV, T) (has_bias ? launch_tiles_w8<MMV, T, EPI_BIAS1D>(p, s) : launch_tiles_w8<MMV, T, EPI_NONE>(p, s))
+    if (x_dtype == SDNQ_BF16) return W8(MM_W8BF16, SDNQ_BF16);
+    return W8(MM_W8F16, SDNQ_F16);
+#undef W8
 }
 
 extern "C" int sdnq_hip_linear_float_multi(const void* x, const void* wd, const void* bias, int dtype, void* const* outs, int n_outs,

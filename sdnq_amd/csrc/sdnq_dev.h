@@ -5,6 +5,7 @@
 
 #include "../../include/sdnq_hip.h"
 
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));

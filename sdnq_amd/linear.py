@@ -29,6 +29,8 @@ from .common import dtype_dict
 CACHE_WEIGHTS = os.environ.get("SDNQ_HIP_CACHE_WEIGHTS", "1").lower() not in {"0", "false", "no"}
 PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "0").lower() not in {"0", "false", "no"}  # measured: no gain
 FUSED_SKINNY = os.environ.get("SDNQ_HIP_FUSED_SKINNY", "1").lower() not in {"0", "false", "no"}
+FUSED_DEQUANT_GEMM = os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM", "1").lower() not in {"0", "false", "no"}
+FUSED_DEQUANT_GEMM_MAX_FLOP = float(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_MAX_FLOP", "4e10"))
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
 
 
@@ -227,6 +229,20 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
         y = group[0].forward_float(mod, group[1], input)
         if y is not None:
             return y
+    if (FUSED_DEQUANT_GEMM and m > 32 and st.svd_up is None and not dq.use_hadamard and dq.weights_dtype in ("int8", "uint8")
+            and dq.group_size <= 0 and dq.kernel_positions == 1 and input.dtype in (torch.bfloat16, torch.float16) and k % 16 == 0 and n % 8 == 0
+            and st.wd is None and input.is_cuda and 2 * m * n * k <= FUSED_DEQUANT_GEMM_MAX_FLOP):
+        # row-wise 8-bit weights, more than 32 rows, a small problem: ONE launch -- the weight goes from HBM to the matrix cores as
+        # bytes and is dequantized (to the very values sdnq_hip_dequant would write) between LDS and the MFMA; no [N, K] float copy,
+        # no second pass.  The in-loop conversion costs ~1.5x the K loop of the plain 16-bit GEMM (22 VALU per weight fragment on
+        # wave tiles of 64 rows, ~1.25x on 128-row wave tiles), so it pays while the dequantize launch it removes (~6 us + the float
+        # copy's traffic) is the larger cost: 1024 x 1280 x 1280: 14.9 vs 16.3 us, 1024 x 10240 x 1280: 47.4 vs 53 us;
+        # 4096^3: 178 vs 159 us (tools/sweep_w8a16.py, profiles/r02_w8a16_sweep.txt)
+        x2 = input.reshape(-1, k)
+        if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+            x2 = x2.contiguous()
+        w_phys, sc, zp = st.qw.keep[0], st.qw.keep[1], st.qw.keep[2]
+        return ops.linear_w8a16(x2, w_phys, sc, zp, _attr(mod, "bias")).view(*input.shape[:-1], n)
     wd = st.wd
     if wd is None:
         wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)
@@ -349,6 +365,31 @@ class ProjectionGroup:
             return False
         return True
 
+    def _float_operands(self, input: torch.Tensor) -> bool:
+        """Unit table for the fused dequantize GEMM of the members (float mode), if every member is a signed-int8 row-wise layer."""
+        tag = ("w8a16", input.dtype)
+        if self._sig_current(tag):
+            return self.gemm is not None
+        self.sig = (tag, [self._member_sig(m) for m in self.mods])
+        self.last = None
+        self.gemm = None
+        if input.dtype not in (torch.bfloat16, torch.float16):
+            return False
+        members = []
+        for m in self.mods:
+            d = m.sdnq_dequantizer
+            st = _state(m)
+            bias = _attr(m, "bias")
+            if (d.weights_dtype != "int8" or d.group_size > 0 or d.use_hadamard or d.kernel_positions != 1 or st.svd_up is not None
+                    or d.in_features % 16 or (bias is not None and bias.dtype != input.dtype) or st.wd is not None):
+                return False
+            members.append((st.qw.keep[0].view(torch.int8).reshape(d.out_features, -1), st.qw.keep[1].reshape(-1), bias))
+        try:
+            self.gemm = ops.GemmGroup(members)
+        except ops._lib.SdnqHipError:
+            return False
+        return True
+
     def _claim(self, idx: int, input: torch.Tensor, key, stream):
         """The stored output of member idx if `input` is the tensor the stored outputs were computed from, else None."""
         last = self.last
@@ -403,6 +444,12 @@ class ProjectionGroup:
         if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
             x2 = x2.contiguous()
         g = len(self.mods)
+        if FUSED_DEQUANT_GEMM and self._float_operands(input):
+            # signed int8 row-wise members: ONE fused dequantize GEMM over the members' own weights (no dequantize launches, no
+            # float copy): 1024 x (3 x 1280) x 1280: 21.9 us vs 3 dequantize launches + a 17.5 us GEMM
+            outs = ops.linear_w8a16_grouped(x2, self.gemm)
+            self.last = (input, key, stream, outs, set(range(g)))
+            return self._claim(idx, input, key, stream)
         wd = torch.empty((g * n, k), device=input.device, dtype=input.dtype)
         for i, m in enumerate(self.mods):
             d = m.sdnq_dequantizer

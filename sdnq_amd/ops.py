@@ -429,6 +429,40 @@ def linear_float(x2d: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
     return out
 
 
+def linear_w8a16(x2d: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, zero_point, bias) -> torch.Tensor:
+    """Fused dequantize + float GEMM for row-wise 8-bit weights (sdnq_hip_linear_w8a16): x2d [M, K] bf16 / f16, w [N, K] int8 /
+    uint8 physical, scale [N] f32, zero_point [N] f32 | None -> [M, N] of x2d's dtype."""
+    _require_cuda(x2d, w, scale, zero_point, bias)
+    m, k = x2d.shape
+    n = w.shape[0]
+    assert w.is_contiguous() and w.element_size() == 1 and x2d.stride(1) == 1 and scale.numel() == n
+    if bias is not None and bias.dtype != x2d.dtype:
+        bias = bias.to(x2d.dtype)
+    out = torch.empty((m, n), device=x2d.device, dtype=x2d.dtype)
+    check(_lib.load().sdnq_hip_linear_w8a16(x2d.data_ptr(), float_code(x2d.dtype), w.data_ptr(), scale.data_ptr(), _ptr(zero_point), _ptr(bias),
+                                            out.data_ptr(), m, n, k, x2d.stride(0), _stream(x2d)), "linear_w8a16")
+    return out
+
+
+def linear_w8a16_grouped(x2d: torch.Tensor, group: GemmGroup):
+    """linear_w8a16 for every (signed int8, row-wise) layer of `group` in one launch; one contiguous [M, N_i] tensor per layer."""
+    _require_cuda(x2d)
+    m, k = x2d.shape
+    if k != group.k or group.mm_torch != torch.int8:
+        raise _lib.SdnqHipError("grouped fused dequantize GEMM: int8 weights of the activation's K")
+    if group.bias_dtype >= 0 and group.bias_dtype != float_code(x2d.dtype):
+        raise _lib.SdnqHipError("grouped fused dequantize GEMM: bias must have the activation dtype")
+    out = torch.empty((m * group.n_total,), device=x2d.device, dtype=x2d.dtype)
+    check(_lib.load().sdnq_hip_linear_w8a16_grouped(x2d.data_ptr(), float_code(x2d.dtype), group.table.data_ptr(), group.n_units, group.unit_n,
+                                                    1 if group.bias_dtype >= 0 else 0, out.data_ptr(), m, k, x2d.stride(0), _stream(x2d)),
+          "linear_w8a16_grouped")
+    outs, start = [], 0
+    for n in group.widths:
+        outs.append(out[m * start:m * (start + n)].view(m, n))
+        start += n
+    return outs
+
+
 def linear_skinny(qw: QuantWeight, x2d: torch.Tensor, bias, hadamard_group: int = 0) -> torch.Tensor:
     """Fused dequant (+ Hadamard un-rotation of the weight in registers) + float linear for M < 32 rows: streams the
     quantized weight once (no SVD)."""

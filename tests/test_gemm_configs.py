@@ -118,3 +118,44 @@ def test_grouped_matmul_rejects_bad_groups(gpu_device):
     ws = torch.ones(96, device=gpu_device)
     with pytest.raises(_lib.SdnqHipError):
         ops.GemmGroup([(w, ws, None)])  # 96 channels: no 64-wide unit
+
+
+@pytest.mark.parametrize("wdt", ["int8", "uint8"])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_fused_dequant_gemm_equals_dequant_then_linear(wdt, dt, gpu_device, tile_override):
+    """sdnq_hip_linear_w8a16 (weights converted between LDS and the MFMA) against the two-launch path it replaces (sdnq_hip_dequant
+    + sdnq_hip_linear_float) on every tile configuration and on ragged shapes -- the weight values are identical by construction
+    and the k order of the fp32 accumulation is the same, so the outputs are expected bit-identical -- and against the CPU oracle."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    from tests.modules_util import oracle_from_module
+    from tests.test_gpu_parity import assert_close_float
+    tag = "bf16" if dt == torch.bfloat16 else "f16"
+    for (m, n, k, bias) in ((200, 392, 528, True), (1031, 1288, 1296, False), (4096, 640, 640, True), (33, 64, 64, True)):
+        torch.manual_seed(m + n)
+        lin = torch.nn.Linear(k, n, bias=bias).to(dt).to(gpu_device)
+        if wdt == "uint8":
+            with torch.no_grad():
+                lin.weight.add_(0.02)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype=wdt, group_size=-1, use_quantized_matmul=False))
+        assert mod.forward_func.__name__ == "quantized_linear_forward" and (mod.zero_point is not None) == (wdt == "uint8")
+        x = torch.randn(m, k, device=gpu_device, dtype=dt)
+        old, old_max = L.FUSED_DEQUANT_GEMM, L.FUSED_DEQUANT_GEMM_MAX_FLOP
+        L.FUSED_DEQUANT_GEMM_MAX_FLOP = 1e18  # every shape through the fused kernel
+        try:
+            L.FUSED_DEQUANT_GEMM = False
+            tile_override(-1)
+            want = mod(x)
+            L.FUSED_DEQUANT_GEMM = True
+            for tile in (-1, 0, 1, 2, 3):
+                tile_override(tile)
+                got = mod(x)
+                assert got.shape == want.shape
+                diff = int((got != want).sum())
+                assert diff == 0 or float((got.float() - want.float()).abs().max()) <= 2 * (2.0 ** (-8 if tag == "bf16" else -11)) * float(want.float().abs().max()), (wdt, tag, (m, n, k), tile, diff)
+        finally:
+            L.FUSED_DEQUANT_GEMM, L.FUSED_DEQUANT_GEMM_MAX_FLOP = old, old_max
+            tile_override(-1)
+        if m <= 1100:
+            ref = O.forward(oracle_from_module(mod), x.float().cpu().numpy(), tag)
+            assert_close_float(to_f32_numpy(got), ref, tag, (wdt, tag, (m, n, k)))
