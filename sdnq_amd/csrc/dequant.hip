@@ -497,10 +497,19 @@ __global__ __launch_bounds__(512) void lowrank_down_kernel(const uint16_t* __res
         for (int64_t k = kbeg; k < kend; k += 64) {
             uint4 fx[4], fd[4];
 #pragma unroll
+            // UNCONDITIONAL loads (a segment past the wave's K range re-reads its first one and is zeroed afterwards): a load under
+            // a condition gets its own s_waitcnt vmcnt(0) from the compiler, and the 8 loads of a step -- 48 per wave over K = 3072
+            // -- then complete one memory round trip after the other (round 1: 24 us per call at 4608 x 3072)
+            for (int u = 0; u < 4; ++u) {
+                const int64_t kk = (k + u * 16 < kend) ? k + u * 16 : kbeg;
+                fx[u] = *(const uint4*)(xrow + kk);
+                fd[u] = *(const uint4*)(drow + kk);
+            }
+#pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool ok = k + u * 16 < kend;
-                fx[u] = ok ? *(const uint4*)(xrow + k + u * 16) : make_uint4(0, 0, 0, 0);
-                fd[u] = (ok && nok) ? *(const uint4*)(drow + k + u * 16) : make_uint4(0, 0, 0, 0);
+                if (!ok) fx[u] = make_uint4(0, 0, 0, 0);
+                if (!ok || !nok) fd[u] = make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

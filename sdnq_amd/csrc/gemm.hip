@@ -667,6 +667,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     if (gm >= p.M) gm = p.M - 1;
                     const uint16_t* up = (const uint16_t*)p.lr_up + gn * p.rank + (lane >> 5) * 8;
                     const uint16_t* tt = (const uint16_t*)p.lr_t + gm * p.rank + (lane >> 5) * 8;
+                    // (fetching every sub-tile's t / svd_up fragments in one burst before the DMA drain -- 48 more live VGPRs --
+                    // spilled 104 registers in the 256x256 kernel and gained nothing: 72.8 vs 69.7 ms per FLUX step, round 2)
                     for (int kr = 0; kr < p.rank; kr += 16) {
                         const uint4 fu = *(const uint4*)(up + kr), ft = *(const uint4*)(tt + kr);
                         if (p.bias_dtype == SDNQ_BF16)
