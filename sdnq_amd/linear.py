@@ -115,11 +115,12 @@ def invalidate(tensor: torch.Tensor | None = None):
     handed out); with no argument, from every tensor.  Needed only when a tensor's contents were changed WITHOUT bumping its
     autograd version counter, e.g. by another library's raw-pointer kernel."""
     _act_cache.invalidate(tensor)
-    for ref in list(_groups):
+    _groups[:] = [ref for ref in _groups if ref() is not None]
+    for ref in _groups:
         g = ref()
         if g is None:
-            _groups.remove(ref)
-        elif g.last is not None and (tensor is None or g.last[0] is tensor
+            continue
+        if g.last is not None and (tensor is None or g.last[0] is tensor
                                      or (tensor.numel() and g.last[0].untyped_storage().data_ptr() == tensor.untyped_storage().data_ptr())):
             g.last = None
 

@@ -51,6 +51,8 @@ def _unlink(module: torch.nn.Module):
 def _clear_step_state(_module=None, _args=None):
     """forward-pre-hook of the root model: nothing derived from activations outlives a step (quantized copies of the previous
     step's inputs, outputs of linked projections nobody claimed)."""
+    if torch.compiler.is_compiling():
+        return  # traced by Dynamo: nothing to clear at trace time (the caches are identity- and version-keyed, never required for correctness)
     from . import linear
     linear.invalidate(None)
 
