@@ -120,6 +120,7 @@ __device__ __forceinline__ uint8_t* out_piece(const GemmParams& p, const TileVie
 template <int MM> struct MmaTraits;
 template <> struct MmaTraits<SDNQ_MM_I8> {
     typedef v16i acc_t;
+    static constexpr int MS = 32;  // the MFMA computes MS x MS output tiles
     static constexpr int KB = 32;  // bytes of K per MFMA per operand row
     static __device__ __forceinline__ void zero(acc_t& c) {
 #pragma unroll
@@ -129,6 +130,7 @@ template <> struct MmaTraits<SDNQ_MM_I8> {
 };
 template <> struct MmaTraits<SDNQ_MM_FP8> {
     typedef v16f acc_t;
+    static constexpr int MS = 32;
     static constexpr int KB = 64;
     static __device__ __forceinline__ void zero(acc_t& c) {
 #pragma unroll
@@ -144,6 +146,7 @@ template <> struct MmaTraits<SDNQ_MM_FP8> {
 enum { MM_BF16 = 2, MM_F16 = 3, MM_F32 = 4 };
 template <int MM> struct FloatMma {
     typedef v16f acc_t;
+    static constexpr int MS = 32;
     static constexpr int KB = 32;
     static __device__ __forceinline__ void zero(acc_t& c) {
 #pragma unroll
@@ -163,7 +166,19 @@ template <> struct MmaTraits<MM_F32> : FloatMma<MM_F32> {};
 enum { MM_W8BF16 = 5, MM_W8F16 = 6 };
 template <> struct MmaTraits<MM_W8BF16> : FloatMma<MM_W8BF16> {};
 template <> struct MmaTraits<MM_W8F16> : FloatMma<MM_W8F16> {};
-template <int MM> constexpr bool is_float_mm = (MM >= MM_BF16);
+// int8 on v_mfma_i32_16x16x64_i8: 16 x 16 output tiles (4 accumulators per lane: lane l holds n = 4 (l >> 4) + 0..3 of m = l & 15 --
+// again a run of 4 output channels of one row), 64 bytes of K per instruction.  Same LDS image and loaders; what it buys is
+// tile shapes in multiples of 16: 64 x 80 tiles cut the 1024 x 1280 outputs of the SDXL attention / feed-forward projections into
+// exactly 256 workgroups with 25 % fewer LDS-fill bytes per CU than 160 tiles of 64 x 128.
+enum { MM_I8_16 = 7 };
+template <> struct MmaTraits<MM_I8_16> {
+    typedef v4i acc_t;
+    static constexpr int MS = 16;
+    static constexpr int KB = 64;
+    static __device__ __forceinline__ void zero(acc_t& c) { c = (v4i){0, 0, 0, 0}; }
+    static __device__ __forceinline__ float tof(const acc_t& c, int i) { return (float)c[i]; }
+};
+template <int MM> constexpr bool is_float_mm = (MM >= MM_BF16 && MM <= 6);
 template <int MM> constexpr bool is_w8a16 = (MM == MM_W8BF16 || MM == MM_W8F16);
 struct WRow { float s, c; };  // scale and additive constant of this lane's weight row (MM_W8*)
 
@@ -213,12 +228,13 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
 template <int MM> struct FragOps {
     typedef v4i frag_t;   // activation-side fragment
     typedef typename std::conditional<is_w8a16<MM>, v2i, v4i>::type fragb_t;  // weight-side fragment as read from LDS
+    static constexpr int CPK = MmaTraits<MM>::KB / 16;  // 16-byte chunks of a row per K sub-step (= lane groups of the MFMA)
     template <int BK> static __device__ __forceinline__ frag_t load(const uint8_t* s, int r, int ks, int fgrp, int swz) {
-        return *(const v4i*)(s + lds_off<BK>(r, ks * 2 + fgrp, swz));
+        return *(const v4i*)(s + lds_off<BK>(r, ks * CPK + fgrp, swz));
     }
     template <int BKW> static __device__ __forceinline__ fragb_t loadb(const uint8_t* s, int r, int ks, int fgrp, int swz) {
         if constexpr (is_w8a16<MM>) return *(const v2i*)(s + lds_off<BKW>(r, ks, swz) + fgrp * 8);  // 8 codes = the lane's 8 k values
-        else return *(const v4i*)(s + lds_off<BKW>(r, ks * 2 + fgrp, swz));
+        else return *(const v4i*)(s + lds_off<BKW>(r, ks * CPK + fgrp, swz));
     }
     // 8 stored bytes -> the 8 16-bit values of the MFMA fragment: v_cvt_f32_ubyteN (the byte extracts below) + fma + packed
     // convert, ~22 VALU per fragment
@@ -240,6 +256,8 @@ template <int MM> struct FragOps {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, x), c, 0, 0, 0);
         } else if constexpr (MM == MM_W8F16) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, x), c, 0, 0, 0);
+        } else if constexpr (MM == MM_I8_16) {
+            c = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, x, c, 0, 0, 0);
         } else if constexpr (MM == SDNQ_MM_I8) {
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, x, c, 0, 0, 0);
         } else if constexpr (MM == MM_BF16) {
@@ -297,7 +315,10 @@ template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, in
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
     typedef MmaTraits<MM> MT;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN, NW = WAVES_M * WAVES_N, NT = NW * 64;
-    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int MS = MT::MS;                 // MFMA output tile edge: 32, or 16 for MM_I8_16
+    constexpr int TM = WM / MS, TN = WN / MS;
+    static_assert(WM % MS == 0 && WN % MS == 0, "wave tile in whole MFMA tiles");
+    static_assert(MS == 32 || (EPI <= EPI_BIAS1D && BM <= 128), "16x16 tiles: plain epilogues of the small tiles only");
     constexpr int RPP = 1024 / BK;   // tile rows per 1-KiB DMA piece (8 for 128-byte rows, 16 for 64-byte rows)
     constexpr int LPR = BK / 16;     // lanes (16-byte chunks) per row
     // the weight operand of the fused dequantize GEMM holds one byte per K element where the activations hold two
@@ -470,7 +491,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         if constexpr (EPI == EPI_LOWRANK) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
     }
 
-    const int frow = lane & 31, fgrp = lane >> 5;
+    const int frow = lane & (MS - 1), fgrp = lane / MS;  // row of the MFMA tile this lane feeds, and its 16-byte K chunk
     // fused dequantize GEMM: scale and additive constant of the TN weight rows this lane converts (one row per 32-channel block)
     // They come through the LDS vectors filled above, NOT straight from global memory: the first use of a global load inside
     // the K loop makes the compiler put an s_waitcnt vmcnt(0) there, which drains the LDS-DMA ring every stage (measured: the
@@ -482,8 +503,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         __syncthreads();  // s_sb / s_zp written by other threads (also waits for the prologue DMAs: once, before the loop)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            wrow[i].s = s_sb[wn * WN + i * 32 + frow];
-            wrow[i].c = s_zp[wn * WN + i * 32 + frow];
+            wrow[i].s = s_sb[wn * WN + i * MS + frow];
+            wrow[i].c = s_zp[wn * WN + i * MS + frow];
         }
     }
     int slot_c = 0;  // ring slot being consumed
@@ -499,9 +520,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
+            for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -522,9 +543,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             const uint8_t* sA = lds + slot * STAGE_BYTES;
             const uint8_t* sB = sA + BM * BK;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[st][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
+            for (int j = 0; j < TM; ++j) fa[st][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
         };
         auto mma_set = [&](auto setc) {
             constexpr int st = decltype(setc)::value;
@@ -587,9 +608,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * 32 + frow, ks, fgrp, p.swz);
+                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * 32 + frow, ks, fgrp, p.swz);
+                    for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
                 }
             }
             if (half == 1) wait_ahead();  // own pieces of stage kt+1, read by half 0 in the next slot
@@ -832,17 +853,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     if (ch > 0) __syncthreads();  // previous chunk fully stored before its staging area is overwritten
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        if (ECH > 1 && (wm * WM + j * 32) / CH != ch) continue;  // wave-uniform: this 32-row block is in another chunk
-        const int ml = wm * WM + j * 32 + frow - ch * CH;        // row inside the chunk
-        int64_t gm = m0 + wm * WM + j * 32 + frow;
+        if (ECH > 1 && (wm * WM + j * MS) / CH != ch) continue;  // wave-uniform: this MFMA row block is in another chunk
+        const int ml = wm * WM + j * MS + frow - ch * CH;        // row inside the chunk
+        int64_t gm = m0 + wm * WM + j * MS + frow;
         const bool m_ok = gm < p.M;
         if (!m_ok) gm = p.M - 1;
         const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;  // 4 consecutive channels
+            for (int q = 0; q < (MS == 32 ? 4 : 1); ++q) {
+                // 4 consecutive channels: 32x32 tiles hold runs (reg & 3) + 8 (reg >> 2) + 4 fgrp, 16x16 tiles the one run 4 fgrp + reg
+                const int nl0 = wn * WN + i * MS + (MS == 32 ? 8 * q + 4 * fgrp : 4 * fgrp);
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -985,6 +1007,9 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 15) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 4, LD_DMA, 64>(p, s);
         if (force == 16) return launch_one<MM, OUT_T, EPI, 128, 320, 32, 160, 4, LD_PIPE, 64>(p, s);
         if (force == 17) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+        // (64x80 tiles on v_mfma_i32_16x16x64_i8 -- MM_I8_16, instantiated by tools/micro/gemm_lab.hip only -- cut 1024 x 1280 outputs
+        //  into exactly 256 workgroups with 25 % fewer LDS-fill bytes per CU, and measured SLOWER than 160 tiles of 64x128: 9.5 vs 7.9 us
+        //  at K = 1280, 23.5 vs 19.0 us at K = 5120: four waves of 16x80 read six fragments per five 16-cycle MFMAs)
     }
     // measured on MI355X (tools/bench_gemm.py, profiles/r01_gemm_tile_sweep.txt). Every kernel launch starts with cold
     // L2s (data comes from MALL/HBM at ~2 us loaded latency) and the L2->LDS fill rate per CU is ~30 B/clk, so:

@@ -23,6 +23,9 @@ static int run_cfg(int id, GemmParams p, hipStream_t s) {
         case 3: return launch_one<MM, OT, EP, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
         case 10: return launch_one<MM, OT, EP, 128, 128, 64, 32, 4, LD_PIPE, 64>(p, s);
         case 13: return launch_one<MM, OT, EP, 256, 160, 32, 160, 3, LD_PIPE, 64>(p, s);
+        case 18: return launch_one<MM_I8_16, OT, EP, 64, 80, 16, 80, 3, LD_DMA, 128>(p, s);
+        case 19: return launch_one<MM_I8_16, OT, EP, 64, 80, 16, 80, 4, LD_DMA, 128>(p, s);
+        case 24: return launch_one<MM, OT, EP, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
 #ifdef LAB_EXTRA
         LAB_EXTRA
 #endif
