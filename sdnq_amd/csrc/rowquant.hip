@@ -13,6 +13,8 @@
 // every global access is a 16-byte (bf16/f16) or 2x16-byte (f32) lane-contiguous vector and a
 // 256/512-wide Hadamard group lives inside one pass (cross-lane butterflies via DPP/bpermute).
 // Two phases over the row: (1) amax, (2) quantize; the second read hits L2.
+#include <cstdlib>
+
 #include "hadamard_dev.h"
 #include "sdnq_dev.h"
 
@@ -91,7 +93,10 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& i
 // T_ID: activation dtype; MM: SdnqMM; HAD: rotate first; NP: 512-element passes of the row held in registers
 // (K <= NP*512: the row is read from HBM exactly once, all loads in flight together); NP == 0: two-phase fallback
 // for very long rows (second read is L2-hot).
-template <int T_ID, int MM, bool HAD, int NP>
+// WPR: waves per row (1, 2 or 4; register-resident path only).  With few rows (M <= 2048: one wave per SIMD at best) a long row
+// is the whole latency of the launch -- 80 elements per lane at K = 5120 -- so the row is cut into WPR contiguous parts, one wave
+// each, and the partial amax / min / max / row sums meet in LDS (two barriers): 1024 x 5120 rows 9.4 -> ... us per launch.
+template <int T_ID, int MM, bool HAD, int NP, int WPR = 1>
 __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
                                                        int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
                                                        int32_t* __restrict__ rowsum, void* __restrict__ xrot,
@@ -111,8 +116,15 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;  // whole wave exits together (wave-uniform)
+    const int wv = threadIdx.x >> 6;
+    int64_t m = (int64_t)blockIdx.x * (4 / WPR) + wv / WPR;
+    const int part = wv % WPR;            // which part of the row this wave owns (WPR > 1)
+    const int64_t k_part = (int64_t)part * NP * 512;  // first element of that part
+    const bool row_ok = m < M;
+    if (WPR == 1 && !row_ok) return;  // whole wave exits together (wave-uniform); with WPR > 1 every wave must reach the barriers
+    if (!row_ok) m = M - 1;
+    __shared__ float s_stat[4][4];
+    __shared__ int s_isum[4];
     const void* row = (const char*)x + m * ldx * FT<T_ID>::bytes;
     const float hscale = HAD ? hadamard_scale(log2g, T_ID) : 1.0f;
     const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
@@ -125,24 +137,24 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
             uint4 ra[NP], rb[NP];  // every pass of the row in flight before the first use
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const int64_t idx = (int64_t)p * 512 + lane * 8;
+                const int64_t idx = k_part + (int64_t)p * 512 + lane * 8;
                 load8_raw<T_ID>(row, idx, idx < K, ra[p], rb[p]);
             }
 #pragma unroll
-            for (int p = 0; p < NP; ++p) unpack8<T_ID>(ra[p], rb[p], (int64_t)p * 512 + lane * 8 < K, v[p]);
+            for (int p = 0; p < NP; ++p) unpack8<T_ID>(ra[p], rb[p], k_part + (int64_t)p * 512 + lane * 8 < K, v[p]);
         }
         const bool asym = xzp != nullptr;  // asymmetric int8 activations of the uint8 matmul (linear_uint8.py:15-23)
         float amax = 0.0f, vmin = 3.4e38f, vmax = -3.4e38f;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if constexpr (HAD) {
-                if ((int64_t)p * 512 < K) {  // wave-uniform
+                if (k_part + (int64_t)p * 512 < K) {  // wave-uniform
                     wave_hadamard(v[p], log2g, hscale);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[p][e] = FT<T_ID>::round(v[p][e]);
                 }
             }
-            const bool in = (int64_t)p * 512 + lane * 8 < K;
+            const bool in = k_part + (int64_t)p * 512 + lane * 8 < K;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 amax = fmaxf(amax, fabsf(v[p][e]));
@@ -150,21 +162,34 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
             }
         }
         float scale, zpv = 0.0f;
+        if constexpr (WPR > 1) {  // the parts of a row meet in LDS
+            amax = wave_max(amax);
+            if (asym) { vmin = wave_min(vmin); vmax = wave_max(vmax); }
+            if (lane == 0) { s_stat[wv][0] = amax; s_stat[wv][1] = vmin; s_stat[wv][2] = vmax; }
+            __syncthreads();
+            const int w0 = wv - part;
+#pragma unroll
+            for (int q = 0; q < WPR; ++q) {
+                amax = fmaxf(amax, s_stat[w0 + q][0]);
+                vmin = fminf(vmin, s_stat[w0 + q][1]);
+                vmax = fmaxf(vmax, s_stat[w0 + q][2]);
+            }
+        }
+        const bool writer = row_ok && lane == 0 && part == 0;
         if (asym) {
-            vmin = wave_min(vmin);
-            vmax = wave_max(vmax);
+            if constexpr (WPR == 1) { vmin = wave_min(vmin); vmax = wave_max(vmax); }
             scale = (vmax - vmin) / 255.0f;          // get_scale_asymmetric, quant_utils.py:10-19 with the int8 range
             zpv = fmaf(128.0f, scale, vmin);         // zero_point.sub_(scale, alpha=-128); 128*scale is exact
-            if (lane == 0) xzp[m] = zpv;
+            if (writer) xzp[m] = zpv;
         } else {
-            amax = wave_max(amax);
+            if constexpr (WPR == 1) amax = wave_max(amax);
             scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
         }
-        if (lane == 0) xs[m] = scale;
+        if (writer) xs[m] = scale;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int64_t idx = (int64_t)p * 512 + lane * 8;
-            if (idx < K) {
+            const int64_t idx = k_part + (int64_t)p * 512 + lane * 8;
+            if (idx < K && row_ok) {
                 if constexpr (HAD) {
                     if (xrot != nullptr) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v[p]);
                 }
@@ -228,7 +253,16 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
     }
     if (rowsum != nullptr) {
         isum = wave_sum_i32(isum);
-        if (lane == 0) rowsum[m] = isum;
+        if constexpr (WPR > 1) {
+            if (lane == 0) s_isum[wv] = isum;
+            __syncthreads();
+            if (part == 0) {
+                isum = 0;
+#pragma unroll
+                for (int q = 0; q < WPR; ++q) isum += s_isum[wv + q];
+            }
+        }
+        if (row_ok && lane == 0 && part == 0) rowsum[m] = isum;
     }
 }
 
@@ -281,7 +315,13 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     }
     if (rowsum && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int row_blocks = (int)((m + 3) / 4);
+    const int np = (int)((k + 511) / 512);
+    // few long rows: two waves per row (see rowquant_kernel); the prefetch blocks are not combined with it
+    static const int split_env = [] { const char* e = getenv("SDNQ_HIP_RQ_SPLIT"); return e ? atoi(e) : 0; }();  // tuning aid: 1, 2, 4
+    const bool can_split = m <= 2048 && np >= 3 && !(prefetch && prefetch_bytes > 0);
+    const bool split4 = can_split && np <= 12 && (split_env == 4 || (split_env == 0 && np >= 7));
+    const bool split2 = can_split && !split4 && np <= 10 && split_env != 1;
+    const int row_blocks = split4 ? (int)m : (split2 ? (int)((m + 1) / 2) : (int)((m + 3) / 4));
     const uint4* pf = (const uint4*)prefetch;
     int64_t pf_vecs = 0;
     if (prefetch && prefetch_bytes > 0 && ((uintptr_t)prefetch % 16) == 0) {
@@ -290,12 +330,21 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     }
     const int pf_blocks = (int)((pf_vecs + 256 * 8 - 1) / (256 * 8));
     dim3 grid((unsigned)(row_blocks + pf_blocks)), block(256);
-    const int np = (int)((k + 511) / 512);
 #define RQ_LAUNCH(T, MMV, H, NPV) \
     hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
+#define RQ_LAUNCH2(T, MMV, H, NPV) \
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV, 2>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
+#define RQ_LAUNCH4(T, MMV, H, NPV) \
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV, 4>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
 #define RQ_DISPATCH_NP(T, MMV, H)               \
     do {                                        \
-        if (np <= 2) RQ_LAUNCH(T, MMV, H, 2);   \
+        if (split4 && np <= 4) RQ_LAUNCH4(T, MMV, H, 1);      \
+        else if (split4 && np <= 8) RQ_LAUNCH4(T, MMV, H, 2); \
+        else if (split4) RQ_LAUNCH4(T, MMV, H, 3);            \
+        else if (split2 && np <= 4) RQ_LAUNCH2(T, MMV, H, 2);      \
+        else if (split2 && np <= 6) RQ_LAUNCH2(T, MMV, H, 3); \
+        else if (split2) RQ_LAUNCH2(T, MMV, H, 5);            \
+        else if (np <= 2) RQ_LAUNCH(T, MMV, H, 2);   \
         else if (np <= 3) RQ_LAUNCH(T, MMV, H, 3); \
         else if (np <= 5) RQ_LAUNCH(T, MMV, H, 5); \
         else if (np <= 10) RQ_LAUNCH(T, MMV, H, 10); \
