@@ -37,10 +37,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 INT8_MFMA_PEAK_TOPS = 5033.0  # dense: 1024 MAC/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz x 2 (MI355X_MICROARCH.md: i8 = 2x bf16 rate)
 FP8_MFMA_PEAK_TFLOPS = 5033.0
 # measured ceilings of the same instructions in a register-resident loop on this part (tools/mfma_peak.hip,
-# profiles/r01_mfma_peak.txt): the issue rate is the datasheet's (one 32x32x32 i8 MFMA per 32 clocks per SIMD) but the shader
-# clock sits at 2.0-2.3 GHz under matrix load, not 2.4
-INT8_MFMA_MEASURED_TOPS = 4200.0
-BF16_MFMA_MEASURED_TFLOPS = 2300.0
+# profiles/r02_mfma_peak.txt): the issue rate is the datasheet's (one 32x32x32 i8 MFMA per 32 clocks per SIMD) but the part clocks
+# to its power budget -- 2.0-2.3 GHz with small-integer operands (4.1-4.8 POP/s, the round-1 probe), 1.63-1.74 GHz with
+# full-entropy operand bytes (3.3-3.5 POP/s), which is what a GEMM on quantized tensors feeds the pipe
+INT8_MFMA_MEASURED_TOPS = 3490.0
+BF16_MFMA_MEASURED_TFLOPS = 1945.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -708,7 +709,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
         traffic, traffic_src = None, None
-        pmc_name = "r01_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
+        pmc_name = "r02_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
         if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -725,7 +726,8 @@ def main():
                                   "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
                                   "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3),
                                   "peak_measured": INT8_MFMA_MEASURED_TOPS, "frac_of_measured_peak": round(ach / INT8_MFMA_MEASURED_TOPS, 4),
-                                  "peak_measured_source": "profiles/r01_mfma_peak.txt (register-resident MFMA loop, tools/mfma_peak.hip)"}
+                                  "peak_measured_source": "profiles/r02_mfma_peak.txt (register-resident MFMA loop on random operand bytes, tools/mfma_peak.hip)",
+                                  "traffic_over_algorithmic": round(traffic / (gk["bytes"] / gk["launches"]), 3) if traffic else None}
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:
                 result["cpu_baseline"] = cpu_baseline(shape_list, mm_name, args.cpu_seconds)
