@@ -116,10 +116,18 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
             for (int j = 0; j < p.KW; ++j) {
                 const int ww = wo * p.SW - p.PW + j * p.DW;
                 const bool inb = h >= 0 && h < p.H && ww >= 0 && ww < p.W;
-                const int64_t base = ((int64_t)b * p.C) * img + (int64_t)h * p.W + ww;
+                // UNCONDITIONAL loads from a clamped (always valid) address, zeroed afterwards: a load under a condition gets its
+                // own s_waitcnt vmcnt(0), and the CPT x KH x KW loads of a thread then run one memory round trip after the other
+                const int hc = h < 0 ? 0 : (h >= p.H ? p.H - 1 : h), wc = ww < 0 ? 0 : (ww >= p.W ? p.W - 1 : ww);
+                const int64_t base = ((int64_t)b * p.C) * img + (int64_t)hc * p.W + wc;
                 float v[CPT];
 #pragma unroll
-                for (int u = 0; u < CPT; ++u) v[u] = (inb && c0 + u < p.C) ? FT<T_ID>::load(p.x, base + (int64_t)(c0 + u) * img) : 0.0f;
+                for (int u = 0; u < CPT; ++u) {
+                    const int cc = c0 + u < p.C ? c0 + u : p.C - 1;
+                    v[u] = FT<T_ID>::load(p.x, base + (int64_t)cc * img);
+                }
+#pragma unroll
+                for (int u = 0; u < CPT; ++u) v[u] = (inb && c0 + u < p.C) ? v[u] : 0.0f;
 #pragma unroll
                 for (int u = 0; u < CPT; ++u) {
                     uint8_t byte;
