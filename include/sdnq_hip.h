@@ -72,7 +72,7 @@ typedef enum SdnqKind {
 /* A quantized Linear weight exactly as the reference state_dict holds it. */
 typedef struct SdnqWeight {
     const void* weight;      /* packed / raw codes, see SdnqStorage */
-    const float* scale;      /* [N][G] */
+    const float* scale;      /* [N][G]; always float32 in memory, see scale_dtype */
     const float* zero_point; /* [N][G] or NULL */
     const void* svd_up;      /* [N][R] or NULL */
     const void* svd_down;    /* [R][K] or NULL */
@@ -90,6 +90,12 @@ typedef struct SdnqWeight {
     int32_t positions;       /* 0 / 1: Linear.  P > 1: conv weight [N][C_in][P] quantized along C_in (quantizer.py:120-123,
                                 205-209): k = C_in * P, group_size counts CHANNELS, scale / zero_point are
                                 [N][C_in / group_size][P] (one per output channel, channel group and kernel position) */
+    int32_t scale_dtype;     /* SdnqFloat the layer STORES scale / zero_point in: SDNQ_F32 (dequantize_fp32=True, the default)
+                                or the model dtype (dequantize_fp32=False, quantizer.py:147-156).  The arrays handed over are
+                                the float32 upcast (exact) either way; with a 16-bit scale_dtype the kernels reproduce the
+                                reference's arithmetic on 16-bit tensors: w * scale (+ zero_point) is rounded to scale_dtype
+                                once (dequantizer.py:27, 63) before anything else uses it, and the re-quantizer's row scale
+                                and quotient are rounded to it as well (dequantizer.py:219-239 with dtype=scale.dtype) */
 } SdnqWeight;
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -119,6 +125,16 @@ int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t 
                       int hadamard_group, void* xq, float* xs, int32_t* rowsum, void* xrot,
                       const void* prefetch, int64_t prefetch_bytes, float* xzp, sdnq_stream_t stream);
 
+/* dequantize_fp32=False form of sdnq_hip_rowquant: the layer's scale is stored in the model dtype (quantizer.py:147-156) and the
+ * reference then quantizes the activation IN that dtype (`input.to(dtype=scale.dtype)`, linear_int8.py:15-22 / linear_fp8.py:13-20;
+ * torch ops on 16-bit tensors compute in fp32 and round each result once):
+ *     xs[m] = round_T(amax_k|x| / qmax),   xq = cast(clamp(round_half_even(round_T(x / xs))))      (fp8: nan_to_num, clamp, cast)
+ * x: [M][K] of x_dtype = T (SDNQ_BF16 or SDNQ_F16 only).  xs receives the T-representable scale as float32 -- for float16 that IS the
+ * reference's promotion "fp16 will overflow" (linear_int8.py:20-21), for bfloat16 the value the bf16 epilogue of
+ * sdnq_hip_scaled_mm_lp reads.  rowsum / xrot / hadamard_group as in sdnq_hip_rowquant; symmetric quantization only. */
+int sdnq_hip_rowquant_lp(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype, int hadamard_group,
+                         void* xq, float* xs, int32_t* rowsum, void* xrot, sdnq_stream_t stream);
+
 /* ---- a15/a16: scaled matmul (the operator seam) --------------------------------------------
  * replaces int_scaled_mm_func / fp8_scaled_mm_func (kernel_wrappers.py:193-204) and the Triton op
  * sdnq::scaled_mm (kernels/triton_scaled_mm.py:127-275):
@@ -130,6 +146,17 @@ int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t k, int64_t 
 int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,
                        const void* bias, int bias_dtype, int bias_ndim, int64_t ld_bias, void* out,
                        int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
+
+/* dequantize_fp32=False with BFLOAT16 scales: int_scaled_mm_torch / fp8_scaled_mm_torch on bf16 tensors (kernel_wrappers.py:132-144),
+ *     t = bf16(acc);  t = bf16(t * sa[m]);  out = bf16(t * sb[n])   or   bf16(fma(t, sb[n], bias))     (fp32 op-math per step)
+ * sa / sb: float32 arrays holding bf16-representable values (sdnq_hip_rowquant_lp's xs; the layer's upcast scale).  bias: NULL,
+ * [N] (bias_ndim 1) or [M][ld_bias] (bias_ndim 2), bfloat16.  t / svd_up (both or neither, bf16, [M][rank] / [N][rank]): the
+ * low-rank bias  bf16(f32(bias[n]) + sum_r t[m][r] * svd_up[n][r])  of the SVD layers (linear_int8.py:57-62), bias_ndim <= 1 then.
+ * out: [M][N] bfloat16.  (float16 scales need no such form: the activation scale is promoted to float32, which makes the whole
+ * epilogue the float32 one of sdnq_hip_scaled_mm.) */
+int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                          int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
+                          int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
 /* the same scaled matmul over the STACKED weights of layers that consume one activation (to_q / to_k / to_v of an attention block),
  * each layer's columns stored in its own contiguous tensor: b [n_outs * seg_n][K], sb / bias [n_outs * seg_n], outs[i] is

@@ -295,8 +295,12 @@ class OracleLinear:
     """An SDNQ-quantized Linear as the reference holds it: logical-layout ndarrays + dequantizer fields."""
 
     def __init__(self, deq: dict, weight, scale, zero_point=None, svd_up=None, svd_down=None, bias=None, svd_tag="bf16",
-                 bias_tag=None, N=None, K=None):
+                 bias_tag=None, N=None, K=None, scale_tag="f32"):
         self.deq = deq
+        # dtype the layer's scale / zero_point are STORED in: "f32" (dequantize_fp32=True, the default) or the model dtype
+        # (dequantize_fp32=False, quantizer.py:147-156); `scale` / `zero_point` are float32 arrays of its values either way.
+        # A 16-bit scale makes the reference carry the whole dequantize / activation-quantization arithmetic in that dtype.
+        self.scale_tag = scale_tag
         self.weight, self.scale, self.zero_point = weight, scale, zero_point
         self.svd_up, self.svd_down, self.bias = svd_up, svd_down, bias  # float32 arrays of dtype-representable values
         self.svd_tag = svd_tag
@@ -366,6 +370,10 @@ class OracleLinear:
         """SDNQDequantizer.__call__ -> dequantize_weight (dequantizer.py:389-429, 135-162): [N,K] in `tag`."""
         tag = tag or self.result_tag
         W = self.dequant_f32_nk()
+        if self.scale_tag != "f32":
+            # weight.to(scale.dtype).mul_(scale) / addcmul(zero_point, weight.to(scale.dtype), scale) (dequantizer.py:63, 27):
+            # 16-bit tensors, float32 op-math, ONE rounding to the scale dtype (the products are exact in float32)
+            W = round_dtype(W, self.scale_tag)
         up, down = self.svd_nr_rk()
         if up is not None and use_svd:
             lib().orc_svd_add(_p(W), _p(up), _p(down), self.N, self.K, up.shape[1], _DT[self.svd_tag])
@@ -378,6 +386,10 @@ class OracleLinear:
         """re_quantize_matmul (dequantizer.py:204-239): fp32 dequant (no SVD, Hadamard not undone) -> per-row quant.
         Returns (wq [N,K] int8 | e4m3 codes uint8, ws [N])."""
         W = self.dequant_f32_nk()
+        if self.scale_tag != "f32":  # dequantize_weight(..., dtype=scale.dtype) then quantize_*_mm in that dtype (dequantizer.py:219-239)
+            if self.deq["quantized_matmul_dtype"] == "uint8":
+                raise NotImplementedError("uint8 matmul with 16-bit scales is not restated")
+            return rowquant_lp(round_dtype(W, self.scale_tag), self.deq["quantized_matmul_dtype"], self.scale_tag)[:2]
         if self.deq["quantized_matmul_dtype"] == "uint8":
             return rowquant_asym(W)  # re_quantize_uint_mm (dequantizer.py:178-187): (wq int8, ws, zero_point)
         return rowquant(W, self.deq["quantized_matmul_dtype"])[:2]
@@ -411,6 +423,47 @@ def rowquant(x_f32: np.ndarray, matmul_dtype: str):
     q = np.empty((M, K), dtype=np.uint8)
     lib().orc_rowquant_fp8(_p(x), M, K, _p(q), _p(s))
     return q, s, None
+
+
+def rowquant_lp(x_t: np.ndarray, matmul_dtype: str, tag: str):
+    """quantize_int_mm / quantize_fp_mm on rows held in a 16-bit dtype `tag` (dequantize_fp32=False: linear_int8.py:15-22
+    `input.to(dtype=scale.dtype)`, quant_utils.py:265-273, 290-299).  Every torch op on 16-bit tensors computes in float32 and
+    rounds its result to the dtype once: scale = round(amax / qmax), quotient = round(x / scale), then round-half-even / clamp
+    (int8) or nan_to_num / clamp / cast (fp8).  Returns (q, scale [M] as float32 values of `tag`, rowsum | None)."""
+    f = np.float32
+    x = round_dtype(_c(x_t, f), tag)
+    qmax = f(127.0 if matmul_dtype == "int8" else 448.0)
+    s = round_dtype((np.abs(x).max(-1, keepdims=True).astype(f) / qmax).astype(f), tag)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = round_dtype((x / s).astype(f), tag)
+    if matmul_dtype == "int8":
+        q = np.clip(np.rint(q), -128, 127)
+        q = np.where(np.isnan(q), 0, q).astype(np.int8)
+        return q, s.reshape(-1), q.astype(np.int32).sum(-1).astype(np.int32)
+    q = np.clip(np.nan_to_num(q, nan=0.0, posinf=3.4028235e38, neginf=-3.4028235e38), -448.0, 448.0).astype(f)
+    codes = np.array([lib().orc_f32_to_e4m3fn(float(v)) for v in q.reshape(-1)], dtype=np.uint8).reshape(q.shape)
+    return codes, s.reshape(-1), None
+
+
+def scaled_mm_lp(matmul_dtype: str, a, b_nk, sa, sb, bias, tag: str) -> np.ndarray:
+    """int_scaled_mm_torch / fp8_scaled_mm_torch with BFLOAT16 scales (kernel_wrappers.py:132-144): the accumulator is
+    converted to the scale dtype FIRST (`int_mm_func(a, b, out_dtype=scale_a.dtype)`), `.mul_(scale_a)` rounds again, and the
+    last step -- `.mul_(scale_b)` or addcmul(bias, ., scale_b) in float32 op-math -- rounds once more.  (float16 scales never
+    get here: the activation scale is promoted to float32, linear_int8.py:20-21, which makes the whole chain float32.)"""
+    f = np.float32
+    if matmul_dtype == "int8":
+        acc = (a.astype(np.int64) @ b_nk.astype(np.int64).T).astype(np.int32).astype(f)  # int32 -> float32 (RNE), then -> tag
+    else:
+        acc = (e4m3_decode(a).astype(np.float64) @ e4m3_decode(b_nk).astype(np.float64).T).astype(f)
+    t = round_dtype(acc, tag)
+    t = round_dtype((t * _c(sa, f).reshape(-1, 1)).astype(f), tag)
+    sbv = _c(sb, f).reshape(1, -1)
+    if bias is None:
+        return round_dtype((t * sbv).astype(f), tag)
+    bias = _c(bias, f)
+    bias = bias.reshape(1, -1) if bias.ndim == 1 else bias
+    # single-rounding fma in float32 as the reference's CPU addcmul compiles to (same as scaled_mm above)
+    return round_dtype((t.astype(np.float64) * sbv.astype(np.float64) + bias.astype(np.float64)).astype(f), tag)
 
 
 def scaled_mm(matmul_dtype: str, a, b_nk, sa, sb, bias, out_tag: str) -> np.ndarray:
@@ -546,8 +599,14 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
         t = linear_float(round_dtype(x2, mod.svd_tag), down, None, mod.svd_tag)
         b1 = None if bias is None else round_dtype(bias, mod.svd_tag)
         bias = lowrank_bias(t, up, b1, mod.svd_tag)
-    xq, xs, rowsum = rowquant(x2, mm)  # linear_int8.py:64
+    lp = mod.scale_tag != "f32"
+    if lp and zp is not None:
+        raise NotImplementedError("zero-point matmul terms with 16-bit scales are not restated")
+    xq, xs, rowsum = rowquant_lp(x2, mm, mod.scale_tag) if lp else rowquant(x2, mm)  # linear_int8.py:64
     inter["xq"], inter["xs"] = xq, xs
+    if lp and mod.scale_tag == "bf16":
+        y = round_dtype(scaled_mm_lp(mm, xq, wq, xs, ws, bias, "bf16"), tag)
+        return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
     if zp is not None:  # linear_int8.py:65-69
         zero_bias = (rowsum.astype(np.float32) * xs).astype(np.float32)[:, None] * zp.astype(np.float32)[None, :]
         zero_bias = zero_bias.astype(np.float32)

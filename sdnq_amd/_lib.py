@@ -29,6 +29,7 @@ EXPORTS = [
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
+    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp",
 ]
 
 
@@ -39,7 +40,7 @@ class SdnqWeight(ctypes.Structure):
         ("n", ctypes.c_int32), ("k", ctypes.c_int32), ("group_size", ctypes.c_int32), ("svd_rank", ctypes.c_int32),
         ("svd_dtype", ctypes.c_int32), ("storage", ctypes.c_int32), ("kind", ctypes.c_int32), ("bits", ctypes.c_int32),
         ("exponent", ctypes.c_int32), ("mantissa", ctypes.c_int32), ("native_float", ctypes.c_int32),
-        ("positions", ctypes.c_int32),
+        ("positions", ctypes.c_int32), ("scale_dtype", ctypes.c_int32),
     ]
 
 
@@ -127,6 +128,8 @@ def _declare(lib):
     lib.sdnq_hip_scaled_mm_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i64, i64, i64, vp]
     lib.sdnq_hip_linear_w8a16_grouped.argtypes = [vp, i32, vp, i64, i64, i32, vp, i64, i64, i64, vp]
     lib.sdnq_hip_linear_w8a16.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
+    lib.sdnq_hip_rowquant_lp.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.sdnq_hip_scaled_mm_lp.argtypes = [i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, i32, vp, i64, i64, i64, vp]
     lib.sdnq_hip_set_tile_override.argtypes = [i32]
     lib.sdnq_hip_set_tile_override.restype = None
     lib.sdnq_hip_scaled_mm_grouped.argtypes = [i32, vp, vp, vp, i64, i64, i32, vp, i32, i64, i64, vp]

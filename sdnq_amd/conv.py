@@ -79,7 +79,7 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
         return fold(linear._float_forward(self, x2d, linear._state(self)))
     st = linear._state(self)
     wq, ws, zp = linear._prepare_mm_weights(self, st, mm)
-    if FUSED_CONV_QUANT and st.svd_up is None and zp is None:
+    if FUSED_CONV_QUANT and st.svd_up is None and zp is None and st.qw.scale_dtype == torch.float32:
         # no SVD / zero-point terms: the float [M, K] matrix is never needed -- row scales straight from the image, then the
         # unfold writes the quantized operand (same values as im2col + rowquant)
         x4, kernel, stride, padding, dilation, nd = _geometry(self, input)

@@ -25,6 +25,7 @@ struct DeqParams {
     int64_t N, K;
     int group_size, G, rank;
     int P, SG;  // conv weights: kernel positions per channel (1 for Linear) and scales per output row (G * P)
+    int sdt;    // SdnqWeight.scale_dtype: 16-bit -> the product below is rounded to it (dequantize_fp32=False)
     WeightFmt fmt;
 };
 
@@ -59,6 +60,12 @@ __device__ __forceinline__ void dequant16(const DeqParams& p, int64_t n, int64_t
             const int g = (int)((k0 + j) / p.group_size);
             v[j] = zrow ? fmaf(v[j], srow[g], zrow[g]) : v[j] * srow[g];
         }
+    }
+    if (p.sdt != SDNQ_F32) {
+        // scale / zero_point stored in the model dtype: weight.to(scale.dtype).mul_(scale) / addcmul on 16-bit tensors compute in
+        // fp32 and round ONCE to that dtype (dequantizer.py:27, 63); w * s is exact in fp32, so this is that one rounding
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = round_rt(v[j], p.sdt);
     }
 }
 
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
     } else {
         amax = wave_max(amax);
         const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
-        scale = amax / qmax;
+        scale = round_rt(amax / qmax, p.sdt);  // 16-bit scale_dtype: quantize_int_mm / quantize_fp_mm run in that dtype
     }
     if (lane == 0) ws[n] = scale;
     for (int64_t ps = 0; ps < npass; ++ps) {
@@ -146,12 +153,12 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
             for (int j = 0; j < 16; ++j) {
                 u32 byte;
                 if constexpr (MM == SDNQ_MM_I8) {
-                    float q = __builtin_rintf((ASYM ? v[j] - zpv : v[j]) / scale);
+                    float q = __builtin_rintf(round_rt((ASYM ? v[j] - zpv : v[j]) / scale, p.sdt));
                     if (q != q) q = 0.0f;  // 0/0 of a constant row: NaN.to(int8) is 0 in the reference
                     q = fminf(fmaxf(q, -128.0f), 127.0f);
                     byte = (u32)(int)q & 0xffu;
                 } else {
-                    float q = v[j] / scale;
+                    float q = round_rt(v[j] / scale, p.sdt);
                     if (q != q) q = 0.0f;
                     q = fminf(fmaxf(q, -448.0f), 448.0f);
                     byte = f32_to_e4m3fn(q);
@@ -558,6 +565,8 @@ int fill_params(const SdnqWeight* w, DeqParams& p) {
     p.w = w->weight; p.scale = w->scale; p.zp = w->zero_point; p.svd_up = w->svd_up; p.svd_down = w->svd_down;
     p.N = w->n; p.K = w->k; p.group_size = w->group_size; p.G = (w->k / pos) / w->group_size; p.rank = w->svd_rank;
     p.P = pos; p.SG = p.G * pos;
+    if (w->scale_dtype < 0 || w->scale_dtype > 2) return SDNQ_ERR_DTYPE;
+    p.sdt = w->scale_dtype;
     p.fmt = WeightFmt{w->storage, w->kind, w->bits, w->exponent, w->mantissa, w->native_float};
     return SDNQ_OK;
 }
@@ -614,6 +623,7 @@ extern "C" int sdnq_hip_requant_asym(const SdnqWeight* w, void* wq, float* ws, f
     if (!wq || !ws || !wzp) return SDNQ_ERR_NULL;
     if ((uintptr_t)wq % 16) return SDNQ_ERR_ALIGN;
     p.svd_up = nullptr; p.svd_down = nullptr;  // as sdnq_hip_requant (linear_uint8.py:110)
+    if (p.sdt != SDNQ_F32) return SDNQ_ERR_UNSUPPORTED;  // the uint8 matmul with 16-bit scales is not built
     dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
     hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8, true>), grid, block, 0, (hipStream_t)stream, p, (uint8_t*)wq, ws, wzp);
     SDNQ_CHECK_LAUNCH();
@@ -693,6 +703,7 @@ extern "C" int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_d
     if (!x || !out || !svd_down_t || !w->svd_up) return SDNQ_ERR_NULL;
     if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
     if (w->svd_dtype != dtype) return SDNQ_ERR_DTYPE;
+    if (p.sdt != SDNQ_F32 && p.sdt != dtype) return SDNQ_ERR_DTYPE;  // 16-bit scales: q * s is rounded to the scale dtype = svd dtype here
     const bool int_fmt = p.fmt.kind == SDNQ_KIND_INT || p.fmt.kind == SDNQ_KIND_UINT;
     const bool raw8 = p.fmt.storage == SDNQ_ST_RAW8 && int_fmt, pk4 = p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && int_fmt;
     if (!(raw8 || pk4) || (p.group_size % 4) != 0 || p.P != 1) return SDNQ_ERR_UNSUPPORTED;
@@ -743,7 +754,8 @@ extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, c
     {
         const bool int_fmt = p.fmt.kind == SDNQ_KIND_INT || p.fmt.kind == SDNQ_KIND_UINT;
         const bool raw8 = p.fmt.storage == SDNQ_ST_RAW8 && int_fmt, pk4 = p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && int_fmt;
-        if ((raw8 || pk4) && m <= 4 && p.P == 1 && (p.group_size % 16) == 0 && (p.K % 16) == 0) {
+        // (the fast kernel rounds q * s straight to the activation dtype: with 16-bit scales that is the scale dtype's rounding too)
+        if ((raw8 || pk4) && m <= 4 && p.P == 1 && (p.group_size % 16) == 0 && (p.K % 16) == 0 && (p.sdt == SDNQ_F32 || p.sdt == dtype)) {
             dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
 #define SF_LAUNCH(T, B, MR) hipLaunchKernelGGL((linear_skinny_fast_kernel<T, B, MR>), grid, block, 0, s, p, x, bias, out, m, ldx, log2had)
 #define SF_M(T, B)                       \

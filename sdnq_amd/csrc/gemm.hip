@@ -217,11 +217,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 enum { EPI_NONE = 0, EPI_BIAS1D = 1, EPI_BIAS2D = 2, EPI_LOWRANK = 3 };
 
+// f32(acc) * sa, the first step of every scaled epilogue; LP: carried on bf16 tensors (see gemm_kernel)
+template <bool LP>
+__device__ __forceinline__ float acc_times_sa(float a, float sa) {
+    if constexpr (LP) return FT<SDNQ_BF16>::round(FT<SDNQ_BF16>::round(a) * sa);
+    else return a * sa;
+}
+
 __device__ __forceinline__ float ldf_rt(const void* p, int64_t i, int dt) {
     return dt == SDNQ_F32 ? ((const float*)p)[i] : (dt == SDNQ_BF16 ? bf16_bits_to_f32(((const uint16_t*)p)[i]) : f16_bits_to_f32(((const uint16_t*)p)[i]));
-}
-__device__ __forceinline__ float round_rt(float v, int dt) {
-    return dt == SDNQ_F32 ? v : (dt == SDNQ_BF16 ? FT<SDNQ_BF16>::round(v) : FT<SDNQ_F16>::round(v));
 }
 
 // One MFMA operand fragment (the K-contiguous bytes of tile row `r` this lane feeds to K sub-step `ks`) and the MFMA on it.
@@ -311,7 +315,10 @@ template <> struct FragOps<SDNQ_MM_FP8> {
 //            (an LDS-DMA costs its wave ~60-180 issue cycles) that in the lock-step schedules above leaves the pipe idle.
 enum { LD_DMA = 0, LD_PIPE = 2, LD_PP = 3 };
 
-template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK>
+// LP: dequantize_fp32=False with BFLOAT16 scales -- the reference's eager epilogue runs on bf16 tensors (kernel_wrappers.py:132-144:
+// `int_mm_func(a, b, out_dtype=scale_a.dtype).mul_(scale_a)` then `.mul_(scale_b)` / addcmul): the accumulator is rounded to bf16,
+// the product with the activation scale is rounded to bf16, and the last fma (fp32 op-math) is rounded by the bf16 store.
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK, bool LP = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
     typedef MmaTraits<MM> MT;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN, NW = WAVES_M * WAVES_N, NT = NW * 64;
@@ -785,7 +792,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float vv = a4[e] * sa;
+                const float vv = acc_times_sa<LP>(a4[e], sa);
                 float res;
                 if constexpr (EPI == EPI_NONE) {
                     res = vv * sb4[e];
@@ -874,7 +881,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     if constexpr (is_float_mm<MM>) {  // F.linear: f32 accumulate, bias added in f32, one rounding
                         res = (EPI == EPI_BIAS1D) ? a + s_bias[cn] : a;
                     } else {
-                        const float vv = a * sa;
+                        const float vv = acc_times_sa<LP>(a, sa);
                         const float sbn = s_sb[cn];
                         if constexpr (EPI == EPI_NONE) {
                             res = vv * sbn;
@@ -934,14 +941,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     TRACE(6);
 }
 
-template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB>
+template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB, bool LP = false>
 int launch_one(GemmParams p, hipStream_t s) {
+    static_assert(!LP || (OUT_T == SDNQ_BF16 && !is_float_mm<MM>), "LP: the bf16-scale epilogue of the quantized matmuls");
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int MAIN = NS * (BM * BK + BN * (is_w8a16<MM> ? BK / 2 : BK));
     constexpr int EPIB = (BM > 128 ? 64 : BM) * ((EPI == EPI_LOWRANK || BM > 128) ? (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : BN * FT<OUT_T>::bytes + 16);
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + ((EPI == EPI_LOWRANK || is_w8a16<MM>) ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK>;
+    auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK, LP>;
     static std::atomic<bool> attr_set{false};
     if (LDS_BYTES > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
@@ -1093,6 +1101,39 @@ extern "C" int sdnq_hip_debug_trace(unsigned long long* host, int n_words) {
     return hipMemset(dptr, 0, sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -7;
 }
 #endif
+
+// dequantize_fp32=False, bfloat16 scales: one plain tile configuration per epilogue (a compatibility mode, not a tuned one)
+template <int MM, int EPI>
+int launch_lp(const GemmParams& p, hipStream_t s) {
+    if (p.M > 128) return launch_one<MM, SDNQ_BF16, EPI, 64, 128, 32, 32, 3, LD_DMA, BKB, true>(p, s);
+    return launch_one<MM, SDNQ_BF16, EPI, 64, 64, 32, 32, 4, LD_PIPE, BKB, true>(p, s);
+}
+
+extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                     int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
+                                     int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+    int st = check_common(mm_dtype, a, b, sa, sb, out, SDNQ_BF16, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (bias_ndim < 0 || bias_ndim > 2 || (bias_ndim != 0 && !bias)) return SDNQ_ERR_NULL;
+    if ((t == nullptr) != (svd_up == nullptr)) return SDNQ_ERR_NULL;
+    if (t && (rank <= 0 || bias_ndim == 2)) return SDNQ_ERR_SHAPE;
+    if (t && (((uintptr_t)t % 16) || ((uintptr_t)svd_up % 16))) return SDNQ_ERR_ALIGN;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.lr_t = t; p.lr_up = svd_up; p.rank = rank;
+    p.M = m; p.N = n; p.K = k; p.ld_bias = ld_bias; p.bias_ndim = bias_ndim; p.bias_dtype = SDNQ_BF16;
+    hipStream_t s = (hipStream_t)stream;
+#define LPD(MMV)                                                              \
+    do {                                                                      \
+        if (t) return launch_lp<MMV, EPI_LOWRANK>(p, s);                      \
+        if (bias_ndim == 0) return launch_lp<MMV, EPI_NONE>(p, s);            \
+        if (bias_ndim == 1) return launch_lp<MMV, EPI_BIAS1D>(p, s);          \
+        return launch_lp<MMV, EPI_BIAS2D>(p, s);                              \
+    } while (0)
+    if (mm_dtype == SDNQ_MM_I8) LPD(SDNQ_MM_I8);
+    LPD(SDNQ_MM_FP8);
+#undef LPD
+}
 
 // internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`
 int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,

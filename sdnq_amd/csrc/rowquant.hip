@@ -63,7 +63,9 @@ __device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[
     }
 }
 
-template <int MM>
+// LP_T: SDNQ_F32 = the reference's default float32 arithmetic; SDNQ_BF16 / SDNQ_F16 = the quotient is rounded to that dtype
+// before round-half-even / the fp8 cast (torch.div on 16-bit tensors, dequantize_fp32=False: linear_int8.py:15-22)
+template <int MM, int LP_T = SDNQ_F32>
 __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& isum, float zp = 0.0f, bool asym = false) {
     u32 w0 = 0, w1 = 0;
 #pragma unroll
@@ -73,13 +75,19 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& i
             // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
             // asymmetric (quantize_uint_mm, quant_utils.py:277-286): (x - zero_point) / scale
             const float xv = asym ? v[e] - zp : v[e];
-            float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(xv / scale);
+            float q;
+            if constexpr (LP_T == SDNQ_F32) {
+                q = (scale == 0.0f) ? 0.0f : __builtin_rintf(xv / scale);
+            } else {  // a 16-bit scale can underflow to 0 under a nonzero row: x / 0 = +-inf -> the clamp, 0 / 0 = NaN -> 0
+                q = __builtin_rintf(FT<LP_T>::round(xv / scale));
+                if (q != q) q = 0.0f;
+            }
             q = fminf(fmaxf(q, -128.0f), 127.0f);
             const int qi = (int)q;
             isum += qi;
             byte = (u32)qi & 0xffu;
         } else {
-            float q = v[e] / scale;
+            float q = FT<LP_T>::round(v[e] / scale);
             if (q != q) q = 0.0f;  // nan_to_num; +-inf fall to the clamp
             q = fminf(fmaxf(q, -448.0f), 448.0f);
             byte = f32_to_e4m3fn(q);
@@ -96,7 +104,10 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& i
 // WPR: waves per row (1, 2 or 4; register-resident path only).  With few rows (M <= 2048: one wave per SIMD at best) a long row
 // is the whole latency of the launch -- 80 elements per lane at K = 5120 -- so the row is cut into WPR contiguous parts, one wave
 // each, and the partial amax / min / max / row sums meet in LDS (two barriers): 1024 x 5120 rows 9.4 -> ... us per launch.
-template <int T_ID, int MM, bool HAD, int NP, int WPR = 1>
+// LP: dequantize_fp32=False -- the layer's scale is stored in the activation dtype and the reference quantizes the activation in
+// THAT dtype (`input.to(dtype=scale.dtype)`, linear_int8.py:15-22): scale = round_T(amax / qmax), q = rint(round_T(x / scale)).
+// Built for the two-phase path only (NP == 0): a compatibility mode, not the tuned one.
+template <int T_ID, int MM, bool HAD, int NP, int WPR = 1, bool LP = false>
 __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
                                                        int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
                                                        int32_t* __restrict__ rowsum, void* __restrict__ xrot,
@@ -229,6 +240,7 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
         } else {
             amax = wave_max(amax);
             scale = amax / qmax;
+            if constexpr (LP) scale = FT<T_ID>::round(scale);
         }
         if (lane == 0) xs[m] = scale;
         // ---- phase 2: quantize
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 }
             }
             int isum_p = 0;
-            const uint2 w = quant8<MM>(v, scale, isum_p, zpv, asym);
+            const uint2 w = quant8<MM, LP ? T_ID : SDNQ_F32>(v, scale, isum_p, zpv, asym);
             if (ok) { *(uint2*)(qrow + idx) = w; isum += isum_p; }
         }
     }
@@ -365,6 +377,35 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
         case SDNQ_BF16: RQ_DISPATCH_MM(SDNQ_BF16); break;
         default: RQ_DISPATCH_MM(SDNQ_F16); break;
     }
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_rowquant_lp(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype, int hadamard_group,
+                                    void* xq, float* xs, int32_t* rowsum, void* xrot, sdnq_stream_t stream) {
+    if (!x || !xq || !xs) return SDNQ_ERR_NULL;
+    if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
+    if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
+    if (x_dtype != SDNQ_BF16 && x_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;  // float32 scales: sdnq_hip_rowquant
+    if (((uintptr_t)x % 16) || ((ldx * 2) % 16) || ((uintptr_t)xq % 8)) return SDNQ_ERR_ALIGN;
+    int log2g = 0;
+    if (hadamard_group != 0) {
+        log2g = ilog2(hadamard_group);
+        if ((1 << log2g) != hadamard_group || hadamard_group < 4 || hadamard_group > 512 || (k % hadamard_group) != 0)
+            return SDNQ_ERR_SHAPE;
+        if (xrot && ((uintptr_t)xrot % 16)) return SDNQ_ERR_ALIGN;
+    }
+    if (rowsum && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int row_blocks = (int)((m + 3) / 4);
+    dim3 grid((unsigned)row_blocks), block(256);
+#define RQLP(T, MMV, H) \
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, 0, 1, true>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, \
+                       (const uint4*)nullptr, (int64_t)0, row_blocks, (float*)nullptr)
+#define RQLP_H(T, MMV) do { if (log2g) RQLP(T, MMV, true); else RQLP(T, MMV, false); } while (0)
+#define RQLP_MM(T) do { if (mm_dtype == SDNQ_MM_I8) RQLP_H(T, SDNQ_MM_I8); else RQLP_H(T, SDNQ_MM_FP8); } while (0)
+    if (x_dtype == SDNQ_BF16) RQLP_MM(SDNQ_BF16);
+    else RQLP_MM(SDNQ_F16);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }

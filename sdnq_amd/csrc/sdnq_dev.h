@@ -57,6 +57,11 @@ template <> struct FT<SDNQ_F16> {
     static __device__ __forceinline__ uint16_t bits(float v) { return f32_to_f16_bits(v); }
 };
 
+// round to a dtype chosen at run time (wave-uniform `dt`)
+__device__ __forceinline__ float round_rt(float v, int dt) {
+    return dt == SDNQ_F32 ? v : (dt == SDNQ_BF16 ? FT<SDNQ_BF16>::round(v) : FT<SDNQ_F16>::round(v));
+}
+
 // 16-byte vector of elements -> 8 (16-bit) or 4 (f32) floats
 template <int T_ID> struct Vec16;
 template <> struct Vec16<SDNQ_F32> {

@@ -121,6 +121,8 @@ class SDNQDequantizer:
             wq, ws, wzp = ops.requant_asym(qw)
             return wq.t(), ws.view(1, -1), wzp.view(1, -1)
         wq, ws = ops.requant(qw, ops.mm_code(self.quantized_matmul_dtype))
+        if scale.dtype in (torch.bfloat16, torch.float16):  # 16-bit scales: the row scale was computed in that dtype (exact cast)
+            ws = ws.to(scale.dtype)
         return wq.t(), ws.view(1, -1)
 
     @torch.no_grad()

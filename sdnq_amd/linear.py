@@ -187,6 +187,9 @@ def _state(mod) -> _State:
     st.key = _signature(mod)
     st.qw = dq.quant_weight(mod.weight, mod.scale, getattr(mod, "zero_point", None), getattr(mod, "svd_up", None),
                             getattr(mod, "svd_down", None))
+    if st.qw.scale_dtype != torch.float32 and st.qw.scale_dtype != dq.result_dtype:
+        raise NotImplementedError(f"scale dtype {st.qw.scale_dtype} differs from the layer's result dtype {dq.result_dtype}: 16-bit "
+                                  "scales are built for the layout apply_sdnq_options_to_model(dequantize_fp32=False) produces")
     st.mm = None
     st.mm_weight = st.mm_scale = st.mm_zp = st.mm_wcs = None
     st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
@@ -473,6 +476,8 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     m = input.numel() // input.shape[-1]
     if m == 0 or (small_batch_branch and m < 32):  # linear_int8.py:102-103: small batches take the dequant + float GEMM branch
         return _float_forward(self, input, st)
+    if st.qw.scale_dtype != torch.float32:
+        return _lp_matmul_forward(self, input, st, mm)
     group = self.__dict__.get("_sdnq_group")
     if group is not None and not group[0].float_mode and LINK_PROJECTIONS and input.is_cuda:
         y = group[0].forward(self, group[1], input, mm)
@@ -512,6 +517,37 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     return y.view(*input.shape[:-1], n)
 
 
+def _lp_matmul_forward(self, input: torch.Tensor, st: _State, mm: int) -> torch.Tensor:
+    """The quantized matmul of a layer whose scale is stored in the model dtype (dequantize_fp32=False, quantizer.py:147-156).
+    The reference then quantizes the activation in that dtype (`input.to(dtype=scale.dtype)`, linear_int8.py:15-22) and, for
+    bfloat16, runs the scaled-matmul epilogue on bf16 tensors (kernel_wrappers.py:132-144); float16 activation scales are
+    promoted to float32 (linear_int8.py:20-21), which makes the epilogue the float32 one.  A compatibility mode: plain
+    launches, no activation cache, no linked projections."""
+    dq = self.sdnq_dequantizer
+    sdt = st.qw.scale_dtype
+    k, n = dq.in_features, dq.out_features
+    if input.dtype != sdt:
+        raise NotImplementedError(f"16-bit scales ({sdt}) with {input.dtype} activations are not built (the layer's dtype must match)")
+    wq, ws, zp = _prepare_mm_weights(self, st, mm)  # re-quantization rounds in the scale dtype (SdnqWeight.scale_dtype)
+    if zp is not None:
+        raise NotImplementedError("zero-point matmul terms with 16-bit scales (dequantize_fp32=False) are not built")
+    had = dq.hadamard_group_size if dq.use_hadamard else 0
+    has_svd = st.svd_up is not None
+    bias = _attr(self, "bias")
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+        x2 = x2.contiguous()
+    xq, xs, _, xrot = ops.rowquant_lp(x2, mm, had, want_xrot=has_svd)
+    t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
+    if sdt == torch.bfloat16:
+        y = ops.scaled_mm_lp(mm, xq, wq, xs, ws, bias, t, st.svd_up if has_svd else None)
+    elif has_svd:
+        y = ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, st.svd_up, None, None, input.dtype)
+    else:
+        y = ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype)
+    return y.view(*input.shape[:-1], n)
+
+
 @torch.no_grad()
 def quantized_linear_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _quantized_matmul_forward(self, input, ops.MM_I8)
@@ -531,6 +567,8 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     m = input.numel() // input.shape[-1]
     if m == 0 or (small_batch_branch and m < 32):
         return _float_forward(self, input, st)
+    if st.qw.scale_dtype != torch.float32:
+        raise NotImplementedError("the uint8 matmul with 16-bit scales (dequantize_fp32=False) is not built")
     wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)
     wcs = st.mm_wcs
     if wcs is None:  # f32(sum_k wq[n][k]) * ws[n]: static per layer (linear_uint8.py:63 computes it every call)

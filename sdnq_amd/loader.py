@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 
+from .common import dtype_dict
 from .dequantizer import SDNQDequantizer
 from .forward import get_forward_func
 from .quantizer import check_quantized_matmul_is_allowed
@@ -187,6 +188,8 @@ def _fusable(mods) -> bool:
         return False
     if any(getattr(m, "svd_up", None) is not None for m in mods):
         return False
+    if any(m.scale.dtype != torch.float32 for m in mods):  # dequantize_fp32=False layers run their own (compatibility) path
+        return False
     return len({m.bias is None for m in mods}) == 1
 
 
@@ -240,8 +243,6 @@ def fuse_projections(model: torch.nn.Module) -> int:
 @torch.no_grad()
 def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
                                 use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):
-    if dequantize_fp32 is False:
-        raise NotImplementedError("dequantize_fp32=False is not supported by the HIP kernels (scales stay float32)")
     for module in model.modules():
         if not is_hot_path_linear(module):
             continue
@@ -253,6 +254,21 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
                 t = getattr(module, name, None)
                 if t is not None and t.dtype != dtype:
                     setattr(module, name, torch.nn.Parameter(t.to(dtype), requires_grad=False))
+        # scale / zero_point dtype (reference loader.py:262-283): float32 when asked for (or for > 8-bit formats), untouched when
+        # already float32 and nothing was asked, else the layer's result dtype.  (The reference's float-matmul clause needs
+        # row-wise fp8 scaling hardware; gfx950 runs tensorwise, kernel_wrappers.use_tensorwise_fp8_matmul.)
+        sdt = module.scale.dtype
+        wide = sdt in (torch.float32, torch.float64)
+        if dequantize_fp32 or dtype_dict[dq.weights_dtype]["num_bits"] > 8:
+            want_sdt = sdt if wide else (torch.float64 if dq.result_dtype == torch.float64 else torch.float32)
+        elif dequantize_fp32 is None and wide:
+            want_sdt = sdt
+        else:
+            want_sdt = dq.result_dtype
+        if want_sdt != sdt:
+            module.scale = torch.nn.Parameter(module.scale.to(want_sdt), requires_grad=False)
+            if getattr(module, "zero_point", None) is not None:
+                module.zero_point = torch.nn.Parameter(module.zero_point.to(want_sdt), requires_grad=False)
         if use_quantized_matmul is not None and use_quantized_matmul != dq.use_quantized_matmul:
             n, k = dq.out_features, dq.in_features
             want = check_quantized_matmul_is_allowed(use_quantized_matmul, n, k)

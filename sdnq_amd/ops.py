@@ -67,6 +67,7 @@ class QuantWeight:
     k: int
     group_size: int
     keep: tuple  # tensors kept alive for the raw pointers in `desc`
+    scale_dtype: torch.dtype = torch.float32  # dtype the LAYER stores scale / zero_point in (dequantize_fp32=False: the model dtype)
 
 
 def _storage_kind(weights_dtype: str):
@@ -130,10 +131,17 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
             # 1-bit types: the reference's pack_uint1 on a bool tensor promotes to int64 words holding 8 bits each
             # (packed_int/pack.py:309-321); the kernels read uint8 words
             w_phys = w_phys.to(torch.uint8)
-    if scale.dtype != torch.float32:
-        raise _lib.SdnqHipError("scale must be float32 (dequantize_fp32=True, the reference default)")
+    scale_dtype = scale.dtype
+    if scale_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise _lib.SdnqHipError(f"scale must be float32, bfloat16 or float16, got {scale_dtype}")
+    if scale_dtype != torch.float32 and bits > 8:
+        raise _lib.SdnqHipError("16-bit scales with formats wider than 8 bits are not built (the codes are not exact in the scale dtype)")
+    if zero_point is not None and zero_point.dtype != scale_dtype:
+        raise _lib.SdnqHipError("scale and zero_point must share one dtype (loader.py:277-280 casts both)")
     g = (k // positions) // group_size * positions
-    sc = scale.contiguous().view(-1)
+    # dequantize_fp32=False keeps scale / zero_point in the model dtype (quantizer.py:147-156); the kernels read the exact float32
+    # upcast and SdnqWeight.scale_dtype tells them where the reference's 16-bit tensors round
+    sc = scale.to(torch.float32).contiguous().view(-1)
     if sc.numel() != n * g:
         raise _lib.SdnqHipError(f"scale has {sc.numel()} elements, expected N*G = {n * g}")
     zp = None
@@ -154,8 +162,9 @@ def make_quant_weight(weights_dtype: str, weight: torch.Tensor, scale: torch.Ten
         svd_dt = float_code(up.dtype)
     d = SdnqWeight(weight=_ptr(w_phys), scale=_ptr(sc), zero_point=_ptr(zp), svd_up=_ptr(up), svd_down=_ptr(down),
                    n=n, k=k, group_size=group_size, svd_rank=rank, svd_dtype=svd_dt, storage=storage, kind=kind,
-                   bits=bits, exponent=ebits, mantissa=mbits, native_float=native, positions=positions)
-    return QuantWeight(desc=d, n=n, k=k, group_size=group_size, keep=(w_phys, sc, zp, up, down))
+                   bits=bits, exponent=ebits, mantissa=mbits, native_float=native, positions=positions,
+                   scale_dtype=float_code(scale_dtype))
+    return QuantWeight(desc=d, n=n, k=k, group_size=group_size, keep=(w_phys, sc, zp, up, down), scale_dtype=scale_dtype)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -186,6 +195,45 @@ def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: b
     if asymmetric:
         return xq, xs, rowsum, xrot, xzp
     return xq, xs, rowsum, xrot
+
+
+def rowquant_lp(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: bool = False, want_xrot: bool = False):
+    """sdnq_hip_rowquant_lp: the activation quantization carried out in x2d's own 16-bit dtype (dequantize_fp32=False layers).
+    Returns (xq, xs [M,1] f32 holding dtype-representable values, rowsum | None, xrot | None)."""
+    _require_cuda(x2d)
+    assert x2d.ndim == 2 and x2d.stride(1) == 1 and x2d.dtype in (torch.bfloat16, torch.float16)
+    m, k = x2d.shape
+    xq = torch.empty((m, k), device=x2d.device, dtype=_MM_TORCH[mm])
+    xs = torch.empty((m, 1), device=x2d.device, dtype=torch.float32)
+    rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
+    xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if (hadamard_group and want_xrot) else None
+    check(_lib.load().sdnq_hip_rowquant_lp(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), mm, hadamard_group,
+                                           xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _stream(x2d)), "rowquant_lp")
+    return xq, xs, rowsum, xrot
+
+
+def scaled_mm_lp(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, t=None, svd_up=None):
+    """sdnq_hip_scaled_mm_lp: the scaled matmul of bfloat16-scale layers (accumulator, activation-scale product and result each
+    rounded to bf16); bias None | [N] | [M,N] bf16; t [M,R] / svd_up [N,R] bf16 add the low-rank bias.  Returns [M,N] bf16."""
+    _require_cuda(a, b_phys, sa, sb, bias, t, svd_up)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    out = torch.empty((m, n), device=a.device, dtype=torch.bfloat16)
+    bias_ndim, ld_bias = 0, 0
+    if bias is not None:
+        if bias.dtype != torch.bfloat16:
+            raise _lib.SdnqHipError("scaled_mm_lp: bias must be bfloat16")
+        bias = bias.contiguous()
+        bias_ndim, ld_bias = bias.ndim, bias.shape[-1]
+    rank = 0
+    if t is not None:
+        if t.dtype != torch.bfloat16 or svd_up.dtype != torch.bfloat16:
+            raise _lib.SdnqHipError("scaled_mm_lp: low-rank factors must be bfloat16")
+        t, svd_up = t.contiguous(), svd_up.contiguous()
+        rank = t.shape[1]
+    check(_lib.load().sdnq_hip_scaled_mm_lp(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), bias_ndim,
+                                            ld_bias, _ptr(t), _ptr(svd_up), rank, out.data_ptr(), m, n, k, _stream(a)), "scaled_mm_lp")
+    return out
 
 
 def scaled_mm(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype):

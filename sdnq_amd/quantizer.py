@@ -169,8 +169,6 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
         raise NotImplementedError(f"{layer_class_name}: only Linear and Conv1d / Conv2d layers are built for MI355X")
     if is_conv and weight.ndim not in (3, 4):
         raise NotImplementedError("Conv3d weights are not built for MI355X")
-    if not dequantize_fp32:
-        raise NotImplementedError("dequantize_fp32=False (low-precision scales) is not supported by the HIP kernels")
     weight = weight.detach()
     original_shape, original_stride = weight.shape, weight.stride()
     torch_dtype = weight.dtype if torch_dtype is None else torch_dtype
@@ -218,9 +216,15 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
     requant = requant or groups > 1
     transpose = use_qmm and not requant and not ent["is_packed"]
     positions = kpos if (is_conv and not flat) else 1
+    # dequantize_fp32=False: scale / zero_point live in the model dtype and the weight is quantized against the ROUNDED scale
+    # (quantizer.py:147-156 + quant_utils.py:33-43).  The float-matmul exclusion of the reference only bites without tensorwise
+    # fp8 scaling, which gfx950 always uses (kernel_wrappers.use_tensorwise_fp8_matmul); 16-bit formats (max > 16384) keep fp32.
+    scale_dtype = None
+    if not dequantize_fp32 and ent["max"] <= 16384 and torch_dtype in (torch.bfloat16, torch.float16):
+        scale_dtype = torch_dtype
 
     if weight.is_cuda and USE_HIP_QUANTIZER and weight.dtype in (torch.float32, torch.bfloat16, torch.float16) and k % 16 == 0 \
-            and (ent["is_packed"] or ent["num_bits"] in (8, 16)) and weights_dtype not in _HIP_QUANTIZER_SKIP:
+            and (ent["is_packed"] or ent["num_bits"] in (8, 16)) and weights_dtype not in _HIP_QUANTIZER_SKIP and scale_dtype is None:
         # GPU tensors: one HIP launch pair does scale/zero-point, quantize and pack (csrc/quantize.hip); the element order
         # [N][K] is the same for the plain, grouped, conv and transposed layouts, only the logical views differ
         from . import ops
@@ -241,7 +245,7 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
         elif ent["num_bits"] in (8, 16):  # custom float8 / float16 codes keep the tensor shape (pack_float :75-80)
             q = q.view(quantized_weight_shape)
     else:
-        q, scale, zero_point = quantize_weight(weight, dim, weights_dtype)
+        q, scale, zero_point = quantize_weight(weight, dim, weights_dtype, dtype=scale_dtype)  # 16-bit scales: torch ops (load-time)
         if transpose:  # logical [K,N] with strides (1,K): the bytes stay [N][K] (prepare_weight_for_matmul on gfx950)
             q = q.t()
             scale = scale.t().contiguous()

@@ -198,6 +198,21 @@ CASES = [
     dict(name="int4_svd_had_uint8mm_qmm_f16", K=512, N=64, Ms=[40], dtype="f16",
          cfg=dict(weights_dtype="int4", quantized_matmul_dtype="uint8", use_svd=True, svd_rank=16, use_hadamard=True,
                   use_quantized_matmul=True)),
+    # dequantize_fp32=False: scales / zero points in the model dtype (quantizer.py:147-156), arithmetic in that dtype
+    dict(name="int8_rowwise_qmm_bf16_lpscale", K=512, N=256, Ms=[4, 48, 77], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="int8_rowwise_qmm_f16_lpscale_nobias", K=256, N=64, Ms=[33], dtype="f16", bias=False,
+         cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="uint4_noqmm_bf16_lpscale", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="uint4", use_quantized_matmul=False, dequantize_fp32=False)),
+    dict(name="int8_svd32_qmm_bf16_lpscale", K=512, N=256, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="int4_had256_qmm_bf16_lpscale", K=768, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="int8_svd32_noqmm_f16_lpscale", K=256, N=64, Ms=[5, 40], dtype="f16",
+         cfg=dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=False, dequantize_fp32=False)),
+    dict(name="fp8_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
 ]
 
 # Every packed storage dtype gets a dequant-only golden (small).
@@ -264,14 +279,17 @@ def run_case(case):
                     H = get_hadamard(dq.hadamard_group_size, dtype=x.dtype, device=x.device)
                     x2 = rotate_hadamard(x2, hadamard=H)
                     put(f"xrot_{M}", x2)
+                # quantize_int_mm_input / quantize_fp_mm_input: input.to(dtype=scale.dtype), fp16 scales promoted to fp32
+                # (linear_int8.py:15-22) -- float32 by default, the model dtype with dequantize_fp32=False
+                qdt = (rq[1] if dq.re_quantize_for_matmul else layer.scale).dtype
                 if dq.quantized_matmul_dtype in ("int8",):
-                    xq, xs = quantize_int_mm(x2.to(torch.float32), dim=-1)
+                    xq, xs = quantize_int_mm(x2.to(qdt), dim=-1)
                     put(f"xq_{M}", xq)
-                    put(f"xs_{M}", xs)
+                    put(f"xs_{M}", xs.to(torch.float32) if xs.dtype == torch.float16 else xs)
                 elif dq.quantized_matmul_dtype in ("fp8", "float8_e4m3fn"):
-                    xq, xs = quantize_fp_mm(x2.to(torch.float32), dim=-1)
+                    xq, xs = quantize_fp_mm(x2.to(qdt), dim=-1)
                     put(f"xq_{M}", xq)
-                    put(f"xs_{M}", xs)
+                    put(f"xs_{M}", xs.to(torch.float32) if xs.dtype == torch.float16 else xs)
     np.savez_compressed(os.path.join(HERE, f"case_{name}.npz"), **out)
     with open(os.path.join(HERE, f"case_{name}.json"), "w") as f:
         json.dump(meta, f, indent=1, default=str)

@@ -59,9 +59,11 @@ class Case:
     def oracle_module(self):
         from oracle import oracle as O
         svd_tag = self.tensor_tag("svd_up") if self.has("svd_up") else "bf16"
-        return O.OracleLinear(self.deq, self.raw("weight"), self.raw("scale"), self.raw("zero_point"), self.f32("svd_up"),
+        scale_tag = self.tensor_tag("scale")  # "f32", or the model dtype with dequantize_fp32=False
+        return O.OracleLinear(self.deq, self.raw("weight"), self.f32("scale"), self.f32("zero_point"), self.f32("svd_up"),
                               self.f32("svd_down"), self.f32("bias"), svd_tag=svd_tag,
-                              bias_tag=self.tensor_tag("bias") if self.has("bias") else None, N=self.N, K=self.K)
+                              bias_tag=self.tensor_tag("bias") if self.has("bias") else None, N=self.N, K=self.K,
+                              scale_tag=scale_tag)
 
     # ---- torch views for the product path -------------------------------------------------------
     def torch_tensor(self, key, device=None):

@@ -65,4 +65,5 @@ def oracle_from_module(mod):
     svd_up = getattr(mod, "svd_up", None)
     return O.OracleLinear(deq, raw(mod.weight), raw(mod.scale), raw(getattr(mod, "zero_point", None)), raw(svd_up),
                           raw(getattr(mod, "svd_down", None)), raw(mod.bias), svd_tag=tag[svd_up.dtype] if svd_up is not None else "bf16",
-                          bias_tag=tag[mod.bias.dtype] if mod.bias is not None else None, N=dq.out_features, K=dq.in_features)
+                          bias_tag=tag[mod.bias.dtype] if mod.bias is not None else None, N=dq.out_features, K=dq.in_features,
+                          scale_tag=tag[mod.scale.dtype])

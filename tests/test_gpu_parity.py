@@ -67,6 +67,35 @@ def test_module_forward_vs_golden_and_oracle(name, gpu_device):
             assert_close_float(got, orc, c.tag, (name, M, "oracle"), hadamard=d["use_hadamard"])
 
 
+@pytest.mark.parametrize("name", ["int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "uint4_qmm_bf16", "int8_svd32_qmm_bf16",
+                                  "int8_rowwise_noqmm_bf16", "fp8_qmm_bf16", "int6_rowwise_packed_qmm_bf16"])
+def test_apply_options_dequantize_fp32_false(name, gpu_device):
+    """A float32-scale checkpoint switched to model-dtype scales by apply_sdnq_options_to_model(dequantize_fp32=False) (loader.py:
+    262-283) computes what the oracle's 16-bit-scale restatement (pinned by the *_lpscale fixtures) gives for the re-typed layer."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    c = Case(name)
+    mod = module_from_case(c, gpu_device)
+    model = torch.nn.Sequential(mod)
+    sdnq_amd.apply_sdnq_options_to_model(model, dequantize_fp32=False)
+    assert mod.scale.dtype == mod.sdnq_dequantizer.result_dtype != torch.float32
+    omod = oracle_from_module(mod)
+    assert omod.scale_tag == c.tag
+    d = c.deq
+    for M in c.ms():
+        x = c.torch_tensor(f"x_{M}", device=gpu_device)
+        got = to_f32_numpy(model(x))
+        orc = O.forward(omod, c.f32(f"x_{M}"), c.tag)
+        qmm = d["use_quantized_matmul"] and M >= 32
+        if qmm and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up"):
+            assert np.array_equal(got, orc), (name, M, int((got != orc).sum()))
+        else:
+            assert_close_float(got, orc, c.tag, (name, M, "oracle"))
+    sdnq_amd.apply_sdnq_options_to_model(model, dequantize_fp32=True)  # and back: float32 scales (values stay the rounded ones)
+    assert mod.scale.dtype == torch.float32
+    assert model(c.torch_tensor(f"x_{c.ms()[-1]}", device=gpu_device)).dtype == mod.sdnq_dequantizer.result_dtype
+
+
 @pytest.mark.parametrize("name", case_names())
 def test_dequant_and_requant_vs_golden(name, gpu_device):
     c = Case(name)
@@ -96,7 +125,7 @@ def test_dequant_and_requant_vs_golden(name, gpu_device):
         assert tuple(wq.shape) == (c.K, c.N) and wq.stride() == (1, c.K)
         rw = c.raw("requant_weight").reshape(c.K, c.N)
         assert np.array_equal(bits_of(wq.contiguous()), rw.view(np.uint8)), name
-        assert np.array_equal(ws.cpu().numpy().reshape(-1), c.raw("requant_scale").reshape(-1)), name
+        assert np.array_equal(ws.float().cpu().numpy().reshape(-1), c.f32("requant_scale").reshape(-1)), name
         assert len(wzp) == int(c.has("requant_zero_point")), name
         if wzp:  # asymmetric re-quantizer of the uint8 matmul (dequantizer.py:178-187)
             assert tuple(wzp[0].shape) == (1, c.N)
@@ -537,7 +566,7 @@ def test_conv_dequant_and_hip_quantizer_vs_golden(name, gpu_device):
     if c.has("requant_weight"):
         wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, mod.zero_point)[:2]
         assert np.array_equal(bits_of(wq.contiguous()), c.raw("requant_weight").view(np.uint8).reshape(bits_of(wq.contiguous()).shape))
-        assert np.array_equal(ws.cpu().numpy().reshape(-1), c.raw("requant_scale").reshape(-1))
+        assert np.array_equal(ws.float().cpu().numpy().reshape(-1), c.f32("requant_scale").reshape(-1))
     from sdnq_amd import quantizer as Q
     from tests.test_quantizer import _conv_quant_kwargs, check_conv_state_dict
     dq2, tensors = Q.sdnq_quantize_layer_weight(c.torch_tensor("w_float", device=gpu_device), layer_class_name=c.deq["layer_class_name"],

@@ -106,6 +106,7 @@ def test_case_dequant_and_requant(name):
     got32 = mod.dequantize("f32", hadamard=False)
     if c.has("svd_up"):
         tol = ulp_bf16(ref32) if c.tag != "f16" else np.maximum(ulp_bf16(ref32), 2.0 ** -24)  # f16 addmm: one subnormal step near 0
+        tol = np.maximum(tol, 1e-8)  # results that cancel to ~0: the ulp of the RESULT says nothing about the addends' rounding
         assert np.all(np.abs(got32 - ref32) <= tol), name  # addmm in bf16: <= 1 bf16 ulp
         assert np.mean(got32 != ref32) < 1e-3
     else:
@@ -119,7 +120,7 @@ def test_case_dequant_and_requant(name):
     if c.has("requant_weight"):
         wq, ws, *wzp = mod.re_quantize_matmul()
         rw = c.raw("requant_weight").reshape(c.K, c.N).T  # logical [K,N] -> [N,K]
-        assert np.array_equal(ws, c.raw("requant_scale").reshape(-1)), name
+        assert np.array_equal(ws, c.f32("requant_scale").reshape(-1)), name
         assert len(wzp) == int(c.has("requant_zero_point"))
         if wzp:  # re_quantize_uint_mm (dequantizer.py:178-187)
             assert np.array_equal(wzp[0], c.raw("requant_zero_point").reshape(-1)), name
@@ -140,7 +141,7 @@ def test_case_forward(name):
         exact_int = (qmm and d["quantized_matmul_dtype"] in ("int8", "uint8") and not d["use_hadamard"] and not c.has("svd_up"))
         if qmm and c.has(f"xq_{M}") and not d["use_hadamard"]:
             assert np.array_equal(inter["xq"].view(np.uint8), c.raw(f"xq_{M}").view(np.uint8)), (name, M)
-            assert np.array_equal(inter["xs"], c.raw(f"xs_{M}").reshape(-1)), (name, M)
+            assert np.array_equal(inter["xs"], c.f32(f"xs_{M}").reshape(-1)), (name, M)
         if exact_int:
             assert np.array_equal(y, y_ref), (name, M)  # int32 accumulate is exact; fma epilogue
         else:
@@ -173,7 +174,7 @@ def test_conv_case_dequant_and_forward(name):
         wq, ws = omod.re_quantize_matmul()[:2]
         rw = c.raw("requant_weight")  # logical [K, N]
         assert np.array_equal(wq.view(np.uint8), np.ascontiguousarray(rw.T).view(np.uint8)), (name, "requant codes")
-        assert np.array_equal(ws, c.raw("requant_scale").reshape(-1)), (name, "requant scale")
+        assert np.array_equal(ws, c.f32("requant_scale").reshape(-1)), (name, "requant scale")
     for i in c.inputs():
         x = c.f32(f"x_{i}")
         y = O.conv_forward(omod, x, c.conv, c.tag)

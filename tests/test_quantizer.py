@@ -12,7 +12,9 @@ from tests.golden_util import Case
 EXACT = ["int8_rowwise_noqmm_f32", "int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "fp8_qmm_bf16", "uint4_qmm_bf16",
          "int6_rowwise_packed_qmm_bf16", "uint7_rowwise_packed_qmm_bf16", "uint8_int8mm_qmm_bf16", "uint8_uint8mm_qmm_bf16",
          "fp4_e2m1_fp8mm_qmm_bf16", "int5_group32_noqmm_bf16", "uint3_noqmm_f16", "int8_group64_uint8mm_qmm_bf16",
-         "uint4_uint8mm_qmm_bf16"]
+         "uint4_uint8mm_qmm_bf16",
+         # dequantize_fp32=False: scale / zero_point in the model dtype, weight quantized against the rounded scale
+         "int8_rowwise_qmm_bf16_lpscale", "int8_rowwise_qmm_f16_lpscale_nobias", "uint4_noqmm_bf16_lpscale", "fp8_qmm_bf16_lpscale"]
 
 
 @pytest.mark.parametrize("name", EXACT)
@@ -32,6 +34,8 @@ def test_quantizer_reproduces_reference_state_dict(name):
         if ref is None:
             continue
         assert tuple(mine.shape) == tuple(ref.shape), (name, key, mine.shape, ref.shape)
+        if key != "weight":
+            assert mine.dtype == ref.dtype, (name, key, mine.dtype, ref.dtype)
         if key == "weight" and mine.ndim == 2 and dq.weight_is_transposed:
             assert mine.stride() == (1, mine.shape[0])
         a = mine.contiguous().view(torch.uint8) if mine.dtype in (torch.float8_e4m3fn, torch.int8) else mine.contiguous()
@@ -67,6 +71,36 @@ def test_apply_to_module_and_config_roundtrip():
     assert cfg2.weights_dtype == "uint4" and cfg2.use_quantized_matmul and cfg2.to_dict()["quant_method"] == "sdnq"
     with pytest.raises(NotImplementedError):
         sdnq_amd.SDNQConfig(use_codebook=True)
+
+
+def test_apply_options_scale_dtype_rules():
+    """apply_sdnq_options_to_model(dequantize_fp32=...) re-types scale / zero_point like the reference (loader.py:262-283)."""
+    def model():
+        m = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 64)).to(torch.bfloat16)
+        m, _ = sdnq_amd.apply_sdnq_to_module(m, sdnq_amd.SDNQConfig(weights_dtype="uint4", minimum_allowed_numel=16))
+        m[1] = sdnq_amd.sdnq_quantize_layer(torch.nn.Linear(64, 64).to(torch.bfloat16), sdnq_amd.SDNQConfig(weights_dtype="int12"))[0]
+        return m
+    m = model()
+    assert m[0].scale.dtype == torch.float32 and m[0].zero_point.dtype == torch.float32
+    sdnq_amd.apply_sdnq_options_to_model(m)  # nothing asked: float32 scales stay
+    assert m[0].scale.dtype == torch.float32
+    before = m[0].scale.detach().clone()
+    sdnq_amd.apply_sdnq_options_to_model(m, dequantize_fp32=False)
+    assert m[0].scale.dtype == torch.bfloat16 and m[0].zero_point.dtype == torch.bfloat16
+    assert torch.equal(m[0].scale, before.to(torch.bfloat16))
+    assert m[1].scale.dtype == torch.float32  # formats wider than 8 bits keep float32 scales
+    sdnq_amd.apply_sdnq_options_to_model(m, dtype=torch.float16)  # nothing asked about fp32, 16-bit scale: follows the result dtype
+    assert m[0].scale.dtype == torch.float16 and m[0].sdnq_dequantizer.result_dtype == torch.float16
+    sdnq_amd.apply_sdnq_options_to_model(m, dequantize_fp32=True)
+    assert m[0].scale.dtype == torch.float32 and m[0].zero_point.dtype == torch.float32
+    # quantizer: dequantize_fp32=False quantizes against the rounded scale; 16-bit formats and float32 models keep float32
+    lin = torch.nn.Linear(64, 64).to(torch.bfloat16)
+    l8 = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", dequantize_fp32=False))[0]
+    assert l8.scale.dtype == torch.bfloat16
+    l16 = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int16", dequantize_fp32=False))[0]
+    assert l16.scale.dtype == torch.float32
+    l32 = sdnq_amd.sdnq_quantize_layer(torch.nn.Linear(64, 64), sdnq_amd.SDNQConfig(weights_dtype="int8", dequantize_fp32=False))[0]
+    assert l32.scale.dtype == torch.float32
 
 
 def _dtype_entries():
