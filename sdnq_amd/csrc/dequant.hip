@@ -478,68 +478,94 @@ __global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, cons
 }
 
 // t[M][R] = cast( x[M][K] . down[R][K]^T ) on the matrix cores (bf16 / f16): the inner torch.mm of the SVD branch
-// (linear_int8.py:60).  One workgroup = 32 activation rows; its 8 waves split K, each accumulating a 32(n) x 32(m)
-// tile with v_mfma_f32_32x32x16 (A-operand = svd_down rows, B-operand = activation rows, both K-contiguous 16-byte
-// lane vectors), partial tiles are summed through LDS.  HBM-bound on x: 2*M*K bytes.
+// (linear_int8.py:60).  HBM-bound on x: 2*M*K bytes (28 MB for a FLUX activation).
+// One workgroup (4 waves) = 16 activation rows x all of K x 32 factor rows, walked in stages of 128 k through an LDS ring:
+//   HBM / L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, so the ring depth -- not the compiler's s_waitcnt model --
+//   decides how many stages are in flight): a piece = 4 rows x 256 bytes, lane l -> row l / 16, 16-byte chunk l % 16, XOR-swizzled
+//   on the global side so that LDS stays lane-linear; 4 activation + 8 factor pieces per stage, 3 per wave;
+//   LDS -> v_mfma_f32_16x16x32 fragments: wave w owns k-step w of every stage (A = factor rows, B = activation rows); the 16 rows of
+//   a fragment read hit 16 different bank groups thanks to the swizzle.
+// History (rounds 1-2): the fragments used to be loaded straight from global memory in the MFMA layout -- lane l = row (l & 15) at
+// a 6 KB row stride = 64 different cache lines per load instruction -- and the L1 tag rate, not HBM, bounded the kernel: 20-24 us
+// per call at 4608 x 3072 whatever the software pipelining, 12 us even for 77 rows.  A register-staged coalesced variant lost to
+// the compiler's pessimistic s_waitcnt on loop-carried loads (47 us).
+__device__ const uint4 g_lr_zero16 = {0u, 0u, 0u, 0u};  // source of chunks past the end of K
 template <bool IS_BF16>
-__global__ __launch_bounds__(512) void lowrank_down_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ down,
+__global__ __launch_bounds__(256) void lowrank_down_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ down,
                                                            uint16_t* __restrict__ t, int64_t M, int64_t K, int64_t ldx, int R) {
-    __shared__ float part[8][16][64];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int NS = 4, XS = 16 * 256, STAGE = XS + 32 * 256;  // 12 KB per stage; 48 KB ring: three workgroups per CU
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t m0 = (int64_t)blockIdx.x * 32;
-    int64_t gm = m0 + (lane & 31);
-    if (gm >= M) gm = M - 1;
-    const uint16_t* xrow = x + gm * ldx + (lane >> 5) * 8;
+    const int64_t m0 = (int64_t)blockIdx.x * 16;
     const int n_tiles = (R + 31) / 32;
-    const int64_t kw = ((K / 16 + 7) / 8) * 16;  // K range of one wave, multiple of 16
-    const int64_t kbeg = wave * kw, kend = (kbeg + kw < K) ? kbeg + kw : K;
+    const int64_t nst = (K + 127) / 128;
+    // DMA role of this lane: row 4 * wave + lane / 16 of the activation tile and of each half of the factor tile; physical chunk
+    // lane % 16 holds logical chunk (lane % 16) ^ row
+    const int drow = wave * 4 + (lane >> 4);
+    const int lchunk = (lane & 15) ^ drow;
+    // fragment role: row lane & 15, logical chunk 4 * wave + lane / 16 of the stage
+    const int frow = lane & 15;
+    const int foff = frow * 256 + (((wave * 4 + (lane >> 4)) ^ frow) << 4);
+    int64_t gm = m0 + drow;
+    if (gm >= M) gm = M - 1;
+    const uint16_t* sx = x + gm * ldx + lchunk * 8;
     for (int nt = 0; nt < n_tiles; ++nt) {
-        const int gn = nt * 32 + (lane & 31);
-        const bool nok = gn < R;
-        const uint16_t* drow = down + (int64_t)(nok ? gn : 0) * K + (lane >> 5) * 8;
-        v16f acc;
+        const int gn0 = nt * 32 + drow, gn1 = gn0 + 16;
+        const uint16_t* sd0 = down + (int64_t)(gn0 < R ? gn0 : 0) * K + lchunk * 8;  // rows past R: valid memory, never stored
+        const uint16_t* sd1 = down + (int64_t)(gn1 < R ? gn1 : 0) * K + lchunk * 8;
+        auto issue = [&](int64_t st) {  // stages past the end of K are all-zero DMAs: the counted vmcnt stays a constant
+            uint8_t* base = lds + (st % NS) * STAGE;
+            const int64_t k0 = st * 128;
+            const bool ok = k0 + lchunk * 8 < K;
+            const uintptr_t z = (uintptr_t)&g_lr_zero16;  // (integer selects: a pointer ternary became three divergent branches)
+            const uintptr_t px = ok ? (uintptr_t)(sx + k0) : z, p0 = ok ? (uintptr_t)(sd0 + k0) : z, p1 = ok ? (uintptr_t)(sd1 + k0) : z;
+            __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(base + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p0, (lptr_t)(base + XS + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)p1, (lptr_t)(base + XS + 4096 + wave * 1024), 16, 0, 0);
+        };
+        v4f a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-        for (int64_t k = kbeg; k < kend; k += 64) {
-            uint4 fx[4], fd[4];
-#pragma unroll
-            // UNCONDITIONAL loads (a segment past the wave's K range re-reads its first one and is zeroed afterwards): a load under
-            // a condition gets its own s_waitcnt vmcnt(0) from the compiler, and the 8 loads of a step -- 48 per wave over K = 3072
-            // -- then complete one memory round trip after the other (round 1: 24 us per call at 4608 x 3072)
-            for (int u = 0; u < 4; ++u) {
-                const int64_t kk = (k + u * 16 < kend) ? k + u * 16 : kbeg;
-                fx[u] = *(const uint4*)(xrow + kk);
-                fd[u] = *(const uint4*)(drow + kk);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = k + u * 16 < kend;
-                if (!ok) fx[u] = make_uint4(0, 0, 0, 0);
-                if (!ok || !nok) fd[u] = make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if constexpr (IS_BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fd[u]), __builtin_bit_cast(v8bf, fx[u]), acc, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fd[u]), __builtin_bit_cast(v8h, fx[u]), acc, 0, 0, 0);
+        for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
+        for (int64_t st = 0; st < nst; ++st) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 3) : "memory");  // this wave's pieces of stage st have landed
+            // ... and everybody's; every wave is also done reading stage st - 1 (its fragments fed MFMAs already), whose slot is
+            // refilled next.  Raw s_barrier: __syncthreads() would drain the DMAs in flight (s_waitcnt vmcnt(0)).
+            __builtin_amdgcn_s_barrier();
+            issue(st + NS - 1);
+            const uint8_t* base = lds + (st % NS) * STAGE;
+            // (ext-vector loads: an LDS read typed as the HIP uint4 struct makes the compiler drain the LDS-DMAs first, vmcnt(0))
+            const v4i fx = *(const v4i*)(base + foff);
+            const v4i f0 = *(const v4i*)(base + XS + foff);
+            const v4i f1 = *(const v4i*)(base + XS + 4096 + foff);
+            if constexpr (IS_BF16) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, f0), __builtin_bit_cast(v8bf, fx), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, f1), __builtin_bit_cast(v8bf, fx), a1, 0, 0, 0);
+            } else {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f0), __builtin_bit_cast(v8h, fx), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f1), __builtin_bit_cast(v8h, fx), a1, 0, 0, 0);
             }
         }
-        __syncthreads();  // previous n-tile's partials consumed
-#pragma unroll
-        for (int e = 0; e < 16; ++e) part[wave][e][lane] = acc[e];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero DMAs target the ring the partial sums reuse
         __syncthreads();
-        // acc[e] of lane l: n = (e&3) + 8*(e>>2) + 4*(l>>5), m = l&31.  1024 outputs, 512 threads: 2 each.
+        float* part = (float*)lds;  // [4 waves][2 tiles][4 regs][64 lanes]
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
-            const int idx = tid + o * 512;
-            const int e = idx >> 6, l = idx & 63;
-            float sum = 0.0f;
+        for (int e = 0; e < 4; ++e) { part[((wave * 2 + 0) * 4 + e) * 64 + lane] = a0[e]; part[((wave * 2 + 1) * 4 + e) * 64 + lane] = a1[e]; }
+        __syncthreads();
+        // accumulator layout: lane l of tile h holds n = 16 h + 4 (l >> 4) + e, m = l & 15.  512 outputs; consecutive threads take
+        // consecutive n of one row (64-byte runs of t)
 #pragma unroll
-            for (int w = 0; w < 8; ++w) sum += part[w][e][l];
-            const int n = nt * 32 + (e & 3) + 8 * (e >> 2) + 4 * (l >> 5);
-            const int64_t m = m0 + (l & 31);
-            if (m < M && n < R) t[m * R + n] = IS_BF16 ? f32_to_bf16_bits(sum) : f32_to_f16_bits(sum);
+        for (int o = tid; o < 512; o += 256) {
+            const int n = o & 31, m = o >> 5;
+            const int h = n >> 4, r = n & 15, l = (r >> 2) * 16 + m, e = r & 3;
+            const int idx = (h * 4 + e) * 64 + l;
+            const float sum = (part[idx] + part[512 + idx]) + (part[1024 + idx] + part[1536 + idx]);
+            const int gn = nt * 32 + n;
+            if (m0 + m < M && gn < R) t[(m0 + m) * R + gn] = IS_BF16 ? f32_to_bf16_bits(sum) : f32_to_f16_bits(sum);
         }
+        __syncthreads();  // partial sums consumed before the next n-tile's DMAs overwrite them
     }
 }
 
@@ -684,7 +710,7 @@ extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int6
     if (x_dtype != SDNQ_F32 && (k % 16) == 0 && rank > 0 && x && svd_down && t && ((uintptr_t)x % 16) == 0 &&
         ((uintptr_t)svd_down % 16) == 0 && ((ldx * 2) % 16) == 0) {
         hipStream_t s = (hipStream_t)stream;
-        dim3 grid((unsigned)((m + 31) / 32)), block(512);
+        dim3 grid((unsigned)((m + 15) / 16)), block(256);
         if (x_dtype == SDNQ_BF16)
             hipLaunchKernelGGL((lowrank_down_kernel<true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)svd_down, (uint16_t*)t, m, k, ldx, rank);
         else

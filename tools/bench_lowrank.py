@@ -1,27 +1,34 @@
-#!/usr/bin/env python3
-"""scaled_mm vs scaled_mm_lowrank (SVD epilogue) at FLUX shapes. usage: bench_lowrank.py"""
-import os, sys
-import torch
+"""Time sdnq_hip_lowrank_down (t = x . svd_down^T) on FLUX / SDXL shapes and check it against torch.  GPU box only."""
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from sdnq_amd import ops
+
 dev = torch.device("cuda:0")
-def t(fn, reps=10):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
-for (m, n, k) in ((4608, 3072, 3072), (4608, 12288, 3072), (4608, 3072, 15360), (4096, 3072, 3072), (512, 3072, 3072)):
-    x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
-    b = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=dev)
-    sb = torch.rand(n, device=dev) * 0.01
-    bias = torch.randn(n, device=dev, dtype=torch.bfloat16)
-    up = (torch.randn(n, 32, device=dev) * 0.1).to(torch.bfloat16)
-    down = (torch.randn(32, k, device=dev) * 0.1).to(torch.bfloat16)
-    xq, xs, _, _ = ops.rowquant(x, ops.MM_I8)
-    tt = ops.lowrank_down(x, down)
-    a = t(lambda: ops.scaled_mm(ops.MM_I8, xq, b, xs, sb, bias, torch.bfloat16))
-    c = t(lambda: ops.scaled_mm_lowrank(ops.MM_I8, xq, b, xs, sb, bias, tt, up, None, None, torch.bfloat16))
-    d = t(lambda: ops.lowrank_down(x, down))
-    print(f"M={m} N={n} K={k}: plain {a:8.1f} us   lowrank {c:8.1f} us   lowrank_down {d:7.1f} us")
+for (m, k, r) in [(4608, 3072, 32), (4608, 12288, 32), (4608, 15360, 32), (4096, 3072, 32), (512, 3072, 32), (1024, 1280, 32), (4096, 640, 32), (77, 2048, 32), (4608, 3072, 16), (4608, 3072, 64), (33, 48, 8)]:
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(dev)
+    d = (torch.randn(r, k, generator=g) * 0.05).to(torch.bfloat16).to(dev)
+    t = ops.lowrank_down(x, d)
+    ref = (x.float() @ d.float().t())
+    err = (t.float() - ref).abs().max().item() / ref.abs().max().item()
+    side = torch.cuda.Stream()
+    n = 50
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ops.lowrank_down(x, d)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):  # launch cost excluded: n back-to-back launches in one graph
+            for _ in range(n):
+                ops.lowrank_down(x, d)
+        graph.replay()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(4):
+            graph.replay()
+        e1.record(side)
+        side.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (4 * n)
+    print(f"lowrank_down {m:5d} x {k:5d} r={r:2d}: {us:7.2f} us  {2 * m * k / us / 1e6:6.2f} TB/s of x   rel err {err:.2e}")
