@@ -477,6 +477,169 @@ __global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, cons
     }
 }
 
+// The same few-row SVD linear for the default rank R = 32, fed by LDS-DMA.  skinny_svd_kernel above loads 4 bytes per lane per load
+// and waits for every 32-k block's loads before using them: 24 dependent memory round trips per wave, 76 us for FLUX's 18432 x 3072
+// modulation layers against 14 us of weight traffic.  Here every wave owns a private ring of D stages (one 32-k block each: the
+// block's codes, 32 rows x 32 bytes, and its 32 rows of down_t, 64 bytes each = 3 LDS-DMAs of 1 KB), D - 1 blocks in flight, no
+// workgroup barrier in the loop (a wave only reads what it fetched itself).  The MFMA's k rows are fed in a PERMUTED order --
+// A-operand row i carries k = 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3) -- so that the 16 accumulator registers of lane (n = lane &
+// 31, half = lane >> 5) are the 16 CONSECUTIVE columns 16 half .. 16 half + 15 of row n: one 16-byte LDS read fetches their codes.
+// LDS swizzles (applied on the global side of the DMA, LDS stays lane-linear): codes: 16-byte half ^= (row >> 3) & 1; down_t:
+// 16-byte chunk ^= (row >> 2) & 3.
+template <bool IS_BF16, int MR, int BITS>
+__global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, const uint16_t* __restrict__ down_t, const void* __restrict__ x,
+                                                           const void* __restrict__ bias, void* __restrict__ out, int64_t M, int64_t ldx) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int T_ID = IS_BF16 ? SDNQ_BF16 : SDNQ_F16;
+    constexpr int D = 4, STG = 3072, R = 32;
+    extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];  // [4 waves][D][STG] rings, xs [MR][K] f32, scales / zero points [32][G] f32 each
+    __shared__ float red[4][MR][32];
+    const int tid = threadIdx.x, lane = tid & 63, nl = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = (int)p.K;
+    uint8_t* ring = smem + wave * (D * STG);
+    float* xs = (float*)(smem + 4 * D * STG);
+    const int64_t n0 = (int64_t)blockIdx.x * 32;
+    // ---- DMA roles
+    const uint8_t* wsrc;  // this lane's code bytes of block 0
+    if constexpr (BITS == 8) {
+        const int r = lane >> 1, lh = (lane & 1) ^ ((r >> 3) & 1);
+        int64_t g = n0 + r;
+        if (g >= p.N) g = p.N - 1;
+        wsrc = (const uint8_t*)p.w + g * K + 16 * lh;
+    } else {  // 32 rows x 16 bytes = half a DMA: the upper 32 lanes fetch the same bytes again (their LDS kilobyte half is not read)
+        int64_t g = n0 + (lane & 31);
+        if (g >= p.N) g = p.N - 1;
+        wsrc = (const uint8_t*)p.w + g * (K / 2);
+    }
+    const int drow = lane >> 2, dchunk = lane & 3;  // down_t piece a: row 16 a + drow, physical chunk dchunk
+    const uint16_t* dsrc0 = down_t + (int64_t)drow * R + ((dchunk ^ ((drow >> 2) & 3)) << 3);
+    const uint16_t* dsrc1 = down_t + (int64_t)(16 + drow) * R + ((dchunk ^ (((16 + drow) >> 2) & 3)) << 3);
+    const int nblk = K / 32, nit = (nblk + 3) / 4;
+    auto issue = [&](int it) {  // block 4 it + wave; past the end of K: the last block again (dropped by `live` below)
+        int b = 4 * it + wave;
+        if (b >= nblk) b = nblk - 1;
+        uint8_t* base = ring + (it % D) * STG;
+        const int k0 = b * 32;
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (BITS == 8 ? k0 : k0 / 2)), (lptr_t)base, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(dsrc0 + (int64_t)k0 * R), (lptr_t)(base + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(dsrc1 + (int64_t)k0 * R), (lptr_t)(base + 2048), 16, 0, 0);
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < D - 1; ++s0) issue(s0);
+    // ---- x as f32 in LDS (while the first blocks are in flight): 8 elements per load, four loads per thread in flight (an
+    // element-at-a-time loop waits one memory round trip per element: 12 of them for K = 3072)
+    {
+        const int kc = K / 8, total = MR * kc;  // 16-byte pieces
+        for (int c0 = tid; c0 < total; c0 += 4 * 256) {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j * 256 < total ? c0 + j * 256 : 0;
+                const int m = c / kc, k8 = c - m * kc;
+                v[j] = *(const uint4*)((const uint16_t*)x + (int64_t)(m < M ? m : 0) * ldx + k8 * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j * 256;
+                if (c < total) {
+                    const int m = c / kc;
+                    float f[8];
+                    Vec16<T_ID>::unpack(v[j], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xs[c * 8 + e] = (m < M) ? f[e] : 0.0f;
+                }
+            }
+        }
+    }
+    // scales / zero points of the 32 rows in LDS: a global load inside the K loop would make the compiler drain the DMA ring
+    // (s_waitcnt vmcnt(0)) at its first use
+    const int G = p.G;
+    float* s_sc = xs + MR * K;
+    float* s_zp = s_sc + 32 * G;
+    for (int i = tid; i < 32 * G; i += 256) {
+        int64_t g = n0 + i / G;
+        if (g >= p.N) g = p.N - 1;
+        s_sc[i] = p.scale[g * G + i % G];
+        s_zp[i] = p.zp ? p.zp[g * G + i % G] : 0.0f;  // fma(q, s, +0) == q * s
+    }
+    int64_t gn = n0 + nl;
+    if (gn >= p.N) gn = p.N - 1;
+    // codes -> numbers without branches: int8 two's complement: (byte ^ 0x80) - 128;  uint8: byte;  packed signed nibble: code - 8
+    const bool is_signed = p.fmt.kind == SDNQ_KIND_INT;
+    const u32 flip = (is_signed && BITS == 8) ? 0x80u : 0u;
+    const float qsub = is_signed ? (BITS == 8 ? 128.0f : 8.0f) : 0.0f;
+    const float inv_group = 1.0f / (float)p.group_size;
+    const uint16_t* up = (const uint16_t*)p.svd_up + gn * R + hi * 8;
+    const v4i fu0 = *(const v4i*)up, fu1 = *(const v4i*)(up + 16);
+    // fragment reads: A row of this lane = the permuted k row; code bytes of row nl
+    const int krow = 16 * ((nl >> 2) & 1) + 4 * (nl >> 3) + (nl & 3);
+    const int a_off0 = 1024 + krow * 64 + (((0 + hi) ^ ((krow >> 2) & 3)) << 4);
+    const int a_off1 = 1024 + krow * 64 + (((2 + hi) ^ ((krow >> 2) & 3)) << 4);
+    const int w_off = BITS == 8 ? nl * 32 + ((hi ^ ((nl >> 3) & 1)) << 4) : nl * 16 + hi * 8;
+    float acc[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[m] = 0.0f;
+    __syncthreads();  // xs complete
+    for (int it = 0; it < nit; ++it) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * 3) : "memory");  // this wave's block `it` has landed
+        issue(it + D - 1);  // refills the slot read in the previous iteration (its reads fed arithmetic already)
+        const uint8_t* base = ring + (it % D) * STG;
+        if (4 * it + wave >= nblk) continue;  // wave-uniform: a block past the end of K (its DMAs re-fetched the last block)
+        const int kb = (4 * it + wave) * 32 + 16 * hi;  // this lane's 16 consecutive columns: one scale group (group_size % 16 == 0)
+        v16f ud;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ud[e] = 0.0f;
+        const v4i fd0 = *(const v4i*)(base + a_off0), fd1 = *(const v4i*)(base + a_off1);
+        if constexpr (IS_BF16) {
+            ud = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fd0), __builtin_bit_cast(v8bf, fu0), ud, 0, 0, 0);
+            ud = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fd1), __builtin_bit_cast(v8bf, fu1), ud, 0, 0, 0);
+        } else {
+            ud = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fd0), __builtin_bit_cast(v8h, fu0), ud, 0, 0, 0);
+            ud = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fd1), __builtin_bit_cast(v8h, fu1), ud, 0, 0, 0);
+        }
+        u32 ww[4];
+        if constexpr (BITS == 8) { const v4i t4 = *(const v4i*)(base + w_off); ww[0] = t4[0]; ww[1] = t4[1]; ww[2] = t4[2]; ww[3] = t4[3]; }
+        else { const v2i t2 = *(const v2i*)(base + w_off); ww[0] = t2[0]; ww[1] = t2[1]; ww[2] = 0; ww[3] = 0; }
+        const int gi = (int)(((float)kb + 0.5f) * inv_group);  // kb / group_size (exact: both are multiples of 16, K < 2^20)
+        const float sc = s_sc[nl * G + gi], zc = s_zp[nl * G + gi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4f xv[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) xv[m] = *(const v4f*)(xs + m * K + kb + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32 code;
+                if constexpr (BITS == 8) code = ((ww[g] >> (8 * e)) & 0xffu) ^ flip;
+                else code = ((ww[g >> 1] >> (16 * (g & 1))) >> (4 * e)) & 15u;  // 16 nibbles in ww[0..1]: column 4 g + e
+                const float q = (float)code - qsub;
+                float wv = FT<T_ID>::round(fmaf(q, sc, zc));    // dequantize -> .to(svd dtype)
+                wv = FT<T_ID>::round(wv + ud[4 * g + e]);       // addmm_(svd_up, svd_down): one rounding of the sum
+#pragma unroll
+                for (int m = 0; m < MR; ++m) acc[m] = fmaf(xv[m][e], wv, acc[m]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing refills
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        acc[m] += __shfl_xor(acc[m], 32, 64);
+        if (hi == 0) red[wave][m][nl] = acc[m];
+    }
+    __syncthreads();
+    if (tid < 32 * MR) {
+        const int m = tid / 32, n = tid % 32;
+        const int64_t on = n0 + n;
+        if (m < M && on < p.N) {
+            float sum = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+            if (bias) sum += FT<T_ID>::load(bias, on);
+            FT<T_ID>::store(out, (int64_t)m * p.N + on, sum);
+        }
+    }
+}
+
 // t[M][R] = cast( x[M][K] . down[R][K]^T ) on the matrix cores (bf16 / f16): the inner torch.mm of the SVD branch
 // (linear_int8.py:60).  HBM-bound on x: 2*M*K bytes (28 MB for a FLUX activation).
 // One workgroup (4 waves) = 16 activation rows x all of K x 32 factor rows, walked in stages of 128 k through an LDS ring:
@@ -739,6 +902,29 @@ extern "C" int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_d
     if (lds > 150 * 1024) return SDNQ_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((p.N + 31) / 32)), block(256);
+    const size_t lds32 = lds + 4 * 4 * 3072 + (size_t)32 * p.G * 8;  // + the four private DMA rings and the rows' scales / zero points
+    if (p.rank == 32 && lds32 <= 150 * 1024 && (p.group_size % 16) == 0 && p.G <= 64 && (p.K % 32) == 0 && (raw8 || (p.K % 64) == 0) &&
+        ((uintptr_t)x % 16) == 0 && ((ldx * 2) % 16) == 0) {
+#define S32_LAUNCH(B, MR)                                                                                                    \
+    do {                                                                                                                     \
+        auto kern = raw8 ? skinny_svd32_kernel<B, MR, 8> : skinny_svd32_kernel<B, MR, 4>;                                    \
+        if (lds32 > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) \
+            return SDNQ_ERR_LAUNCH;                                                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds32, s, p, (const uint16_t*)svd_down_t, x, bias, out, m, ldx);               \
+    } while (0)
+#define S32_DISPATCH(B)            \
+    do {                           \
+        if (m <= 1) S32_LAUNCH(B, 1); \
+        else if (m <= 2) S32_LAUNCH(B, 2); \
+        else S32_LAUNCH(B, 4);     \
+    } while (0)
+        if (dtype == SDNQ_BF16) S32_DISPATCH(true);
+        else S32_DISPATCH(false);
+#undef S32_DISPATCH
+#undef S32_LAUNCH
+        SDNQ_CHECK_LAUNCH();
+        return SDNQ_OK;
+    }
 #define SS_LAUNCH(B, MR)                                                                                                     \
     do {                                                                                                                     \
         auto kern = raw8 ? skinny_svd_kernel<B, MR, 8> : skinny_svd_kernel<B, MR, 4>;                                        \
