@@ -217,6 +217,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 enum { EPI_NONE = 0, EPI_BIAS1D = 1, EPI_BIAS2D = 2, EPI_LOWRANK = 3 };
 
+// rows of final values the register-layout epilogues stage at a time (LDS: 160 KB minus <= 4 KB of per-channel vectors)
+template <int EPI, int BM, int BN, int OUT_B> constexpr int epi_chunk_rows() {
+    const int lr = (EPI == EPI_LOWRANK) ? (BM + BN) * 64 : 0;
+    return (BM <= 128 || lr + BM * (BN * OUT_B + 16) <= 155 * 1024) ? BM : 128;
+}
+
 // f32(acc) * sa, the first step of every scaled epilogue; LP: carried on bf16 tensors (see gemm_kernel)
 template <bool LP>
 __device__ __forceinline__ float acc_times_sa(float a, float sa) {
@@ -347,10 +353,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int STAGE_BYTES = BM * BK + BN * BKW;
     constexpr int LDS_STAGES = NS;
     constexpr int OUT_B = FT<OUT_T>::bytes;
-    constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // the tile leaves in ECH chunks of CH rows (LDS budget)
+    constexpr int CH = BM > 128 ? 64 : BM, ECH = BM / CH;  // general low-rank epilogue: the tile leaves in ECH chunks of CH rows (LDS budget)
+    // register-layout epilogues stage FINAL values: the whole tile at once when it fits next to the staged low-rank factor tiles (every
+    // wave then finishes its sub-tiles at the same time), else two chunks of 128 rows (only the waves of that half work)
+    constexpr int CHR = epi_chunk_rows<EPI, BM, BN, FT<OUT_T>::bytes>(), ECHR = BM / CHR;
+    static_assert(ECHR == 1 || CHR % WM == 0, "all rows of a wave lie in one chunk");
     // epilogue staging: final values (simple epilogues) or raw accumulators + low-rank tile (EPI_LOWRANK)
     constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES;
-    constexpr int EPI_BYTES = (EPI == EPI_LOWRANK || BM > 128) ? CH * (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : CH * (BN * OUT_B + 16);
+    // EPI_LOWRANK: [t tile BM x 64 B | svd_up tile BN x 64 B] (rank-32 factors staged for the low-rank MFMAs), then the raw accumulator
+    // plane (32-bit) and the bias2d plane (16-bit: cast_svd(bias + low-rank), linear_int8.py:57-62) of one chunk
+    constexpr int LR_BYTES = (EPI == EPI_LOWRANK) ? (BM + BN) * 64 : 0;
+    constexpr int B2_ROW = BN * 2 + 16;
+    constexpr int EPI_GEN = LR_BYTES + CH * (BN * 4 + 16) + CH * B2_ROW, EPI_REG = LR_BYTES + CHR * (BN * OUT_B + 16);
+    constexpr int EPI_BYTES = (EPI == EPI_LOWRANK) ? ((EPI_GEN > EPI_REG || OUT_T == SDNQ_F32) ? EPI_GEN : EPI_REG) : EPI_REG;  // f32 low-rank outputs: general path only
     constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
@@ -662,23 +677,125 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // operands are 16-byte rows of t [M][R] / svd_up [N][R] straight from global (R/16 MFMAs per sub-tile).
     // (computed per 32x32 sub-tile right before that sub-tile is staged: only 16 extra accumulator registers are live at a
     // time -- holding all TN x TM low-rank tiles next to the main accumulators spilled 104 VGPRs in the 256x256 kernel)
-    bool lr_mfma = false;
-    if constexpr (EPI == EPI_LOWRANK) lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
+    bool lr_mfma = false, lr_lds = false;
+    if constexpr (EPI == EPI_LOWRANK) {
+        lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
+        // rank 32 (the default): the tile's rows of t and svd_up -- 64 bytes each -- are fetched ONCE into the (now idle) ring by
+        // LDS-DMA and the sub-tile fragments come from LDS.  Fetching every sub-tile's fragments from global right before its MFMAs
+        // exposed one L2 round trip per sub-tile, 8 per wave: ~26 us per FLUX GEMM (round 2 profile: 47 ms of GEMMs vs 36 ms
+        // without the low-rank term).  16 rows per DMA; 16-byte chunk ^= (row >> 2) & 3 keeps the fragment reads conflict-free.
+        lr_lds = lr_mfma && p.rank == 32;
+        if (lr_lds) {
+            for (int pc = wave; pc < (BM + BN) / 16; pc += NW) {
+                const bool is_t = pc < BM / 16;
+                const int row = (is_t ? pc : pc - BM / 16) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                int64_t g = (is_t ? m0 : n0) + row;
+                const int64_t lim = is_t ? p.M : p.N;
+                if (g >= lim) g = lim - 1;
+                const uint8_t* src = (const uint8_t*)(is_t ? p.lr_t : p.lr_up) + g * 64 + c * 16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + pc * 1024), 16, 0, 0);
+            }
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    constexpr bool STAGED_EPILOGUE = (EPI == EPI_LOWRANK) || (BM > 128);
+    constexpr bool STAGED_EPILOGUE = (EPI == EPI_LOWRANK);
     if constexpr (STAGED_EPILOGUE) {
     // ======== LDS-staged epilogue with a compact runtime loop: low-rank / zero-point terms, and every 256-row tile ====
     // The low-rank arithmetic is long; fully unrolled over the accumulator registers (as the epilogue below is) it becomes
     // ~8k instructions of straight-line code that every wave executes once at instruction-fetch speed (measured: 2.5x slower
     // GEMM).  The 256-row tiles (128 accumulator registers per lane) also measured 2 % faster this way.  So the raw
     // accumulators (and the low-rank tile) are staged as 32-bit values and a small loop finishes them.
+    if constexpr (EPI == EPI_LOWRANK && OUT_T != SDNQ_F32) {
+        if (lr_lds && p.zp == nullptr && p.a_zp == nullptr) {
+            // ======== SVD-only layers (no zero-point terms; FLUX int8 + SVD): finish in the MFMA register layout ========
+            // Every lane owns outputs m = wm*WM + j*32 + (lane & 31), n = wn*WN + i*32 + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Per
+            // sub-tile: two MFMAs on the staged factor tiles give the low-rank values of exactly those outputs; bias2d = cast_svd(bias +
+            // low-rank); out = cast(fma(f32(acc) * sa, sb, bias2d)) (linear_int8.py:57-62, kernel_wrappers.py:132-136).  Only the FINAL
+            // 16-bit values go through LDS (chunks of up to 128 rows) to leave as 16-byte row pieces.  The general staged loop below
+            // (raw accumulators + a bias2d plane through LDS, chunk by chunk) cost 45 us per 256x256 tile: as four unrolled chunk
+            // copies it was 15.7 K lines of ISA executed once at instruction-fetch speed, as a runtime loop it spilled.
+            constexpr int CH2 = CHR, ECH2 = ECHR;
+            constexpr int O_ROW = BN * OUT_B + 16;
+            uint8_t* ostage = lds + LR_BYTES;
+            static_assert(LR_BYTES + CH2 * O_ROW <= EPI_BYTES, "register-layout low-rank epilogue fits the staged epilogue's LDS budget");
+            const bool hb = p.bias != nullptr;
+            const bool is_bf = p.bias_dtype == SDNQ_BF16;
+#pragma nounroll
+            for (int ch = 0; ch < ECH2; ++ch) {
+                if (ch > 0) __syncthreads();  // previous chunk copied out before its staging area is overwritten
+                if ((wm * WM) / CH2 == ch) {  // wave-uniform: all of this wave's rows lie in one chunk (CH2 % WM == 0)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        const int tr = wm * WM + j * 32 + (lane & 31);  // tile row = this lane's output row
+                        int64_t gm = m0 + tr;
+                        if (gm >= p.M) gm = p.M - 1;
+                        const float sa = p.sa[gm];
+                        const uint8_t* lt = lds + tr * 64;
+                        const int tsw = (tr >> 2) & 3;
+                        const v4i ft0 = *(const v4i*)(lt + (((lane >> 5) ^ tsw) << 4)), ft1 = *(const v4i*)(lt + (((2 + (lane >> 5)) ^ tsw) << 4));
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) {
+                            const int ur = wn * WN + i * 32 + (lane & 31);
+                            const uint8_t* lu = lds + (BM + ur) * 64;
+                            const int usw = (ur >> 2) & 3;
+                            const v4i fu0 = *(const v4i*)(lu + (((lane >> 5) ^ usw) << 4)), fu1 = *(const v4i*)(lu + (((2 + (lane >> 5)) ^ usw) << 4));
+                            v16f lrt;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) lrt[e] = 0.0f;
+                            if (is_bf) {
+                                lrt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fu0), __builtin_bit_cast(v8bf, ft0), lrt, 0, 0, 0);
+                                lrt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fu1), __builtin_bit_cast(v8bf, ft1), lrt, 0, 0, 0);
+                            } else {
+                                lrt = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fu0), __builtin_bit_cast(v8h, ft0), lrt, 0, 0, 0);
+                                lrt = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fu1), __builtin_bit_cast(v8h, ft1), lrt, 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
+                                const v4f sb4 = *(const v4f*)(s_sb + nl0), b4 = *(const v4f*)(s_bias + nl0);
+                                u32 h[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float lv = hb ? lrt[4 * q + e] + b4[e] : lrt[4 * q + e];
+                                    const float b2 = is_bf ? FT<SDNQ_BF16>::round(lv) : FT<SDNQ_F16>::round(lv);
+                                    const float vv = acc_times_sa<LP>(MT::tof(acc[i][j], 4 * q + e), sa);
+                                    h[e] = (u32)FT<OUT_T>::bits(fmaf(vv, sb4[e], b2));
+                                }
+                                *(v2i*)(ostage + (tr - ch * CH2) * O_ROW + nl0 * OUT_B) = (v2i){(int)(h[0] | (h[1] << 16)), (int)(h[2] | (h[3] << 16))};
+                            }
+                            __builtin_amdgcn_sched_barrier(0);  // one sub-tile at a time (register pressure next to 128 accumulators)
+                        }
+                    }
+                }
+                __syncthreads();
+                constexpr int PPR2 = BN * OUT_B / 16, EPP2 = 16 / OUT_B;
+#pragma nounroll
+                for (int v = tid; v < CH2 * PPR2; v += NT) {
+                    const int r = v / PPR2, c = v % PPR2;
+                    const int64_t gm = m0 + ch * CH2 + r, gn0 = n0 + c * EPP2;
+                    if (gm >= p.M || c * EPP2 >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
+                    store16(out_piece(p, tv, gm, gn0, c * EPP2, OUT_B), *(const uint4*)(ostage + r * O_ROW + c * 16));
+                }
+            }
+            return;
+        }
+    }
     constexpr int ACC_ROW = BN * 4 + 16;
     // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
     //     acc[i][j][reg]: n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = wm*WM + j*32 + (lane&31)
-    uint8_t* stage = lds;
-    static_for_up<ECH>([&](auto chc) {
-    constexpr int ch = decltype(chc)::value;
+    uint8_t* stage = lds + LR_BYTES;
+    uint8_t* stage2 = stage + CH * ACC_ROW;  // EPI_LOWRANK: bias2d plane, 16-bit
+    const bool has_bias_lr = p.bias != nullptr;
+    // RUNTIME loop over the chunks: unrolled (it used to be a static_for) the LOWRANK kernel carried four copies of the staging and
+    // of the compact loop -- 15.7 K lines of ISA executed once, at instruction-fetch speed: 45 us of epilogue per 256x256 tile against
+    // a 47 us main loop at K = 3072 (tools/trace_gemm.py --lowrank, round 2)
+#pragma nounroll
+    for (int ch = 0; ch < ECH; ++ch) {
+
     if (ch > 0) __syncthreads();  // previous chunk fully stored before its staging area is overwritten
 #pragma unroll
     for (int j = 0; j < TM; ++j)
@@ -695,10 +812,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     if (gm >= p.M) gm = p.M - 1;
                     const uint16_t* up = (const uint16_t*)p.lr_up + gn * p.rank + (lane >> 5) * 8;
                     const uint16_t* tt = (const uint16_t*)p.lr_t + gm * p.rank + (lane >> 5) * 8;
+                    // staged tiles (rank 32): row r of t at lds + r * 64, of svd_up at lds + (BM + r) * 64, chunk-swizzled
+                    const int tr = wm * WM + j * 32 + (lane & 31), ur = wn * WN + i * 32 + (lane & 31);
+                    const uint8_t* lt = lds + tr * 64, *lu = lds + (BM + ur) * 64;
+                    const int tsw = (tr >> 2) & 3, usw = (ur >> 2) & 3;
                     // (fetching every sub-tile's t / svd_up fragments in one burst before the DMA drain -- 48 more live VGPRs --
                     // spilled 104 registers in the 256x256 kernel and gained nothing: 72.8 vs 69.7 ms per FLUX step, round 2)
                     for (int kr = 0; kr < p.rank; kr += 16) {
-                        const uint4 fu = *(const uint4*)(up + kr), ft = *(const uint4*)(tt + kr);
+                        v4i fu, ft;
+                        if (lr_lds) {
+                            const int c = (kr >> 3) + (lane >> 5);
+                            fu = *(const v4i*)(lu + ((c ^ usw) << 4));
+                            ft = *(const v4i*)(lt + ((c ^ tsw) << 4));
+                        } else {
+                            fu = *(const v4i*)(up + kr);
+                            ft = *(const v4i*)(tt + kr);
+                        }
                         if (p.bias_dtype == SDNQ_BF16)
                             lrt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, fu), __builtin_bit_cast(v8bf, ft), lrt, 0, 0, 0);
                         else
@@ -715,8 +844,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 else
                     *(v4f*)(stage + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 if constexpr (EPI == EPI_LOWRANK) {
-                    if (lr_mfma)
-                        *(v4f*)(stage + CH * ACC_ROW + ml * ACC_ROW + nl0 * 4) = (v4f){lrt[4 * q], lrt[4 * q + 1], lrt[4 * q + 2], lrt[4 * q + 3]};
+                    if (lr_mfma) {
+                        // bias2d = cast_svd(f32(bias[n]) + low-rank) (addmm in the svd dtype, linear_int8.py:57-62; no bias: s_bias = 0)
+                        const v4f b4 = *(const v4f*)(s_bias + nl0);
+                        u32 h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = has_bias_lr ? lrt[4 * q + e] + b4[e] : lrt[4 * q + e];
+                            h[e] = (p.bias_dtype == SDNQ_BF16) ? (u32)f32_to_bf16_bits(v) : (u32)f32_to_f16_bits(v);
+                        }
+                        *(v2i*)(stage2 + ml * B2_ROW + nl0 * 2) = (v2i){(int)(h[0] | (h[1] << 16)), (int)(h[2] | (h[3] << 16))};
+                    }
                 }
             }
         }
@@ -752,10 +890,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 const int64_t img = gm / p.out_hw, px = gm - img * p.out_hw;
                 *(uint4*)((uint8_t*)p.out + ((img * p.N + gn) * p.out_hw + px) * OUT_B) = Vec16<OUT_T>::pack(o);
             }
-            return;
+            continue;  // next chunk
         }
     }
-    const bool lr_fast = EPI == EPI_LOWRANK && lr_mfma && p.bias_dtype == SDNQ_BF16 && p.zp == nullptr && p.a_zp == nullptr;
+    const bool lr_fast = EPI == EPI_LOWRANK && lr_mfma && p.zp == nullptr && p.a_zp == nullptr;
 #pragma nounroll
     for (int v = tid; v < CH * G8; v += NT) {
         const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
@@ -786,9 +924,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 continue;
             }
             const v4f sb4 = *(const v4f*)(s_sb + c8 + 4 * h);
-            v4f lr4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            v4f lr4 = {0.0f, 0.0f, 0.0f, 0.0f};  // bias2d values (already cast to the svd dtype) of the staged low-rank plane
             if constexpr (EPI == EPI_LOWRANK) {
-                if (lr_mfma) lr4 = *(const v4f*)(stage + CH * ACC_ROW + r * ACC_ROW + (c8 + 4 * h) * 4);
+                if (lr_mfma) {
+                    const v2i b2 = *(const v2i*)(stage2 + r * B2_ROW + (c8 + 4 * h) * 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint16_t bits = (uint16_t)(((u32)b2[e >> 1]) >> (16 * (e & 1)));
+                        lr4[e] = (p.bias_dtype == SDNQ_BF16) ? bf16_bits_to_f32(bits) : f16_bits_to_f32(bits);
+                    }
+                }
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -804,22 +949,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     // bias2d = cast_svd(f32(bias[n]) + sum_r t[m][r]*up[n][r]) (linear_int8.py:57-62), then the zero-point
                     // term f32(rowsum)*sa*zp[n] + bias2d (linear_int8.py:65-69), all f32 into the single-rounding fma
                     const int cn = c8 + 4 * h + e;
-                    if (lr_fast) {  // SVD only (cfg5): staged MFMA low-rank value, bf16 bias2d, no zero-point terms
-                        const float sacc = lr4[e];
-                        res = fmaf(vv, sb4[e], FT<SDNQ_BF16>::round(has_bias ? sacc + s_bias[cn] : sacc));
+                    if (lr_fast) {  // SVD only (cfg5): staged bias2d, no zero-point terms
+                        res = fmaf(vv, sb4[e], lr4[e]);
                     } else {
                         float bv = s_bias[cn];
                         bool has = has_bias;
                         if (p.lr_t) {
-                            float sacc;
                             if (lr_mfma) {
-                                sacc = lr4[e];
+                                bv = lr4[e];  // staged: cast_svd(bias + low-rank)
                             } else {  // f32 factors or a rank that is not a multiple of 16: plain fma chain
-                                sacc = 0.0f;
+                                float sacc = 0.0f;
                                 for (int rr = 0; rr < p.rank; ++rr)
                                     sacc = fmaf(ldf_rt(p.lr_t, gm * p.rank + rr, p.bias_dtype), ldf_rt(p.lr_up, (n0 + cn) * p.rank + rr, p.bias_dtype), sacc);
+                                bv = round_rt(has ? sacc + bv : sacc, p.bias_dtype);
                             }
-                            bv = round_rt(has ? sacc + bv : sacc, p.bias_dtype);
                             has = true;
                         }
                         float zb = 0.0f;
@@ -846,7 +989,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             store16(dst, Vec16<OUT_T>::pack(o));
         }
     }
-    });
+    }
     } else {
     // ======== simple epilogues of the 64-row tiles: arithmetic in the MFMA register layout (+2.6 % on the SDXL step's GEMMs) ==
     // Every lane owns output position m = wm*WM + j*32 + (lane&31) and channels n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) +
@@ -855,13 +998,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // traffic of staging raw 32-bit accumulators, and ~6 instructions per output, so unrolling it stays small.
     constexpr int OUT_ROW = BN * OUT_B + 16;  // staging row pitch in bytes
     uint8_t* stage = lds;
-    static_for_up<ECH>([&](auto chc) {
-    constexpr int ch = decltype(chc)::value;
+    // 256-row tiles leave in two chunks of 128 rows.  A RUNTIME loop with one wave-uniform test per chunk: the arithmetic of a wave's
+    // sub-tiles is emitted once (unrolled per chunk -- or staged as raw accumulators with a compact loop, as these tiles used to
+    // be -- the epilogue is thousands of instructions executed once at instruction-fetch speed).
+#pragma nounroll
+    for (int ch = 0; ch < ECHR; ++ch) {
     if (ch > 0) __syncthreads();  // previous chunk fully stored before its staging area is overwritten
+    if (ECHR == 1 || (wm * WM) / CHR == ch) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        if (ECH > 1 && (wm * WM + j * MS) / CH != ch) continue;  // wave-uniform: this MFMA row block is in another chunk
-        const int ml = wm * WM + j * MS + frow - ch * CH;        // row inside the chunk
+        const int ml = wm * WM + j * MS + frow - ch * CHR;        // row inside the chunk
         int64_t gm = m0 + wm * WM + j * MS + frow;
         const bool m_ok = gm < p.M;
         if (!m_ok) gm = p.M - 1;
@@ -906,6 +1052,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             }
         }
     }
+    }  // this wave's rows are in chunk ch
     __syncthreads();
     TRACE(5);
     if constexpr (EPI <= EPI_BIAS1D && OUT_T != SDNQ_F32) {
@@ -913,9 +1060,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             // channel-major store for the conv forwards: 8 consecutive output positions of ONE channel per thread (they are
             // contiguous in the [B][N][HW] image: HW % 8 == 0 and tiles start on multiples of 64)
 #pragma nounroll
-            for (int v = tid; v < (CH / 8) * BN; v += NT) {
-                const int n = v / (CH / 8), r8 = (v % (CH / 8)) * 8;
-                const int64_t gm = m0 + ch * CH + r8, gn = n0 + n;
+            for (int v = tid; v < (CHR / 8) * BN; v += NT) {
+                const int n = v / (CHR / 8), r8 = (v % (CHR / 8)) * 8;
+                const int64_t gm = m0 + ch * CHR + r8, gn = n0 + n;
                 if (gm >= p.M || gn >= p.N) continue;
                 uint16_t h8[8];
 #pragma unroll
@@ -923,20 +1070,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 const int64_t img = gm / p.out_hw, px = gm - img * p.out_hw;
                 *(uint4*)((uint8_t*)p.out + ((img * p.N + gn) * p.out_hw + px) * 2) = *(const uint4*)h8;
             }
-            return;
+            continue;  // next chunk
         }
     }
     // plain copy: 16-byte pieces of the output rows
     constexpr int PPR = BN * OUT_B / 16;  // pieces per row
     constexpr int EPP = 16 / OUT_B;       // output elements per piece
 #pragma nounroll
-    for (int v = tid; v < CH * PPR; v += NT) {
+    for (int v = tid; v < CHR * PPR; v += NT) {
         const int r = v / PPR, c = v % PPR;
-        const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c * EPP;
+        const int64_t gm = m0 + ch * CHR + r, gn0 = n0 + c * EPP;
         if (gm >= p.M || c * EPP >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
         store16(out_piece(p, tv, gm, gn0, c * EPP, OUT_B), *(const uint4*)(stage + r * OUT_ROW + c * 16));
     }
-    });
+    }
     }
     TRACE(6);
 }
@@ -946,7 +1093,10 @@ int launch_one(GemmParams p, hipStream_t s) {
     static_assert(!LP || (OUT_T == SDNQ_BF16 && !is_float_mm<MM>), "LP: the bf16-scale epilogue of the quantized matmuls");
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int MAIN = NS * (BM * BK + BN * (is_w8a16<MM> ? BK / 2 : BK));
-    constexpr int EPIB = (BM > 128 ? 64 : BM) * ((EPI == EPI_LOWRANK || BM > 128) ? (BN * 4 + 16) * (EPI == EPI_LOWRANK ? 2 : 1) : BN * FT<OUT_T>::bytes + 16);
+    constexpr int CHS = BM > 128 ? 64 : BM, CHR = epi_chunk_rows<EPI, BM, BN, FT<OUT_T>::bytes>();  // rows per epilogue chunk (as in gemm_kernel)
+    constexpr int EPI_GEN = (BM + BN) * 64 + CHS * (BN * 4 + 16) + CHS * (BN * 2 + 16);
+    constexpr int EPI_REG = ((EPI == EPI_LOWRANK) ? (BM + BN) * 64 : 0) + CHR * (BN * FT<OUT_T>::bytes + 16);
+    constexpr int EPIB = (EPI == EPI_LOWRANK && (EPI_GEN > EPI_REG || OUT_T == SDNQ_F32)) ? EPI_GEN : EPI_REG;
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + ((EPI == EPI_LOWRANK || is_w8a16<MM>) ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK, LP>;
