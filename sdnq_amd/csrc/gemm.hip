@@ -1182,7 +1182,9 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto fits = [&](int bn) { return p.units == nullptr || (p.unit_n % bn) == 0; };  // grouped launch: a tile stays inside one unit
     // (round 2, tools/micro/gemm_lab.hip + tools/sweep_gemm.py, profiles/r02_gemm_tile_sweep.txt) short-K problems do not amortise
     // the 256x256 tile's prologue / epilogue: 4096 x 5120 x 640 ran 39 us on it vs 29 us on 256x128
-    if (tiles(256, 256) >= 200 && p.K >= 2048 && fits(256)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    // (160 rather than 200 tiles since the register-layout epilogue: 4096 x 3072 x 3072 -- 192 tiles -- 56.5 us vs 57.7-62.6 on 256x128,
+    //  4096 x 3072 x 12288 160 vs 198 us; profiles/r02_gemm_tile_sweep.txt)
+    if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
     //  * tall problems that cannot fill the chip with 256x256 tiles (conv GEMMs 16384 x 320 x 2880..8640, 4096 x 5120 x 640):
     //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
     if (p.M >= 2048 && tiles(256, 128) >= 150 && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);

@@ -331,7 +331,10 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     // few long rows: two waves per row (see rowquant_kernel); the prefetch blocks are not combined with it
     static const int split_env = [] { const char* e = getenv("SDNQ_HIP_RQ_SPLIT"); return e ? atoi(e) : 0; }();  // tuning aid: 1, 2, 4
     const bool can_split = m <= 2048 && np >= 3 && !(prefetch && prefetch_bytes > 0);
-    const bool split4 = can_split && np <= 12 && (split_env == 4 || (split_env == 0 && np >= 7));
+    // very long rows (5120 < K <= 16384: FLUX's 12288 / 15360-wide activations): four waves per row hold a quarter each in registers
+    // -- ONE pass over HBM instead of the two-phase fallback's two (4608 x 15360: 66 us per launch on the two-phase path)
+    const bool long4 = np > 10 && np <= 32 && !(prefetch && prefetch_bytes > 0) && split_env != 1;
+    const bool split4 = long4 || (can_split && np <= 12 && (split_env == 4 || (split_env == 0 && np >= 7)));
     const bool split2 = can_split && !split4 && np <= 10 && split_env != 1;
     const int row_blocks = split4 ? (int)m : (split2 ? (int)((m + 1) / 2) : (int)((m + 3) / 4));
     const uint4* pf = (const uint4*)prefetch;
@@ -352,7 +355,8 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     do {                                        \
         if (split4 && np <= 4) RQ_LAUNCH4(T, MMV, H, 1);      \
         else if (split4 && np <= 8) RQ_LAUNCH4(T, MMV, H, 2); \
-        else if (split4) RQ_LAUNCH4(T, MMV, H, 3);            \
+        else if (split4 && np <= 12) RQ_LAUNCH4(T, MMV, H, 3); \
+        else if (split4) RQ_LAUNCH4(T, MMV, H, 8);            \
         else if (split2 && np <= 4) RQ_LAUNCH2(T, MMV, H, 2);      \
         else if (split2 && np <= 6) RQ_LAUNCH2(T, MMV, H, 3); \
         else if (split2) RQ_LAUNCH2(T, MMV, H, 5);            \
