@@ -278,6 +278,163 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
     }
 }
 
+// ---- group-256 Hadamard rotation on the matrix cores -------------------------------------------------------------------------------
+// H_256 = kron^4(H4) / 16 = (H16 / 4) (x) (H16 / 4) with H16 = H4 (x) H4 (quant_utils.py:157-165), so for a group seen as a 16 x 16
+// row-major matrix X (element 16 r + c):  rotate(x) = vec( (H16/4) . X . (H16/4) )  -- two 16 x 16 x 16 matrix products instead of
+// four radix-4 butterfly stages over registers and lanes (the FWHT of wave_hadamard costs ~13 VALU per element, most of them DPP /
+// ds_swizzle moves: 4608 x 15360 rows took 130 us rotated vs 61 us plain).
+//   stage 1: D1 = X . (H16/4)      v_mfma_f32_16x16x16 (bf16 / f16): A = X in the A layout -- lane l holds X[l & 15][4 (l >> 4) .. +3], one
+//            8-byte load, a whole group per wave-load (512 contiguous bytes) -- B = the constant matrix, generated in registers;
+//   stage 2: Y^T = D1^T . (H16/4)  4 x v_mfma_f32_16x16x4_f32: stage 1's accumulator registers (lane l: D1[4 (l >> 4) + s][l & 15]) ARE the
+//            A operand of D1^T, full fp32, no rounding in between; the output lands in the layout the input came in: lane l holds
+//            Y[l & 15][4 (l >> 4) .. +3], so codes / the rotated copy leave as 4- / 8-byte pieces of 256- / 512-byte contiguous runs.
+// Products are exact (x . +-1/4), sums are fp32, ONE rounding to the activation dtype at the end, as rotate_hadamard's matmul.
+// One workgroup = 4 waves; WPR = 1: a row per wave (K <= 4096), WPR = 4: the row split over the four waves (K <= 16384).
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+// the constant operand of both stages: H16[k][n] / 4 for k = 4 (lane >> 4) + e, n = lane & 15;  H16[a][b] = H4[a >> 2][b >> 2] H4[a & 3][b & 3],
+// H4[i][j] = -1 on the anti-diagonal
+__device__ __forceinline__ void had16_operand(int lane, float (&hf)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * (lane >> 4) + e, n = lane & 15;
+        const bool neg = (((k >> 2) + (n >> 2)) == 3) != (((k & 3) + (n & 3)) == 3);
+        hf[e] = neg ? -0.25f : 0.25f;
+    }
+}
+// one group: raw = this lane's 4 consecutive elements X[lane & 15][4 (lane >> 4) .. +3] -> the rotated values of the same 4 positions (fp32)
+template <int T_ID>
+__device__ __forceinline__ v4f had256_group(const uint2& raw, const float (&hf)[4]) {
+    v4f d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (T_ID == SDNQ_BF16) {
+        const v4s hb = {(short)f32_to_bf16_bits(hf[0]), (short)f32_to_bf16_bits(hf[1]), (short)f32_to_bf16_bits(hf[2]), (short)f32_to_bf16_bits(hf[3])};
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(v4s, raw), hb, d1, 0, 0, 0);
+    } else {
+        const v4h hh = {(_Float16)hf[0], (_Float16)hf[1], (_Float16)hf[2], (_Float16)hf[3]};
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(v4h, raw), hh, d1, 0, 0, 0);
+    }
+    v4f y = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) y = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[sidx], hf[sidx], y, 0, 0, 0);
+    return y;
+}
+
+// standalone rotation with the same arithmetic (sdnq_hip_hadamard, group 256, 16-bit): one wave per row, a group per step
+template <int T_ID>
+__global__ __launch_bounds__(256) void hadamard256_kernel(const void* __restrict__ x, int64_t rows, int64_t K, int64_t ldx, void* __restrict__ y, int64_t ldy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int eoff = 16 * (lane & 15) + 4 * (lane >> 4);
+    const uint16_t* src = (const uint16_t*)x + r * ldx + eoff;
+    uint16_t* dst = (uint16_t*)y + r * ldy + eoff;
+    float hf[4];
+    had16_operand(lane, hf);
+    const int ngroups = (int)(K / 256);
+    for (int g0 = 0; g0 < ngroups; g0 += 4) {  // four groups' loads in flight
+        uint2 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *(const uint2*)(src + (int64_t)(g0 + u < ngroups ? g0 + u : g0) * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (g0 + u < ngroups) {
+                const v4f v = had256_group<T_ID>(raw[u], hf);
+                const uint32_t lo = (uint32_t)FT<T_ID>::bits(v[0]) | ((uint32_t)FT<T_ID>::bits(v[1]) << 16);
+                const uint32_t hi = (uint32_t)FT<T_ID>::bits(v[2]) | ((uint32_t)FT<T_ID>::bits(v[3]) << 16);
+                *(uint2*)(dst + (int64_t)(g0 + u) * 256) = make_uint2(lo, hi);
+            }
+        }
+    }
+}
+
+template <int T_ID, int MM, int NG, int WPR>
+__global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, uint8_t* __restrict__ xq,
+                                                              float* __restrict__ xs, int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
+    static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int64_t m = (int64_t)blockIdx.x * (4 / WPR) + wv / WPR;
+    const int part = wv % WPR;
+    const bool row_ok = m < M;
+    if (WPR == 1 && !row_ok) return;
+    if (!row_ok) m = M - 1;
+    __shared__ float s_amax[4];
+    __shared__ int s_isum[4];
+    const int ngroups = (int)(K / 256);
+    const int g0 = part * NG;  // first group of this wave
+    const int eoff = 16 * (lane & 15) + 4 * (lane >> 4);  // this lane's 4 consecutive elements inside a group
+    const uint16_t* row = (const uint16_t*)x + m * ldx + eoff;
+    float hf[4];
+    had16_operand(lane, hf);
+    uint2 raw[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {  // all loads in flight; a group past the end of the row re-reads the first one and is dropped
+        const int gg = (g0 + g < ngroups) ? g0 + g : 0;
+        raw[g] = *(const uint2*)(row + (int64_t)gg * 256);
+    }
+    float v[NG][4];
+    float amax = 0.0f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const v4f y = had256_group<T_ID>(raw[g], hf);
+        const bool live = g0 + g < ngroups;  // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[g][e] = live ? FT<T_ID>::round(y[e]) : 0.0f;
+            amax = fmaxf(amax, fabsf(v[g][e]));
+        }
+    }
+    amax = wave_max(amax);
+    if constexpr (WPR > 1) {
+        if (lane == 0) s_amax[wv] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(s_amax[0], s_amax[1]), fmaxf(s_amax[2], s_amax[3]));
+    }
+    const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
+    const float scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
+    if (row_ok && lane == 0 && part == 0) xs[m] = scale;
+    uint8_t* qrow = xq + m * K + eoff;
+    int isum = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g0 + g < ngroups && row_ok) {
+            const int64_t go = (int64_t)(g0 + g) * 256;
+            if (xrot != nullptr) {
+                const uint32_t lo = (uint32_t)FT<T_ID>::bits(v[g][0]) | ((uint32_t)FT<T_ID>::bits(v[g][1]) << 16);
+                const uint32_t hi = (uint32_t)FT<T_ID>::bits(v[g][2]) | ((uint32_t)FT<T_ID>::bits(v[g][3]) << 16);
+                *(uint2*)((uint16_t*)xrot + m * K + eoff + go) = make_uint2(lo, hi);
+            }
+            u32 w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32 byte;
+                if constexpr (MM == SDNQ_MM_I8) {
+                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[g][e] / scale);
+                    q = fminf(fmaxf(q, -128.0f), 127.0f);
+                    const int qi = (int)q;
+                    isum += qi;
+                    byte = (u32)qi & 0xffu;
+                } else {
+                    float q = v[g][e] / scale;
+                    if (q != q) q = 0.0f;
+                    q = fminf(fmaxf(q, -448.0f), 448.0f);
+                    byte = f32_to_e4m3fn(q);
+                }
+                w |= byte << (8 * e);
+            }
+            *(u32*)(qrow + go) = w;
+        }
+    }
+    if (rowsum != nullptr) {
+        isum = wave_sum_i32(isum);
+        if constexpr (WPR > 1) {
+            if (lane == 0) s_isum[wv] = isum;
+            __syncthreads();
+            isum = (s_isum[0] + s_isum[1]) + (s_isum[2] + s_isum[3]);
+        }
+        if (row_ok && lane == 0 && part == 0) rowsum[m] = isum;
+    }
+}
+
 // standalone rotation: y = rotate(x), rounded to dtype
 template <int T_ID>
 __global__ __launch_bounds__(256) void hadamard_kernel(const void* __restrict__ x, int64_t rows, int64_t K, int64_t ldx,
@@ -327,6 +484,23 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     }
     if (rowsum && mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    static const int had_mfma = [] { const char* e = getenv("SDNQ_HIP_HADAMARD_MFMA"); return e ? atoi(e) : 1; }();  // 0: always the FWHT (A/B aid)
+    if (hadamard_group == 256 && x_dtype != SDNQ_F32 && !xzp && k <= 16384 && had_mfma && ((uintptr_t)x % 8) == 0 && ((ldx * 2) % 8) == 0 &&
+        ((uintptr_t)xq % 4) == 0 && (!xrot || ((uintptr_t)xrot % 8) == 0)) {
+        // the default group size, 16-bit activations: rotation on the matrix cores (rowquant_had256_kernel)
+        const int groups = (int)(k / 256);
+        const bool wide = groups > 16;  // the row split over four waves
+        const int per = wide ? (groups + 3) / 4 : groups;
+        dim3 grid((unsigned)(wide ? m : (m + 3) / 4)), block(256);
+#define RQH(T, MMV, NGV, W) hipLaunchKernelGGL((rowquant_had256_kernel<T, MMV, NGV, W>), grid, block, 0, s, x, m, k, ldx, (uint8_t*)xq, xs, rowsum, xrot)
+#define RQH_NG(T, MMV, W) do { if (per <= 4) RQH(T, MMV, 4, W); else if (per <= 8) RQH(T, MMV, 8, W); else RQH(T, MMV, 16, W); } while (0)
+#define RQH_W(T, MMV) do { if (wide) RQH_NG(T, MMV, 4); else RQH_NG(T, MMV, 1); } while (0)
+#define RQH_MM(T) do { if (mm_dtype == SDNQ_MM_I8) RQH_W(T, SDNQ_MM_I8); else RQH_W(T, SDNQ_MM_FP8); } while (0)
+        if (x_dtype == SDNQ_BF16) RQH_MM(SDNQ_BF16);
+        else RQH_MM(SDNQ_F16);
+        SDNQ_CHECK_LAUNCH();
+        return SDNQ_OK;
+    }
     const int np = (int)((k + 511) / 512);
     // few long rows: two waves per row (see rowquant_kernel); the prefetch blocks are not combined with it
     static const int split_env = [] { const char* e = getenv("SDNQ_HIP_RQ_SPLIT"); return e ? atoi(e) : 0; }();  // tuning aid: 1, 2, 4
@@ -426,6 +600,13 @@ extern "C" int sdnq_hip_hadamard(const void* x, int dtype, int64_t rows, int64_t
     if (((uintptr_t)x % 16) || ((uintptr_t)y % 16) || ((ldx * eb) % 16) || ((ldy * eb) % 16)) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    static const int had_mfma = [] { const char* e = getenv("SDNQ_HIP_HADAMARD_MFMA"); return e ? atoi(e) : 1; }();
+    if (hadamard_group == 256 && dtype != SDNQ_F32 && had_mfma) {  // the matrix-core rotation of rowquant_had256_kernel, bit for bit
+        if (dtype == SDNQ_BF16) hipLaunchKernelGGL((hadamard256_kernel<SDNQ_BF16>), grid, block, 0, s, x, rows, k, ldx, y, ldy);
+        else hipLaunchKernelGGL((hadamard256_kernel<SDNQ_F16>), grid, block, 0, s, x, rows, k, ldx, y, ldy);
+        SDNQ_CHECK_LAUNCH();
+        return SDNQ_OK;
+    }
     switch (dtype) {
         case SDNQ_F32: hipLaunchKernelGGL((hadamard_kernel<SDNQ_F32>), grid, block, 0, s, x, rows, k, ldx, log2g, y, ldy); break;
         case SDNQ_BF16: hipLaunchKernelGGL((hadamard_kernel<SDNQ_BF16>), grid, block, 0, s, x, rows, k, ldx, log2g, y, ldy); break;

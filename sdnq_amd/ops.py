@@ -183,7 +183,9 @@ def rowquant(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum: b
     rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
     # rows beyond the kernel's register cache (K > 5120) are rotated once into this buffer and quantized from it, so it is
     # allocated for them even when the caller does not want the rotated copy
-    need_rot = bool(hadamard_group) and (want_xrot or k > 5120)
+    # (group 256 on 16-bit activations up to K = 16384 rotates on the matrix cores, whole row in registers: no scratch copy)
+    mfma_rot = hadamard_group == 256 and x2d.dtype != torch.float32 and k <= 16384 and not asymmetric
+    need_rot = bool(hadamard_group) and (want_xrot or (k > 5120 and not mfma_rot))
     xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if need_rot else None
     xzp = torch.empty((m,), device=x2d.device, dtype=torch.float32) if asymmetric else None
     check(_lib.load().sdnq_hip_rowquant(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), mm, hadamard_group,
