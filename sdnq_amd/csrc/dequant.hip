@@ -317,17 +317,29 @@ __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams
     const float* srow = p.scale + n * p.G;
     const float* zrow = p.zp ? p.zp + n * p.G : nullptr;
     const bool is_signed = p.fmt.kind == SDNQ_KIND_INT;
+    constexpr bool PFX = MROWS == 1 && T_ID != SDNQ_F32;  // single activation row: its pieces are fetched with the weights
     for (int64_t kb = 0; kb < p.K; kb += 4096) {
-        uint4 raw[4];
+        // every load of this 4096-element stretch first -- codes, scales / zero points, (one-row case) activations -- all
+        // UNCONDITIONAL with clamped addresses: a load under a per-lane condition gets its own s_waitcnt vmcnt(0), and a scale
+        // fetched next to its use adds a dependent round trip per chunk (round 2: 45 us for FLUX's 18432 x 3072 int4 layers, 7 us of
+        // weight traffic)
+        uint4 raw[4], xr[PFX ? 4 : 1][2];
+        float scv[4], zpv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {  // all weight loads of this 4096-element stretch first
+        for (int c = 0; c < 4; ++c) {
             const int64_t k0 = kb + c * 1024 + (int64_t)lane * 16;
-            raw[c] = make_uint4(0, 0, 0, 0);
-            if (k0 < p.K) {
-                if constexpr (BITS == 8) raw[c] = *(const uint4*)(wrow + k0);
-                else { const uint2 q = *(const uint2*)(wrow + k0 / 2); raw[c].x = q.x; raw[c].y = q.y; }
+            const int64_t ks = k0 < p.K ? k0 : 0;
+            if constexpr (BITS == 8) raw[c] = *(const uint4*)(wrow + ks);
+            else { const uint2 q = *(const uint2*)(wrow + ks / 2); raw[c] = make_uint4(q.x, q.y, 0, 0); }
+            const int g = (int)(ks / p.group_size);  // group_size % 16 == 0: one group per 16-run
+            scv[c] = srow[g];
+            zpv[c] = zrow ? zrow[g] : 0.0f;
+            if constexpr (PFX) {
+                xr[c][0] = *(const uint4*)((const uint16_t*)x + ks);
+                xr[c][1] = *(const uint4*)((const uint16_t*)x + ks + 8);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (kb + c * 1024 >= p.K) break;  // wave-uniform
@@ -348,10 +360,9 @@ __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams
                 w[j] = (float)code;
             }
             if (live) {
-                const int g = (int)(k0 / p.group_size);  // group_size % 16 == 0: one group per 16-run
-                const float sc = srow[g];
+                const float sc = scv[c];
                 if (zrow) {
-                    const float z = zrow[g];
+                    const float z = zpv[c];
 #pragma unroll
                     for (int j = 0; j < 16; ++j) w[j] = fmaf(w[j], sc, z);
                 } else {
@@ -374,7 +385,10 @@ __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams
             for (int i = 0; i < MROWS; ++i) {
                 const int64_t m = (i < M) ? i : M - 1;
                 float xv[16];
-                if constexpr (T_ID == SDNQ_F32) {
+                if constexpr (PFX) {
+                    Vec16<T_ID>::unpack(xr[c][0], xv);
+                    Vec16<T_ID>::unpack(xr[c][1], xv + 8);
+                } else if constexpr (T_ID == SDNQ_F32) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) Vec16<SDNQ_F32>::unpack(*(const uint4*)((const float*)x + m * ldx + k0 + 4 * q), xv + 4 * q);
                 } else {
@@ -383,6 +397,100 @@ __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[i] = fmaf(xv[j], w[j], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MROWS; ++i) {
+        float sum = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if (lane == 0 && i < M) {
+            if (bias) sum += FT<T_ID>::load(bias, n);
+            FT<T_ID>::store(out, (int64_t)i * p.N + n, sum);
+        }
+    }
+}
+
+// The few-row linear of HADAMARD layers with the default rotation group 256 (FLUX int4 + Hadamard adaLN projections): the weight row is
+// un-rotated on the matrix cores.  linear_skinny_fast_kernel's FWHT (16 elements per lane: two radix-4 stages across lanes = 96 DPP /
+// ds_swizzle moves per 16 elements) took 37 of the 59 us of an 18432 x 3072 int4 layer.  Here a wave owns one output channel and
+// walks its row group by group in the MFMA layout of hadamard_dev.h: lane l holds the 4 consecutive columns 16 (l & 15) + 4 (l >> 4)
+// .. +3 of the group -- 2 bytes of int4 codes / 4 bytes of int8 codes per lane, a whole group = one contiguous 128 / 256 bytes per
+// wave-load -- dequantizes them (f32(q) * s | fma, rounded to T: dequantizer.py:27, 63), rotates (five MFMAs, rounded to T:
+// dequantizer.py:82-87) and multiplies with the same 4 columns of x.  All loads of up to 16 groups are issued before the first use.
+template <int T_ID, int BITS, int MROWS>
+__global__ __launch_bounds__(256) void linear_skinny_had256_kernel(const DeqParams p, const void* __restrict__ x, const void* __restrict__ bias,
+                                                                   void* __restrict__ out, int64_t M, int64_t ldx) {
+    static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
+    constexpr int NG = 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    float acc[MROWS];
+#pragma unroll
+    for (int i = 0; i < MROWS; ++i) acc[i] = 0.0f;
+    const int eoff = 16 * (lane & 15) + 4 * (lane >> 4);
+    const uint8_t* wrow = (const uint8_t*)p.w + (BITS == 8 ? n * p.K : n * p.K / 2) + (BITS == 8 ? eoff : eoff / 2);
+    const float* srow = p.scale + n * p.G;
+    const float* zrow = p.zp ? p.zp + n * p.G : nullptr;
+    const bool is_signed = p.fmt.kind == SDNQ_KIND_INT;
+    // codes -> numbers without branches: int8 two's complement: (byte ^ 0x80) - 128;  uint8: byte;  packed signed nibble: code - 8
+    const u32 flip8 = (is_signed && BITS == 8) ? 0x80808080u : 0u;
+    const float qsub = is_signed ? (BITS == 8 ? 128.0f : 8.0f) : 0.0f;
+    float hf[4];
+    had16_operand(lane, hf);
+    const int ngroups = (int)(p.K / 256);
+    for (int g0 = 0; g0 < ngroups; g0 += NG) {
+        u32 code[NG];
+        float sc[NG], zp[NG];
+        uint2 xr[NG][MROWS];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {  // unconditional, clamped: a group past the end re-reads group 0 and is dropped
+            const int64_t kk = (int64_t)(g0 + g < ngroups ? g0 + g : 0) * 256;
+            if constexpr (BITS == 8) code[g] = *(const u32*)(wrow + kk);
+            else code[g] = *(const uint16_t*)(wrow + kk / 2);
+            const int gi = (int)((kk + eoff) / p.group_size);  // group_size % 4 == 0: the 4 columns share one scale group
+            sc[g] = srow[gi];
+            zp[g] = zrow ? zrow[gi] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MROWS; ++i) xr[g][i] = *(const uint2*)((const uint16_t*)x + (int64_t)(i < M ? i : 0) * ldx + kk + eoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g0 + g < ngroups) {  // wave-uniform
+            // VALU diet (the kernel is VALU + MFMA bound, not HBM bound): codes -> floats with one extract + one convert each, the two
+            // roundings to T as PACKED converts whose results feed the MFMA / the dot product directly, x . w as packed dot products
+            float w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float q;
+                if constexpr (BITS == 8) q = (float)(((code[g] ^ flip8) >> (8 * e)) & 0xffu) - qsub;   // v_cvt_f32_ubyteN
+                else q = (float)((code[g] >> (4 * e)) & 15u) - qsub;
+                w[e] = zrow ? fmaf(q, sc[g], zp[g]) : q * sc[g];
+            }
+            uint2 wp;
+            if constexpr (T_ID == SDNQ_BF16) {
+                const v2bf p0 = {(__bf16)w[0], (__bf16)w[1]}, p1 = {(__bf16)w[2], (__bf16)w[3]};
+                wp = make_uint2(__builtin_bit_cast(u32, p0), __builtin_bit_cast(u32, p1));
+            } else {
+                const v2h p0 = {(_Float16)w[0], (_Float16)w[1]}, p1 = {(_Float16)w[2], (_Float16)w[3]};
+                wp = make_uint2(__builtin_bit_cast(u32, p0), __builtin_bit_cast(u32, p1));
+            }
+            const v4f y = had256_group<T_ID>(wp, hf);
+#pragma unroll
+            for (int i = 0; i < MROWS; ++i) {
+                if constexpr (T_ID == SDNQ_BF16) {
+                    const v2bf y0 = {(__bf16)y[0], (__bf16)y[1]}, y1 = {(__bf16)y[2], (__bf16)y[3]};
+                    acc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xr[g][i].x), y0, acc[i], false);
+                    acc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xr[g][i].y), y1, acc[i], false);
+                } else {
+                    const v2h y0 = {(_Float16)y[0], (_Float16)y[1]}, y1 = {(_Float16)y[2], (_Float16)y[3]};
+                    acc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xr[g][i].x), y0, acc[i], false);
+                    acc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xr[g][i].y), y1, acc[i], false);
+                }
+            }
             }
         }
     }
@@ -966,6 +1074,21 @@ extern "C" int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, c
     {
         const bool int_fmt = p.fmt.kind == SDNQ_KIND_INT || p.fmt.kind == SDNQ_KIND_UINT;
         const bool raw8 = p.fmt.storage == SDNQ_ST_RAW8 && int_fmt, pk4 = p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && int_fmt;
+        static const int had_mfma = [] { const char* e = getenv("SDNQ_HIP_HADAMARD_MFMA"); return e ? atoi(e) : 1; }();
+        if ((raw8 || pk4) && m <= 4 && p.P == 1 && hadamard_group == 256 && dtype != SDNQ_F32 && (p.group_size % 4) == 0 && had_mfma &&
+            (p.sdt == SDNQ_F32 || p.sdt == dtype) && ((uintptr_t)x % 8) == 0 && ((ldx * 2) % 8) == 0) {
+            dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
+#define SH_LAUNCH(T, B, MR) hipLaunchKernelGGL((linear_skinny_had256_kernel<T, B, MR>), grid, block, 0, s, p, x, bias, out, m, ldx)
+#define SH_M(T, B) do { if (m == 1) SH_LAUNCH(T, B, 1); else if (m == 2) SH_LAUNCH(T, B, 2); else SH_LAUNCH(T, B, 4); } while (0)
+#define SH_T(B) do { if (dtype == SDNQ_BF16) SH_M(SDNQ_BF16, B); else SH_M(SDNQ_F16, B); } while (0)
+            if (raw8) SH_T(8);
+            else SH_T(4);
+#undef SH_T
+#undef SH_M
+#undef SH_LAUNCH
+            SDNQ_CHECK_LAUNCH();
+            return SDNQ_OK;
+        }
         // (the fast kernel rounds q * s straight to the activation dtype: with 16-bit scales that is the scale dtype's rounding too)
         if ((raw8 || pk4) && m <= 4 && p.P == 1 && (p.group_size % 16) == 0 && (p.K % 16) == 0 && (p.sdt == SDNQ_F32 || p.sdt == dtype)) {
             dim3 grid((unsigned)((p.N + 3) / 4)), block(256);

@@ -199,3 +199,34 @@ __device__ __forceinline__ void wave_hadamard16(float (&v)[16], int log2g, float
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] *= scale;
 }
+
+// ---- group-256 rotation on the matrix cores (see rowquant_had256_kernel in rowquant.hip for the derivation) ------------------------
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+// the constant operand of both stages: H16[k][n] / 4 for k = 4 (lane >> 4) + e, n = lane & 15;  H16[a][b] = H4[a >> 2][b >> 2] H4[a & 3][b & 3],
+// H4[i][j] = -1 on the anti-diagonal
+__device__ __forceinline__ void had16_operand(int lane, float (&hf)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * (lane >> 4) + e, n = lane & 15;
+        const bool neg = (((k >> 2) + (n >> 2)) == 3) != (((k & 3) + (n & 3)) == 3);
+        hf[e] = neg ? -0.25f : 0.25f;
+    }
+}
+// one group: raw = this lane's 4 consecutive elements X[lane & 15][4 (lane >> 4) .. +3] -> the rotated values of the same 4 positions (fp32)
+template <int T_ID>
+__device__ __forceinline__ v4f had256_group(const uint2& raw, const float (&hf)[4]) {
+    v4f d1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if constexpr (T_ID == SDNQ_BF16) {
+        const v4s hb = {(short)f32_to_bf16_bits(hf[0]), (short)f32_to_bf16_bits(hf[1]), (short)f32_to_bf16_bits(hf[2]), (short)f32_to_bf16_bits(hf[3])};
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(v4s, raw), hb, d1, 0, 0, 0);
+    } else {
+        const v4h hh = {(_Float16)hf[0], (_Float16)hf[1], (_Float16)hf[2], (_Float16)hf[3]};
+        d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(v4h, raw), hh, d1, 0, 0, 0);
+    }
+    v4f y = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) y = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[sidx], hf[sidx], y, 0, 0, 0);
+    return y;
+}
+

@@ -13,6 +13,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef unsigned int u32;
 
