@@ -1160,3 +1160,68 @@ def test_sdxl_size_fp8_layer_vs_oracle(gpu_device):
     y = mod(x.to(gpu_device))
     ref = O.forward(oracle_from_module(mod), x.float().numpy(), "bf16")
     assert_close_float(to_f32_numpy(y), ref, "bf16", "sdxl-size fp8")
+
+
+@pytest.mark.parametrize("m,k,r", [(33, 48, 8), (16, 128, 32), (100, 192, 16), (257, 640, 48), (1000, 3072, 32), (77, 2048, 64), (4608, 1280, 32)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_lowrank_down_vs_float_reference(m, k, r, dt, gpu_device):
+    """t = cast(x . svd_down^T) (linear_int8.py:60) through the LDS-DMA ring kernel: ragged M (16-row workgroups), K that is not a
+    multiple of the 128-element stage, ranks below / above the 32-column tile.  fp32 accumulation, one rounding: <= 1 ulp of the
+    output dtype at the output scale against a float64 product of the same 16-bit inputs."""
+    g = torch.Generator().manual_seed(m * 7 + k + r)
+    x = torch.randn(m, k, generator=g).to(dt)
+    x[min(2, m - 1)] = 0
+    d = (torch.randn(r, k, generator=g) * 0.05).to(dt)
+    t = ops.lowrank_down(x.to(gpu_device), d.to(gpu_device))
+    assert t.dtype == dt and tuple(t.shape) == (m, r)
+    ref = (x.double() @ d.double().t()).numpy()
+    got = t.double().cpu().numpy()
+    ulp = 2.0 ** (-8 if dt == torch.bfloat16 else -11)
+    assert np.all(np.abs(got - ref) <= ulp * np.maximum(np.abs(ref), np.abs(ref).max() * 2.0 ** -6) + 1e-30), (m, k, r, float(np.abs(got - ref).max()))
+    assert np.all(got[min(2, m - 1)] == 0)
+
+
+@pytest.mark.parametrize("m", [1, 2, 4])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("wdt,gs", [("int4", 64), ("int8", -1), ("uint4", 32), ("uint8", -1)])
+def test_hadamard_layers_few_rows_vs_oracle(m, dt, wdt, gs, gpu_device):
+    """The M < 32 branch of Hadamard-256 layers (dequantize incl. un-rotation + F.linear, linear_int8.py:102-103 + dequantizer.py:82-87):
+    the weight row is un-rotated on the matrix cores (linear_skinny_had256_kernel); against the oracle and the unfused pair."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(17)
+    k, n = 768, 136
+    lin = torch.nn.Linear(k, n, bias=True).to(dt).to(gpu_device)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype=wdt, group_size=gs, use_hadamard=True, hadamard_group_size=256,
+                                                                   use_quantized_matmul=True))
+    assert mod.sdnq_dequantizer.use_hadamard and mod.sdnq_dequantizer.hadamard_group_size == 256
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(m)).to(dt).to(gpu_device)
+    try:
+        L.FUSED_SKINNY = True
+        y_fused = mod(x)
+        L.FUSED_SKINNY = False
+        y_plain = mod(x)
+    finally:
+        L.FUSED_SKINNY = True
+    tag = "bf16" if dt == torch.bfloat16 else "f16"
+    ref = O.forward(oracle_from_module(mod), to_f32_numpy(x), tag)
+    assert_close_float(to_f32_numpy(y_fused), ref, tag, (m, tag, wdt, "fused vs oracle"), hadamard=True)
+    assert_close_float(to_f32_numpy(y_plain), ref, tag, (m, tag, wdt, "plain vs oracle"), hadamard=True)
+    assert_close_float(to_f32_numpy(y_fused), to_f32_numpy(y_plain), tag, (m, tag, wdt, "fused vs plain"), hadamard=True)
+
+
+@pytest.mark.parametrize("rank", [16, 48])
+@pytest.mark.parametrize("m", [1, 4])
+def test_skinny_svd_other_ranks(rank, m, gpu_device):
+    """Ranks other than the default 32 take the generic few-row SVD kernel (rank 32: skinny_svd32_kernel, covered above)."""
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    torch.manual_seed(19)
+    k, n = 384, 200
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=rank,
+                                                                   use_quantized_matmul=True))
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(m)).to(torch.bfloat16).to(gpu_device)
+    ref = O.forward(oracle_from_module(mod), to_f32_numpy(x), "bf16")
+    assert_close_float(to_f32_numpy(mod(x)), ref, "bf16", (rank, m))
