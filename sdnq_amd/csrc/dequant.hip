@@ -470,25 +470,17 @@ __global__ __launch_bounds__(256) void linear_skinny_had256_kernel(const DeqPara
                 else q = (float)((code[g] >> (4 * e)) & 15u) - qsub;
                 w[e] = zrow ? fmaf(q, sc[g], zp[g]) : q * sc[g];
             }
-            uint2 wp;
-            if constexpr (T_ID == SDNQ_BF16) {
-                const v2bf p0 = {(__bf16)w[0], (__bf16)w[1]}, p1 = {(__bf16)w[2], (__bf16)w[3]};
-                wp = make_uint2(__builtin_bit_cast(u32, p0), __builtin_bit_cast(u32, p1));
-            } else {
-                const v2h p0 = {(_Float16)w[0], (_Float16)w[1]}, p1 = {(_Float16)w[2], (_Float16)w[3]};
-                wp = make_uint2(__builtin_bit_cast(u32, p0), __builtin_bit_cast(u32, p1));
-            }
+            const uint2 wp = make_uint2(pack2<T_ID>(w[0], w[1]), pack2<T_ID>(w[2], w[3]));  // the rounding to T (dequantizer.py:27, 63)
             const v4f y = had256_group<T_ID>(wp, hf);
 #pragma unroll
             for (int i = 0; i < MROWS; ++i) {
+                const u32 y0 = pack2<T_ID>(y[0], y[1]), y1 = pack2<T_ID>(y[2], y[3]);  // the rounding to T after the rotation (:82-87)
                 if constexpr (T_ID == SDNQ_BF16) {
-                    const v2bf y0 = {(__bf16)y[0], (__bf16)y[1]}, y1 = {(__bf16)y[2], (__bf16)y[3]};
-                    acc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xr[g][i].x), y0, acc[i], false);
-                    acc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xr[g][i].y), y1, acc[i], false);
+                    acc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xr[g][i].x), __builtin_bit_cast(v2bf, y0), acc[i], false);
+                    acc[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xr[g][i].y), __builtin_bit_cast(v2bf, y1), acc[i], false);
                 } else {
-                    const v2h y0 = {(_Float16)y[0], (_Float16)y[1]}, y1 = {(_Float16)y[2], (_Float16)y[3]};
-                    acc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xr[g][i].x), y0, acc[i], false);
-                    acc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xr[g][i].y), y1, acc[i], false);
+                    acc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xr[g][i].x), __builtin_bit_cast(v2h, y0), acc[i], false);
+                    acc[i] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xr[g][i].y), __builtin_bit_cast(v2h, y1), acc[i], false);
                 }
             }
             }

@@ -757,15 +757,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                             for (int q = 0; q < 4; ++q) {
                                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
                                 const v4f sb4 = *(const v4f*)(s_sb + nl0), b4 = *(const v4f*)(s_bias + nl0);
-                                u32 h[4];
+                                float r[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const float lv = hb ? lrt[4 * q + e] + b4[e] : lrt[4 * q + e];
                                     const float b2 = is_bf ? FT<SDNQ_BF16>::round(lv) : FT<SDNQ_F16>::round(lv);
                                     const float vv = acc_times_sa<LP>(MT::tof(acc[i][j], 4 * q + e), sa);
-                                    h[e] = (u32)FT<OUT_T>::bits(fmaf(vv, sb4[e], b2));
+                                    r[e] = fmaf(vv, sb4[e], b2);
                                 }
-                                *(v2i*)(ostage + (tr - ch * CH2) * O_ROW + nl0 * OUT_B) = (v2i){(int)(h[0] | (h[1] << 16)), (int)(h[2] | (h[3] << 16))};
+                                *(v2i*)(ostage + (tr - ch * CH2) * O_ROW + nl0 * OUT_B) = (v2i){(int)pack2<OUT_T>(r[0], r[1]), (int)pack2<OUT_T>(r[2], r[3])};
                             }
                             __builtin_amdgcn_sched_barrier(0);  // one sub-tile at a time (register pressure next to 128 accumulators)
                         }
@@ -1045,8 +1045,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 if constexpr (OUT_T == SDNQ_F32) {
                     *(uint4*)dst = Vec16<SDNQ_F32>::pack(o);
                 } else {
-                    const uint32_t lo = (uint32_t)FT<OUT_T>::bits(o[0]) | ((uint32_t)FT<OUT_T>::bits(o[1]) << 16);
-                    const uint32_t hi = (uint32_t)FT<OUT_T>::bits(o[2]) | ((uint32_t)FT<OUT_T>::bits(o[3]) << 16);
+                    const uint32_t lo = pack2<OUT_T>(o[0], o[1]), hi = pack2<OUT_T>(o[2], o[3]);
                     *(uint2*)dst = make_uint2(lo, hi);
                 }
             }

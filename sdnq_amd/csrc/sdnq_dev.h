@@ -64,6 +64,17 @@ __device__ __forceinline__ float round_rt(float v, int dt) {
     return dt == SDNQ_F32 ? v : (dt == SDNQ_BF16 ? FT<SDNQ_BF16>::round(v) : FT<SDNQ_F16>::round(v));
 }
 
+// two floats -> one dword of 16-bit elements (low half = a), round-to-nearest-even: ONE v_cvt_pk_bf16_f32 on gfx950 when written as a
+// vector conversion (converting the halves separately and OR-ing them costs a convert per element plus the merge)
+template <int T_ID> __device__ __forceinline__ u32 pack2(float a, float b) {
+    if constexpr (T_ID == SDNQ_BF16) {
+        const v2bf p = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(u32, p);
+    } else {  // f16: element-wise converts (the packed vector conversion differed from RNE on one value in 10^5: kept scalar)
+        return (u32)f32_to_f16_bits(a) | ((u32)f32_to_f16_bits(b) << 16);
+    }
+}
+
 // 16-byte vector of elements -> 8 (16-bit) or 4 (f32) floats
 template <int T_ID> struct Vec16;
 template <> struct Vec16<SDNQ_F32> {
@@ -88,7 +99,7 @@ template <> struct Vec16<SDNQ_BF16> {
     static __device__ __forceinline__ uint4 pack(const float* f) {
         u32 w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (u32)f32_to_bf16_bits(f[2 * i]) | ((u32)f32_to_bf16_bits(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack2<SDNQ_BF16>(f[2 * i], f[2 * i + 1]);
         return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
@@ -105,7 +116,7 @@ template <> struct Vec16<SDNQ_F16> {
     static __device__ __forceinline__ uint4 pack(const float* f) {
         u32 w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (u32)f32_to_f16_bits(f[2 * i]) | ((u32)f32_to_f16_bits(f[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = pack2<SDNQ_F16>(f[2 * i], f[2 * i + 1]);
         return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
