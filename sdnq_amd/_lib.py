@@ -79,6 +79,7 @@ def source_hash() -> str:
         g = hashlib.sha256((f"{hdr_hash} {flags} {extra}\n").encode())
         g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())
         parts += f" {f}:{g.hexdigest()}"
+    parts += " binding:" + hashlib.sha256(open(os.path.join(_CSRC, "binding.c"), "rb").read()).hexdigest()
     return hashlib.sha256((parts + "\n").encode()).hexdigest()
 
 
@@ -156,8 +157,37 @@ def load():
                         "(hipcc --offload-arch=gfx950). There is no fallback path.")
                 lib = ctypes.CDLL(LIB_PATH)
                 _declare(lib)
-                _lib = lib
+                _lib = _with_typed_binding(lib)
     return _lib
+
+
+USE_BINDING = os.environ.get("SDNQ_HIP_BINDING", "1").lower() not in {"0", "false", "no"}
+
+
+class _BoundLib:
+    """The ctypes handle with its hot entry points served by the typed CPython binding (csrc/binding.c: the same named symbols of
+    the same library, ~0.5 us instead of ~10 us of argument conversion per call; an eager diffusion step makes ~900 calls).
+    Every other entry point -- and every entry point when _binding.so is absent or SDNQ_HIP_BINDING=0 -- goes through ctypes."""
+
+    def __init__(self, lib, binding):
+        self._ctypes = lib
+        for name in dir(binding):
+            if name.startswith("sdnq_hip_"):
+                setattr(self, name, getattr(binding, name))
+
+    def __getattr__(self, name):  # not in the binding: the ctypes function
+        return getattr(self._ctypes, name)
+
+
+def _with_typed_binding(lib):
+    if not USE_BINDING:
+        return lib
+    try:
+        from . import _binding  # built by csrc/build.sh next to the library
+    except ImportError:
+        return lib  # binding only: every call still lands in libsdnq_hip.so, through ctypes
+    _binding.init(LIB_PATH)
+    return _BoundLib(lib, _binding)
 
 
 def check(status: int, what: str = ""):

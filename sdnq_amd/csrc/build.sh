@@ -29,5 +29,10 @@ for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OBJ/$f.o"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$OUT" $OBJS
+# typed CPython binding of the hot entry points (host C; calls the library's named symbols, see binding.c): sdnq_amd/_binding.so
+BD_HASH=$(sha256sum "$HERE/binding.c" | cut -d' ' -f1)
+ALL="$ALL binding:$BD_HASH"
+PYINC=$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')
+gcc -O2 -Wall -Werror -shared -fPIC -I"$PYINC" "$HERE/binding.c" -o "$(dirname "$OUT")/_binding.so" -ldl
 echo "$ALL" | sha256sum | cut -d' ' -f1 > "$OUT.srchash"
 echo "built $OUT ($(cat "$OUT.srchash" | cut -c1-12))"
