@@ -203,8 +203,7 @@ def time_gemm_kernel(layers, mm_name, device):
         if m < 32 or not hasattr(mod, "sdnq_dequantizer"):
             continue
         dq = mod.sdnq_dequantizer
-        if dq.svd_rank and getattr(mod, "svd_up", None) is not None:
-            continue
+        has_svd = bool(dq.svd_rank) and getattr(mod, "svd_up", None) is not None
         group = mod.__dict__.get("_sdnq_group") if L.LINK_PROJECTIONS else None
         group = group[0] if group is not None else None
         if group is not None:  # linked projections: ONE launch for the members, exactly as in the step
@@ -226,8 +225,16 @@ def time_gemm_kernel(layers, mm_name, device):
         if x.ndim == 4:  # conv layer: the GEMM sees the unfolded input
             from sdnq_amd import conv as C
             x = C._unfold(mod, x)[0]
-        xq, xs, _, _ = ops.rowquant(x, mm, dq.hadamard_group_size if dq.use_hadamard else 0)
-        calls.append((xq, wq, xs, ws, mod.bias, 1))
+        had = dq.hadamard_group_size if dq.use_hadamard else 0
+        xq, xs, rowsum, xrot = ops.rowquant(x, mm, had, want_rowsum=zp is not None, want_xrot=has_svd and bool(had))
+        if has_svd or zp is not None:  # the scaled matmul with the low-rank / zero-point epilogue, its t = x . svd_down^T precomputed
+            t = ops.lowrank_down(xrot if xrot is not None else x.reshape(-1, k), st.svd_down) if has_svd else None
+            calls.append((xq, wq, xs, ws, mod.bias, ("lowrank", t, st.svd_up if has_svd else None, rowsum, zp)))
+            r = int(st.svd_up.shape[1]) if has_svd else 0
+            total_ops += 2 * m * n * r
+            total_bytes += 2 * r * (m + n)
+        else:
+            calls.append((xq, wq, xs, ws, mod.bias, 1))
         total_ops += 2 * m * k * n + (m * n if has_bias else 0)
         total_bytes += m * k + n * k + 2 * m * n + 4 * (m + n) + (2 * n if has_bias else 0)  # xq + Wq + y(bf16) + xs + ws + bias
     if not calls:
@@ -237,6 +244,8 @@ def time_gemm_kernel(layers, mm_name, device):
         for (xq, wq, xs, ws, bias, g) in calls:
             if g == 1:
                 ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
+            elif isinstance(g, tuple):
+                ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, g[1], g[2], g[3], g[4], torch.bfloat16)
             else:
                 ops.scaled_mm_grouped(mm, xq, xs, wq, torch.bfloat16)
     launch_all()
