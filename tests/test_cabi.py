@@ -55,6 +55,16 @@ def test_argument_validation_without_gpu():
     assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -1                                   # uint without zero_point
     w.kind, w.bits, w.storage = 0, 9, 0
     assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -2                                   # 9 bits in uint8 words
+    w.bits, w.scale_dtype = 4, 5
+    assert lib.sdnq_hip_dequant(ctypes.byref(w), 0, p, 1, None) == -2                                   # unknown scale dtype
+    # model-dtype-scale entry points (dequantize_fp32=False)
+    assert lib.sdnq_hip_rowquant_lp(p, 0, 4, 64, 64, 0, 0, p, p, None, None, None) == -2               # float32 activations: sdnq_hip_rowquant
+    assert lib.sdnq_hip_rowquant_lp(None, 1, 4, 64, 64, 0, 0, p, p, None, None, None) == -1
+    assert lib.sdnq_hip_rowquant_lp(p, 1, 4, 64, 64, 1, 0, p, p, p, None, None) == -5                  # rowsum with fp8 codes
+    assert lib.sdnq_hip_scaled_mm_lp(0, p, p, p, p, None, 1, 0, None, None, 0, p, 32, 32, 32, None) == -1   # bias_ndim without a bias
+    assert lib.sdnq_hip_scaled_mm_lp(0, p, p, p, p, None, 0, 0, p, None, 32, p, 32, 32, 32, None) == -1     # t without svd_up
+    assert lib.sdnq_hip_scaled_mm_lp(0, p, p, p, p, None, 0, 0, None, None, 0, p, 32, 32, 24, None) == -3   # K % 16
+    assert lib.sdnq_hip_lowrank_down(p, 1, 4, 64, 64, p, 2, 32, p, None) == -2                         # activation / factor dtype mismatch
 
 
 def test_attention_argument_validation_without_gpu():
