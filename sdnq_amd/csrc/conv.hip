@@ -108,6 +108,9 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
         }
         const float scale = amax / qmax;
         if (blockIdx.y == 0 && w == 0) xs[m] = scale;
+        RowDiv rd;  // correctly rounded x / scale in 3 VALU (sdnq_dev.h); the scale differs per lane here, so the fast form is used
+        rd.set(scale);  // when EVERY lane's scale qualifies
+        const bool all_fast = __all(rd.fast);
         constexpr int CPT = CT / 4;  // channels per thread
         const int c0 = c_base + w * CPT;
         uint8_t* row = tile + lane * pitch + (w * CPT) * P;
@@ -128,15 +131,23 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
                 }
 #pragma unroll
                 for (int u = 0; u < CPT; ++u) v[u] = (inb && c0 + u < p.C) ? v[u] : 0.0f;
+                if (all_fast) {  // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < CPT; ++u) v[u] = rd.fastdiv(v[u]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CPT; ++u) v[u] = v[u] / scale;
+                }
 #pragma unroll
                 for (int u = 0; u < CPT; ++u) {
                     uint8_t byte;
+                    const float qd = v[u];
                     if constexpr (MM == SDNQ_MM_I8) {
-                        float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[u] / scale);
+                        float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(qd);
                         q = fminf(fmaxf(q, -128.0f), 127.0f);
                         byte = (uint8_t)((int)q & 0xff);
                     } else {
-                        float q = v[u] / scale;
+                        float q = qd;
                         if (q != q) q = 0.0f;
                         q = fminf(fmaxf(q, -448.0f), 448.0f);
                         byte = f32_to_e4m3fn(q);

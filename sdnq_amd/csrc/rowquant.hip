@@ -66,7 +66,16 @@ __device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[
 // LP_T: SDNQ_F32 = the reference's default float32 arithmetic; SDNQ_BF16 / SDNQ_F16 = the quotient is rounded to that dtype
 // before round-half-even / the fp8 cast (torch.div on 16-bit tensors, dequantize_fp32=False: linear_int8.py:15-22)
 template <int MM, int LP_T = SDNQ_F32>
-__device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& isum, float zp = 0.0f, bool asym = false) {
+__device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, int& isum, float zp = 0.0f, bool asym = false) {
+    const float scale = d.scale;
+    float qv[8];
+    if (LP_T == SDNQ_F32 && d.fast) {  // wave-uniform
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = d.fastdiv(asym ? v[e] - zp : v[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = (asym ? v[e] - zp : v[e]) / scale;
+    }
     u32 w0 = 0, w1 = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -74,12 +83,11 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& i
         if constexpr (MM == SDNQ_MM_I8) {
             // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
             // asymmetric (quantize_uint_mm, quant_utils.py:277-286): (x - zero_point) / scale
-            const float xv = asym ? v[e] - zp : v[e];
             float q;
             if constexpr (LP_T == SDNQ_F32) {
-                q = (scale == 0.0f) ? 0.0f : __builtin_rintf(xv / scale);
+                q = (scale == 0.0f) ? 0.0f : __builtin_rintf(qv[e]);
             } else {  // a 16-bit scale can underflow to 0 under a nonzero row: x / 0 = +-inf -> the clamp, 0 / 0 = NaN -> 0
-                q = __builtin_rintf(FT<LP_T>::round(xv / scale));
+                q = __builtin_rintf(FT<LP_T>::round(qv[e]));
                 if (q != q) q = 0.0f;
             }
             q = fminf(fmaxf(q, -128.0f), 127.0f);
@@ -87,7 +95,7 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], float scale, int& i
             isum += qi;
             byte = (u32)qi & 0xffu;
         } else {
-            float q = FT<LP_T>::round(v[e] / scale);
+            float q = FT<LP_T>::round(qv[e]);
             if (q != q) q = 0.0f;  // nan_to_num; +-inf fall to the clamp
             q = fminf(fmaxf(q, -448.0f), 448.0f);
             byte = f32_to_e4m3fn(q);
@@ -197,6 +205,8 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
             scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
         }
         if (writer) xs[m] = scale;
+        RowDiv rd;
+        rd.set(scale);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int64_t idx = k_part + (int64_t)p * 512 + lane * 8;
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 if constexpr (HAD) {
                     if (xrot != nullptr) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v[p]);
                 }
-                *(uint2*)(qrow + idx) = quant8<MM>(v[p], scale, isum, zpv, asym);
+                *(uint2*)(qrow + idx) = quant8<MM>(v[p], rd, isum, zpv, asym);
             }
         }
     } else {
@@ -243,6 +253,8 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
             if constexpr (LP) scale = FT<T_ID>::round(scale);
         }
         if (lane == 0) xs[m] = scale;
+        RowDiv rd;
+        rd.set(scale);
         // ---- phase 2: quantize
         for (int64_t p = 0; p < npass; ++p) {
             const int64_t idx = p * 512 + lane * 8;
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 }
             }
             int isum_p = 0;
-            const uint2 w = quant8<MM, LP ? T_ID : SDNQ_F32>(v, scale, isum_p, zpv, asym);
+            const uint2 w = quant8<MM, LP ? T_ID : SDNQ_F32>(v, rd, isum_p, zpv, asym);
             if (ok) { *(uint2*)(qrow + idx) = w; isum += isum_p; }
         }
     }
@@ -363,29 +375,48 @@ __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __rest
     const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
     const float scale = amax / qmax;  // IEEE division (get_scale_symmetric, quant_utils.py:23-24)
     if (row_ok && lane == 0 && part == 0) xs[m] = scale;
+    RowDiv rd;
+    rd.set(scale);
     uint8_t* qrow = xq + m * K + eoff;
     int isum = 0;
+    if (xrot != nullptr) {  // the rotated copy (needed by the SVD branch), before the values turn into quotients
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g0 + g < ngroups && row_ok) {
+                const uint32_t lo = (uint32_t)FT<T_ID>::bits(v[g][0]) | ((uint32_t)FT<T_ID>::bits(v[g][1]) << 16);
+                const uint32_t hi = (uint32_t)FT<T_ID>::bits(v[g][2]) | ((uint32_t)FT<T_ID>::bits(v[g][3]) << 16);
+                *(uint2*)((uint16_t*)xrot + m * K + eoff + (int64_t)(g0 + g) * 256) = make_uint2(lo, hi);
+            }
+        }
+    }
+    if (rd.fast) {  // wave-uniform: the quotients in place, one branch for the row instead of a select per element
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[g][e] = rd.fastdiv(v[g][e]);
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] / scale;
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g0 + g < ngroups && row_ok) {
             const int64_t go = (int64_t)(g0 + g) * 256;
-            if (xrot != nullptr) {
-                const uint32_t lo = (uint32_t)FT<T_ID>::bits(v[g][0]) | ((uint32_t)FT<T_ID>::bits(v[g][1]) << 16);
-                const uint32_t hi = (uint32_t)FT<T_ID>::bits(v[g][2]) | ((uint32_t)FT<T_ID>::bits(v[g][3]) << 16);
-                *(uint2*)((uint16_t*)xrot + m * K + eoff + go) = make_uint2(lo, hi);
-            }
             u32 w = 0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 u32 byte;
+                const float qd = v[g][e];
                 if constexpr (MM == SDNQ_MM_I8) {
-                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(v[g][e] / scale);
+                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(qd);
                     q = fminf(fmaxf(q, -128.0f), 127.0f);
                     const int qi = (int)q;
                     isum += qi;
                     byte = (u32)qi & 0xffu;
                 } else {
-                    float q = v[g][e] / scale;
+                    float q = qd;
                     if (q != q) q = 0.0f;
                     q = fminf(fmaxf(q, -448.0f), 448.0f);
                     byte = f32_to_e4m3fn(q);

@@ -121,6 +121,29 @@ template <> struct Vec16<SDNQ_F16> {
     }
 };
 
+// x / scale for MANY x and one scale, correctly rounded, in 3 VALU instead of the ~10 of an IEEE division sequence (row quantization of
+// long rows is VALU-bound, not HBM-bound: 64 quotients per lane at K = 15360).  Markstein's correction: with y = RN(1 / s) (one IEEE
+// division per row), q0 = RN(x y), r = x - s q0 (exact in one fma), RN(q0 + r y) = RN(x / s) -- provided nothing over- or underflows
+// and the significand of s is not all ones (then RN(1 / s) is too coarse).  `fast` (wave-uniform) says the row's scale is inside
+// 2^-60 .. 2^60 with an ordinary significand; otherwise the IEEE division is used.  |x| <= 127.5 s by construction, so q0 is at most
+// 128 in magnitude and r, r y are far from overflow; quotients so small that they underflow round to 0 either way.  Checked against
+// IEEE division on 2 x 10^7 random and near-half-integer cases (none differ) and by the bit-exact row quantization tests.
+struct RowDiv {
+    float scale, rcp;
+    bool fast;
+    __device__ __forceinline__ void set(float s) {
+        scale = s;
+        const u32 b = __float_as_uint(s);
+        const int e = (int)((b >> 23) & 0xffu);
+        fast = e > 127 - 60 && e < 127 + 60 && (b & 0x7fffffu) != 0x7fffffu;
+        rcp = 1.0f / s;
+    }
+    __device__ __forceinline__ float fastdiv(float x) const {
+        const float q0 = x * rcp;
+        return fmaf(fmaf(-scale, q0, x), rcp, q0);
+    }
+};
+
 // ---- fp8 e4m3fn (OCP) -------------------------------------------------------------------------
 // float -> e4m3fn, round-to-nearest-even, input already clamped to [-448, 448] (quant_utils.py:298),
 // so no overflow handling is needed; matches torch's .to(torch.float8_e4m3fn) on that range.
