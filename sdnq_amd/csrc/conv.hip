@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
                         float q = qd;
                         if (q != q) q = 0.0f;
                         q = fminf(fmaxf(q, -448.0f), 448.0f);
-                        byte = f32_to_e4m3fn(q);
+                        byte = f32_to_e4m3fn_clamped(q);
                     }
                     row[u * P + i * p.KW + j] = byte;
                 }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
                     float q = round_rt(v[j] / scale, p.sdt);
                     if (q != q) q = 0.0f;
                     q = fminf(fmaxf(q, -448.0f), 448.0f);
-                    byte = f32_to_e4m3fn(q);
+                    byte = f32_to_e4m3fn_clamped(q);
                 }
                 o[j >> 2] |= byte << (8 * (j & 3));
             }

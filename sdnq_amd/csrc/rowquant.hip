@@ -76,6 +76,16 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, in
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[e] = (asym ? v[e] - zp : v[e]) / scale;
     }
+    if constexpr (MM == SDNQ_MM_FP8) {  // nan_to_num, clamp (+-inf fall to it), hardware conversion of four values at a time
+        float c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float q = FT<LP_T>::round(qv[e]);
+            if (q != q) q = 0.0f;
+            c[e] = fminf(fmaxf(q, -448.0f), 448.0f);
+        }
+        return make_uint2(pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]), pack4_e4m3fn_clamped(c[4], c[5], c[6], c[7]));
+    }
     u32 w0 = 0, w1 = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -405,6 +415,17 @@ __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __rest
         if (g0 + g < ngroups && row_ok) {
             const int64_t go = (int64_t)(g0 + g) * 256;
             u32 w = 0;
+            if constexpr (MM == SDNQ_MM_FP8) {
+                float c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float q = v[g][e];
+                    if (q != q) q = 0.0f;
+                    c[e] = fminf(fmaxf(q, -448.0f), 448.0f);
+                }
+                *(u32*)(qrow + go) = pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 u32 byte;
