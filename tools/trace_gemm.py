@@ -10,6 +10,7 @@ lib = _lib.load()
 lib.sdnq_hip_debug_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 shapes = [(4096, 640, 640), (1024, 1280, 1280), (1024, 1280, 5120), (77, 640, 2048), (4096, 5120, 640)]
 LOWRANK = "--lowrank" in sys.argv  # the SVD epilogue on FLUX shapes, next to the plain epilogue
+W8A16 = "--w8a16" in sys.argv      # the fused dequantize GEMM next to the int8 one
 if LOWRANK:
     shapes = [(4608, 3072, 3072), (4608, 3072, 12288)]
 names = ["entry", "issued", "stage0", "steady_end", "mainloop_end", "epi_compute", "stored"]
@@ -21,10 +22,12 @@ for (m, n, k) in shapes:
     xq, xs, _, _ = ops.rowquant(x, ops.MM_I8)
     t_lr = torch.randn(m, 32, device=dev, dtype=torch.bfloat16)
     up = torch.randn(n, 32, device=dev, dtype=torch.bfloat16)
-    for mode in (("plain", "lowrank") if LOWRANK else ("plain",)):
+    for mode in (("plain", "lowrank") if LOWRANK else (("plain", "w8a16") if W8A16 else ("plain",))):
         def run():
             if mode == "plain":
                 ops.scaled_mm(ops.MM_I8, xq, b, xs, sb, bias, torch.bfloat16)
+            elif mode == "w8a16":
+                ops.linear_w8a16(x, b, sb, None, bias)
             else:
                 ops.scaled_mm_lowrank(ops.MM_I8, xq, b, xs, sb, bias, t_lr, up, None, None, torch.bfloat16)
         buf = np.zeros(4096 * 8, dtype=np.uint64)
