@@ -1225,3 +1225,39 @@ def test_skinny_svd_other_ranks(rank, m, gpu_device):
     x = torch.randn(m, k, generator=torch.Generator().manual_seed(m)).to(torch.bfloat16).to(gpu_device)
     ref = O.forward(oracle_from_module(mod), to_f32_numpy(x), "bf16")
     assert_close_float(to_f32_numpy(mod(x)), ref, "bf16", (rank, m))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_rowquant_division_shortcut_over_the_exponent_range(dt, gpu_device):
+    """The row kernels divide by the row scale with Markstein's correction (RowDiv, sdnq_dev.h) when the scale is an ordinary
+    number, with the IEEE sequence otherwise.  Rows spanning the whole exponent range -- both sides of the 2^+-60 guard,
+    subnormal-scale rows, scales whose significand is all ones (the one case where RN(1 / s) is too coarse), ties and near-ties at
+    every magnitude -- must give the reference's codes and scales bit for bit, int8 and fp8."""
+    rng = np.random.default_rng(11)
+    k = 1536
+    rows = []
+    for e in list(range(-120, 121, 4)) + [-126, -61, -60, -59, 59, 60, 61, 120]:
+        base = rng.standard_normal(k).astype(np.float32) * np.float32(0.3)
+        base[0] = 1.0
+        rows.append(np.ldexp(base, e).astype(np.float32))
+        # scale with an all-ones significand: amax = 127 * (2 - 2^-23) * 2^e
+        s = np.ldexp(np.float32(2.0) - np.float32(2.0 ** -23), e)
+        r = (rng.integers(-126, 127, size=k) + rng.choice([0.0, 0.5], size=k)).astype(np.float64) * np.float64(s)
+        r[0] = 127.0 * np.float64(s)
+        rows.append(r.astype(np.float32))
+        # ties / near ties around an ordinary scale at this magnitude
+        s2 = np.ldexp(np.float32(1.25), e)
+        t = ((rng.integers(-126, 126, size=k) + 0.5).astype(np.float64) * np.float64(s2)).astype(np.float32)
+        t[1::2] = np.nextafter(t[1::2], np.float32(np.inf))
+        t[0] = np.float32(127.0) * s2
+        rows.append(t)
+    x = torch.from_numpy(np.stack(rows)).to(dt)
+    xf = x.float().numpy()
+    for mm, name in ((ops.MM_I8, "int8"), (ops.MM_FP8, "fp8")):
+        xq, xs, rs, _ = ops.rowquant(x.to(gpu_device), mm, want_rowsum=(mm == ops.MM_I8))
+        q, s, rowsum = O.rowquant(xf, name)
+        assert np.array_equal(xs.cpu().numpy().reshape(-1), s), (dt, name)
+        bad = np.nonzero((bits_of(xq) != q.view(np.uint8)).any(axis=1))[0]
+        assert bad.size == 0, (dt, name, bad[:8], [float(s[b]) for b in bad[:8]])
+        if rowsum is not None:
+            assert np.array_equal(rs.cpu().numpy(), rowsum)
