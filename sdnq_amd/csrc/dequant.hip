@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = (int)p.K;
     uint8_t* ring = smem + wave * (D * STG);
-    float* xs = (float*)(smem + 4 * D * STG);
+    uint16_t* xs = (uint16_t*)(smem + 4 * D * STG);  // [MR][K] activations, 16-bit
     const int64_t n0 = (int64_t)blockIdx.x * 32;
     // ---- DMA roles
     const uint8_t* wsrc;  // this lane's code bytes of block 0
@@ -628,8 +628,8 @@ __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, co
     };
 #pragma unroll
     for (int s0 = 0; s0 < D - 1; ++s0) issue(s0);
-    // ---- x as f32 in LDS (while the first blocks are in flight): 8 elements per load, four loads per thread in flight (an
-    // element-at-a-time loop waits one memory round trip per element: 12 of them for K = 3072)
+    // ---- x in LDS as it is (16-bit elements; rows past M are zero) while the first blocks are in flight: 16-byte pieces, four loads
+    // per thread in flight (an element-at-a-time loop waits one memory round trip per element: 12 of them for K = 3072)
     {
         const int kc = K / 8, total = MR * kc;  // 16-byte pieces
         for (int c0 = tid; c0 < total; c0 += 4 * 256) {
@@ -643,20 +643,14 @@ __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, co
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + j * 256;
-                if (c < total) {
-                    const int m = c / kc;
-                    float f[8];
-                    Vec16<T_ID>::unpack(v[j], f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xs[c * 8 + e] = (m < M) ? f[e] : 0.0f;
-                }
+                if (c < total) *(uint4*)(xs + c * 8) = (c / kc < M) ? v[j] : make_uint4(0, 0, 0, 0);
             }
         }
     }
     // scales / zero points of the 32 rows in LDS: a global load inside the K loop would make the compiler drain the DMA ring
     // (s_waitcnt vmcnt(0)) at its first use
     const int G = p.G;
-    float* s_sc = xs + MR * K;
+    float* s_sc = (float*)(xs + MR * K);
     float* s_zp = s_sc + 32 * G;
     for (int i = tid; i < 32 * G; i += 256) {
         int64_t g = n0 + i / G;
@@ -668,7 +662,7 @@ __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, co
     if (gn >= p.N) gn = p.N - 1;
     // codes -> numbers without branches: int8 two's complement: (byte ^ 0x80) - 128;  uint8: byte;  packed signed nibble: code - 8
     const bool is_signed = p.fmt.kind == SDNQ_KIND_INT;
-    const u32 flip = (is_signed && BITS == 8) ? 0x80u : 0u;
+    const u32 flip = (is_signed && BITS == 8) ? 0x80808080u : 0u;
     const float qsub = is_signed ? (BITS == 8 ? 128.0f : 8.0f) : 0.0f;
     const float inv_group = 1.0f / (float)p.group_size;
     const uint16_t* up = (const uint16_t*)p.svd_up + gn * R + hi * 8;
@@ -704,21 +698,37 @@ __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, co
         else { const v2i t2 = *(const v2i*)(base + w_off); ww[0] = t2[0]; ww[1] = t2[1]; ww[2] = 0; ww[3] = 0; }
         const int gi = (int)(((float)kb + 0.5f) * inv_group);  // kb / group_size (exact: both are multiples of 16, K < 2^20)
         const float sc = s_sc[nl * G + gi], zc = s_zp[nl * G + gi];
+        // VALU diet (the kernel is bound by the per-element arithmetic, ~14 instructions before): codes -> floats with one
+        // v_cvt_f32_ubyteN each, both roundings to T as PACKED converts of a column pair, the products as packed dot products
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            v4f xv[MR];
+            u32 xq[MR][2];  // columns (4 g, 4 g + 1) and (4 g + 2, 4 g + 3) of every activation row, as stored
 #pragma unroll
-            for (int m = 0; m < MR; ++m) xv[m] = *(const v4f*)(xs + m * K + kb + 4 * g);
+            for (int m = 0; m < MR; ++m) {
+                const v2i t2 = *(const v2i*)(xs + m * K + kb + 4 * g);
+                xq[m][0] = (u32)t2[0];
+                xq[m][1] = (u32)t2[1];
+            }
+            u32 cw;  // the 4 codes of columns 4 g .. 4 g + 3, one per byte
+            if constexpr (BITS == 8) {
+                cw = ww[g] ^ flip;
+            } else {
+                const u32 n4 = (ww[g >> 1] >> (16 * (g & 1))) & 0xffffu;  // 4 nibbles -> 4 bytes
+                cw = (n4 & 0xfu) | ((n4 & 0xf0u) << 4) | ((n4 & 0xf00u) << 8) | ((n4 & 0xf000u) << 12);
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32 code;
-                if constexpr (BITS == 8) code = ((ww[g] >> (8 * e)) & 0xffu) ^ flip;
-                else code = ((ww[g >> 1] >> (16 * (g & 1))) >> (4 * e)) & 15u;  // 16 nibbles in ww[0..1]: column 4 g + e
-                const float q = (float)code - qsub;
-                float wv = FT<T_ID>::round(fmaf(q, sc, zc));    // dequantize -> .to(svd dtype)
-                wv = FT<T_ID>::round(wv + ud[4 * g + e]);       // addmm_(svd_up, svd_down): one rounding of the sum
+            for (int h = 0; h < 2; ++h) {
+                const float q0 = (float)((cw >> (16 * h)) & 0xffu) - qsub, q1 = (float)((cw >> (16 * h + 8)) & 0xffu) - qsub;
+                const u32 pw = pack2<T_ID>(fmaf(q0, sc, zc), fmaf(q1, sc, zc));  // dequantize -> .to(svd dtype)
+                float r0, r1;
+                if constexpr (IS_BF16) { r0 = __uint_as_float(pw << 16); r1 = __uint_as_float(pw & 0xffff0000u); }
+                else { r0 = f16_bits_to_f32((uint16_t)pw); r1 = f16_bits_to_f32((uint16_t)(pw >> 16)); }
+                const u32 ps = pack2<T_ID>(r0 + ud[4 * g + 2 * h], r1 + ud[4 * g + 2 * h + 1]);  // addmm_: one rounding of the sum
 #pragma unroll
-                for (int m = 0; m < MR; ++m) acc[m] = fmaf(xv[m][e], wv, acc[m]);
+                for (int m = 0; m < MR; ++m) {
+                    if constexpr (IS_BF16) acc[m] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2bf, xq[m][h]), __builtin_bit_cast(v2bf, ps), acc[m], false);
+                    else acc[m] = __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, xq[m][h]), __builtin_bit_cast(v2h, ps), acc[m], false);
+                }
             }
         }
     }
@@ -1002,7 +1012,8 @@ extern "C" int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_d
     if (lds > 150 * 1024) return SDNQ_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid((unsigned)((p.N + 31) / 32)), block(256);
-    const size_t lds32 = lds + 4 * 4 * 3072 + (size_t)32 * p.G * 8;  // + the four private DMA rings and the rows' scales / zero points
+    // skinny_svd32_kernel: x as 16-bit elements + the four private DMA rings + the rows' scales / zero points
+    const size_t lds32 = lds / 2 + 4 * 4 * 3072 + (size_t)32 * p.G * 8;
     if (p.rank == 32 && lds32 <= 150 * 1024 && (p.group_size % 16) == 0 && p.G <= 64 && (p.K % 32) == 0 && (raw8 || (p.K % 64) == 0) &&
         ((uintptr_t)x % 16) == 0 && ((ldx * 2) % 16) == 0) {
 #define S32_LAUNCH(B, MR)                                                                                                    \
