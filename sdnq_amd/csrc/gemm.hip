@@ -36,6 +36,9 @@ constexpr int BKB = 128;  // default bytes of K per LDS stage row (a full 128-by
 
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};  // source of K-tail chunks for the LDS-DMA
 
+#ifdef SDNQ_TRACE2
+__device__ unsigned g_trace2[64];
+#endif
 #ifdef SDNQ_TRACE  // development build only: per-workgroup phase timestamps (shader clock), read back by tools/trace_gemm.py
 __device__ unsigned long long g_trace[4096 * 8];
 #define TRACE(slot)                                                                    \
@@ -215,11 +218,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-enum { EPI_NONE = 0, EPI_BIAS1D = 1, EPI_BIAS2D = 2, EPI_LOWRANK = 3 };
+// EPI_LRFAST: EPI_LOWRANK restricted (by the launcher) to what the register-layout low-rank epilogue handles -- rank-32 16-bit factors,
+// no zero-point terms, 16-bit output -- with the general staged path compiled OUT: the 256x256 tiles (128 live accumulators per lane)
+// are only instantiated for it; with both paths in one kernel the allocator spilled 46-59 registers (round-2 verdict, cfg5's
+// dominant kernel), tools/check_spills.py now keeps every kernel free of scratch.
+enum { EPI_NONE = 0, EPI_BIAS1D = 1, EPI_BIAS2D = 2, EPI_LOWRANK = 3, EPI_LRFAST = 4 };
+template <int EPI> constexpr bool is_lr = (EPI == EPI_LOWRANK || EPI == EPI_LRFAST);
 
 // rows of final values the register-layout epilogues stage at a time (LDS: 160 KB minus <= 4 KB of per-channel vectors)
 template <int EPI, int BM, int BN, int OUT_B> constexpr int epi_chunk_rows() {
-    const int lr = (EPI == EPI_LOWRANK) ? (BM + BN) * 64 : 0;
+    const int lr = is_lr<EPI> ? (BM + BN) * 64 : 0;
     return (BM <= 128 || lr + BM * (BN * OUT_B + 16) <= 155 * 1024) ? BM : 128;
 }
 
@@ -319,7 +327,47 @@ template <> struct FragOps<SDNQ_MM_FP8> {
 //            instructions back to back at raised priority), the second half running one phase behind the first, one raw
 //            s_barrier per phase: while one wave of a SIMD feeds the matrix pipe, its partner does the issue-heavy work
 //            (an LDS-DMA costs its wave ~60-180 issue cycles) that in the lock-step schedules above leaves the pipe idle.
-enum { LD_DMA = 0, LD_PIPE = 2, LD_PP = 3 };
+//   LD_8P  : the fine-grained form of the ping-pong (round 3).  A K stage is consumed in TWO phases -- phase 0: every weight
+//            fragment + the first half of the wave's activation row blocks, phase 1: the second half -- and each phase is
+//            {LDS->register reads of THIS phase, then this wave's share of the LDS-DMA issue (half a stage), raw barrier,
+//            lgkmcnt(0), the phase's MFMAs back to back at raised priority, raw barrier}.  The second half of the workgroup
+//            (waves 4-7, the SIMD partners of waves 0-3) runs one barrier behind, so at any time one wave of every SIMD is
+//            in its MFMA section while its partner does the slow-issuing work (an LDS-DMA piece occupies its wave's issue
+//            port for 60-180 cycles, during which an in-order wave cannot feed the matrix pipe).  What differs from LD_PP:
+//            reads come BEFORE the DMA issue and are waited for AFTER the barrier (their latency hides under the DMA issue
+//            and the barrier instead of delaying the partner's release), the counted vmcnt sits once per stage, and the
+//            phases are half as long (8 MFMAs), so neither role starves.  Hazards (slots = intervals between barriers;
+//            group 0 reads/issues in even slots, group 1 in odd ones):
+//              RAW  stage j is first read in phase 2j; every wave waits for ITS pieces of stage j (vmcnt leaving the AHEAD-1
+//                   younger stages in flight) at the end of the read/issue section of phase 2j-1, in front of a barrier that
+//                   both groups pass before phase 2j's reads;
+//              WAR  the DMA for stage j+AHEAD lands in the ring slot of stage j-1.  A region read in phase P is safe to
+//                   overwrite by DMAs issued in phase P+2 or later (the later group's reads retire at its lgkmcnt(0) one slot
+//                   after it issued them; the next barrier orders them before any later issue).  Phase 2j (the first of
+//                   stage j) therefore refills only the WEIGHT rows of slot j-1 (last read in phase 2j-2), phase 2j+1 the
+//                   activation rows (second half last read in phase 2j-1).
+//   LD_HT  : LD_8P on 128-BYTE K tiles staged in HALF-TILES, with NO vector-ALU work in the K loop (round 3; 256x256 tile, 8 waves of
+//            128x64).  Two measurements shaped it (tools/micro/dma_shape_lab.hip, tools/micro/dma_mfma_lab.hip, profiles/r03_*):
+//            (1) an LDS-DMA piece of 16 rows x 64 B (the 64-byte stages every 256-row tile used so far) moves at ~1/1.75 of the rate
+//                of 8 rows x 128 B (full cache lines): 64 vs 100 GB/s per CU;
+//            (2) a vector-memory instruction whose ADDRESS registers were written by a vector-ALU instruction of the same wave is
+//                held back while the other wave of the SIMD streams MFMAs: global_load_lds behind its 64-bit address arithmetic
+//                costs ~2000 cycles per piece beside a dense MFMA stream and 86 alone; buffer_load ... lds with a CONSTANT per-lane
+//                voffset and the K advance in the scalar soffset costs 86 in both cases.  That -- not DMA throughput, not latency,
+//                not the schedule -- is why every earlier K loop sat at ~60 % matrix utilisation whatever its structure.
+//            So: rows are 128 B, the DMAs are buffer loads whose only per-K-tile operand is an SGPR, the LDS read addresses are
+//            per-lane constants + immediate offsets (ring slot parity is a compile-time constant: two copies of the K-tile body),
+//            and the ring is kept per HALF-TILE (128 rows x 128 B = 16 KiB, one per phase, two pieces per wave), refilled in the
+//            order it is consumed:
+//              HA0 / HA1 = first / second 64 activation rows of every wave row, HB0 / HB1 = first / second 32 weight rows of every
+//              wave column; two slots each (8 x 16 KiB); K tile t (parity p) = phases 4t..4t+3:
+//                0: read B0       acc[0][0..1]     refill HB1(t+1)          2: read A1        acc[1][2..3]     refill HA0(t+2)
+//                1: read B1       acc[1][0..1]     refill HA1(t+1)          3: read A0(t+1)   acc[0][2..3]     refill HB0(t+2)
+//              a half-tile is refilled two phases after its last read (the WAR rule of LD_8P) and needed six phases after that; every
+//              phase ends its read/issue section with vmcnt(8): all but the four youngest half-tiles have landed, which covers the
+//              reads of the next phase.  Needs K % 128 == 0 (a partial K tile would read the next row's bytes).
+enum { LD_DMA = 0, LD_PIPE = 2, LD_PP = 3, LD_8P = 4, LD_HT = 5 };
+constexpr int HT_BYTES = 16384, HT_SLOTS = 8;
 
 // LP: dequantize_fp32=False with BFLOAT16 scales -- the reference's eager epilogue runs on bf16 tensors (kernel_wrappers.py:132-144:
 // `int_mm_func(a, b, out_dtype=scale_a.dtype).mul_(scale_a)` then `.mul_(scale_b)` / addcmul): the accumulator is rounded to bf16,
@@ -349,7 +397,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int REM = JOINT ? TOT % NW : 0;  // JOINT: waves below REM own PPW pieces, the others PPW - 1 (0: all own PPW)
     static_assert(BM % RPP == 0 && BN % RPP == 0 && BM % 16 == 0, "tile rows must split into DMA pieces");
     static_assert(BK == 64 || BK == 128, "stage rows are 64 or 128 bytes");
-    static_assert(PPW * (NS - 2) <= 63 && NS >= 2, "vmcnt field / stage count");
+    static_assert(LD == LD_HT || (PPW * (NS - 2) <= 63 && NS >= 2), "vmcnt field / stage count");
     constexpr int STAGE_BYTES = BM * BK + BN * BKW;
     constexpr int LDS_STAGES = NS;
     constexpr int OUT_B = FT<OUT_T>::bytes;
@@ -359,13 +407,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     constexpr int CHR = epi_chunk_rows<EPI, BM, BN, FT<OUT_T>::bytes>(), ECHR = BM / CHR;
     static_assert(ECHR == 1 || CHR % WM == 0, "all rows of a wave lie in one chunk");
     // epilogue staging: final values (simple epilogues) or raw accumulators + low-rank tile (EPI_LOWRANK)
-    constexpr int MAIN_BYTES = LDS_STAGES * STAGE_BYTES;
+    constexpr int MAIN_BYTES = (LD == LD_HT) ? HT_SLOTS * HT_BYTES : LDS_STAGES * STAGE_BYTES;
     // EPI_LOWRANK: [t tile BM x 64 B | svd_up tile BN x 64 B] (rank-32 factors staged for the low-rank MFMAs), then the raw accumulator
     // plane (32-bit) and the bias2d plane (16-bit: cast_svd(bias + low-rank), linear_int8.py:57-62) of one chunk
-    constexpr int LR_BYTES = (EPI == EPI_LOWRANK) ? (BM + BN) * 64 : 0;
+    constexpr int LR_BYTES = is_lr<EPI> ? (BM + BN) * 64 : 0;
     constexpr int B2_ROW = BN * 2 + 16;
     constexpr int EPI_GEN = LR_BYTES + CH * (BN * 4 + 16) + CH * B2_ROW, EPI_REG = LR_BYTES + CHR * (BN * OUT_B + 16);
-    constexpr int EPI_BYTES = (EPI == EPI_LOWRANK) ? ((EPI_GEN > EPI_REG || OUT_T == SDNQ_F32) ? EPI_GEN : EPI_REG) : EPI_REG;  // f32 low-rank outputs: general path only
+    constexpr int EPI_BYTES = is_lr<EPI> ? ((EPI_GEN > EPI_REG || OUT_T == SDNQ_F32) ? EPI_GEN : EPI_REG) : EPI_REG;  // f32 low-rank outputs: general path only
     constexpr int VEC_OFF = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;  // per-channel epilogue vectors live after the ring
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     float* s_sb = (float*)(lds + VEC_OFF);  // [BN] column scales
@@ -469,11 +517,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     };
     int slot_i = 0;  // ring slot the next issued stage goes to
     const int K_B = is_w8a16<MM> ? K / 2 : K;  // bytes of a B row
-    auto issue = [&](int kt) {
-        uint8_t* stage = lds + slot_i * STAGE_BYTES;
-        slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
+    // this wave's piece slots [I0, I1) of K stage kt into ring slot `slot`
+    auto issue_range = [&](int kt, int slot, auto i0c, auto i1c) {
+        constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+        uint8_t* stage = lds + slot * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) {
+        for (int i = I0; i < I1; ++i) {
             if (JOINT && i == PPW - 1 && !full) break;  // this wave's last slot is empty
             bool isA;
             const int piece = piece_of(i, isA);
@@ -483,6 +532,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             const uint8_t* s = (k0 + kofs(i) < (isA ? K : K_B)) ? src[i] + k0 : (const uint8_t*)&g_zero16;
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
         }
+    };
+    auto issue = [&](int kt) {
+        const int slot = slot_i;
+        slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
+        issue_range(kt, slot, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{});
     };
 
     typename MT::acc_t acc[TN][TM];  // [n-subtile][m-subtile]; MFMA A-operand = weights (n), B-operand = activations (m)
@@ -498,8 +552,46 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         if (JOINT && !full) wait_vmcnt<(AHEAD - 1) * (PPW - (REM != 0 ? 1 : 0))>();
         else wait_vmcnt<(AHEAD - 1) * PPW>();
     };
+    if constexpr (LD != LD_HT) {
 #pragma nounroll
-    for (int s = 0; s < AHEAD; ++s) issue(s);
+        for (int s = 0; s < AHEAD; ++s) issue(s);
+    }
+    // LD_HT: buffer descriptors of the tile's activation / weight rows, this lane's constant byte offsets into them for its two
+    // pieces (8 rows x 128 B each) of every half-tile, and the prologue DMAs.  Slots: HA0 0-1, HA1 2-3, HB0 4-5, HB1 6-7.
+    int hvo[4][2] = {};  // [HA0, HA1, HB0, HB1][piece]: clamped row * pitch + (swizzle-inverse) chunk
+    auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+    auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)tv.b, 0, 0x7fffffff, 0x00020000);
+    const int k_last = K - 128;  // K tiles past the end are fetched from the last one (never consumed; keeps the vmcnt a constant)
+    auto issue_ht = [&](auto typec, int slot, int kt) {
+        constexpr int ty = decltype(typec)::value;
+        int k0 = kt * 128;
+        k0 = k0 < k_last ? k0 : k_last;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ty < 2 ? rsA : rsB, (lptr_t)(lds + slot * HT_BYTES + (2 * wave + u) * 1024), 16, hvo[ty][u], k0, 0, 0);
+    };
+    if constexpr (LD == LD_HT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rho = (2 * wave + u) * 8 + (lane >> 3);  // row inside the half-tile
+            const int ck = ((lane & 7) ^ ((rho >> 1) & p.swz)) << 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int64_t ra = (rho >> 6) * 128 + h * 64 + (rho & 63);  // tile row of this half-tile row
+                if (m0 + ra >= p.M) ra = p.M - 1 - m0;
+                hvo[h][u] = (int)(ra * p.lda) + ck;
+                int64_t rb = (rho >> 5) * 64 + h * 32 + (rho & 31);
+                if (rb >= tv.n_lim) rb = tv.n_lim - 1;
+                hvo[2 + h][u] = (int)(rb * p.ldb) + ck;
+            }
+        }
+        issue_ht(std::integral_constant<int, 0>{}, 0, 0);
+        issue_ht(std::integral_constant<int, 2>{}, 4, 0);
+        issue_ht(std::integral_constant<int, 3>{}, 6, 0);
+        issue_ht(std::integral_constant<int, 1>{}, 2, 0);
+        issue_ht(std::integral_constant<int, 0>{}, 1, 1);
+        issue_ht(std::integral_constant<int, 2>{}, 5, 1);
+    }
     TRACE(1);
 
     // per-output-channel epilogue vectors -> LDS once per workgroup (after the DMA prologue so its load latency hides
@@ -509,8 +601,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int64_t gn = n0 + li;
         if constexpr (!is_float_mm<MM> || is_w8a16<MM>) s_sb[i] = tv.sb[li];
         if constexpr (is_w8a16<MM>) s_zp[i] = p.zp ? p.zp[gn] : -128.0f * tv.sb[li];  // additive constant of the row's dequantization
-        if constexpr (EPI == EPI_BIAS1D || EPI == EPI_LOWRANK) s_bias[i] = tv.bias ? ldf_rt(tv.bias, tv.bias0 + li, p.bias_dtype) : 0.0f;
-        if constexpr (EPI == EPI_LOWRANK) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
+        if constexpr (EPI == EPI_BIAS1D || is_lr<EPI>) s_bias[i] = tv.bias ? ldf_rt(tv.bias, tv.bias0 + li, p.bias_dtype) : 0.0f;
+        if constexpr (is_lr<EPI>) { s_zp[i] = p.zp ? p.zp[gn] : 0.0f; s_wcs[i] = p.wcs ? p.wcs[gn] : 0.0f; }
     }
 
     const int frow = lane & (MS - 1), fgrp = lane / MS;  // row of the MFMA tile this lane feeds, and its 16-byte K chunk
@@ -655,6 +747,218 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
         }
         if (half == 0) __builtin_amdgcn_s_barrier();  // matches half 1's extra barrier at the start
+    } else if constexpr (LD == LD_8P) {
+        static_assert(NW == 8 && !JOINT && (TM % 2) == 0 && NS >= 3 && A_PIECES >= 1 && B_PIECES >= 1, "fine ping-pong: 8 waves, even activation blocks");
+        typedef typename FragOps<MM>::frag_t frag_t;
+        constexpr int KS = BK / MT::KB, TH = TM / 2;
+        frag_t fa0[KS][TH], fa1[KS][TH];
+        typename FragOps<MM>::fragb_t fb[KS][TN];
+        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+        wait_ahead();  // own pieces of stage 0 (stages 1..AHEAD-1 stay in flight)
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 sits out the first slot
+        int slot_r = AHEAD;  // ring slot stage kt + AHEAD goes to (the one stage kt - 1 occupied)
+#pragma nounroll
+        for (int kt = 0; kt < nk; ++kt) {
+            const uint8_t* sA = lds + slot_c * STAGE_BYTES;
+            const uint8_t* sB = sA + BM * BK;
+            slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+            // ---- phase 0: weight fragments + first half of the activation blocks
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
+#pragma unroll
+                for (int j = 0; j < TH; ++j) fa0[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_range(kt + AHEAD, slot_r, std::integral_constant<int, A_PIECES>{}, std::integral_constant<int, PPW>{});  // weight rows
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TH; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa0[ks][j], wrow[i], wflip);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase 1: second half of the activation blocks
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < TH; ++j) fa1[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + (TH + j) * MS + frow, ks, fgrp, p.swz);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_range(kt + AHEAD, slot_r, std::integral_constant<int, 0>{}, std::integral_constant<int, A_PIECES>{});  // activation rows
+            slot_r = (slot_r + 1 == NS) ? 0 : slot_r + 1;
+            wait_ahead();  // own pieces of stage kt + 1
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TH; ++j) FragOps<MM>::mma(acc[i][TH + j], fb[ks][i], fa1[ks][j], wrow[i], wflip);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier at the start
+    } else if constexpr (LD == LD_HT) {
+        static_assert(BM == 256 && BN == 256 && WM == 128 && WN == 64 && BK == 128 && MS == 32 && !is_w8a16<MM>, "half-tile ring: the 256x256 tile of 8 waves");
+        typedef typename FragOps<MM>::frag_t frag_t;
+        typedef typename FragOps<MM>::fragb_t fragb_t;
+        constexpr int KS = BK / MT::KB;
+        frag_t fa0[KS][2], fa1[KS][2];
+        fragb_t fb0[KS], fb1[KS];
+        const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+        const int nkt = K / 128;
+        // this lane's rows inside the activation / weight half-tiles; the fragment addresses below are (row, k sub-step) constants of the
+        // lane + immediates (slot, second row block): no address arithmetic inside the loop
+        const uint8_t* ldsA = lds + (wm * 64 + frow) * 128;                  // slot 0 (HA0, parity 0)
+        const uint8_t* ldsB = lds + 4 * HT_BYTES + (wn * 32 + frow) * 128;   // slot 4 (HB0, parity 0)
+        const int rswA = ((wm * 64 + frow) >> 1) & p.swz, rswB = ((wn * 32 + frow) >> 1) & p.swz;
+        // chunk offsets (swizzled) of this lane's 16-byte pieces: [k sub-step][piece of the fragment]
+        constexpr int CPK = MT::KB / 16, NPC = (MM == SDNQ_MM_FP8) ? 2 : 1;  // chunks per sub-step; 16-byte reads per lane and fragment
+        int coA[KS][NPC], coB[KS][NPC];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int c = 0; c < NPC; ++c) {
+                const int ch = ks * CPK + fgrp * NPC + c;
+                coA[ks][c] = (ch ^ rswA) << 4;
+                coB[ks][c] = (ch ^ rswB) << 4;
+            }
+        auto ldA = [&](int ks, int imm) -> frag_t {
+            if constexpr (NPC == 1) return *(const v4i*)(ldsA + coA[ks][0] + imm);
+            else {
+                const v4i lo = *(const v4i*)(ldsA + coA[ks][0] + imm), hi = *(const v4i*)(ldsA + coA[ks][1] + imm);
+                return (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        auto ldB = [&](int ks, int imm) -> fragb_t {
+            if constexpr (NPC == 1) return *(const v4i*)(ldsB + coB[ks][0] + imm);
+            else {
+                const v4i lo = *(const v4i*)(ldsB + coB[ks][0] + imm), hi = *(const v4i*)(ldsB + coB[ks][1] + imm);
+                return (v8i){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+#ifdef SDNQ_TRACE2  // development build: per-segment cycle totals of waves 0 and 4 (tools/micro/gemm_lab.hip prints them)
+        unsigned tacc[4][5] = {};
+        unsigned ts0 = (unsigned)__builtin_amdgcn_s_memtime(), ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+#define TS(v) v = (unsigned)__builtin_amdgcn_s_memtime()
+#else
+#define TS(v) do { } while (0)
+#endif
+        auto phase_sync = [&](bool reads) {
+            // end of the read / issue section: counted vmcnt (four half-tiles stay in flight), barrier, then this phase's own reads
+            __builtin_amdgcn_sched_barrier(0);
+            TS(ts1);
+            wait_vmcnt<8>();
+            TS(ts2);
+            __builtin_amdgcn_s_barrier();
+            if (reads) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            TS(ts3);
+            __builtin_amdgcn_s_setprio(1);
+        };
+        auto phase_end = [&](auto qc) {
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            TS(ts4);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef SDNQ_TRACE2
+            constexpr int q = decltype(qc)::value;
+            const unsigned ts5 = (unsigned)__builtin_amdgcn_s_memtime();
+            tacc[q][0] += ts1 - ts0; tacc[q][1] += ts2 - ts1; tacc[q][2] += ts3 - ts2; tacc[q][3] += ts4 - ts3; tacc[q][4] += ts5 - ts4;
+            ts0 = ts5;
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        };
+        wait_vmcnt<8>();  // HA0(0), HB0(0) have landed: everything phase 0 reads
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 sits out the first slot
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)  // A0 of K tile 0 (every later one is read in the phase 3 before its K tile)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fa0[ks][j] = ldA(ks, j * 4096);
+        // one K tile; PAR = t & 1 selects the ring slots at compile time (slot offsets become instruction immediates)
+        auto ktile = [&](auto parc, int t) {
+            constexpr int PAR = decltype(parc)::value;
+            // ---- phase 0: B0 (A0 was read in the previous phase 3) -> acc[0][0..1]; refill HB1 for K tile t + 1
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fb0[ks] = ldB(ks, PAR * HT_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_ht(std::integral_constant<int, 3>{}, 6 + (PAR ^ 1), t + 1);
+            phase_sync(true);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[0][j], fb0[ks], fa0[ks][j], wrow[0], wflip);
+            phase_end(std::integral_constant<int, 0>{});
+            // ---- phase 1: B1 -> acc[1][0..1]; refill HA1 for K tile t + 1
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) fb1[ks] = ldB(ks, (2 + PAR) * HT_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_ht(std::integral_constant<int, 1>{}, 2 + (PAR ^ 1), t + 1);
+            phase_sync(true);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[1][j], fb1[ks], fa0[ks][j], wrow[1], wflip);
+            phase_end(std::integral_constant<int, 1>{});
+            // ---- phase 2: A1 -> acc[1][2..3]; refill HA0 for K tile t + 2
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fa1[ks][j] = ldA(ks, (2 + PAR) * HT_BYTES + j * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_ht(std::integral_constant<int, 0>{}, PAR, t + 2);
+            phase_sync(true);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[1][2 + j], fb1[ks], fa1[ks][j], wrow[1], wflip);
+            phase_end(std::integral_constant<int, 2>{});
+            // ---- phase 3: A0 of K tile t + 1 (its registers are free since phase 1; landed: it is the fifth-youngest half-tile) ->
+            //      acc[0][2..3]; refill HB0 for K tile t + 2.  Reads per phase: 4 / 4 / 8 / 8 instead of 12 / 4 / 8 / 0.
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fa0[ks][j] = ldA(ks, (PAR ^ 1) * HT_BYTES + j * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_ht(std::integral_constant<int, 2>{}, 4 + PAR, t + 2);
+            phase_sync(true);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[0][2 + j], fb0[ks], fa1[ks][j], wrow[0], wflip);
+            phase_end(std::integral_constant<int, 3>{});
+        };
+#pragma nounroll
+        for (int t = 0; t < nkt; t += 2) {
+            ktile(std::integral_constant<int, 0>{}, t);
+            if (t + 1 < nkt) ktile(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();  // matches group 1's extra barrier at the start
+#ifdef SDNQ_TRACE2
+        if (blockIdx.x == 300 && (tid == 0 || tid == 256)) {
+            for (int q = 0; q < 4; ++q)
+                for (int e = 0; e < 5; ++e) g_trace2[(tid >> 8) * 20 + q * 5 + e] = tacc[q][e];
+        }
+#endif
+#undef TS
     } else if constexpr (LD == LD_DMA) {
         // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
         // single raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs.
@@ -678,7 +982,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // (computed per 32x32 sub-tile right before that sub-tile is staged: only 16 extra accumulator registers are live at a
     // time -- holding all TN x TM low-rank tiles next to the main accumulators spilled 104 VGPRs in the 256x256 kernel)
     bool lr_mfma = false, lr_lds = false;
-    if constexpr (EPI == EPI_LOWRANK) {
+    if constexpr (is_lr<EPI>) {
         lr_mfma = p.lr_t != nullptr && (p.rank % 16) == 0 && p.bias_dtype != SDNQ_F32;
         // rank 32 (the default): the tile's rows of t and svd_up -- 64 bytes each -- are fetched ONCE into the (now idle) ring by
         // LDS-DMA and the sub-tile fragments come from LDS.  Fetching every sub-tile's fragments from global right before its MFMAs
@@ -702,15 +1006,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
-    constexpr bool STAGED_EPILOGUE = (EPI == EPI_LOWRANK);
+    constexpr bool STAGED_EPILOGUE = is_lr<EPI>;
     if constexpr (STAGED_EPILOGUE) {
     // ======== LDS-staged epilogue with a compact runtime loop: low-rank / zero-point terms, and every 256-row tile ====
     // The low-rank arithmetic is long; fully unrolled over the accumulator registers (as the epilogue below is) it becomes
     // ~8k instructions of straight-line code that every wave executes once at instruction-fetch speed (measured: 2.5x slower
     // GEMM).  The 256-row tiles (128 accumulator registers per lane) also measured 2 % faster this way.  So the raw
     // accumulators (and the low-rank tile) are staged as 32-bit values and a small loop finishes them.
-    if constexpr (EPI == EPI_LOWRANK && OUT_T != SDNQ_F32) {
-        if (lr_lds && p.zp == nullptr && p.a_zp == nullptr) {
+    if constexpr (is_lr<EPI> && OUT_T != SDNQ_F32) {
+        if (EPI == EPI_LRFAST || (lr_lds && p.zp == nullptr && p.a_zp == nullptr)) {
             // ======== SVD-only layers (no zero-point terms; FLUX int8 + SVD): finish in the MFMA register layout ========
             // Every lane owns outputs m = wm*WM + j*32 + (lane & 31), n = wn*WN + i*32 + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Per
             // sub-tile: two MFMAs on the staged factor tiles give the low-rank values of exactly those outputs; bias2d = cast_svd(bias +
@@ -727,6 +1031,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma nounroll
             for (int ch = 0; ch < ECH2; ++ch) {
                 if (ch > 0) __syncthreads();  // previous chunk copied out before its staging area is overwritten
+                // an unknown zero in every LDS address of the chunk body: without it the per-sub-tile address arithmetic (32 channel
+                // offsets x 3 scalings) is hoisted out of this run-time loop and, next to 128 live accumulators, spilled 46-59 registers
+                int opq = 0;
+                if constexpr (ECH2 > 1) asm volatile("" : "+s"(opq));
+                const uint8_t* ldsq = lds + opq;
+                uint8_t* ostq = ostage + opq;
+                const float* sbq = (const float*)((const uint8_t*)s_sb + opq);
+                const float* biasq = (const float*)((const uint8_t*)s_bias + opq);
                 if ((wm * WM) / CH2 == ch) {  // wave-uniform: all of this wave's rows lie in one chunk (CH2 % WM == 0)
 #pragma unroll
                     for (int j = 0; j < TM; ++j) {
@@ -734,13 +1046,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         int64_t gm = m0 + tr;
                         if (gm >= p.M) gm = p.M - 1;
                         const float sa = p.sa[gm];
-                        const uint8_t* lt = lds + tr * 64;
+                        const uint8_t* lt = ldsq + tr * 64;
                         const int tsw = (tr >> 2) & 3;
                         const v4i ft0 = *(const v4i*)(lt + (((lane >> 5) ^ tsw) << 4)), ft1 = *(const v4i*)(lt + (((2 + (lane >> 5)) ^ tsw) << 4));
 #pragma unroll
                         for (int i = 0; i < TN; ++i) {
                             const int ur = wn * WN + i * 32 + (lane & 31);
-                            const uint8_t* lu = lds + (BM + ur) * 64;
+                            const uint8_t* lu = ldsq + (BM + ur) * 64;
                             const int usw = (ur >> 2) & 3;
                             const v4i fu0 = *(const v4i*)(lu + (((lane >> 5) ^ usw) << 4)), fu1 = *(const v4i*)(lu + (((2 + (lane >> 5)) ^ usw) << 4));
                             v16f lrt;
@@ -756,7 +1068,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
-                                const v4f sb4 = *(const v4f*)(s_sb + nl0), b4 = *(const v4f*)(s_bias + nl0);
+                                const v4f sb4 = *(const v4f*)(sbq + nl0), b4 = *(const v4f*)(biasq + nl0);
                                 float r[4];
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
@@ -765,7 +1077,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                                     const float vv = acc_times_sa<LP>(MT::tof(acc[i][j], 4 * q + e), sa);
                                     r[e] = fmaf(vv, sb4[e], b2);
                                 }
-                                *(v2i*)(ostage + (tr - ch * CH2) * O_ROW + nl0 * OUT_B) = (v2i){(int)pack2<OUT_T>(r[0], r[1]), (int)pack2<OUT_T>(r[2], r[3])};
+                                *(v2i*)(ostq + (tr - ch * CH2) * O_ROW + nl0 * OUT_B) = (v2i){(int)pack2<OUT_T>(r[0], r[1]), (int)pack2<OUT_T>(r[2], r[3])};
                             }
                             __builtin_amdgcn_sched_barrier(0);  // one sub-tile at a time (register pressure next to 128 accumulators)
                         }
@@ -784,6 +1096,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             return;
         }
     }
+    if constexpr (EPI != EPI_LRFAST) {
     constexpr int ACC_ROW = BN * 4 + 16;
     // (1) raw accumulators -> LDS [BM][BN] 32-bit (one 16-byte store per run of 4 consecutive output channels):
     //     acc[i][j][reg]: n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) + 4*(lane>>5),  m = wm*WM + j*32 + (lane&31)
@@ -797,13 +1110,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int ch = 0; ch < ECH; ++ch) {
 
     if (ch > 0) __syncthreads();  // previous chunk fully stored before its staging area is overwritten
+    // an unknown zero in every LDS address of the chunk body (see the register-layout loop above: hoisted out of this run-time loop,
+    // the per-sub-tile address arithmetic spilled next to the 128 live accumulators of the 256-row tiles)
+    int opq = 0;
+    if constexpr (ECH > 1) asm volatile("" : "+s"(opq));
+    const uint8_t* ldsq = lds + opq;
+    uint8_t* stageq = stage + opq;
+    uint8_t* stage2q = stage2 + opq;
+    const float* s_sbq = (const float*)((const uint8_t*)s_sb + opq);
+    const float* s_biasq = (const float*)((const uint8_t*)s_bias + opq);
+    const float* s_zpq = (const float*)((const uint8_t*)s_zp + opq);
+    const float* s_wcsq = (const float*)((const uint8_t*)s_wcs + opq);
+    (void)ldsq; (void)stage2q; (void)s_zpq; (void)s_wcsq; (void)s_biasq; (void)s_sbq;
+
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             if (ECH > 1 && (wm * WM + j * 32) / CH != ch) continue;  // wave-uniform: this 32-row block is in another chunk
             v16f lrt;
-            if constexpr (EPI == EPI_LOWRANK) {
+            if constexpr (is_lr<EPI>) {
                 if (lr_mfma) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) lrt[e] = 0.0f;
@@ -814,7 +1140,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     const uint16_t* tt = (const uint16_t*)p.lr_t + gm * p.rank + (lane >> 5) * 8;
                     // staged tiles (rank 32): row r of t at lds + r * 64, of svd_up at lds + (BM + r) * 64, chunk-swizzled
                     const int tr = wm * WM + j * 32 + (lane & 31), ur = wn * WN + i * 32 + (lane & 31);
-                    const uint8_t* lt = lds + tr * 64, *lu = lds + (BM + ur) * 64;
+                    const uint8_t* lt = ldsq + tr * 64, *lu = ldsq + (BM + ur) * 64;
                     const int tsw = (tr >> 2) & 3, usw = (ur >> 2) & 3;
                     // (fetching every sub-tile's t / svd_up fragments in one burst before the DMA drain -- 48 more live VGPRs --
                     // spilled 104 registers in the 256x256 kernel and gained nothing: 72.8 vs 69.7 ms per FLUX step, round 2)
@@ -840,20 +1166,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 const int ml = wm * WM + j * 32 + frow - ch * CH;
                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
                 if constexpr (MM == SDNQ_MM_I8)
-                    *(v4i*)(stage + ml * ACC_ROW + nl0 * 4) = (v4i){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *(v4i*)(stageq + ml * ACC_ROW + nl0 * 4) = (v4i){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 else
-                    *(v4f*)(stage + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if constexpr (EPI == EPI_LOWRANK) {
+                    *(v4f*)(stageq + ml * ACC_ROW + nl0 * 4) = (v4f){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if constexpr (is_lr<EPI>) {
                     if (lr_mfma) {
-                        // bias2d = cast_svd(f32(bias[n]) + low-rank) (addmm in the svd dtype, linear_int8.py:57-62; no bias: s_bias = 0)
-                        const v4f b4 = *(const v4f*)(s_bias + nl0);
+                        // bias2d = cast_svd(f32(bias[n]) + low-rank) (addmm in the svd dtype, linear_int8.py:57-62; no bias: s_biasq = 0)
+                        const v4f b4 = *(const v4f*)(s_biasq + nl0);
                         u32 h[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float v = has_bias_lr ? lrt[4 * q + e] + b4[e] : lrt[4 * q + e];
                             h[e] = (p.bias_dtype == SDNQ_BF16) ? (u32)f32_to_bf16_bits(v) : (u32)f32_to_f16_bits(v);
                         }
-                        *(v2i*)(stage2 + ml * B2_ROW + nl0 * 2) = (v2i){(int)(h[0] | (h[1] << 16)), (int)(h[2] | (h[3] << 16))};
+                        *(v2i*)(stage2q + ml * B2_ROW + nl0 * 2) = (v2i){(int)(h[0] | (h[1] << 16)), (int)(h[2] | (h[3] << 16))};
                     }
                 }
             }
@@ -872,14 +1198,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 const int n = v / (CH / 8), r8 = (v % (CH / 8)) * 8;
                 const int64_t gm = m0 + ch * CH + r8, gn = n0 + n;
                 if (gm >= p.M || gn >= p.N) continue;
-                const float sbn = is_float_mm<MM> ? 1.0f : s_sb[n];
-                const float bn = (EPI == EPI_BIAS1D) ? s_bias[n] : 0.0f;
+                const float sbn = is_float_mm<MM> ? 1.0f : s_sbq[n];
+                const float bn = (EPI == EPI_BIAS1D) ? s_biasq[n] : 0.0f;
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float a;
-                    if constexpr (MM == SDNQ_MM_I8) a = (float)*(const int*)(stage + (r8 + e) * ACC_ROW + n * 4);
-                    else a = *(const float*)(stage + (r8 + e) * ACC_ROW + n * 4);
+                    if constexpr (MM == SDNQ_MM_I8) a = (float)*(const int*)(stageq + (r8 + e) * ACC_ROW + n * 4);
+                    else a = *(const float*)(stageq + (r8 + e) * ACC_ROW + n * 4);
                     if constexpr (is_float_mm<MM>) {
                         o[e] = (EPI == EPI_BIAS1D) ? a + bn : a;
                     } else {
@@ -893,7 +1219,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             continue;  // next chunk
         }
     }
-    const bool lr_fast = EPI == EPI_LOWRANK && lr_mfma && p.zp == nullptr && p.a_zp == nullptr;
+    const bool lr_fast = is_lr<EPI> && lr_mfma && p.zp == nullptr && p.a_zp == nullptr;
 #pragma nounroll
     for (int v = tid; v < CH * G8; v += NT) {
         const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
@@ -901,7 +1227,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         if (gm >= p.M || c8 >= tv.n_lim) continue;  // N % 8 == 0: a group of 8 never straddles N
         const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
         float zsum = 0.0f, azp = 0.0f;
-        if constexpr (EPI == EPI_LOWRANK) {
+        if constexpr (is_lr<EPI>) {
             if (p.zp_rowsum) zsum = (float)p.zp_rowsum[gm] * sa;  // .to(f32).mul_(input_scale), linear_int8.py:66
             if (p.a_zp) azp = p.a_zp[gm];
         }
@@ -910,24 +1236,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         for (int h = 0; h < 2; ++h) {
             float a4[4];
             if constexpr (MM == SDNQ_MM_I8) {
-                const v4i t = *(const v4i*)(stage + r * ACC_ROW + (c8 + 4 * h) * 4);
+                const v4i t = *(const v4i*)(stageq + r * ACC_ROW + (c8 + 4 * h) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a4[e] = (float)t[e];  // int32 -> f32 (RNE above 2^24)
             } else {
-                const v4f t = *(const v4f*)(stage + r * ACC_ROW + (c8 + 4 * h) * 4);
+                const v4f t = *(const v4f*)(stageq + r * ACC_ROW + (c8 + 4 * h) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a4[e] = t[e];
             }
             if constexpr (is_float_mm<MM>) {  // F.linear: f32 accumulate, bias added in f32, one rounding
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[4 * h + e] = (EPI == EPI_BIAS1D) ? a4[e] + s_bias[c8 + 4 * h + e] : a4[e];
+                for (int e = 0; e < 4; ++e) o[4 * h + e] = (EPI == EPI_BIAS1D) ? a4[e] + s_biasq[c8 + 4 * h + e] : a4[e];
                 continue;
             }
-            const v4f sb4 = *(const v4f*)(s_sb + c8 + 4 * h);
+            const v4f sb4 = *(const v4f*)(s_sbq + c8 + 4 * h);
             v4f lr4 = {0.0f, 0.0f, 0.0f, 0.0f};  // bias2d values (already cast to the svd dtype) of the staged low-rank plane
-            if constexpr (EPI == EPI_LOWRANK) {
+            if constexpr (is_lr<EPI>) {
                 if (lr_mfma) {
-                    const v2i b2 = *(const v2i*)(stage2 + r * B2_ROW + (c8 + 4 * h) * 2);
+                    const v2i b2 = *(const v2i*)(stage2q + r * B2_ROW + (c8 + 4 * h) * 2);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const uint16_t bits = (uint16_t)(((u32)b2[e >> 1]) >> (16 * (e & 1)));
@@ -942,7 +1268,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 if constexpr (EPI == EPI_NONE) {
                     res = vv * sb4[e];
                 } else if constexpr (EPI == EPI_BIAS1D) {
-                    res = fmaf(vv, sb4[e], s_bias[c8 + 4 * h + e]);
+                    res = fmaf(vv, sb4[e], s_biasq[c8 + 4 * h + e]);
                 } else if constexpr (EPI == EPI_BIAS2D) {
                     res = fmaf(vv, sb4[e], ldf_rt(p.bias, gm * p.ld_bias + gn0 + 4 * h + e, p.bias_dtype));
                 } else {
@@ -952,7 +1278,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     if (lr_fast) {  // SVD only (cfg5): staged bias2d, no zero-point terms
                         res = fmaf(vv, sb4[e], lr4[e]);
                     } else {
-                        float bv = s_bias[cn];
+                        float bv = s_biasq[cn];
                         bool has = has_bias;
                         if (p.lr_t) {
                             if (lr_mfma) {
@@ -967,11 +1293,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         }
                         float zb = 0.0f;
                         bool hasz = false;
-                        if (p.zp) { zb = zsum * s_zp[cn]; hasz = true; }
+                        if (p.zp) { zb = zsum * s_zpq[cn]; hasz = true; }
                         if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
-                            const float t2 = s_wcs[cn] * azp;
+                            const float t2 = s_wcsq[cn] * azp;
                             zb = hasz ? zb + t2 : t2;
-                            if (p.zp) zb = fmaf(azp * s_zp[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
+                            if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
                             hasz = true;
                         }
                         if (hasz) { bv = has ? zb + bv : zb; has = true; }
@@ -990,6 +1316,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
     }
     }
+    }  // EPI != EPI_LRFAST
     } else {
     // ======== simple epilogues of the 64-row tiles: arithmetic in the MFMA register layout (+2.6 % on the SDXL step's GEMMs) ==
     // Every lane owns output position m = wm*WM + j*32 + (lane&31) and channels n = wn*WN + i*32 + (reg&3) + 8*(reg>>2) +
@@ -1091,12 +1418,12 @@ template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, in
 int launch_one(GemmParams p, hipStream_t s) {
     static_assert(!LP || (OUT_T == SDNQ_BF16 && !is_float_mm<MM>), "LP: the bf16-scale epilogue of the quantized matmuls");
     constexpr int NW = (BM / WM) * (BN / WN);
-    constexpr int MAIN = NS * (BM * BK + BN * (is_w8a16<MM> ? BK / 2 : BK));
+    constexpr int MAIN = (LD == LD_HT) ? HT_SLOTS * HT_BYTES : NS * (BM * BK + BN * (is_w8a16<MM> ? BK / 2 : BK));
     constexpr int CHS = BM > 128 ? 64 : BM, CHR = epi_chunk_rows<EPI, BM, BN, FT<OUT_T>::bytes>();  // rows per epilogue chunk (as in gemm_kernel)
     constexpr int EPI_GEN = (BM + BN) * 64 + CHS * (BN * 4 + 16) + CHS * (BN * 2 + 16);
-    constexpr int EPI_REG = ((EPI == EPI_LOWRANK) ? (BM + BN) * 64 : 0) + CHR * (BN * FT<OUT_T>::bytes + 16);
-    constexpr int EPIB = (EPI == EPI_LOWRANK && (EPI_GEN > EPI_REG || OUT_T == SDNQ_F32)) ? EPI_GEN : EPI_REG;
-    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + ((EPI == EPI_LOWRANK || is_w8a16<MM>) ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
+    constexpr int EPI_REG = (is_lr<EPI> ? (BM + BN) * 64 : 0) + CHR * (BN * FT<OUT_T>::bytes + 16);
+    constexpr int EPIB = (is_lr<EPI> && (EPI_GEN > EPI_REG || OUT_T == SDNQ_F32)) ? EPI_GEN : EPI_REG;
+    constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + ((is_lr<EPI> || is_w8a16<MM>) ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK, LP>;
     static std::atomic<bool> attr_set{false};
@@ -1138,6 +1465,12 @@ inline int forced_tile() {
     return f;
 }
 
+// the half-tile ring addresses a tile's rows with 32-bit byte offsets from the tile's first row
+inline bool ht_ok(const GemmParams& p) {
+    const int64_t lda = p.lda ? p.lda : p.K, ldb = p.ldb ? p.ldb : p.K;
+    return (p.K % 128) == 0 && 256 * lda + p.K < (int64_t)1 << 31 && 256 * ldb + p.K < (int64_t)1 << 31;
+}
+
 // the ping-pong configurations exist for the quantized matmuls with the plain epilogues and 16-bit outputs (the model paths)
 template <int MM, int OUT_T, int EPI> constexpr bool PP_OK = !is_float_mm<MM> && EPI <= EPI_BIAS1D && OUT_T != SDNQ_F32;
 
@@ -1145,7 +1478,9 @@ template <int MM, int OUT_T, int EPI>
 int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
     const int force = forced_tile();  // tuning aid
-    if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    if constexpr (EPI != EPI_BIAS2D && EPI != EPI_LOWRANK) {
+        if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    } else if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
     if (force == 1) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     if (force == 2) return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
     if (force == 3) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
@@ -1164,6 +1499,10 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 15) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 4, LD_DMA, 64>(p, s);
         if (force == 16) return launch_one<MM, OUT_T, EPI, 128, 320, 32, 160, 4, LD_PIPE, 64>(p, s);
         if (force == 17) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+        if (force == 18) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_8P, 64>(p, s);
+        if (force == 19) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
+        if (force == 20 && (p.K % 128) == 0 && ht_ok(p)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
+        if (force == 20) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
         // (64x80 tiles on v_mfma_i32_16x16x64_i8 -- MM_I8_16, instantiated by tools/micro/gemm_lab.hip only -- cut 1024 x 1280 outputs
         //  into exactly 256 workgroups with 25 % fewer LDS-fill bytes per CU, and measured SLOWER than 160 tiles of 64x128: 9.5 vs 7.9 us
         //  at K = 1280, 23.5 vs 19.0 us at K = 5120: four waves of 16x80 read six fragments per five 16-cycle MFMAs)
@@ -1183,7 +1522,25 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     // the 256x256 tile's prologue / epilogue: 4096 x 5120 x 640 ran 39 us on it vs 29 us on 256x128
     // (160 rather than 200 tiles since the register-layout epilogue: 4096 x 3072 x 3072 -- 192 tiles -- 56.5 us vs 57.7-62.6 on 256x128,
     //  4096 x 3072 x 12288 160 vs 198 us; profiles/r02_gemm_tile_sweep.txt)
-    if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    // (a 2-D bias -- the operator seam's rare form -- never runs on the 256x256 tiles: next to 128 accumulators its per-element global
+    //  bias loads spilled 780-920 registers; tools/check_spills.py keeps the library free of scratch)
+    if constexpr (EPI == EPI_LOWRANK) {
+        // low-rank layers reach the 256x256 tiles through EPI_LRFAST only (see the enum)
+        if constexpr (OUT_T != SDNQ_F32) {
+            if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256) && p.lr_t != nullptr && p.rank == 32 && p.bias_dtype != SDNQ_F32 &&
+                p.zp == nullptr && p.a_zp == nullptr) {
+                if (ht_ok(p)) return launch_one<MM, OUT_T, EPI_LRFAST, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
+                return launch_one<MM, OUT_T, EPI_LRFAST, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+            }
+        }
+    } else if constexpr (EPI != EPI_BIAS2D) {
+        if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256)) {
+            // round 3: the half-tile ring (LD_HT: 128-byte rows, buffer-load DMAs with no vector-ALU address work, fine ping-pong) is
+            // 15-22 % faster than the 64-byte-stage software pipeline on every FLUX / large shape (profiles/r03_gemm_ht.txt)
+            if (ht_ok(p)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
+            return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+        }
+    }
     //  * tall problems that cannot fill the chip with 256x256 tiles (conv GEMMs 16384 x 320 x 2880..8640, 4096 x 5120 x 640):
     //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
     if (p.M >= 2048 && tiles(256, 128) >= 150 && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
@@ -1205,7 +1562,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
 inline bool force_tile_unfit(const GemmParams& p) {
     const int force = forced_tile();
     if (force < 0 || p.units == nullptr) return false;
-    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128};
+    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128, 256, 128, 256};
     return force < (int)(sizeof(bn_of) / sizeof(int)) ? (p.unit_n % bn_of[force]) != 0 : false;
 }
 

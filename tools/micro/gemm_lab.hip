@@ -26,6 +26,9 @@ static int run_cfg(int id, GemmParams p, hipStream_t s) {
         case 18: return launch_one<MM_I8_16, OT, EP, 64, 80, 16, 80, 3, LD_DMA, 128>(p, s);
         case 19: return launch_one<MM_I8_16, OT, EP, 64, 80, 16, 80, 4, LD_DMA, 128>(p, s);
         case 24: return launch_one<MM, OT, EP, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+        case 30: return launch_one<MM, OT, EP, 256, 256, 128, 64, 4, LD_8P, 64>(p, s);
+        case 31: return launch_one<MM, OT, EP, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
+        case 32: return launch_one<MM, OT, EP, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
 #ifdef LAB_EXTRA
         LAB_EXTRA
 #endif
@@ -33,6 +36,15 @@ static int run_cfg(int id, GemmParams p, hipStream_t s) {
     }
 }
 
+__global__ void fill_uniform(int8_t* p, size_t n, unsigned seed) {  // LAB_UNIFORM=1: full-entropy bytes (the power-limited case)
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned x = (unsigned)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (int8_t)(x & 0xff);
+    }
+}
 __global__ void fill_kernel(int8_t* p, size_t n, unsigned seed) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -80,10 +92,20 @@ int main(int argc, char** argv) {
         int8_t *a, *b;
         float *sa, *sb;
         uint16_t *bias, *out, *ref;
-        HC(hipMalloc(&a, m * k)); HC(hipMalloc(&b, n * k)); HC(hipMalloc(&sa, m * 4)); HC(hipMalloc(&sb, n * 4));
+        const int64_t pad = getenv("LAB_PAD") ? atoi(getenv("LAB_PAD")) : 0;  // row pitch = K + pad bytes (L2 channel spread experiment)
+        const int64_t kp = k + pad;
+        HC(hipMalloc(&a, m * kp)); HC(hipMalloc(&b, n * kp)); HC(hipMalloc(&sa, m * 4)); HC(hipMalloc(&sb, n * 4));
         HC(hipMalloc(&bias, n * 2)); HC(hipMalloc(&out, m * n * 2)); HC(hipMalloc(&ref, m * n * 2));
-        fill_kernel<<<2048, 256, 0, s>>>(a, m * k, 1u);
-        fill_kernel<<<2048, 256, 0, s>>>(b, n * k, 77u);
+        if (getenv("LAB_ZERO")) {
+            HC(hipMemsetAsync(a, 0, m * kp, s));
+            HC(hipMemsetAsync(b, 0, n * kp, s));
+        } else if (getenv("LAB_UNIFORM")) {
+            fill_uniform<<<2048, 256, 0, s>>>(a, m * kp, 1u);
+            fill_uniform<<<2048, 256, 0, s>>>(b, n * kp, 77u);
+        } else {
+            fill_kernel<<<2048, 256, 0, s>>>(a, m * kp, 1u);
+            fill_kernel<<<2048, 256, 0, s>>>(b, n * kp, 77u);
+        }
         fill_f<<<(m + 255) / 256, 256, 0, s>>>(sa, m, 1e-3f, 1e-5f);
         fill_f<<<(n + 255) / 256, 256, 0, s>>>(sb, n, 2e-3f, 1e-5f);
         HC(hipMemsetAsync(bias, 0x3c, n * 2, s));
@@ -93,7 +115,7 @@ int main(int argc, char** argv) {
         for (int id : ids) {
             GemmParams p{};
             p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
-            p.M = m; p.N = n; p.K = k; p.bias_ndim = 1; p.bias_dtype = SDNQ_BF16;
+            p.M = m; p.N = n; p.K = k; p.lda = kp; p.ldb = kp; p.bias_ndim = 1; p.bias_dtype = SDNQ_BF16;
             HC(hipMemsetAsync(out, 0xff, m * n * 2, s));
             int st = run_cfg(id, p, s);
             if (st != 0) { printf(" %d:ERR%d", id, st); continue; }
@@ -116,6 +138,20 @@ int main(int argc, char** argv) {
             float ms;
             HC(hipEventElapsedTime(&ms, e0, e1));
             printf("  %d:%7.2f us%s", id, ms * 1e3 / reps, same ? "" : " MISMATCH");
+#ifdef SDNQ_TRACE2
+            if (id == 32) {
+                unsigned h[64];
+                HC(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace2), sizeof(h)));
+                const double nk = (double)((k + 127) / 128);
+                printf("\n   cycles per phase (issue | vmcnt | barrier1+lgkm | mfma | barrier2), per K tile average:\n");
+                for (int g = 0; g < 2; ++g)
+                    for (int q = 0; q < 4; ++q) {
+                        printf("   group %d phase %d:", g, q);
+                        for (int e = 0; e < 5; ++e) printf(" %7.1f", h[g * 20 + q * 5 + e] / nk);
+                        printf("\n");
+                    }
+            }
+#endif
         }
         printf("\n");
         hipFree(a); hipFree(b); hipFree(sa); hipFree(sb); hipFree(bias); hipFree(out); hipFree(ref);
