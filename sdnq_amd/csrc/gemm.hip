@@ -214,6 +214,17 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void static_f
     }
 }
 
+// LDS-DMA through a buffer descriptor.  The descriptor type and its builtins exist in the DEVICE pass only; the host pass also parses
+// kernel bodies, and a generic lambda that uses them there makes it drop the kernel's launch stub without any diagnostic (the library
+// then fails to load with an undefined gemm_kernel symbol) -- so the host pass sees inert stand-ins.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDNQ_MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, 0x7fffffff, 0x00020000)
+#define SDNQ_DMA16(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst), 16, voff, soff, 0, 0)
+#else
+#define SDNQ_MAKE_RSRC(ptr) ((const void*)(ptr))
+#define SDNQ_DMA16(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
+#endif
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
@@ -312,7 +323,8 @@ template <> struct FragOps<SDNQ_MM_FP8> {
 // speed (cold I-cache: ~600 cycles per ~100 instructions were measured in the unrolled pipeline-drain copies of an
 // earlier version), and diffusion-size GEMMs only run 5-40 K-steps, so everything outside the K loop is kept
 // compact: the DMA prologue and the epilogue are runtime loops, and the K loop has ONE body for fill, steady state
-// and drain (stages past the end of K are issued as zero-fill DMAs, which keeps the counted vmcnt a constant).
+// and drain (stages past the end of K are issued as re-fetches of a valid stage that nobody consumes, which keeps the counted
+// vmcnt a constant).
 // LD selects how HBM/L2 -> LDS is done:
 //   LD_DMA : global_load_lds_dwordx4 into an NS-deep LDS ring (no VGPR round trip, but ~100+ issue cycles per 1-KiB
 //            piece and ~1 us latency: bytes in flight are bounded by the LDS ring);
@@ -472,7 +484,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // ---- LDS-DMA assignment: piece = 8 tile rows x 128 B; lane l -> row l/8, physical chunk l%8 ----------------
     // wave w owns A pieces w, w+NW, ... and B pieces w, w+NW, ...; the source chunk is the swizzle-inverse of the
     // physical chunk so that LDS stays lane-linear (base + lane*16) as the DMA requires.
-    const uint8_t* src[PPW];
+    // The DMAs are BUFFER loads (buffer_load_dwordx4 ... lds): a per-lane byte offset that never changes (row * pitch + chunk, relative to
+    // the tile's first row) in a VGPR, the K advance in the scalar offset operand -- no vector-ALU instruction feeds a DMA address.
+    // (round 3, tools/micro/dma_mfma_lab.hip: a global_load_lds whose 64-bit address comes out of vector-ALU arithmetic costs ~2000
+    // cycles beside a wave that streams MFMAs on the same SIMD, 86 alone; the buffer form costs 86 in both cases.)
+    // K tail (K % BK != 0): the partial stage is consumed FIRST -- it is fetched by the prologue (executed once, so its per-lane
+    // "past K -> zeros" select may cost what it likes) and the K loop only ever fetches whole stages: the accumulation order over K
+    // changes nothing for int8 (exact) and only the fp32 summation order for fp8 / float.  Logical stage j = 0 is K stage nk - 1,
+    // j >= 1 is K stage j - 1; stages past the end re-fetch K stage 0 (never consumed; keeps the counted vmcnt a constant).
+    int voff[PPW];
     // row of this lane inside a DMA piece and the (swizzle-inverse) 16-byte chunk it fetches, per operand geometry
     auto r8_of = [&](bool isA) { return lane / (isA ? LPR : LPR_B); };
     auto chunk_of = [&](int r, bool isA) {
@@ -491,6 +511,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             return (isA ? i : i - A_PIECES) * NW + wave;
         }
     };
+    const int nk = (K + BK - 1) / BK;
+    const int K_B = is_w8a16<MM> ? K / 2 : K;  // bytes of a B row
+    const bool has_tail = (K % BK) != 0;
+    const uint8_t* baseA = p.a + m0 * p.lda;
+    auto rsA = SDNQ_MAKE_RSRC(baseA);
+    auto rsB = SDNQ_MAKE_RSRC(tv.b);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         bool isA;
@@ -499,44 +525,55 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int c = chunk_of(r, isA);
         // clamp: rows past the edge are computed on valid memory and never stored
         if (isA) {
-            int64_t g = m0 + r;
-            if (g >= p.M) g = p.M - 1;
-            src[i] = p.a + g * p.lda + c * 16;
+            int64_t g = r;
+            if (m0 + g >= p.M) g = p.M - 1 - m0;
+            voff[i] = (int)(g * p.lda) + c * 16;
         } else {
             const int64_t g = r < tv.n_lim ? r : tv.n_lim - 1;
-            src[i] = tv.b + g * p.ldb + c * 16;
+            voff[i] = (int)(g * p.ldb) + c * 16;
         }
     }
-    // logical K offset (bytes) of this lane's chunk: the swizzle only depends on (piece*8 + r8) >> 1, and piece*8 is a
-    // multiple of 8, so the chunk is the same for every piece of an operand up to the parity of piece*4 -- NW is even,
-    // hence (piece*8 >> 1) & 7 alternates with `piece & 1`; it is recomputed (2 VALU) instead of stored.
+    // logical K offset (bytes) of this lane's chunk inside a stage row (recomputed: 2 VALU, prologue only)
     auto kofs = [&](int i) {
         bool isA;
         const int piece = piece_of(i, isA);
         return chunk_of(piece * (isA ? RPP : RPP_B) + r8_of(isA), isA) << 4;
     };
     int slot_i = 0;  // ring slot the next issued stage goes to
-    const int K_B = is_w8a16<MM> ? K / 2 : K;  // bytes of a B row
-    // this wave's piece slots [I0, I1) of K stage kt into ring slot `slot`
-    auto issue_range = [&](int kt, int slot, auto i0c, auto i1c) {
+    // this wave's piece slots [I0, I1) of LOGICAL stage j >= 1 into ring slot `slot`: whole K stages only
+    auto issue_range = [&](int j, int slot, auto i0c, auto i1c) {
         constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
         uint8_t* stage = lds + slot * STAGE_BYTES;
+        int st = j - (has_tail ? 1 : 0);
+        st = st < nk - (has_tail ? 1 : 0) ? st : 0;
 #pragma unroll
         for (int i = I0; i < I1; ++i) {
             if (JOINT && i == PPW - 1 && !full) break;  // this wave's last slot is empty
             bool isA;
             const int piece = piece_of(i, isA);
             uint8_t* dst = stage + (isA ? 0 : BM * BK) + piece * 1024;
-            // chunks past K (K % 16 == 0) and whole stages past the end of K come from a 16-byte zero constant
-            const int k0 = kt * (isA ? BK : BKW);
-            const uint8_t* s = (k0 + kofs(i) < (isA ? K : K_B)) ? src[i] + k0 : (const uint8_t*)&g_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
+            if (isA) SDNQ_DMA16(rsA, dst, voff[i], st * BK);
+            else SDNQ_DMA16(rsB, dst, voff[i], st * BKW);
         }
     };
-    auto issue = [&](int kt) {
+    // logical stage 0 when K has a tail: K stage nk - 1, chunks past K from a 16-byte zero constant (plain global_load_lds)
+    auto issue_tail = [&](int slot) {
+        uint8_t* stage = lds + slot * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (JOINT && i == PPW - 1 && !full) break;
+            bool isA;
+            const int piece = piece_of(i, isA);
+            uint8_t* dst = stage + (isA ? 0 : BM * BK) + piece * 1024;
+            const int k0 = (nk - 1) * (isA ? BK : BKW);
+            const uint8_t* sp = (k0 + kofs(i) < (isA ? K : K_B)) ? (isA ? baseA : tv.b) + voff[i] + k0 : (const uint8_t*)&g_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)dst, 16, 0, 0);
+        }
+    };
+    auto issue = [&](int j) {  // j >= 1 (the K loop), or j == 0 without a K tail
         const int slot = slot_i;
         slot_i = (slot_i + 1 == NS) ? 0 : slot_i + 1;
-        issue_range(kt, slot, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{});
+        issue_range(j, slot, std::integral_constant<int, 0>{}, std::integral_constant<int, PPW>{});
     };
 
     typename MT::acc_t acc[TN][TM];  // [n-subtile][m-subtile]; MFMA A-operand = weights (n), B-operand = activations (m)
@@ -545,7 +582,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
         for (int j = 0; j < TM; ++j) MT::zero(acc[i][j]);
 
-    const int nk = (K + BK - 1) / BK;
     constexpr int AHEAD = NS - 1;  // stages in flight ahead of the one being consumed (LD_DMA)
     // counted wait: everything but this wave's pieces of the AHEAD - 1 youngest stages has landed
     auto wait_ahead = [&]() {
@@ -553,14 +589,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         else wait_vmcnt<(AHEAD - 1) * PPW>();
     };
     if constexpr (LD != LD_HT) {
+        if (has_tail) { issue_tail(0); slot_i = 1; }
+        else issue(0);
 #pragma nounroll
-        for (int s = 0; s < AHEAD; ++s) issue(s);
+        for (int s = 1; s < AHEAD; ++s) issue(s);
     }
     // LD_HT: buffer descriptors of the tile's activation / weight rows, this lane's constant byte offsets into them for its two
     // pieces (8 rows x 128 B each) of every half-tile, and the prologue DMAs.  Slots: HA0 0-1, HA1 2-3, HB0 4-5, HB1 6-7.
     int hvo[4][2] = {};  // [HA0, HA1, HB0, HB1][piece]: clamped row * pitch + (swizzle-inverse) chunk
-    auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + m0 * p.lda), 0, 0x7fffffff, 0x00020000);
-    auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)tv.b, 0, 0x7fffffff, 0x00020000);
     const int k_last = K - 128;  // K tiles past the end are fetched from the last one (never consumed; keeps the vmcnt a constant)
     auto issue_ht = [&](auto typec, int slot, int kt) {
         constexpr int ty = decltype(typec)::value;
@@ -568,7 +604,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         k0 = k0 < k_last ? k0 : k_last;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ty < 2 ? rsA : rsB, (lptr_t)(lds + slot * HT_BYTES + (2 * wave + u) * 1024), 16, hvo[ty][u], k0, 0, 0);
+            SDNQ_DMA16(ty < 2 ? rsA : rsB, lds + slot * HT_BYTES + (2 * wave + u) * 1024, hvo[ty][u], k0);
     };
     if constexpr (LD == LD_HT) {
 #pragma unroll
@@ -691,7 +727,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
                     load_set(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, cur ^ 1>{});
                 }
-                mma_set(std::integral_constant<int, cur>{});
+                // (two stages per trip and an odd stage count: the second half of the last trip sees a stage past the end of K, which
+                //  now holds re-fetched data instead of zeros -- skip its MFMAs; wave-uniform)
+                if (U == 1 || kt + u < nk) mma_set(std::integral_constant<int, cur>{});
             });
         }
     } else if constexpr (LD == LD_PP) {
@@ -961,7 +999,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #undef TS
     } else if constexpr (LD == LD_DMA) {
         // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
-        // single raw barrier), refill the ring slot stage kt-1 occupied (zero-fill past the end of K), run the MFMAs.
+        // single raw barrier), refill the ring slot stage kt-1 occupied (an unconsumed re-fetch past the end of K), run the MFMAs.
 #pragma nounroll
         for (int kt = 0; kt < nk; ++kt) {
             wait_ahead();
@@ -972,7 +1010,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
     }
     TRACE(3);
-    wait_vmcnt<0>();  // the trailing zero-fill DMAs target ring slots the epilogue is about to reuse
+    wait_vmcnt<0>();  // the trailing (unconsumed) DMAs target ring slots the epilogue is about to reuse
     __syncthreads();
     TRACE(4);
 
