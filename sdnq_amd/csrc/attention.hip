@@ -274,10 +274,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int64_t kv_lin = z * p.kh + (h * p.kh) / p.qh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
 
     const int64_t qi = q0 + ql, qrow = qi < p.qn ? qi : p.qn - 1;
-    const int8_t* qbase = p.qq + (head_lin * p.qn + qrow) * D + 16 * g;
+    auto rsQ = SDNQ_MAKE_RSRC(p.qq + head_lin * p.qn * D);  // (buffer form: see the K / V loads below)
     v4i qf[KK];
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const v4i*)(qbase + 32 * kk);
+    for (int kk = 0; kk < KK; ++kk) qf[kk] = SDNQ_BUF_LOAD16(rsQ, (int)qrow * D + 16 * g, 32 * kk);
     // ((acc * q_scale) * k_scale) * log2_sm_scale of triton_atten.py:278 as acc * (k_scale * (q_scale * log2_sm_scale))
     const float qsl = p.qs[head_lin * p.qn + qrow] * p.log2_sm_scale;
 
@@ -290,26 +290,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     v2f l2 = {0.0f, 0.0f};  // this lane's half of the row sum (16 of every 32 keys), two partial sums
 
     // K and V arrive in MFMA-fragment order (sdnq_hip_attn_prepare): 1-KiB tiles, lane l reads bytes [16 l, 16 l + 16)
-    const int8_t* kbase = p.kq + kv_lin * p.knp * D + lane * 16;
-    const float* ksbase = p.ks + kv_lin * p.knp + 8 * g;
-    const uint16_t* vbase = p.vt + kv_lin * p.knp * D + lane * 8;
+    // Every load of the loop goes through a buffer descriptor (head base in SGPRs, constant 16-byte-per-lane offset, block offset in
+    // the scalar operand): a global load with a 64-bit VGPR address waits ~1000 cycles at issue while another wave of the SIMD
+    // streams MFMAs (sdnq_dev.h; the loop has 10 vector-memory instructions per key block).
+    auto rsK = SDNQ_MAKE_RSRC(p.kq + kv_lin * p.knp * D);
+    auto rsV = SDNQ_MAKE_RSRC(p.vt + kv_lin * p.knp * D);
+    auto rsS = SDNQ_MAKE_RSRC(p.ks + kv_lin * p.knp);
+    const int lofs = lane * 16, sofs = 32 * g;  // byte offsets of this lane inside a fragment tile / a block's 32 k_scales
 
     struct Blk { v4i v[KK][2]; v4f ks[4]; };
     auto load_k = [&](int kb, v4i (&kf)[KK]) {
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + (int64_t)kb * (KK * 1024) + kk * 1024);
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = SDNQ_BUF_LOAD16(rsK, lofs, kb * (KK * 1024) + kk * 1024);
     };
     auto load_vs = [&](int kb, Blk& b) {
-        const int64_t key0 = (int64_t)kb * 32;
 #pragma unroll
         for (int dd = 0; dd < KK; ++dd)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) b.v[dd][c] = *(const v4i*)(vbase + (int64_t)kb * (KK * 1024) + (dd * 2 + c) * 512);
+            for (int c = 0; c < 2; ++c) b.v[dd][c] = SDNQ_BUF_LOAD16(rsV, lofs, kb * (KK * 2048) + (dd * 2 + c) * 1024);
         // registers 8c..8c+7 <-> keys key0 + 16c + 8g + 0..7 (k_scale rows are padded to knp, so this never leaves the row)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            b.ks[2 * c] = *(const v4f*)(ksbase + key0 + 16 * c);
-            b.ks[2 * c + 1] = *(const v4f*)(ksbase + key0 + 16 * c + 4);
+            b.ks[2 * c] = __builtin_bit_cast(v4f, SDNQ_BUF_LOAD16(rsS, sofs, kb * 128 + 64 * c));
+            b.ks[2 * c + 1] = __builtin_bit_cast(v4f, SDNQ_BUF_LOAD16(rsS, sofs, kb * 128 + 64 * c + 16));
         }
     };
     auto qk_mfma = [&](const v4i (&kf)[KK]) {
@@ -463,18 +466,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STG_BYTES > COMB_BYTES ? 2 * STG_BYTES : COMB_BYTES];
     if (!CAUSAL && !HAS_MASK && p.shared_kv) {
         const int n_st = n_plain / 2;  // full two-block stages; the same for every wave (no causal limit)
-        const uint8_t* gk = (const uint8_t*)p.kq + kv_lin * p.knp * D + lane * 16;
-        const uint8_t* gv = (const uint8_t*)p.vt + kv_lin * p.knp * D * 2 + lane * 16;
-        const uint8_t* gs = (const uint8_t*)(p.ks + kv_lin * p.knp) + lane * 4;
         auto dma_stage = [&](int st, int buf) {
             uint8_t* dst = smem + buf * STG_BYTES;
 #pragma unroll
             for (int i = 0; i < 6 * KK / 4; ++i) {  // 1-KiB tiles w, w + 4, ...: first the 2 KK tiles of K, then the 4 KK of V
-                const int tile = wave + 4 * i;
-                const uint8_t* src = tile < 2 * KK ? gk + (int64_t)st * STG_K + tile * 1024 : gv + (int64_t)st * STG_V + (tile - 2 * KK) * 1024;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + tile * 1024), 16, 0, 0);
+                const int tile = wave + 4 * i;  // wave-uniform
+                if (tile < 2 * KK) SDNQ_DMA16(rsK, dst + tile * 1024, lofs, st * STG_K + tile * 1024);
+                else SDNQ_DMA16(rsV, dst + tile * 1024, lofs, st * STG_V + (tile - 2 * KK) * 1024);
             }
-            if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(gs + (int64_t)st * 256), (lptr_t)(dst + STG_K + STG_V), 4, 0, 0);  // 64 k_scales
+            if (wave == 0) SDNQ_DMA4(rsS, dst + STG_K + STG_V, lane * 4, st * 256);  // 64 k_scales
         };
         auto lds_block = [&](int buf, int blk, v4i (&kf)[KK], Blk& b) {
             const uint8_t* base = smem + buf * STG_BYTES;

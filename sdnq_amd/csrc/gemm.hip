@@ -214,17 +214,6 @@ template <int N, int I = 0, typename F> __device__ __forceinline__ void static_f
     }
 }
 
-// LDS-DMA through a buffer descriptor.  The descriptor type and its builtins exist in the DEVICE pass only; the host pass also parses
-// kernel bodies, and a generic lambda that uses them there makes it drop the kernel's launch stub without any diagnostic (the library
-// then fails to load with an undefined gemm_kernel symbol) -- so the host pass sees inert stand-ins.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SDNQ_MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, 0x7fffffff, 0x00020000)
-#define SDNQ_DMA16(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dst), 16, voff, soff, 0, 0)
-#else
-#define SDNQ_MAKE_RSRC(ptr) ((const void*)(ptr))
-#define SDNQ_DMA16(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
-#endif
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }

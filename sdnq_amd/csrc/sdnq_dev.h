@@ -10,6 +10,32 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+// ---- vector-memory instructions beside MFMAs (round 3, tools/micro/dma_mfma_lab.hip, profiles/r03_dma_beside_mfma.txt) ---------------
+// A global / flat memory instruction whose address is a 64-bit VGPR pair (`global_load_dwordx4 v, v[a:b], off`, the same for stores and
+// for global_load_lds) waits ~1000-2000 cycles at issue while the OTHER wave of its SIMD streams MFMAs (65-86 cycles alone); the forms
+// with a scalar base and a 32-bit per-lane offset -- `global_load v, v_off, s[base]` and every buffer instruction -- are not affected.
+// hipcc picks the 64-bit form for almost every pointer expression, so kernels whose waves share a SIMD with matrix work address
+// memory through buffer descriptors: wave-uniform base in SGPRs, 32-bit byte offset per lane, optional scalar offset.
+// The descriptor type and its builtins exist in the DEVICE pass only; the host pass also parses kernel bodies, and a generic lambda
+// that uses them there makes it drop the kernel's launch stub without a diagnostic -- so the host pass sees inert stand-ins.
+typedef __attribute__((address_space(3))) void* sdnq_lds_ptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SDNQ_MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, 0x7fffffff, 0x00020000)
+#define SDNQ_DMA16(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sdnq_lds_ptr_t)(dst), 16, voff, soff, 0, 0)
+#define SDNQ_DMA4(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sdnq_lds_ptr_t)(dst), 4, voff, soff, 0, 0)
+#define SDNQ_BUF_LOAD16(rs, voff, soff) __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0))
+#define SDNQ_BUF_STORE16(rs, v, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs, voff, soff, 0)
+#define SDNQ_BUF_STORE16_NT(rs, v, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs, voff, soff, 2)
+#else
+#define SDNQ_MAKE_RSRC(ptr) ((const void*)(ptr))
+#define SDNQ_DMA16(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
+#define SDNQ_DMA4(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
+#define SDNQ_BUF_LOAD16(rs, voff, soff) ((void)(rs), (void)(voff), (void)(soff), (v4i){0, 0, 0, 0})
+#define SDNQ_BUF_STORE16(rs, v, voff, soff) ((void)(rs), (void)(v), (void)(voff), (void)(soff))
+#define SDNQ_BUF_STORE16_NT(rs, v, voff, soff) ((void)(rs), (void)(v), (void)(voff), (void)(soff))
+#endif
+
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v8s __attribute__((ext_vector_type(8)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
