@@ -26,6 +26,31 @@ class SDNQLayer(torch.nn.Module):
             from . import torch_ops
             torch_ops.layer_handle(self)
 
+    # per-object runtime state that must not travel with a copy: the operator handle names THIS module, the projection group and the
+    # kernel-ready tensor cache point at the original's siblings / parameters
+    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_group", "_sdnq_hip_state")
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for key, value in self.__dict__.items():
+            if key not in self._RUNTIME_KEYS:
+                new.__dict__[key] = copy.deepcopy(value, memo)
+        if _traceable(new):
+            from . import torch_ops
+            torch_ops.layer_handle(new)
+        return new
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._RUNTIME_KEYS}
+
+    def __setstate__(self, state):
+        torch.nn.Module.__setstate__(self, state)
+        if _traceable(self):
+            from . import torch_ops
+            torch_ops.layer_handle(self)
+
     @property
     def dtype(self) -> torch.dtype:
         return self.sdnq_dequantizer.result_dtype if hasattr(self, "sdnq_dequantizer") else self.weight.dtype

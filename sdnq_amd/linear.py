@@ -69,7 +69,7 @@ class _ActivationCache:
         self.entries = []  # most recent last: (tensor, key, params, result, pinned bytes)
 
     def get(self, t: torch.Tensor, params):
-        key = tensor_key(t)
+        key = None if _no_identity_reuse[0] else tensor_key(t)
         if key is None:
             return None
         for i in range(len(self.entries) - 1, -1, -1):
@@ -80,7 +80,7 @@ class _ActivationCache:
         return None
 
     def put(self, t: torch.Tensor, params, result):
-        key = tensor_key(t)
+        key = None if _no_identity_reuse[0] else tensor_key(t)
         if key is None:
             return
         nbytes = t.numel() * t.element_size() + sum(r.numel() * r.element_size() for r in result if isinstance(r, torch.Tensor) and r is not t)
@@ -103,6 +103,22 @@ class _ActivationCache:
 
 
 _act_cache = _ActivationCache()
+
+# Identity-keyed reuse (the activation cache, outputs parked in a ProjectionGroup) rests on "the very same tensor object, unchanged
+# by every writer autograd knows about".  Inside a torch.compile'd graph that does not hold: Inductor recycles dead buffers in place
+# (`buf7 = buf1; del buf1  # reuse`: same Python object, address and geometry) and its kernels write through raw pointers, so
+# `_version` never moves -- a norm1 output cached for to_q / to_k / to_v would be served again for the norm2 output that now lives in
+# the same buffer.  The `sdnq_hip::layer_forward` operator therefore runs the eager forward under `identity_reuse_disabled()`.
+_no_identity_reuse = [0]
+
+
+class identity_reuse_disabled:
+    def __enter__(self):
+        _no_identity_reuse[0] += 1
+
+    def __exit__(self, *exc):
+        _no_identity_reuse[0] -= 1
+        return False
 _groups = []  # weak references to the live SharedInputGroups (invalidate() reaches their pending outputs)
 
 
@@ -353,11 +369,24 @@ class ProjectionGroup:
         # bias (a changed, moved or offloaded parameter rebuilds the unit table)
         if self._sig_current(mm):
             return self.gemm is not None
-        states = [_state(m) for m in self.mods]
-        parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
         self.sig = (mm, [self._member_sig(m) for m in self.mods])
         self.last = None
         self.gemm = None
+        # every member's parameters must be resident on ONE device now: with group / sequential offload or a multi-device
+        # device_map another block's weights are still on the CPU (or meta) when the first member is called -- the group then
+        # steps aside (the members run alone, like the reference's layers) instead of failing the forward
+        devs = set()
+        for m in self.mods:
+            for name in ("weight", "scale"):
+                t = _attr(m, name)
+                devs.add(None if t is None else t.device)
+        if len(devs) != 1 or None in devs or next(iter(devs)).type != "cuda":
+            return False
+        try:
+            states = [_state(m) for m in self.mods]
+            parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
+        except ops._lib.SdnqHipError:
+            return False
         if any(zp is not None for (_, _, zp) in parts) or len({w.device for (w, _, _) in parts}) != 1:
             return False
         members = []
@@ -416,9 +445,9 @@ class ProjectionGroup:
         return True
 
     def forward(self, mod, idx: int, input: torch.Tensor, mm: int):
-        key = tensor_key(input)
+        key = None if _no_identity_reuse[0] else tensor_key(input)
         if key is None:
-            return None  # inference tensor: no way to tell whether it changed between the members' calls
+            return None  # inference tensor / compiled graph: no way to tell whether it changed between the members' calls
         stream = ops._stream(input)
         y = self._claim(idx, input, key, stream)
         if y is not None:

@@ -14,8 +14,9 @@ the same C ABI (``include/sdnq_hip.h``) and with the same signatures / asserts a
 
 ``layer_forward`` is what makes ``torch.compile(model, fullgraph=True)`` work on an SDNQ model: under compilation
 ``SDNQLayer.forward`` emits ONE opaque op per layer (the module is found through an integer handle, a Dynamo constant), whose
-implementation is the ordinary eager forward -- linked projections, weight caches and all; its fake implementation only
-needs the layer's out_features.
+implementation is the ordinary eager forward with its weight-side caches, but WITHOUT the identity-keyed reuse of activations
+(activation cache, linked projections): Inductor recycles buffers in place, so "same tensor object, same version" proves nothing
+inside a compiled graph.  Its fake implementation only needs the layer's out_features.
 """
 from __future__ import annotations
 
@@ -105,6 +106,10 @@ def layer_handle(module: torch.nn.Module) -> int:
     stored as the plain attribute ``_sdnq_hip_handle`` -- a constant to Dynamo -- and registered here so that the operator (and
     its fake implementation, at trace time) can find the layer."""
     h = module.__dict__.get("_sdnq_hip_handle")
+    if h is not None:
+        ref = _layers.get(h)
+        if ref is None or ref() is not module:  # a handle copied along with the module's __dict__ (copy / pickle): not this module's
+            h = None
     if h is None:
         h = _next_handle[0]
         _next_handle[0] += 1
@@ -124,7 +129,9 @@ def _layer(handle: int) -> torch.nn.Module:
 @custom_op("sdnq_hip::layer_forward", mutates_args=())
 def layer_forward(input: torch.Tensor, handle: int) -> torch.Tensor:
     mod = _layer(handle)
-    y = mod.forward_func(mod, input)
+    from .linear import identity_reuse_disabled
+    with identity_reuse_disabled():  # no tensor-identity-keyed reuse inside a compiled graph (linear.py: Inductor recycles buffers in place)
+        y = mod.forward_func(mod, input)
     return y.clone() if y._base is not None and y._base is input else y  # a custom op must not return an alias of its input
 
 

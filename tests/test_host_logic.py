@@ -125,6 +125,10 @@ def test_link_projections_wiring():
     deq = quantized(Attn(64, 0), weights_dtype="uint4", use_quantized_matmul=False)
     assert sdnq_amd.link_projections(deq) == 1 and deq.to_q.__dict__["_sdnq_group"][0].float_mode
     assert not blk.to_q.__dict__["_sdnq_group"][0].float_mode
+    # members whose parameters are not all resident on one GPU (group / sequential offload, multi-device device_map: here simply
+    # the CPU): the group steps aside instead of raising -- the members then run alone, as the reference's layers do
+    from sdnq_amd import ops
+    assert g._operands(ops.MM_I8) is False and g.gemm is None
     # accelerate() re-links from scratch and honours the switch
     from sdnq_amd import linear as L
     old = L.LINK_PROJECTIONS

@@ -97,3 +97,46 @@ def test_compiled_block_equals_eager(cfg, gpu_device):
     b = torch.randint(-128, 128, (128, 96), dtype=torch.int8, device=gpu_device)
     sa, sb = torch.rand(64, 1, device=gpu_device), torch.rand(1, 96, device=gpu_device)
     assert torch.equal(torch.ops.sdnq_hip.scaled_mm(a, b, sa, sb, None, torch.bfloat16), sdnq_amd.int_scaled_mm_func(a, b, sa, sb, None, torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_layer_forward_op_never_reuses_by_tensor_identity(gpu_device):
+    """Inductor recycles dead buffers in place and writes through raw pointers: the same tensor object, address, geometry and
+    version can hold NEW values when the next layer is called (round-2 advisor finding).  The `sdnq_hip::layer_forward` operator
+    therefore must not serve a quantized activation (or a parked sibling output) keyed on tensor identity.  Emulated here without
+    Inductor: the input of linked q / k / v projections is overwritten in place with its version counter preserved."""
+    blk = _quantized_block(gpu_device, weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    sdnq_amd.accelerate(blk)
+    x = torch.randn(1, 64, 128, device=gpu_device, dtype=torch.bfloat16)
+    x2 = torch.randn(1, 64, 128, device=gpu_device, dtype=torch.bfloat16)
+    with torch.no_grad():
+        want_q = blk.to_q(x.clone())
+        want_k2 = blk.to_k(x2.clone())
+        sdnq_amd.invalidate()
+        buf = x.clone()
+        q = torch.ops.sdnq_hip.layer_forward(buf, blk.to_q._sdnq_hip_handle)
+        with torch.autograd._unsafe_preserve_version_counter(buf):
+            buf.copy_(x2)  # "buf7 = buf1  # reuse": new contents, same object / address / geometry / version
+        k2 = torch.ops.sdnq_hip.layer_forward(buf, blk.to_k._sdnq_hip_handle)
+        assert torch.equal(q, want_q)
+        assert torch.equal(k2, want_k2)  # stale with identity-keyed reuse: to_k would be served from x's quantized copy / group outputs
+
+
+def test_copies_of_a_layer_get_their_own_operator_handle():
+    """copy.deepcopy / pickle must not carry the original's operator handle, projection group or kernel-ready tensor cache
+    (round-2 advisor finding: a deep-copied model ran the ORIGINAL module's weights under torch.compile)."""
+    import copy
+    import pickle
+    lin = torch.nn.Linear(64, 32).to(torch.bfloat16)
+    layer, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True))
+    layer.__dict__["_sdnq_hip_state"] = object()
+    h = layer._sdnq_hip_handle
+    for clone in (copy.deepcopy(layer), pickle.loads(pickle.dumps(layer))):
+        assert clone._sdnq_hip_handle != h
+        assert torch_ops._layer(clone._sdnq_hip_handle) is clone and torch_ops._layer(h) is layer
+        assert "_sdnq_hip_state" not in clone.__dict__ and "_sdnq_group" not in clone.__dict__
+        assert torch.equal(clone.weight, layer.weight) and clone.weight is not layer.weight
+    # a handle copied by hand (clone.__dict__.update) is re-issued on the next registration
+    other = copy.copy(layer)
+    other.__dict__["_sdnq_hip_handle"] = h
+    assert torch_ops.layer_handle(other) != h and torch_ops._layer(h) is layer
