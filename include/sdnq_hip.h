@@ -10,7 +10,9 @@
  *   - stream-ordered and non-blocking on `stream` (a hipStream_t passed as void*);
  *   - no allocation: outputs and workspace are caller-provided;
  *   - returns SDNQ_OK (0) or a negative SdnqStatus; never throws across the ABI;
- *   - thread-safe: no mutable global state.
+ *   - thread-safe: no mutable global state on any data path.  The one process-wide knob, sdnq_hip_set_tile_override (a tuning /
+ *     test aid that pins the GEMM tile configuration; atomic, default "off"), changes which kernel computes a result, never the
+ *     result: every configuration is bit-identical for int8 and within the stated tolerance for fp8 / float.
  *
  * Memory layouts ("physical" = what is in HBM):
  *   weight   physical [N][K] with K contiguous (the reference's transposed qmm layout, logical

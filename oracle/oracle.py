@@ -57,6 +57,12 @@ def build_oracle() -> str:
                "-o", tmp, _SRC, "-lm"]
         subprocess.run(cmd, check=True)
         os.replace(tmp, so)
+        for other in os.listdir(out_dir):  # builds for another host CPU / an older source: stale, do not let them pile up or travel
+            if other.startswith("libsdnq_oracle_") and other.endswith(".so") and os.path.join(out_dir, other) != so:
+                try:
+                    os.remove(os.path.join(out_dir, other))
+                except OSError:
+                    pass
     return so
 
 

@@ -650,13 +650,15 @@ def test_fused_conv_quant_ties_and_large_image(gpu_device):
         assert torch.equal(xq, rq), int((xq != rq).sum())
 
 
-def test_flux_size_int4_hadamard_layer_vs_oracle(gpu_device):
+@pytest.mark.parametrize("n", [1024, 12288])
+def test_flux_size_int4_hadamard_layer_vs_oracle(n, gpu_device):
     """BASELINE configs[3] geometry (FLUX.1-dev: 4096 + 512 tokens, d = 3072), int4 + Hadamard-256, int8 MFMA: one full-size
-    layer against the oracle on all rows (rel-L2 bound of the Hadamard configs) plus row-slab independence (bit-exact)."""
+    layer against the oracle on all rows (rel-L2 bound of the Hadamard configs) plus row-slab independence (bit-exact).
+    N = 12288 (proj_mlp) is 864 tiles: the 256x256 half-tile-ring configuration the FLUX step spends most of its time in."""
     import sdnq_amd
     from tests.modules_util import oracle_from_module
     torch.manual_seed(3)
-    m, k, n = 4608, 3072, 1024
+    m, k = 4608, 3072
     lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
     mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256,
                                                                    use_quantized_matmul=True))
