@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant",
                             "sdxl_attn_int8", "flux_attn_int8", "sdxl_unet_all"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
+    p.add_argument("--tp-chunks", type=int, default=2, help="with --tp: M chunks per layer (gather of chunk i on a side stream under the matmul of chunk i + 1; 1 = plain)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -101,7 +102,7 @@ def expand_layers(shape_list, scale=1.0):
     return seq
 
 
-def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0):
+def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0, tp_chunks=1):
     """-> list of (name, module, x, M, K, N, bias). One module per layer instance (distinct weights, like a real UNet /
     DiT); one activation tensor per distinct input_key: layers that consume the same tensor in the real model (q/k/v
     projections, every cross-attention k/v) get the SAME tensor object here, all others get their own."""
@@ -124,7 +125,7 @@ def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=
             # tensor parallel: every rank holds the same quantized "checkpoint" layer and takes its slab of output channels
             # (views of the stored tensors, sdnq_amd.parallel.column_shard_module); M = 1 embedding layers stay replicated
             from sdnq_amd.parallel import column_shard_module
-            mod = column_shard_module(mod, tp_rank, tp_world)
+            mod = column_shard_module(mod, tp_rank, tp_world, chunks=tp_chunks)
         layers.append((name, mod, x, m, k, n, has_bias))
     return layers
 
@@ -638,7 +639,7 @@ def main():
         layers = build_conv_layers(shape_list, cfg_kwargs, device, seed=rank)
     else:
         layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
-                              tp_world=world if tp else 1, seed=0 if tp else rank)
+                              tp_world=world if tp else 1, seed=0 if tp else rank, tp_chunks=args.tp_chunks)
     if args.fuse_projections and not is_conv and not tp:
         layers = fuse_shared_input_layers(layers)
     linked = 0
@@ -707,7 +708,7 @@ def main():
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         **({"tp": {"ranks": world, "rank_devices": [f"cuda:{r}" for r in range(world)], "rccl_version": list(torch.cuda.nccl.version()),
                    "sharded_layers": sum(1 for l in layers if type(l[1]).__name__ == "ColumnShardedLinear"),
-                   "collective": "all_gather_into_tensor of [M, N/W] bf16 per layer + one transposing copy"}} if tp else {}),
+                   "collective": "all_gather_into_tensor of [M, N/W] bf16 per layer + sdnq_hip_unshard_columns", "m_chunks": args.tp_chunks}} if tp else {}),
         "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
         "step_latency_ms": round(ms_per_step, 4),
     }

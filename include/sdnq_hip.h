@@ -298,6 +298,18 @@ int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, const void* 
 int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, const SdnqWeight* w, float qmin,
                              float qmax, sdnq_stream_t stream);
 
+/* ---- 8(e): tensor-parallel glue ------------------------------------------------------------------
+ * Re-assembly of a column-sharded Linear's output after the RCCL all-gather (the reference has no inference parallelism, SURVEY 2.1;
+ * north_star: "large Linear layers are optionally column-sharded across the 8 GPUs of one node with RCCL all-gather over xGMI").
+ * gathered: [world][m_rows][wmax] -- rank r's slab y_r (its N / world output channels of rows [m0, m0 + m_rows)), padded to the
+ * widest slab; out: row-major [m][N] with N = starts[world]; out[m0 + i][starts[r] + c] = gathered[r][i][c] for c < starts[r+1] -
+ * starts[r].  starts: HOST array of world + 1 channel offsets (multiples of 16 / elem_bytes... of 8 elements at least; the
+ * reference's N % 16 rule gives multiples of 16).  One HBM-bound pass; m0 / m_rows let a pipelined caller un-shard one M chunk
+ * while the next chunk's gather is in flight. */
+#define SDNQ_MAX_TP_RANKS 64
+int sdnq_hip_unshard_columns(const void* gathered, void* out, int elem_bytes, int64_t m0, int64_t m_rows, int64_t m,
+                             int64_t wmax, int world, const int64_t* starts, sdnq_stream_t stream);
+
 /* ---- 8(f) rank 3: convolution as GEMM -----------------------------------------------------------
  * replaces the F.unfold(...).transpose(1, 2) of process_conv_input (layers/conv/forward.py:30-76) for Conv1d (height = 1,
  * kh = 1) and Conv2d inputs x [batch][channels][height][width] of `dtype`: out [M][K] with rows m = (b, h_out, w_out),

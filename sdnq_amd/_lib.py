@@ -29,7 +29,7 @@ EXPORTS = [
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
-    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp",
+    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns",
 ]
 
 
@@ -58,7 +58,7 @@ _lock = threading.Lock()
 _lib = None
 
 
-_SRCS = ("api", "rowquant", "gemm", "dequant", "quantize", "conv", "attention")
+_SRCS = ("api", "rowquant", "gemm", "dequant", "quantize", "conv", "attention", "parallel")
 _FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
 
 
@@ -114,6 +114,7 @@ def _declare(lib):
     lib.sdnq_hip_device_supported.argtypes = [c.c_int]
     lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_unshard_columns.argtypes = [vp, vp, i32, i64, i64, i64, i64, i32, c.POINTER(c.c_int64), vp]
     lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
     lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
     lib.sdnq_hip_requant_asym.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, vp]

@@ -10,7 +10,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="${SDNQ_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
 OBJ="$HERE/../../build/obj"
 mkdir -p "$OBJ"
-SRCS="api rowquant gemm dequant quantize conv attention"
+SRCS="api rowquant gemm dequant quantize conv attention parallel"
 HDR_HASH=$(cat "$HERE"/*.h "$HERE/../../include/sdnq_hip.h" | sha256sum | cut -d' ' -f1)
 pids=()
 ALL=""

@@ -550,6 +550,17 @@ def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor
     return t
 
 
+def unshard_columns(gathered: torch.Tensor, out: torch.Tensor, starts, m0: int = 0) -> torch.Tensor:
+    """out[m0 + i][starts[r] + c] = gathered[r][i][c]: the row-major re-assembly of a column-sharded layer's all-gathered output
+    (sdnq_hip_unshard_columns).  gathered [W, rows, wmax] (rank-major, slabs padded to the widest), out [M, N] with N = starts[W]."""
+    _require_cuda(gathered, out)
+    world, rows, wmax = gathered.shape
+    arr = (ctypes.c_int64 * (world + 1))(*[int(v) for v in starts])
+    check(_lib.load().sdnq_hip_unshard_columns(gathered.data_ptr(), out.data_ptr(), out.element_size(), m0, rows, out.shape[0], wmax,
+                                               world, arr, _stream(out)), "unshard_columns")
+    return out
+
+
 def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Tensor, tuple]:
     """F.unfold(x, ...).transpose(1, 2) for x [B, C, H, W] -> ([B * H_out * W_out, C * kh * kw], (B, H_out, W_out));
     HIP replacement of process_conv_input's unfold (layers/conv/forward.py:75)."""

@@ -23,9 +23,9 @@ per output row (N / W stays a multiple of 16, utils.py:96-97).  ``column_shard_l
 slab) is kept for building sharded models from float checkpoints; with SVD it derives per-shard factors, the module slicer does not.
 
 Why the gather is not "in place": RCCL collectives move one contiguous buffer per rank, and rank r's columns of a row-major
-[M, N] matrix are M strided pieces, so the gathered [W, M, N/W] buffer needs one transposing copy (fused here into a single
-strided copy kernel).  A copy-free variant needs the GEMM epilogue to store straight into every peer's [M, N] buffer over xGMI
-(IPC-mapped peer memory): not built.
+[M, N] matrix are M strided pieces, so the gathered [W, M, N/W] buffer needs one transposing copy: ``sdnq_hip_unshard_columns``
+(csrc/parallel.hip), one HBM-bound pass that also trims the padding of uneven shards.  A copy-free variant needs the GEMM epilogue
+to store straight into every peer's [M, N] buffer over xGMI (IPC-mapped peer memory): not built.
 """
 from __future__ import annotations
 
@@ -46,33 +46,86 @@ def shard_bounds(n: int, rank: int, world: int, multiple: int = 16) -> tuple[int
 
 
 class ColumnShardedLinear(torch.nn.Module):
-    """Holds this rank's slab of a Linear; forward = local forward + all-gather along the channel axis."""
+    """Holds this rank's slab of a Linear; forward = local forward + all-gather along the channel axis.
 
-    def __init__(self, local: torch.nn.Module, n_total: int, rank: int, world: int, group=None):
+    On GPU tensors the re-assembly [W, M, w] -> [M, N] is ONE HIP pass (``sdnq_hip_unshard_columns``; uneven shards included: the
+    local slab is written into a padded gather buffer, no zeros / cat), and with ``chunks > 1`` the M rows are processed as a
+    pipeline: the all-gather of chunk i runs on a side stream while the local matmul of chunk i + 1 runs on the caller's stream
+    (row-wise activation quantization, the matmul and its epilogue are all per activation row, so a chunked layer is bit-identical
+    to the unchunked one).  The gather itself stays the bound -- 2 M N / W bytes per rank over one 153 GB/s xGMI link -- the
+    pipeline only hides the matmul under it.  CPU tensors (the gloo tests) take the torch path."""
+
+    def __init__(self, local: torch.nn.Module, n_total: int, rank: int, world: int, group=None, chunks: int = 1):
         super().__init__()
         self.local = local
         self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
         self.bounds = [shard_bounds(n_total, r, world) for r in range(world)]
         self.even = len({b - a for a, b in self.bounds}) == 1
+        self.chunks = max(1, int(chunks))
+        self._side = None  # side stream of the pipelined gather (per device)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_torch(self, y2: torch.Tensor, m: int) -> torch.Tensor:
         import torch.distributed as dist
-        y_local = self.local(x)
-        lead = y_local.shape[:-1]
-        y2 = y_local.reshape(-1, y_local.shape[-1]).contiguous()
-        m = y2.shape[0]
         if self.even:
             gathered = torch.empty((self.world * m, y2.shape[1]), device=y2.device, dtype=y2.dtype)  # rank-major concat
             dist.all_gather_into_tensor(gathered, y2, group=self.group)
-            out = gathered.view(self.world, m, y2.shape[1]).permute(1, 0, 2).reshape(m, self.n_total)
-        else:  # uneven shards: pad every slab to the widest one (collectives want equal messages), gather, trim
-            wmax = max(b - a for a, b in self.bounds)
-            padded = torch.zeros((m, wmax), device=y2.device, dtype=y2.dtype)
-            padded[:, : y2.shape[1]] = y2
-            gathered = torch.empty((self.world * m, wmax), device=y2.device, dtype=y2.dtype)
-            dist.all_gather_into_tensor(gathered, padded, group=self.group)
-            g3 = gathered.view(self.world, m, wmax)
-            out = torch.cat([g3[r, :, : b - a] for r, (a, b) in enumerate(self.bounds)], dim=-1)
+            return gathered.view(self.world, m, y2.shape[1]).permute(1, 0, 2).reshape(m, self.n_total)
+        # uneven shards: pad every slab to the widest one (collectives want equal messages), gather, trim
+        wmax = max(b - a for a, b in self.bounds)
+        padded = torch.zeros((m, wmax), device=y2.device, dtype=y2.dtype)
+        padded[:, : y2.shape[1]] = y2
+        gathered = torch.empty((self.world * m, wmax), device=y2.device, dtype=y2.dtype)
+        dist.all_gather_into_tensor(gathered, padded, group=self.group)
+        g3 = gathered.view(self.world, m, wmax)
+        return torch.cat([g3[r, :, : b - a] for r, (a, b) in enumerate(self.bounds)], dim=-1)
+
+    def _gather_chunk(self, y2: torch.Tensor, out: torch.Tensor, m0: int):
+        """All-gather the slab rows y2 [rows, w_r] and scatter them into out[m0 : m0 + rows] (current stream)."""
+        import torch.distributed as dist
+        from . import ops
+        rows = y2.shape[0]
+        wmax = max(b - a for a, b in self.bounds)
+        if y2.shape[1] == wmax and y2.is_contiguous():
+            send = y2
+        else:  # the narrower slabs of an uneven split travel padded (the pad columns are never read back)
+            send = torch.empty((rows, wmax), device=y2.device, dtype=y2.dtype)
+            send[:, : y2.shape[1]] = y2
+        gathered = torch.empty((self.world, rows, wmax), device=y2.device, dtype=y2.dtype)
+        dist.all_gather_into_tensor(gathered.view(self.world * rows, wmax), send, group=self.group)
+        ops.unshard_columns(gathered, out, [a for a, _ in self.bounds] + [self.n_total], m0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        k = x.shape[-1]
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, k)
+        m = x2.shape[0]
+        es = x.element_size()
+        if not x.is_cuda or m == 0 or any((a * es) % 16 for a, _ in self.bounds):
+            y_local = self.local(x)
+            return self._forward_torch(y_local.reshape(-1, y_local.shape[-1]).contiguous(), m).view(*lead, self.n_total)
+        out = torch.empty((m, self.n_total), device=x.device, dtype=x.dtype)
+        chunks = min(self.chunks, max(1, m // 256))
+        if chunks == 1:
+            y = self.local(x2)
+            self._gather_chunk(y, out, 0)
+            return out.view(*lead, self.n_total)
+        # pipeline over M: matmul of chunk i + 1 (caller's stream) overlaps gather + scatter of chunk i (side stream)
+        cur = torch.cuda.current_stream(x.device)
+        if self._side is None or self._side.device != x.device:
+            self._side = torch.cuda.Stream(device=x.device)
+        side = self._side
+        side.wait_stream(cur)  # `out` was allocated on the caller's stream
+        step = -(-m // chunks)
+        step = (step + 31) // 32 * 32
+        for m0 in range(0, m, step):
+            y = self.local(x2[m0:m0 + step])
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                self._gather_chunk(y, out, m0)
+            y.record_stream(side)
+        cur.wait_stream(side)
         return out.view(*lead, self.n_total)
 
 
@@ -143,12 +196,13 @@ def shard_quantized_module(mod: torch.nn.Module, a: int, b: int) -> torch.nn.Mod
 
 
 @torch.no_grad()
-def column_shard_module(mod: torch.nn.Module, rank: int, world: int, group=None) -> ColumnShardedLinear:
+def column_shard_module(mod: torch.nn.Module, rank: int, world: int, group=None, chunks: int = 1) -> ColumnShardedLinear:
     """Tensor-parallel shard of a PRE-QUANTIZED SDNQLinear (checkpoint layout untouched): this rank's slab (views of mod's
-    parameters) + the RCCL all-gather of the outputs.  Bit-identical to `mod` for every storage format."""
+    parameters) + the RCCL all-gather of the outputs.  Bit-identical to `mod` for every storage format.  chunks > 1 pipelines the
+    gather of one M chunk under the matmul of the next (ColumnShardedLinear)."""
     n = int(mod.sdnq_dequantizer.original_shape[0])
     a, b = shard_bounds(n, rank, world)
-    return ColumnShardedLinear(shard_quantized_module(mod, a, b), n, rank, world, group)
+    return ColumnShardedLinear(shard_quantized_module(mod, a, b), n, rank, world, group, chunks=chunks)
 
 
 @torch.no_grad()

@@ -45,6 +45,8 @@ def _rccl_worker(rank, world, port, q):
             x = torch.randn(2, 100, 640, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(dev)
             y = column_shard_module(mod, rank, world)(x)
             ok = ok and torch.equal(y, mod(x))
+            x3 = torch.randn(700, 640, generator=torch.Generator().manual_seed(2)).to(torch.bfloat16).to(dev)
+            ok = ok and torch.equal(column_shard_module(mod, rank, world, chunks=2)(x3), mod(x3))  # gather of chunk 0 under the matmul of chunk 1
         torch.cuda.synchronize()
         q.put((rank, bool(ok)))
     finally:
@@ -68,3 +70,83 @@ def test_column_shard_module_two_rccl_ranks(gpu_device):
         p.join(300)
         assert p.exitcode == 0
     assert dict(q.get(timeout=10) for _ in range(2)) == {0: True, 1: True}
+
+
+def test_sequential_shards_at_cfg5_geometry(gpu_device):
+    """BASELINE configs[4]: FLUX.1-dev proj_mlp, int8 + SVD rank 32, TP = 8 -- N = 12288, K = 3072, bias, 4096 + 512 tokens.  The
+    eight slabs of 1536 channels (their own tile choices: 18 x 12 tiles of 256 x 128 instead of the 864 tiles of the whole layer)
+    computed one after the other and concatenated must equal the unsharded layer bit for bit, for the w8a8 GEMM rows and for the
+    M = 1 (adaLN-style) branch."""
+    import sdnq_amd
+    from sdnq_amd.parallel import shard_bounds, shard_quantized_module
+    torch.manual_seed(0)
+    n, k, world = 12288, 3072, 8
+    lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True, use_svd=True,
+                                                                   svd_rank=32))
+    slabs = [shard_quantized_module(mod, *shard_bounds(n, r, world)) for r in range(world)]
+    assert all(s.weight.shape[1 if s.sdnq_dequantizer.weight_is_transposed else 0] == 1536 for s in slabs)
+    for m in (4608, 1):
+        x = torch.randn(m, k, device=gpu_device, dtype=torch.bfloat16)
+        x[:, 11] *= 20
+        want = mod(x)
+        got = torch.cat([s(x) for s in slabs], dim=-1)
+        assert torch.equal(got, want), (m, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("world,n,m0,rows,m", [(8, 12288, 0, 4608, 4608), (4, 1280 + 16, 64, 100, 300), (3, 96, 0, 1, 1), (2, 4096, 1024, 1024, 2048)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_unshard_columns_kernel(world, n, m0, rows, m, dt, gpu_device):
+    """sdnq_hip_unshard_columns against the torch re-assembly it replaces: even and uneven shard widths (padded slabs), a row
+    window of the output (the M-chunked pipeline), 16- and 32-bit elements; rows outside the window stay untouched."""
+    from sdnq_amd import ops
+    from sdnq_amd.parallel import shard_bounds
+    bounds = [shard_bounds(n, r, world) for r in range(world)]
+    wmax = max(b - a for a, b in bounds)
+    g = torch.randn(world, rows, wmax, device=gpu_device).to(dt)
+    out = torch.full((m, n), -7.0, device=gpu_device, dtype=dt)
+    ops.unshard_columns(g, out, [a for a, _ in bounds] + [n], m0)
+    want = torch.full((m, n), -7.0, device=gpu_device, dtype=dt)
+    want[m0:m0 + rows] = torch.cat([g[r, :, : b - a] for r, (a, b) in enumerate(bounds)], dim=-1)
+    assert torch.equal(out, want)
+
+
+def _rccl_single_rank_worker(port, q):
+    import torch.distributed as dist
+    import sdnq_amd
+    from sdnq_amd.parallel import column_shard_module
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(640, 1280, bias=True).to(torch.bfloat16).to(dev)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True))
+        x = torch.randn(2, 1000, 640, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(dev)
+        want = mod(x)
+        ok = True
+        for chunks in (1, 3):  # the pipelined (side-stream) gather is bit-identical to the plain one
+            y = column_shard_module(mod, 0, 1, chunks=chunks)(x)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(y, want)
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_shard_module_one_rccl_rank_plain_and_pipelined(gpu_device):
+    """The RCCL path end to end on the one GPU a test box has: all-gather (world 1) + the un-shard kernel, plain and M-chunked with
+    the gather on a side stream, against the unsharded layer."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(port, q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=10) is True

@@ -7,6 +7,6 @@ cd "$ROOT/sdnq_amd/csrc"
 mkdir -p "$ROOT/build"
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument -DSDNQ_TRACE"
 OBJS=()
-for f in api rowquant gemm dequant quantize conv attention; do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/trace_$f.o & OBJS+=(/tmp/trace_$f.o); done; wait
+for f in api rowquant gemm dequant quantize conv attention parallel; do /opt/rocm/bin/hipcc $F -c $f.hip -o /tmp/trace_$f.o & OBJS+=(/tmp/trace_$f.o); done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$ROOT/build/libsdnq_hip_trace.so" "${OBJS[@]}"
 echo built
