@@ -307,6 +307,65 @@ def cpu_baseline(shape_list, mm_name, budget_s):
             "sample": f"row-quantize + {mm_name} scaled-mm over the step's {len(sample)} distinct GEMM shapes (MxKxN " + ",".join(sample) + f"), {passes} passes, {t_total:.1f}s"}
 
 
+def _physical_cores() -> int:
+    """Physical cores of this host (SMT siblings counted once), from the kernel's topology files; os.cpu_count() if unreadable."""
+    seen = set()
+    try:
+        base = "/sys/devices/system/cpu"
+        for d in os.listdir(base):
+            if d.startswith("cpu") and d[3:].isdigit():
+                f = os.path.join(base, d, "topology", "thread_siblings_list")
+                if os.path.exists(f):
+                    seen.add(open(f).read().strip())
+    except OSError:
+        pass
+    return len(seen) if seen else (os.cpu_count() or 1)
+
+
+def cpu_baseline_torch_eager(shape_list, mm_name, budget_s):
+    """The reference's CPU-EAGER path of the quantized matmul restated with the torch CPU operators it issues -- quantize_int_mm_input
+    (linear_int8.py:15-22 -> quant_utils.py:265-273: amax, divide, round, clamp, cast), torch._int_mm (kernel_wrappers.py:107) and the
+    addcmul epilogue (kernel_wrappers.py:132-136) -- on a bounded sample of the step's layer list, torch threads pinned to the
+    PHYSICAL core count.  This is what a user of the reference gets on this host's CPU; the C oracle ("port") is 10-15x slower at
+    the matmul (a plain triple loop, the checker's job is to be obviously right)."""
+    import torch
+    phys = _physical_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(phys)
+    try:
+        g = torch.Generator().manual_seed(0)
+        seen = sorted({(e[1], e[2], e[3], e[4]) for e in shape_list if e[1] >= 32}, key=lambda s: s[0] * s[1] * s[2])
+        data = {}
+        for (m, k, n, b) in seen:
+            x = torch.randn(m, k, generator=g).to(torch.bfloat16)
+            w = torch.randint(-127, 128, (n, k), dtype=torch.int8, generator=g)
+            ws = torch.rand(1, n, generator=g) * 0.01 + 1e-4
+            bias = torch.randn(n, generator=g).to(torch.bfloat16) if b else None
+            data[(m, k, n, b)] = (x, w.t(), ws, bias)  # weight as the reference holds it: logical [K, N], strides (1, K)
+        done_ops, t_total, passes = 0, 0.0, 0
+        while t_total < budget_s:
+            for key in seen:
+                m, k, n, b = key
+                x, wt, ws, bias = data[key]
+                t0 = time.perf_counter()
+                xf = x.to(torch.float32)
+                xs = torch.amax(xf.abs(), dim=-1, keepdims=True).div_(127)
+                xq = torch.div(xf, xs).round_().clamp_(-128, 127).to(torch.int8)
+                acc = torch._int_mm(xq, wt)
+                y = acc.to(torch.float32).mul_(xs)
+                y = torch.addcmul(bias, y, ws) if bias is not None else y.mul_(ws)
+                y = y.to(torch.bfloat16)
+                t_total += time.perf_counter() - t0
+                done_ops += 2 * m * k * n + (m * n if b else 0)
+            passes += 1
+    finally:
+        torch.set_num_threads(old)
+    return {"value": round(done_ops / t_total / 1e9, 2), "unit": "GOP/s", "cores": phys, "threads": phys, "host_logical_cpus": os.cpu_count(),
+            "kind": "port", "impl": "torch_eager",
+            "sample": f"torch CPU restatement of the reference's eager path (row-quantize, torch._int_mm, addcmul epilogue) over the step's {len(seen)} "
+                      f"distinct GEMM shapes, {passes} passes, {t_total:.1f}s, torch threads = physical cores ({phys} of {os.cpu_count()} logical CPUs)"}
+
+
 def _cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -384,6 +443,38 @@ def cpu_baseline_cfg1(budget_s: float = 12.0):
     ops = 2 * 4096 * n * k
     out["value_gops_M4096_all_cores_port"] = round(ops / (out["port"]["M4096_all_cores"]["ms"] / 1e3) / 1e9, 2)
     out["value_gops_M4096_all_cores_torch_eager"] = round(ops / (out["torch_eager"]["M4096_all_cores"]["ms"] / 1e3) / 1e9, 2)
+    return out
+
+
+def cfg1_gpu(device):
+    """The GPU twin of cpu_baseline.cfg1 (BASELINE configs[0]: one 4096 x 4096 int8 row-wise Linear, use_quantized_matmul=False): the
+    layer's forward on this GPU at M in {1, 64, 4096}, fp32 and bf16, graph-replayed launches timed with events -> ms per call."""
+    import sdnq_amd
+    out = {}
+    for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+        torch.manual_seed(0)
+        lin = torch.nn.Linear(4096, 4096, bias=True).to(dt).to(device)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=False))
+        for m in (1, 64, 4096):
+            x = torch.randn(m, 4096, device=device, dtype=dt)
+            st = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(st), torch.no_grad():
+                mod(x)
+                st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    for _ in range(10):
+                        mod(x)
+                g.replay()
+                st.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(st)
+                for _ in range(3):
+                    g.replay()
+                e1.record(st)
+                st.synchronize()
+            ms = e0.elapsed_time(e1) / 30
+            out[f"M{m}_{name}"] = {"ms": round(ms, 4), "gflops": round(2 * m * 4096 * 4096 / ms / 1e6, 1)}
     return out
 
 
@@ -740,9 +831,19 @@ def main():
                                   "traffic_over_algorithmic": round(traffic / (gk["bytes"] / gk["launches"]), 3) if traffic else None}
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:
-                result["cpu_baseline"] = cpu_baseline(shape_list, mm_name, args.cpu_seconds)
+                port = cpu_baseline(shape_list, mm_name, args.cpu_seconds / 2)
+                result["cpu_baseline"] = port
+                if mm_name == "int8":
+                    # headline CPU figure = the torch-eager restatement (the reference's CPU path IS torch); the C oracle stays beside it
+                    try:
+                        te = cpu_baseline_torch_eager(shape_list, mm_name, args.cpu_seconds / 2)
+                        te["port_c_oracle"] = {"value": port["value"], "unit": port["unit"], "cores": port["cores"], "sample": port["sample"]}
+                        result["cpu_baseline"] = te
+                    except Exception as e:  # noqa: BLE001  (torch._int_mm missing on this host's build: keep the C port)
+                        result["cpu_baseline"]["torch_eager_error"] = repr(e)
                 if args.workload == "sdxl_int8":  # the reference's own CPU-runnable case (BASELINE configs[0])
                     result["cpu_baseline"]["cfg1"] = cpu_baseline_cfg1(args.cpu_seconds)
+                    result["cpu_baseline"]["cfg1"]["gpu"] = cfg1_gpu(device)  # the same layer on this GPU, side by side
                     result["cpu_baseline"]["cpu_model"] = result["cpu_baseline"]["cfg1"]["cpu_model"]
                     result["cpu_baseline"]["torch_version"] = torch.__version__
             except Exception as e:  # noqa: BLE001
