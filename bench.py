@@ -55,6 +55,9 @@ def parse():
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--tp-chunks", type=int, default=2, help="with --tp: M chunks per layer (gather of chunk i on a side stream under the matmul of chunk i + 1; 1 = plain)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--launch", choices=["graph", "eager", "compile"], default=None,
+                   help="how a step is launched: one captured hipGraph (default), eager Python (= --no-graph), or torch.compile(mode='reduce-overhead') "
+                        "over the layer list (every SDNQ layer one sdnq_hip::layer_forward op; Inductor's own CUDA-graph trees do the replay)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--fuse-projections", action="store_true",
@@ -544,7 +547,9 @@ def attention_bench(args, device, distributed, world, rank):
         "config": {"workload": f"{args.workload}: {n_calls} attention calls of one denoising step, bs=1 ("
                                + ", ".join(f"{rep} x {h} heads {qn}x{kn}x{d}" for (_, h, qn, kn, d, rep) in calls) + ")",
                    "parallelism": f"{world} independent replicas" if distributed else "single GPU",
-                   "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16", "smooth_k": True,
+                   "launch": ("torch.compile(mode='reduce-overhead'): one sdnq_hip::layer_forward op per layer, no activation cache / linked projections inside the graph"
+                              if compiled is not None else ("eager" if graph is None else "hipGraph replay")), "activations": "bf16",
+                   **({"compile_seconds": round(compile_s, 1)} if compiled is not None else {}), "smooth_k": True,
                    "matmul_dtype": "int8", "pv_matmul_dtype": None, "ops_per_step": ops_per_step},
         "step_latency_ms": round(ms_per_step, 4),
     }
@@ -743,6 +748,42 @@ def main():
         run_step(layers)
     torch.cuda.synchronize()
     graph = None
+    if args.launch == "eager":
+        args.no_graph = True
+    compiled = None
+    if args.launch == "compile" and not tp:
+        # what `torch.compile(pipeline.unet, mode="reduce-overhead")` does to the Linear layers of an unmodified pipeline: Dynamo traces the
+        # module calls (SDNQLayer.forward emits one sdnq_hip::layer_forward op per layer), Inductor wraps the result in CUDA-graph trees
+        class Step(torch.nn.Module):
+            def __init__(self, layers):
+                super().__init__()
+                self.mods = torch.nn.ModuleList([l[1] for l in layers])
+                # the step's activations are buffers of the module (static addresses: the CUDA-graph trees do not copy them into
+                # private input buffers every replay, as they would 446 positional inputs); shared tensors stay ONE buffer
+                self.slot, seen = [], {}
+                for l in layers:
+                    if id(l[2]) not in seen:
+                        seen[id(l[2])] = len(seen)
+                        self.register_buffer(f"x{seen[id(l[2])]}", l[2], persistent=False)
+                    self.slot.append(seen[id(l[2])])
+
+            def forward(self):
+                xs = [getattr(self, f"x{i}") for i in self.slot]
+                return [mod(x) for mod, x in zip(self.mods, xs)]  # every output is a graph output: nothing is dead code
+
+        from sdnq_amd import torch_ops
+        for l in layers:
+            if hasattr(l[1], "sdnq_dequantizer"):
+                torch_ops.layer_handle(l[1])
+        step_mod = Step(layers)
+        t_c = time.perf_counter()
+        compiled = torch.compile(step_mod, mode="reduce-overhead", fullgraph=True)
+        with torch.no_grad():
+            for _ in range(3):
+                compiled()
+        torch.cuda.synchronize()
+        compile_s = time.perf_counter() - t_c
+        args.no_graph = True
     if not args.no_graph and not tp:
         side = torch.cuda.Stream(device=device)
         with torch.cuda.stream(side):
@@ -754,7 +795,10 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        if graph is not None:
+        if compiled is not None:
+            with torch.no_grad():
+                compiled()
+        elif graph is not None:
             graph.replay()
         else:
             run_step(layers)
@@ -792,7 +836,9 @@ def main():
         "config": {"workload": f"{args.workload}: {len(layers)} quantized {'Conv2d' if is_conv else 'Linear'} layers of one denoising step, bs=1 "
                                f"({sum(1 for l in layers if l[3] >= 32)} w8a8 GEMMs + {sum(1 for l in layers if l[3] < 32)} M=1 layers)",
                    "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
-                   "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16",
+                   "launch": ("torch.compile(mode='reduce-overhead'): one sdnq_hip::layer_forward op per layer, no activation cache / linked projections inside the graph"
+                              if compiled is not None else ("eager" if graph is None else "hipGraph replay")), "activations": "bf16",
+                   **({"compile_seconds": round(compile_s, 1)} if compiled is not None else {}),
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
                    "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
                    "linked_projection_groups": linked,

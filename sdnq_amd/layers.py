@@ -28,7 +28,7 @@ class SDNQLayer(torch.nn.Module):
 
     # per-object runtime state that must not travel with a copy: the operator handle names THIS module, the projection group and the
     # kernel-ready tensor cache point at the original's siblings / parameters
-    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_group", "_sdnq_hip_state")
+    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_hip_plan", "_sdnq_group", "_sdnq_hip_state")
 
     def __deepcopy__(self, memo):
         import copy
@@ -76,7 +76,15 @@ class SDNQLayer(torch.nn.Module):
             # under torch.compile: ONE opaque operator per layer (sdnq_amd/torch_ops.py) instead of a graph break at the ctypes calls
             handle = getattr(self, "_sdnq_hip_handle", None)
             if handle is not None:
-                return torch.ops.sdnq_hip.layer_forward(args[0], handle)
+                x = args[0]
+                plan = getattr(self, "_sdnq_hip_plan", None)
+                if plan is not None and x.numel() // x.shape[-1] >= 32:
+                    # rowquant + matmul as TWO operators: layers that consume one tensor then share its row quantization through
+                    # the graph's common-subexpression elimination (torch_ops.layer_matmul)
+                    xq, xs = torch.ops.sdnq_hip.rowquant(x, plan[1], plan[2])
+                    y = torch.ops.sdnq_hip.layer_matmul(xq, xs, handle, x.dtype)
+                    return y.view(*x.shape[:-1], y.shape[-1])
+                return torch.ops.sdnq_hip.layer_forward(x, handle)
         return self.forward_func(self, *args, **kwargs)
 
     def __repr__(self) -> str:

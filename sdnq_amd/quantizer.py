@@ -299,6 +299,9 @@ def sdnq_quantize_layer(layer: torch.nn.Module, quantization_config: SDNQConfig,
     layer = get_sdnq_wrapper_class(layer, get_forward_func(name, dq.quantized_matmul_dtype, dq.use_quantized_matmul))
     for key, value in tensors.items():
         setattr(layer, key, None if value is None else torch.nn.Parameter(value.to(dev), requires_grad=False))
+    if "_sdnq_hip_handle" in layer.__dict__:  # the tensors are in place now: decide how the layer traces under torch.compile
+        from . import torch_ops
+        torch_ops.layer_handle(layer)
     if kw["use_quantized_matmul"] and not dq.use_quantized_matmul and param_name not in quantization_config.modules_to_not_use_matmul:
         quantization_config.modules_to_not_use_matmul.append(param_name)
     return layer, quantization_config

@@ -115,6 +115,10 @@ def layer_handle(module: torch.nn.Module) -> int:
         _next_handle[0] += 1
         module.__dict__["_sdnq_hip_handle"] = h
         _layers[h] = weakref.ref(module, lambda _r, h=h: _layers.pop(h, None))
+    try:
+        module.__dict__["_sdnq_hip_plan"] = layer_plan(module)
+    except Exception:  # noqa: BLE001  (a foreign / half-built module: the whole-layer operator handles it)
+        module.__dict__["_sdnq_hip_plan"] = None
     return h
 
 
@@ -133,6 +137,49 @@ def layer_forward(input: torch.Tensor, handle: int) -> torch.Tensor:
     with identity_reuse_disabled():  # no tensor-identity-keyed reuse inside a compiled graph (linear.py: Inductor recycles buffers in place)
         y = mod.forward_func(mod, input)
     return y.clone() if y._base is not None and y._base is input else y  # a custom op must not return an alias of its input
+
+
+@custom_op("sdnq_hip::layer_matmul", mutates_args=())
+def layer_matmul(xq: torch.Tensor, xs: torch.Tensor, handle: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """The matmul half of a plain w8a8 layer on an activation that `sdnq_hip::rowquant` already quantized:
+    y [M, N] = scaled_mm(xq, Wq, xs, ws, bias).  Under torch.compile a layer whose forward is exactly rowquant + scaled_mm is traced
+    as these two operators (``layer_plan``), so that the graph's own common-subexpression elimination merges the row quantization of
+    layers that consume one tensor (to_q / to_k / to_v, every cross-attention to_k / to_v) -- the dataflow-level, and therefore safe,
+    form of the eager path's identity-keyed activation cache."""
+    from . import linear as L
+    mod = _layer(handle)
+    st = L._state(mod)
+    mm = ops.MM_I8 if xq.dtype == torch.int8 else ops.MM_FP8
+    wq, ws, zp = L._prepare_mm_weights(mod, st, mm)
+    if zp is not None or st.svd_up is not None:
+        raise _lib.SdnqHipError("sdnq_hip::layer_matmul: the layer changed to a form with zero-point / low-rank terms after tracing")
+    return ops.scaled_mm(mm, xq, wq, xs, ws, L._attr(mod, "bias"), out_dtype)
+
+
+@layer_matmul.register_fake
+def _(xq, xs, handle, out_dtype):
+    return xq.new_empty((xq.shape[0], _layer(handle).sdnq_dequantizer.out_features), dtype=out_dtype)
+
+
+def layer_plan(module: torch.nn.Module):
+    """("q", matmul dtype name, hadamard group) when the layer's forward at M >= 32 is exactly rowquant + scaled_mm (row-wise or
+    re-quantized weights, no zero-point term, no SVD, fp32 scales), else None: decided from the module's static configuration."""
+    from .common import dtype_dict
+    dq = module.__dict__.get("sdnq_dequantizer")
+    if dq is None or not dq.use_quantized_matmul or dq.is_conv or getattr(module, "svd_up", None) is not None:
+        return None
+    mmd = str(dq.quantized_matmul_dtype).replace("torch.", "")
+    if mmd not in ("int8", "float8_e4m3fn", "fp8"):
+        return None
+    sc = module.__dict__.get("_parameters", {}).get("scale")
+    if sc is None or sc.dtype != torch.float32:
+        return None
+    if dtype_dict[dq.weights_dtype]["is_unsigned"] and not dq.re_quantize_for_matmul:
+        return None  # zero-point term in the epilogue
+    had = dq.hadamard_group_size if dq.use_hadamard else 0
+    if had and dq.in_features > 5120:
+        return None
+    return ("q", "int8" if mmd == "int8" else "fp8", int(had))
 
 
 @layer_forward.register_fake
