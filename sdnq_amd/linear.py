@@ -68,8 +68,9 @@ class _ActivationCache:
         self.max_bytes = max_bytes
         self.entries = []  # most recent last: (tensor, key, params, result, pinned bytes)
 
-    def get(self, t: torch.Tensor, params):
-        key = None if _no_identity_reuse[0] else tensor_key(t)
+    def get(self, t: torch.Tensor, params, key=None):
+        if key is None:
+            key = None if _no_identity_reuse[0] else tensor_key(t)
         if key is None:
             return None
         for i in range(len(self.entries) - 1, -1, -1):
@@ -79,11 +80,13 @@ class _ActivationCache:
                 return e[3]
         return None
 
-    def put(self, t: torch.Tensor, params, result):
-        key = None if _no_identity_reuse[0] else tensor_key(t)
+    def put(self, t: torch.Tensor, params, result, key=None, nbytes=None):
+        if key is None:
+            key = None if _no_identity_reuse[0] else tensor_key(t)
         if key is None:
             return
-        nbytes = t.numel() * t.element_size() + sum(r.numel() * r.element_size() for r in result if isinstance(r, torch.Tensor) and r is not t)
+        if nbytes is None:
+            nbytes = t.numel() * t.element_size() + sum(r.numel() * r.element_size() for r in result if isinstance(r, torch.Tensor) and r is not t)
         self.entries.append((t, key, params, result, nbytes))
         cap = max(CACHE_ACTIVATIONS, 0) if self.size is None else self.size
         lim = CACHE_ACTIVATION_BYTES if self.max_bytes is None else self.max_bytes
@@ -521,17 +524,18 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
         # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers
         params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
         use_cache = cache_input and CACHE_ACTIVATIONS > 0
-        hit = _act_cache.get(input, params) if use_cache else None
+        key = tensor_key(input) if (use_cache and not _no_identity_reuse[0]) else None  # one key for the look-up and the store
+        hit = _act_cache.get(input, params, key) if key is not None else None
         if hit is None:
-            x2 = input.reshape(-1, k)
+            x2 = input if input.dim() == 2 else input.reshape(-1, k)
             if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
                 x2 = x2.contiguous()
             if not x2.is_cuda:
                 raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
             y, xq, xs = ops.linear_w8a8(mm, x2, wq, ws, bias, input.dtype, had)
-            if use_cache:
-                _act_cache.put(input, params, (x2, xq, xs, None, None))
-            return y.view(*input.shape[:-1], n)
+            if key is not None:
+                _act_cache.put(input, params, (x2, xq, xs, None, None), key, m * k * (input.element_size() + 1) + 4 * m)
+            return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         x2, xq, xs, rowsum, xrot = hit
         return ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype).view(*input.shape[:-1], n)
     x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, wq if PREFETCH_WEIGHTS else None,
