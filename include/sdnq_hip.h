@@ -231,6 +231,13 @@ int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* out, int out
  * per-output-row symmetric quantization to the matmul dtype. wq: physical [N][K]; ws: [N] f32. */
 int sdnq_hip_requant(const SdnqWeight* w, int mm_dtype, void* wq, float* ws, sdnq_stream_t stream);
 
+/* sdnq_hip_requant with the option of KNOWN row scales: ws_known != 0 means ws[N] already holds the per-row scales (they depend
+ * only on the static weights; a caller that re-quantizes on every forward -- the reference's behaviour, dequantizer.py:204-239 --
+ * keeps these N floats and skips the pass that derives them).  Values are identical to sdnq_hip_requant.  4-bit packed weights in
+ * groups of a multiple of 64 take a table path (16 possible bytes per (row, group): four exact divisions per lane instead of
+ * sixteen); other formats recompute the scales and ignore ws_known. */
+int sdnq_hip_requant_ws(const SdnqWeight* w, int mm_dtype, void* wq, float* ws, int ws_known, sdnq_stream_t stream);
+
 /* asymmetric form for quantized_matmul_dtype "uint8": replaces re_quantize_uint_mm (dequantizer.py:178-187) ->
  * quantize_uint_mm (quant_utils.py:277-286): scale = (max - min) / 255, zero_point = min + 128 * scale per output row,
  * wq = int8 codes of (w - zero_point) / scale.  wq: physical [N][K] int8; ws, wzp: [N] f32. */

@@ -29,7 +29,7 @@ EXPORTS = [
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
-    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns",
+    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws",
 ]
 
 
@@ -117,6 +117,7 @@ def _declare(lib):
     lib.sdnq_hip_unshard_columns.argtypes = [vp, vp, i32, i64, i64, i64, i64, i32, c.POINTER(c.c_int64), vp]
     lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
     lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
+    lib.sdnq_hip_requant_ws.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, i32, vp]
     lib.sdnq_hip_requant_asym.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, vp]
     lib.sdnq_hip_unpack_mm.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp]
     lib.sdnq_hip_hadamard.argtypes = [vp, i32, i64, i64, i64, i32, vp, i64, vp]

@@ -294,7 +294,10 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
     if dq.re_quantize_for_matmul and asymmetric:
         wq, ws, zp = ops.requant_asym(st.qw)  # linear_uint8.py:109-111
     elif dq.re_quantize_for_matmul:
-        wq, ws = ops.requant(st.qw, mm)  # linear_int8.py:104-107; zero_point folded, none afterwards
+        # linear_int8.py:104-107; zero_point folded, none afterwards.  Per-call mode (SDNQ_HIP_CACHE_WEIGHTS=0): the N row scales of
+        # the first call are kept (4 bytes per output channel), the [N][K] operand is not
+        known = st.mm_scale if (st.mm == key and st.mm_weight is None) else None
+        wq, ws = ops.requant(st.qw, mm, known)
     else:
         ws = st.qw.keep[1]  # row-wise scale [N]
         ent = dtype_dict[dq.weights_dtype]
@@ -312,6 +315,8 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
                 zp = torch.add(zp, ws, alpha=128) if zp is not None else ws * 128
     if CACHE_WEIGHTS:
         st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, wq, ws, zp, None
+    elif dq.re_quantize_for_matmul and not asymmetric:
+        st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, None, ws, None, None  # row scales only
     return wq, ws, zp
 
 

@@ -424,12 +424,16 @@ def dequant(qw: QuantWeight, out_dtype: torch.dtype, hadamard_group: int = 0, us
     return out
 
 
-def requant(qw: QuantWeight, mm: int):
+def requant(qw: QuantWeight, mm: int, ws: torch.Tensor | None = None):
+    """re_quantize_int_mm / re_quantize_fp_mm (dequantizer.py:166-174, 204-239): (wq [N, K] int8 | fp8, ws [N] f32).  `ws`: the row
+    scales of an earlier call on the same weights (sdnq_hip_requant_ws: the pass that derives them is skipped where the kernel can)."""
     dev = qw.keep[0].device
     wq = torch.empty((qw.n, qw.k), device=dev, dtype=_MM_TORCH[mm])
-    ws = torch.empty((qw.n,), device=dev, dtype=torch.float32)
-    check(_lib.load().sdnq_hip_requant(ctypes.byref(qw.desc), mm, wq.data_ptr(), ws.data_ptr(),
-                                       torch.cuda.current_stream(dev).cuda_stream), "requant")
+    known = ws is not None
+    if not known:
+        ws = torch.empty((qw.n,), device=dev, dtype=torch.float32)
+    check(_lib.load().sdnq_hip_requant_ws(ctypes.byref(qw.desc), mm, wq.data_ptr(), ws.data_ptr(), 1 if known else 0,
+                                          torch.cuda.current_stream(dev).cuda_stream), "requant")
     return wq, ws
 
 

@@ -1263,3 +1263,36 @@ def test_rowquant_division_shortcut_over_the_exponent_range(dt, gpu_device):
         assert bad.size == 0, (dt, name, bad[:8], [float(s[b]) for b in bad[:8]])
         if rowsum is not None:
             assert np.array_equal(rs.cpu().numpy(), rowsum)
+
+
+@pytest.mark.parametrize("wd", ["int4", "uint4", "float4_e2m1fn", "float4_e3m0fn"])
+@pytest.mark.parametrize("mm_name", ["int8", "fp8"])
+@pytest.mark.parametrize("group", [64, 128, 32])
+def test_requant_table_path_equals_oracle_and_known_scales(wd, mm_name, group, gpu_device):
+    """4-bit weights in groups of a multiple of 64 are re-quantized through a 16-entry table per (row, group)
+    (requant_lut4_kernel); group 32 takes the general kernel.  Codes and row scales must equal the oracle's re_quantize_matmul bit
+    for bit, and a second call that is handed the row scales (sdnq_hip_requant_ws, the per-call mode of SDNQ_HIP_CACHE_WEIGHTS=0)
+    must reproduce the first."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    from tests.modules_util import oracle_from_module
+    if wd not in sdnq_amd.common.dtype_dict:
+        pytest.skip(f"{wd} not in the dtype table")
+    torch.manual_seed(5)
+    n, k = 200, 640
+    lin = torch.nn.Linear(k, n, bias=False).to(torch.bfloat16).to(gpu_device)
+    lin.weight.data[:, 3] *= 9
+    lin.weight.data[7] = 0  # a constant row: 0 / 0 -> code 0
+    mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype=wd, group_size=group, use_quantized_matmul=True,
+                                                                   quantized_matmul_dtype="int8" if mm_name == "int8" else "float8_e4m3fn"))
+    dq = mod.sdnq_dequantizer
+    if not (dq.use_quantized_matmul and dq.re_quantize_for_matmul):
+        pytest.skip("configuration does not re-quantize")
+    mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
+    st = L._state(mod)
+    wq, ws = ops.requant(st.qw, mm)
+    wq2, ws2 = ops.requant(st.qw, mm, ws.clone())
+    assert torch.equal(ws, ws2) and np.array_equal(bits_of(wq), bits_of(wq2))
+    rq, rs = oracle_from_module(mod).re_quantize_matmul()[:2]
+    assert np.array_equal(ws.cpu().numpy().reshape(-1), np.asarray(rs, dtype=np.float32).reshape(-1))
+    assert np.array_equal(bits_of(wq).reshape(n, k), np.ascontiguousarray(rq).view(np.uint8).reshape(n, k))
