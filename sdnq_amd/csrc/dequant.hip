@@ -177,55 +177,78 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
 // three DPP quad moves, and expand their 16 codes through v_perm byte look-ups.  `ws_known`: the row scales were computed before
 // (they depend only on the static weights) and are read from `ws` instead of being derived in a first pass over the row: the
 // per-call path of SDNQ_HIP_CACHE_WEIGHTS=0 then reads the codes once.  Needs packed 4-bit storage, group_size % 64 == 0, P == 1.
-template <int MM>
+template <int MM, int NP>
 __global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws, int ws_known) {
+    // NP = passes of 1024 elements per row (K <= 1024 NP), compile time: every load of the row -- codes and group scales of all
+    // passes -- is issued before the first use (unconditionally, from clamped addresses: a load under a condition gets its own
+    // vmcnt(0)), so a row costs one memory round trip instead of one per pass
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= p.N) return;
-    const int64_t npass = (p.K + 1023) / 1024;
-    float scale;
-    if (!ws_known) {
-        float amax = 0.0f;
-        for (int64_t ps = 0; ps < npass; ++ps) {
-            const int64_t k0 = ps * 1024 + lane * 16;
-            if (k0 < p.K) {
-                float v[16];
-                dequant16(p, n, k0, v);
+    const float* srow = p.scale + n * p.SG;
+    const float* zrow = p.zp ? p.zp + n * p.SG : nullptr;
+    const uint8_t* crow = (const uint8_t*)p.w + ((n * p.K) >> 1);
+    uint2 cw[NP];
+    float sg[NP], zg[NP];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    for (int ps = 0; ps < NP; ++ps) {
+        int64_t k0 = (int64_t)ps * 1024 + lane * 16;
+        if (k0 >= p.K) k0 = p.K - 16;  // out-of-range lanes read the row's last run and store nothing
+        const int g = (int)(k0 / p.group_size);
+        cw[ps] = *(const uint2*)(crow + (k0 >> 1));
+        sg[ps] = srow[g];
+        zg[ps] = zrow ? zrow[g] : 0.0f;
+    }
+    const float knownscale = ws_known ? ws[n] : 0.0f;
+    auto value_of = [&](u32 code, float s, float z) {
+        float x;
+        if (p.fmt.kind == SDNQ_KIND_INT) x = (float)((int)code - 8);
+        else if (p.fmt.kind == SDNQ_KIND_UINT) x = (float)code;
+        else x = decode_exmy(code, p.fmt.ebits, p.fmt.mbits, p.fmt.kind == SDNQ_KIND_UFLOAT);
+        float v = zrow ? fmaf(x, s, z) : x * s;  // dequant16
+        if (p.sdt != SDNQ_F32) v = round_rt(v, p.sdt);
+        return v;
+    };
+    const int quad = lane & 3;
+    float scale = knownscale;
+    if (!ws_known) {
+        // amax over the row = max over (group, code present) of |value|: the four lanes of a group each test four codes against
+        // the codes that actually occur in their 16 elements
+        float amax = 0.0f;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const bool live = (int64_t)ps * 1024 + lane * 16 < p.K;
+            u32 present = 0;  // bit c set: code c occurs among this lane's 16 elements
+#pragma unroll
+            for (int j = 0; j < 8; ++j) present |= (1u << ((cw[ps].x >> (4 * j)) & 15u)) | (1u << ((cw[ps].y >> (4 * j)) & 15u));
+            if (!live) present = 0;
+            // union over the quad (the table entries are split by code, the occurrences by lane)
+            present |= (u32)__builtin_amdgcn_update_dpp(0, (int)present, 0xB1, 0xf, 0xf, false);
+            present |= (u32)__builtin_amdgcn_update_dpp(0, (int)present, 0x4E, 0xf, 0xf, false);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const u32 code = 4u * quad + e;
+                const float v = fabsf(value_of(code, sg[ps], zg[ps]));
+                if ((present >> code) & 1u) amax = fmaxf(amax, v);
             }
         }
         amax = wave_max(amax);
         const float qmax = (MM == SDNQ_MM_I8) ? 127.0f : 448.0f;
         scale = round_rt(amax / qmax, p.sdt);
         if (lane == 0) ws[n] = scale;
-    } else {
-        scale = ws[n];
     }
-    const float* srow = p.scale + n * p.SG;
-    const float* zrow = p.zp ? p.zp + n * p.SG : nullptr;
-    const int quad = lane & 3;
-    for (int64_t ps = 0; ps < npass; ++ps) {
-        const int64_t k0 = ps * 1024 + lane * 16;
-        if (k0 >= p.K) continue;  // (K % 64 == 0: the four lanes of a group are in or out together)
-        const int g = (int)(k0 / p.group_size);
-        const float s = srow[g];
-        const float z = zrow ? zrow[g] : 0.0f;
-        // this lane's four table entries: codes 4 * quad .. 4 * quad + 3
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        const int64_t k0 = (int64_t)ps * 1024 + lane * 16;
+        // this lane's four table entries: codes 4 * quad .. 4 * quad + 3 (the expression of requant_kernel's second pass)
         u32 mine = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const u32 code = 4u * quad + e;
-            float x;
-            if (p.fmt.kind == SDNQ_KIND_INT) x = (float)((int)code - 8);
-            else if (p.fmt.kind == SDNQ_KIND_UINT) x = (float)code;
-            else x = decode_exmy(code, p.fmt.ebits, p.fmt.mbits, p.fmt.kind == SDNQ_KIND_UFLOAT);
-            float v = zrow ? fmaf(x, s, z) : x * s;            // dequant16
-            if (p.sdt != SDNQ_F32) v = round_rt(v, p.sdt);
+            const float v = value_of(4u * quad + e, sg[ps], zg[ps]);
             u32 byte;
-            if constexpr (MM == SDNQ_MM_I8) {                    // requant_kernel, second pass
+            if constexpr (MM == SDNQ_MM_I8) {
                 float q = __builtin_rintf(round_rt(v / scale, p.sdt));
-                if (q != q) q = 0.0f;
+                if (q != q) q = 0.0f;  // 0/0 of a constant row: NaN.to(int8) is 0 in the reference
                 q = fminf(fmaxf(q, -128.0f), 127.0f);
                 byte = (u32)(int)q & 0xffu;
             } else {
@@ -241,20 +264,18 @@ __global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, ui
         const u32 t1 = (u32)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xf, 0xf, false);  // [1,1,1,1]
         const u32 t2 = (u32)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xf, 0xf, false);  // [2,2,2,2]
         const u32 t3 = (u32)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xf, 0xf, false);  // [3,3,3,3]
-        const uint2 cw = *(const uint2*)((const uint8_t*)p.w + ((n * p.K + k0) >> 1));  // 16 codes: element j = nibble j
         u32 o[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const u32 half = ((h < 2 ? cw.x : cw.y) >> (16 * (h & 1))) & 0xffffu;  // 4 codes
-            // one code per byte: [n0, n1, n2, n3]
+            const u32 half = ((h < 2 ? cw[ps].x : cw[ps].y) >> (16 * (h & 1))) & 0xffffu;  // 4 codes: element j = nibble j
             const u32 a = __builtin_amdgcn_perm(0u, half, 0x01010000u);            // bytes [b0, b0, b1, b1]
-            const u32 sel = (a & 0x000f000fu) | ((a >> 4) & 0x0f000f00u);
-            const u32 lo = __builtin_amdgcn_perm(t1, t0, sel & 0x07070707u);       // entries 0..7  (v_perm: selector k picks byte k of {t1:t0})
+            const u32 sel = (a & 0x000f000fu) | ((a >> 4) & 0x0f000f00u);          // one code per byte
+            const u32 lo = __builtin_amdgcn_perm(t1, t0, sel & 0x07070707u);       // entries 0..7 (selector k = byte k of {t1:t0})
             const u32 hi = __builtin_amdgcn_perm(t3, t2, sel & 0x07070707u);       // entries 8..15
             const u32 m = ((sel >> 3) & 0x01010101u) * 0xffu;                      // 0xff where the code is >= 8
             o[h] = (hi & m) | (lo & ~m);
         }
-        *(uint4*)(wq + n * p.K + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (k0 < p.K) *(uint4*)(wq + n * p.K + k0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -994,15 +1015,27 @@ static int launch_requant(const DeqParams& p, int mm_dtype, void* wq, float* ws,
     static const bool no_lut = [] { const char* e = getenv("SDNQ_HIP_REQUANT_LUT"); return e && atoi(e) == 0; }();  // test / tuning aid
     const bool lut = !no_lut && p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && p.P == 1 && (p.group_size % 64) == 0 && (p.K % 64) == 0 &&
                      !p.fmt.native_float;
+    const int np = (int)((p.K + 1023) / 1024);
+#define LUT_NP(MMV, NPV) hipLaunchKernelGGL((requant_lut4_kernel<MMV, NPV>), grid, block, 0, s, p, (uint8_t*)wq, ws, ws_known)
+#define LUT_CASES(MMV)                                                                                   \
+    switch (np) {                                                                                        \
+        case 1: LUT_NP(MMV, 1); break;   case 2: LUT_NP(MMV, 2); break;   case 3: LUT_NP(MMV, 3); break;   \
+        case 4: LUT_NP(MMV, 4); break;   case 5: LUT_NP(MMV, 5); break;   case 6: LUT_NP(MMV, 6); break;   \
+        case 7: case 8: LUT_NP(MMV, 8); break;                                                           \
+        case 9: case 10: case 11: case 12: LUT_NP(MMV, 12); break;                                       \
+        default: LUT_NP(MMV, 16); break;                                                                 \
+    }
     if (mm_dtype == SDNQ_MM_I8) {
-        if (lut) hipLaunchKernelGGL((requant_lut4_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws, ws_known);
+        if (lut && np <= 16) { LUT_CASES(SDNQ_MM_I8) }
         else hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws, (float*)nullptr);
     } else if (mm_dtype == SDNQ_MM_FP8) {
-        if (lut) hipLaunchKernelGGL((requant_lut4_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws, ws_known);
+        if (lut && np <= 16) { LUT_CASES(SDNQ_MM_FP8) }
         else hipLaunchKernelGGL((requant_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws, (float*)nullptr);
     } else {
         return SDNQ_ERR_DTYPE;
     }
+#undef LUT_CASES
+#undef LUT_NP
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }
