@@ -550,20 +550,29 @@ __global__ __launch_bounds__(256) void linear_skinny_had256_kernel(const DeqPara
     float hf[4];
     had16_operand(lane, hf);
     const int ngroups = (int)(p.K / 256);
+    auto rsW = SDNQ_MAKE_RSRC((const uint8_t*)p.w + (BITS == 8 ? n * p.K : n * p.K / 2));
+    auto rsS = SDNQ_MAKE_RSRC(srow);
+    auto rsZ = SDNQ_MAKE_RSRC(zrow ? zrow : srow);
+    auto rsX = SDNQ_MAKE_RSRC(x);
     for (int g0 = 0; g0 < ngroups; g0 += NG) {
         u32 code[NG];
         float sc[NG], zp[NG];
         uint2 xr[NG][MROWS];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {  // unconditional, clamped: a group past the end re-reads group 0 and is dropped
-            const int64_t kk = (int64_t)(g0 + g < ngroups ? g0 + g : 0) * 256;
-            if constexpr (BITS == 8) code[g] = *(const u32*)(wrow + kk);
-            else code[g] = *(const uint16_t*)(wrow + kk / 2);
-            const int gi = (int)((kk + eoff) / p.group_size);  // group_size % 4 == 0: the 4 columns share one scale group
-            sc[g] = srow[gi];
-            zp[g] = zrow ? zrow[gi] : 0.0f;
+            // (buffer loads -- wave-uniform base, 32-bit lane offset, group offset in the scalar operand: a load with a 64-bit VGPR
+            //  address waits ~1000 cycles at issue while another wave of the SIMD runs the rotation's MFMAs, sdnq_dev.h)
+            const int kk = (g0 + g < ngroups ? g0 + g : 0) * 256;
+            if constexpr (BITS == 8) code[g] = (u32)SDNQ_BUF_LOAD4(rsW, eoff, kk);
+            else code[g] = (u32)SDNQ_BUF_LOAD2(rsW, eoff / 2, kk / 2);
+            const int gi = (kk + eoff) / p.group_size;  // group_size % 4 == 0: the 4 columns share one scale group
+            sc[g] = __builtin_bit_cast(float, SDNQ_BUF_LOAD4(rsS, gi * 4, 0));
+            zp[g] = zrow ? __builtin_bit_cast(float, SDNQ_BUF_LOAD4(rsZ, gi * 4, 0)) : 0.0f;
 #pragma unroll
-            for (int i = 0; i < MROWS; ++i) xr[g][i] = *(const uint2*)((const uint16_t*)x + (int64_t)(i < M ? i : 0) * ldx + kk + eoff);
+            for (int i = 0; i < MROWS; ++i) {
+                const v2i t = SDNQ_BUF_LOAD8(rsX, (int)((i < M ? i : 0) * ldx + eoff) * 2, kk * 2);
+                xr[g][i] = make_uint2((u32)t[0], (u32)t[1]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -25,6 +25,9 @@ typedef __attribute__((address_space(3))) void* sdnq_lds_ptr_t;
 #define SDNQ_DMA16(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sdnq_lds_ptr_t)(dst), 16, voff, soff, 0, 0)
 #define SDNQ_DMA4(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sdnq_lds_ptr_t)(dst), 4, voff, soff, 0, 0)
 #define SDNQ_BUF_LOAD16(rs, voff, soff) __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0))
+#define SDNQ_BUF_LOAD8(rs, voff, soff) __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0))
+#define SDNQ_BUF_LOAD4(rs, voff, soff) ((int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0))
+#define SDNQ_BUF_LOAD2(rs, voff, soff) ((int)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0))
 #define SDNQ_BUF_STORE16(rs, v, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs, voff, soff, 0)
 #define SDNQ_BUF_STORE16_NT(rs, v, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs, voff, soff, 2)
 #else
@@ -32,6 +35,9 @@ typedef __attribute__((address_space(3))) void* sdnq_lds_ptr_t;
 #define SDNQ_DMA16(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
 #define SDNQ_DMA4(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
 #define SDNQ_BUF_LOAD16(rs, voff, soff) ((void)(rs), (void)(voff), (void)(soff), (v4i){0, 0, 0, 0})
+#define SDNQ_BUF_LOAD8(rs, voff, soff) ((void)(rs), (void)(voff), (void)(soff), (v2i){0, 0})
+#define SDNQ_BUF_LOAD4(rs, voff, soff) ((void)(rs), (void)(voff), (void)(soff), 0)
+#define SDNQ_BUF_LOAD2(rs, voff, soff) ((void)(rs), (void)(voff), (void)(soff), 0)
 #define SDNQ_BUF_STORE16(rs, v, voff, soff) ((void)(rs), (void)(v), (void)(voff), (void)(soff))
 #define SDNQ_BUF_STORE16_NT(rs, v, voff, soff) ((void)(rs), (void)(v), (void)(voff), (void)(soff))
 #endif

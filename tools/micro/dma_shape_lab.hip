@@ -11,7 +11,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-template <int RB, int DEPTH, int READS>
+template <int RB, int DEPTH, int READS, int SWZ = 0>
 __global__ __launch_bounds__(512) void k_fill(const uint8_t* __restrict__ src, uint4* out, int iters, int rows_total, int ld) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int LPR = RB / 16, RP = 1024 / RB;
@@ -26,7 +26,9 @@ __global__ __launch_bounds__(512) void k_fill(const uint8_t* __restrict__ src, u
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u) {
             const int r = (row0 + (wave * DEPTH + u) * RP + lane / LPR) % rows_total;
-            const uint8_t* s = src + (size_t)r * ld + ((kofs + (lane % LPR) * 16) & (ld - 1));
+            // SWZ: the 16-byte chunks of a row are fetched in XOR-permuted lane order (the source side of the GEMM's LDS swizzle)
+            const int ch = SWZ ? ((lane % LPR) ^ ((r >> 1) & (LPR - 1))) : (lane % LPR);
+            const uint8_t* s = src + (size_t)r * ld + ((kofs + ch * 16) & (ld - 1));
             __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)(lds + (((it & 1) * 8 * DEPTH + wave * DEPTH + u) * 1024)), 16, 0, 0);
         }
         if constexpr (READS > 0) {
@@ -51,14 +53,14 @@ template <typename F> float time_it(F launch, hipStream_t s) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 1e3f / 5;
 }
-template <int RB, int DEPTH, int READS>
+template <int RB, int DEPTH, int READS, int SWZ = 0>
 void run(const uint8_t* src, uint4* out, int rows_total, hipStream_t s) {
     const int iters = 512, ld = 8192;
-    auto kern = k_fill<RB, DEPTH, READS>;
+    auto kern = k_fill<RB, DEPTH, READS, SWZ>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     float t = time_it([&] { hipLaunchKernelGGL(kern, dim3(256), dim3(512), 128 * 1024, s, src, out, iters, rows_total, ld); }, s);
     const double bytes = 256.0 * 8 * DEPTH * 1024 * iters;
-    printf("  rows x bytes %2d x %4d  depth %d  reads/iter %2d  region %4d MB: %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (@2.1 GHz)\n", 1024 / RB, RB, DEPTH, READS,
+    printf("  %s rows x bytes %2d x %4d  depth %d  reads/iter %2d  region %4d MB: %8.1f us  %6.2f TB/s  %5.1f B/clk/CU (@2.1 GHz)\n", SWZ ? "swizzled" : "linear  ", 1024 / RB, RB, DEPTH, READS,
            (int)((size_t)rows_total * ld >> 20), t, bytes / t / 1e6, bytes / t / 1e6 * 1e12 / 256 / 2.1e9);
 }
 int main() {
@@ -69,6 +71,7 @@ int main() {
         run<64, 4, 0>(src, out, rows, s);  run<128, 4, 0>(src, out, rows, s);  run<256, 4, 0>(src, out, rows, s);  run<1024, 4, 0>(src, out, rows, s);
         run<64, 2, 0>(src, out, rows, s);  run<128, 2, 0>(src, out, rows, s);
         run<64, 4, 12>(src, out, rows, s); run<128, 4, 12>(src, out, rows, s); run<1024, 4, 12>(src, out, rows, s);
+        run<128, 4, 0, 1>(src, out, rows, s); run<128, 2, 0, 1>(src, out, rows, s); run<64, 4, 0, 1>(src, out, rows, s);
     }
     return 0;
 }
