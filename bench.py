@@ -547,9 +547,7 @@ def attention_bench(args, device, distributed, world, rank):
         "config": {"workload": f"{args.workload}: {n_calls} attention calls of one denoising step, bs=1 ("
                                + ", ".join(f"{rep} x {h} heads {qn}x{kn}x{d}" for (_, h, qn, kn, d, rep) in calls) + ")",
                    "parallelism": f"{world} independent replicas" if distributed else "single GPU",
-                   "launch": ("torch.compile(mode='reduce-overhead'): one sdnq_hip::layer_forward op per layer, no activation cache / linked projections inside the graph"
-                              if compiled is not None else ("eager" if graph is None else "hipGraph replay")), "activations": "bf16",
-                   **({"compile_seconds": round(compile_s, 1)} if compiled is not None else {}), "smooth_k": True,
+                   "launch": "eager" if graph is None else "hipGraph replay", "activations": "bf16", "smooth_k": True,
                    "matmul_dtype": "int8", "pv_matmul_dtype": None, "ops_per_step": ops_per_step},
         "step_latency_ms": round(ms_per_step, 4),
     }
