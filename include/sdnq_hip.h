@@ -334,6 +334,51 @@ int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, in
                          void* xq, float* xs, const void* b, const float* sb, const void* bias, int bias_dtype, void* out,
                          int out_dtype, int64_t n, sdnq_stream_t stream);
 
+/* ---- the whole quantized-matmul forward of one layer behind ONE call -------------------------------------------------
+ * int8_matmul / fp8_matmul / uint8_matmul (layers/linear/linear_int8.py:75-97, linear_fp8.py:58-78, linear_uint8.py:80-102) for every
+ * layer form: row quantization of the activation (Hadamard-rotated when the layer is, asymmetric for the uint8 matmul), the low-rank
+ * (SVD) product t = x . svd_down^T, and the scaled matmul whose epilogue adds bias, low-rank and zero-point terms -- the sequence
+ * sdnq_hip_rowquant -> [sdnq_hip_lowrank_down] -> sdnq_hip_scaled_mm | sdnq_hip_scaled_mm_lowrank, with identical results.
+ * A POD: plain pointers and sizes, no ownership.  Set struct_size = sizeof(SdnqLinearArgs) (the library refuses a struct it does not
+ * know).  The weight side is the matmul operand as the kernels take it: wq [N][K] int8 / fp8 codes and ws [N] row scales -- the
+ * stored tensors of a row-wise int8 / fp8 layer, or the output of sdnq_hip_requant / sdnq_hip_unpack_mm for group-wise / packed ones.
+ * Intermediates: xq [M][K] bytes, xs [M] f32, rowsum [M] i32 (with zp), xrot [M][K] of x_dtype (SVD on a Hadamard layer), xzp [M] f32
+ * (asymmetric) and t [M][svd_rank] of svd_dtype.  Each of xq / xs / rowsum / xrot / xzp may be supplied by the caller (to keep them,
+ * e.g. for sibling layers that consume the same activation) or left NULL, in which case it lives in `workspace`; with x_prequantized
+ * the supplied ones are INPUTS and the row quantization is skipped.  sdnq_hip_linear_workspace_bytes tells how much workspace the
+ * call needs for the pointers left NULL (256-byte aligned device memory, used by one stream at a time). */
+typedef struct SdnqLinearArgs {
+    int32_t struct_size;
+    int32_t mm_dtype;        /* SDNQ_MM_I8 | SDNQ_MM_FP8 */
+    int32_t x_dtype;         /* SdnqFloat of x (and of xrot) */
+    int32_t out_dtype;       /* SdnqFloat of out */
+    int32_t bias_dtype;      /* SdnqFloat of bias (ignored without one) */
+    int32_t svd_dtype;       /* SdnqFloat of svd_down / svd_up / t */
+    int32_t hadamard_group;  /* 0: the layer is not rotated */
+    int32_t svd_rank;        /* 0: no low-rank term */
+    int32_t asymmetric;      /* 1: asymmetric activations (the uint8 matmul); int8 matmul dtype only */
+    int32_t x_prequantized;  /* 1: xq / xs (and rowsum / xrot / xzp where the layer needs them) are inputs */
+    int64_t m, n, k, ldx;    /* x is [M][ldx] with K valid columns */
+    const void* x;
+    void* out;               /* [M][N] */
+    const void* wq;          /* [N][K] */
+    const float* ws;         /* [N] */
+    const void* bias;        /* [N] or NULL */
+    const void* svd_down;    /* physical [R][K] or NULL */
+    const void* svd_up;      /* physical [N][R] or NULL */
+    const float* zp;         /* [N] weight zero-point term (unsigned weights, linear_int8.py:65-69) or NULL */
+    const float* w_colsum_scaled; /* [N] f32(sum_k wq[n][k]) * ws[n]: required with asymmetric */
+    void* xq;
+    float* xs;
+    int32_t* rowsum;
+    void* xrot;
+    float* xzp;
+    void* workspace;
+    int64_t workspace_bytes;
+} SdnqLinearArgs;
+int sdnq_hip_linear(const SdnqLinearArgs* args, sdnq_stream_t stream);
+int sdnq_hip_linear_workspace_bytes(const SdnqLinearArgs* args, int64_t* bytes);
+
 /* the scaled matmul of the conv forwards with the channel-major store fused into the epilogue: out is the conv output
  * [B][N][hw] (NCHW / NCL), rows m = b * hw + pixel -- replaces int_scaled_mm_func(...).view(mm_output_shape) followed by
  * .permute(0, 3, 1, 2).contiguous() (conv_int8.py:71, 81-88).  bias: NULL or [N] of bias_dtype; hw % 8 == 0, m % hw == 0,

@@ -29,7 +29,7 @@ EXPORTS = [
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
-    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws",
+    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
 ]
 
 
@@ -41,6 +41,20 @@ class SdnqWeight(ctypes.Structure):
         ("svd_dtype", ctypes.c_int32), ("storage", ctypes.c_int32), ("kind", ctypes.c_int32), ("bits", ctypes.c_int32),
         ("exponent", ctypes.c_int32), ("mantissa", ctypes.c_int32), ("native_float", ctypes.c_int32),
         ("positions", ctypes.c_int32), ("scale_dtype", ctypes.c_int32),
+    ]
+
+
+class SdnqLinearArgs(ctypes.Structure):
+    """POD arguments of sdnq_hip_linear (include/sdnq_hip.h): the whole quantized-matmul forward of one layer behind one call."""
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("mm_dtype", ctypes.c_int32), ("x_dtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32),
+        ("bias_dtype", ctypes.c_int32), ("svd_dtype", ctypes.c_int32), ("hadamard_group", ctypes.c_int32), ("svd_rank", ctypes.c_int32),
+        ("asymmetric", ctypes.c_int32), ("x_prequantized", ctypes.c_int32),
+        ("m", ctypes.c_int64), ("n", ctypes.c_int64), ("k", ctypes.c_int64), ("ldx", ctypes.c_int64),
+        ("x", ctypes.c_void_p), ("out", ctypes.c_void_p), ("wq", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("svd_down", ctypes.c_void_p), ("svd_up", ctypes.c_void_p), ("zp", ctypes.c_void_p), ("w_colsum_scaled", ctypes.c_void_p),
+        ("xq", ctypes.c_void_p), ("xs", ctypes.c_void_p), ("rowsum", ctypes.c_void_p), ("xrot", ctypes.c_void_p), ("xzp", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -118,6 +132,8 @@ def _declare(lib):
     lib.sdnq_hip_dequant.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp]
     lib.sdnq_hip_requant.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, vp]
     lib.sdnq_hip_requant_ws.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, i32, vp]
+    lib.sdnq_hip_linear.argtypes = [c.POINTER(SdnqLinearArgs), vp]
+    lib.sdnq_hip_linear_workspace_bytes.argtypes = [c.POINTER(SdnqLinearArgs), c.POINTER(c.c_int64)]
     lib.sdnq_hip_requant_asym.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, vp]
     lib.sdnq_hip_unpack_mm.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp]
     lib.sdnq_hip_hadamard.argtypes = [vp, i32, i64, i64, i64, i32, vp, i64, vp]

@@ -38,3 +38,84 @@ extern "C" int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, in
     if (st != SDNQ_OK) return st;
     return sdnq_hip_scaled_mm(mm_dtype, xq, b, xs, sb, bias, bias_dtype, bias ? 1 : 0, 0, out, out_dtype, m, n, k, stream);
 }
+
+
+// ---- one POD-args call for the whole quantized-matmul forward of a layer (see the header) ---------------------------
+namespace {
+
+struct LinearPlan {
+    int64_t off_xq, off_xs, off_rowsum, off_xrot, off_xzp, off_t, total;
+    bool need_rowsum, need_xrot, need_xzp, need_t;
+};
+
+inline int64_t up256(int64_t v) { return (v + 255) & ~(int64_t)255; }
+
+int plan_linear(const SdnqLinearArgs* a, LinearPlan& p) {
+    if (!a) return SDNQ_ERR_NULL;
+    if (a->struct_size != (int32_t)sizeof(SdnqLinearArgs)) return SDNQ_ERR_UNSUPPORTED;
+    if (a->mm_dtype != SDNQ_MM_I8 && a->mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
+    if (a->x_dtype < 0 || a->x_dtype > 2 || a->out_dtype < 0 || a->out_dtype > 2) return SDNQ_ERR_DTYPE;
+    if (a->m <= 0 || a->n <= 0 || a->k <= 0 || a->ldx < a->k || (a->k % 16) != 0 || (a->n % 8) != 0) return SDNQ_ERR_SHAPE;
+    if (a->asymmetric && a->mm_dtype != SDNQ_MM_I8) return SDNQ_ERR_DTYPE;
+    if (a->svd_rank < 0 || (a->svd_rank > 0 && (!a->svd_down || !a->svd_up || a->svd_dtype < 0 || a->svd_dtype > 2))) return SDNQ_ERR_NULL;
+    if (a->asymmetric && !a->w_colsum_scaled) return SDNQ_ERR_NULL;
+    const int64_t eb = a->x_dtype == SDNQ_F32 ? 4 : 2, sb = a->svd_dtype == SDNQ_F32 ? 4 : 2;
+    p.need_rowsum = a->zp != nullptr;
+    p.need_xrot = a->svd_rank > 0 && a->hadamard_group != 0;
+    p.need_xzp = a->asymmetric != 0;
+    p.need_t = a->svd_rank > 0;
+    int64_t o = 0;
+    p.off_xq = o;     if (!a->xq) o += up256(a->m * a->k);
+    p.off_xs = o;     if (!a->xs) o += up256(a->m * 4);
+    p.off_rowsum = o; if (p.need_rowsum && !a->rowsum) o += up256(a->m * 4);
+    p.off_xrot = o;   if (p.need_xrot && !a->xrot) o += up256(a->m * a->k * eb);
+    p.off_xzp = o;    if (p.need_xzp && !a->xzp) o += up256(a->m * 4);
+    p.off_t = o;      if (p.need_t) o += up256(a->m * a->svd_rank * sb);
+    p.total = o;
+    return SDNQ_OK;
+}
+
+}  // namespace
+
+extern "C" int sdnq_hip_linear_workspace_bytes(const SdnqLinearArgs* args, int64_t* bytes) {
+    if (!bytes) return SDNQ_ERR_NULL;
+    LinearPlan p;
+    const int st = plan_linear(args, p);
+    if (st != SDNQ_OK) return st;
+    *bytes = p.total;
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_linear(const SdnqLinearArgs* a, sdnq_stream_t stream) {
+    LinearPlan p;
+    int st = plan_linear(a, p);
+    if (st != SDNQ_OK) return st;
+    if (!a->x || !a->out || !a->wq || !a->ws) return SDNQ_ERR_NULL;
+    if (p.total > 0 && (!a->workspace || a->workspace_bytes < p.total)) return SDNQ_ERR_NULL;
+    if (a->workspace && ((uintptr_t)a->workspace % 256)) return SDNQ_ERR_ALIGN;
+    if (a->x_prequantized && (!a->xq || !a->xs || (p.need_rowsum && !a->rowsum) || (p.need_xzp && !a->xzp) || (p.need_xrot && !a->xrot)))
+        return SDNQ_ERR_NULL;  // inputs cannot come out of the scratch buffer
+    uint8_t* w = (uint8_t*)a->workspace;
+    void* xq = a->xq ? a->xq : (void*)(w + p.off_xq);
+    float* xs = a->xs ? a->xs : (float*)(w + p.off_xs);
+    int32_t* rowsum = p.need_rowsum ? (a->rowsum ? a->rowsum : (int32_t*)(w + p.off_rowsum)) : nullptr;
+    void* xrot = p.need_xrot ? (a->xrot ? a->xrot : (void*)(w + p.off_xrot)) : nullptr;
+    float* xzp = p.need_xzp ? (a->xzp ? a->xzp : (float*)(w + p.off_xzp)) : nullptr;
+    if (!a->x_prequantized) {
+        st = sdnq_hip_rowquant(a->x, a->x_dtype, a->m, a->k, a->ldx, a->mm_dtype, a->hadamard_group, xq, xs, rowsum, xrot, nullptr, 0, xzp, stream);
+        if (st != SDNQ_OK) return st;
+    }
+    const int bias_ndim = a->bias ? 1 : 0;
+    if (!p.need_t && !a->zp && !a->asymmetric)
+        return sdnq_hip_scaled_mm(a->mm_dtype, xq, a->wq, xs, a->ws, a->bias, a->bias_dtype, bias_ndim, 0, a->out, a->out_dtype, a->m, a->n, a->k, stream);
+    void* t = nullptr;
+    if (p.need_t) {
+        // mm(x, svd_down) of addmm(bias, mm(x, svd_down), svd_up) (linear_int8.py:57-62): on the ROTATED activation of a Hadamard layer
+        t = (void*)(w + p.off_t);
+        st = sdnq_hip_lowrank_down(xrot ? xrot : a->x, a->x_dtype, a->m, a->k, xrot ? a->k : a->ldx, a->svd_down, a->svd_dtype, a->svd_rank, t, stream);
+        if (st != SDNQ_OK) return st;
+    }
+    return sdnq_hip_scaled_mm_lowrank(a->mm_dtype, xq, a->wq, xs, a->ws, a->bias, a->bias_dtype, t, p.need_t ? a->svd_up : nullptr, a->svd_dtype,
+                                      a->svd_rank, rowsum, a->zp, xzp, a->asymmetric ? a->w_colsum_scaled : nullptr, a->out, a->out_dtype,
+                                      a->m, a->n, a->k, stream);
+}

@@ -543,15 +543,30 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
             return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         x2, xq, xs, rowsum, xrot = hit
         return ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype).view(*input.shape[:-1], n)
-    x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, wq if PREFETCH_WEIGHTS else None,
-                                                cache=cache_input)
-    if has_svd or zp is not None:
-        t = None
-        if has_svd:  # mm(x, svd_down) of addmm(bias, mm(x, svd_down), svd_up), linear_int8.py:57-62
-            t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down)
-        y = ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, st.svd_up, rowsum, zp, input.dtype)
+    # every other layer form (SVD low-rank term, zero-point term, long Hadamard rows): still ONE C call -- sdnq_hip_linear sequences
+    # row quantization, the low-rank product and the matmul with its full epilogue (SURVEY 8b's POD-args entry point)
+    params = (mm, had, zp is not None, has_svd, False, ops._stream(input) if input.is_cuda else -1)
+    use_cache = cache_input and CACHE_ACTIVATIONS > 0
+    key = tensor_key(input) if (use_cache and not _no_identity_reuse[0]) else None
+    hit = _act_cache.get(input, params, key) if key is not None else None
+    if hit is not None:
+        x2, xq, xs, rowsum, xrot = hit
+        pre = (xq, xs, rowsum, xrot, None)
     else:
-        y = ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype)
+        x2 = input if input.dim() == 2 else input.reshape(-1, k)
+        if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+            x2 = x2.contiguous()
+        pre = None
+    svd_ok = (not has_svd) or st.svd_up.dtype == x2.dtype
+    if not svd_ok:  # mixed svd / activation dtypes: the separate calls (which report the mismatch)
+        if pre is None:
+            x2, xq, xs, rowsum, xrot = _rowquant_cached(input, k, mm, had, zp is not None, has_svd, None, cache=cache_input)
+        t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down)
+        return ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, st.svd_up, rowsum, zp, input.dtype).view(*input.shape[:-1], n)
+    y, inter = ops.linear_call(mm, x2, wq, ws, bias, input.dtype, had, st.svd_down if has_svd else None, st.svd_up if has_svd else None, zp,
+                               pre=pre)
+    if hit is None and key is not None:
+        _act_cache.put(input, params, (x2,) + tuple(inter[:4]), key)
     return y.view(*input.shape[:-1], n)
 
 

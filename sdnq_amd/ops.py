@@ -554,6 +554,72 @@ def lowrank_down(x2d: torch.Tensor, svd_down_phys: torch.Tensor) -> torch.Tensor
     return t
 
 
+_workspaces: dict = {}
+
+
+def _workspace(dev: torch.device, stream: int, nbytes: int) -> torch.Tensor:
+    """Scratch buffer of sdnq_hip_linear for (device, stream): grown on demand, reused by every layer on that stream (calls on one
+    stream are ordered, so a buffer per stream is never used by two calls at once)."""
+    key = (dev.index, stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((max(nbytes, 1 << 20) + 255,), device=dev, dtype=torch.uint8)
+        _workspaces[key] = buf
+    return buf
+
+
+def linear_call(mm: int, x2d: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, bias, out_dtype: torch.dtype, hadamard_group: int = 0,
+                svd_down=None, svd_up=None, zp=None, asymmetric: bool = False, w_colsum_scaled=None, pre=None):
+    """The whole quantized-matmul forward of one layer through ONE C call (sdnq_hip_linear): row quantization (unless `pre` =
+    (xq, xs, rowsum, xrot, xzp) of an earlier call on the same activation is handed in), low-rank product, scaled matmul with every
+    epilogue term.  Returns (out [M, N], (xq, xs, rowsum, xrot, xzp)); the intermediates are torch tensors (they may be cached), only the
+    low-rank product lives in the per-stream scratch buffer."""
+    _require_cuda(x2d, wq, ws, bias, svd_down, svd_up, zp)
+    m, k = x2d.shape
+    n = wq.shape[0]
+    dev = x2d.device
+    a = _lib.SdnqLinearArgs()
+    a.struct_size = ctypes.sizeof(_lib.SdnqLinearArgs)
+    a.mm_dtype, a.x_dtype, a.out_dtype = mm, float_code(x2d.dtype), float_code(out_dtype)
+    a.hadamard_group, a.asymmetric = int(hadamard_group), 1 if asymmetric else 0
+    a.m, a.n, a.k, a.ldx = m, n, k, x2d.stride(0)
+    out = torch.empty((m, n), device=dev, dtype=out_dtype)
+    a.x, a.out, a.wq, a.ws = x2d.data_ptr(), out.data_ptr(), wq.data_ptr(), ws.data_ptr()
+    if bias is not None:
+        bias = bias.contiguous()
+        a.bias, a.bias_dtype = bias.data_ptr(), float_code(bias.dtype)
+    if svd_up is not None:
+        a.svd_down, a.svd_up, a.svd_rank, a.svd_dtype = svd_down.data_ptr(), svd_up.data_ptr(), svd_up.shape[1], float_code(svd_up.dtype)
+        if bias is not None and bias.dtype != svd_up.dtype:
+            bias = bias.to(svd_up.dtype)  # the [M, N] bias of the reference lives in the svd dtype (linear_int8.py:60)
+            a.bias, a.bias_dtype = bias.data_ptr(), float_code(bias.dtype)
+    if zp is not None:
+        a.zp = zp.data_ptr()
+    if asymmetric:
+        a.w_colsum_scaled = w_colsum_scaled.data_ptr()
+    need_rowsum, need_xrot = zp is not None, svd_up is not None and hadamard_group != 0
+    if pre is not None:
+        xq, xs, rowsum, xrot, xzp = pre
+        a.x_prequantized = 1
+    else:
+        xq = torch.empty((m, k), device=dev, dtype=_MM_TORCH[mm])
+        xs = torch.empty((m, 1), device=dev, dtype=torch.float32)
+        rowsum = torch.empty((m,), device=dev, dtype=torch.int32) if need_rowsum else None
+        xrot = torch.empty((m, k), device=dev, dtype=x2d.dtype) if need_xrot else None
+        xzp = torch.empty((m, 1), device=dev, dtype=torch.float32) if asymmetric else None
+    a.xq, a.xs, a.rowsum, a.xrot, a.xzp = xq.data_ptr(), xs.data_ptr(), _ptr(rowsum), _ptr(xrot), _ptr(xzp)
+    lib = _lib.load()
+    need = ctypes.c_int64(0)
+    check(lib.sdnq_hip_linear_workspace_bytes(ctypes.byref(a), ctypes.byref(need)), "linear_workspace_bytes")
+    stream = _stream(x2d)
+    if need.value > 0:
+        w = _workspace(dev, stream, need.value)
+        base = (w.data_ptr() + 255) & ~255
+        a.workspace, a.workspace_bytes = base, w.numel() - (base - w.data_ptr())
+    check(lib.sdnq_hip_linear(ctypes.byref(a), stream), "linear")
+    return out, (xq, xs, rowsum, xrot, xzp)
+
+
 def unshard_columns(gathered: torch.Tensor, out: torch.Tensor, starts, m0: int = 0) -> torch.Tensor:
     """out[m0 + i][starts[r] + c] = gathered[r][i][c]: the row-major re-assembly of a column-sharded layer's all-gathered output
     (sdnq_hip_unshard_columns).  gathered [W, rows, wmax] (rank-major, slabs padded to the widest), out [M, N] with N = starts[W]."""

@@ -89,3 +89,24 @@ def test_attention_argument_validation_without_gpu():
     assert fwd(p, p, p, p, p, 1, 0.125, 0, p, 5, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -2          # mask dtype
     assert fwd(p, p, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 0, 64, None) == -3       # kv_len 0
     assert fwd(p, p, p, p, p, 0, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -2       # f32 value operand
+
+
+def test_linear_args_struct_matches_the_header():
+    """The ctypes mirror of SdnqLinearArgs has the header's field order and the size the library checks (struct_size)."""
+    import ctypes
+    import re
+    from sdnq_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sdnq_hip.h")).read()
+    body = hdr[hdr.index("typedef struct SdnqLinearArgs {"):hdr.index("} SdnqLinearArgs;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.replace("*", " ").split()
+        for nm in decl.split(",") if "," in decl else [decl]:
+            names.append(nm.replace("*", " ").split()[-1])
+        del parts
+    assert names == [f[0] for f in _lib.SdnqLinearArgs._fields_], names
+    assert ctypes.sizeof(_lib.SdnqLinearArgs) == 10 * 4 + 4 * 8 + 16 * 8

@@ -1296,3 +1296,46 @@ def test_requant_table_path_equals_oracle_and_known_scales(wd, mm_name, group, g
     rq, rs = oracle_from_module(mod).re_quantize_matmul()[:2]
     assert np.array_equal(ws.cpu().numpy().reshape(-1), np.asarray(rs, dtype=np.float32).reshape(-1))
     assert np.array_equal(bits_of(wq).reshape(n, k), np.ascontiguousarray(rq).view(np.uint8).reshape(n, k))
+
+
+@pytest.mark.parametrize("form", ["plain", "svd", "zp", "svd+zp", "had+svd", "uint8mm", "fp8+svd"])
+def test_one_call_linear_equals_the_separate_calls(form, gpu_device):
+    """sdnq_hip_linear (POD args, workspace query) against the sequence of entry points it replaces -- rowquant,
+    lowrank_down, scaled_mm / scaled_mm_lowrank -- for every layer form, with scratch-resident and caller-supplied intermediates and
+    with a pre-quantized activation: bit-identical outputs and intermediates."""
+    torch.manual_seed(11)
+    m, k, n, r = 300, 512, 264, 32
+    mm = ops.MM_FP8 if form.startswith("fp8") else ops.MM_I8
+    had = 256 if form.startswith("had") else 0
+    dt = torch.bfloat16
+    x = torch.randn(m, k, device=gpu_device, dtype=dt)
+    x[:, 5] *= 17
+    wq = torch.randint(-127, 128, (n, k), dtype=torch.int8, device=gpu_device)
+    if mm == ops.MM_FP8:
+        wq = (torch.randn(n, k, device=gpu_device) * 40).clamp(-448, 448).to(torch.float8_e4m3fn)
+    ws = torch.rand(n, device=gpu_device) * 0.01 + 1e-4
+    bias = torch.randn(n, device=gpu_device, dtype=dt)
+    svd = "svd" in form
+    down = torch.randn(r, k, device=gpu_device, dtype=dt) * 0.05 if svd else None
+    up = torch.randn(n, r, device=gpu_device, dtype=dt) * 0.05 if svd else None
+    zp = torch.randn(n, device=gpu_device) * 0.1 if ("zp" in form or form == "uint8mm") else None
+    asym = form == "uint8mm"
+    wcs = wq.to(torch.int32).sum(dim=1).to(torch.float32).mul_(ws) if asym else None
+    # the separate calls
+    res = ops.rowquant(x, mm, had, want_rowsum=zp is not None, want_xrot=svd and had != 0, asymmetric=asym)
+    xq, xs, rowsum, xrot = res[:4]
+    xzp = res[4] if asym else None
+    t = ops.lowrank_down(xrot if xrot is not None else x, down) if svd else None
+    if svd or zp is not None or asym:
+        want = ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, up, rowsum, zp, dt, a_zp=xzp, w_colsum_scaled=wcs)
+    else:
+        want = ops.scaled_mm(mm, xq, wq, xs, ws, bias, dt)
+    # one call, intermediates returned as tensors
+    got, inter = ops.linear_call(mm, x, wq, ws, bias, dt, had, down, up, zp, asymmetric=asym, w_colsum_scaled=wcs)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), form
+    assert np.array_equal(bits_of(inter[0]), bits_of(xq)) and torch.equal(inter[1].reshape(-1), xs.reshape(-1))
+    if rowsum is not None:
+        assert torch.equal(inter[2], rowsum)
+    # one call on the pre-quantized activation (what sibling layers of a shared input do)
+    got2, _ = ops.linear_call(mm, x, wq, ws, bias, dt, had, down, up, zp, asymmetric=asym, w_colsum_scaled=wcs, pre=inter)
+    assert torch.equal(got2.view(torch.int16), want.view(torch.int16)), form
