@@ -387,6 +387,18 @@ int sdnq_hip_scaled_mm_nchw(int mm_dtype, const void* a, const void* b, const fl
                             int bias_dtype, void* out, int out_dtype, int64_t m, int64_t n, int64_t k, int64_t hw,
                             sdnq_stream_t stream);
 
+/* sdnq_hip_scaled_mm / sdnq_hip_scaled_mm_nchw on VIEWS, for the per-group matmuls of grouped convs (conv_int8.py:73-79, conv_fp8.py:56-60:
+ * `int_mm_func(input[:, i], weight[:, i])` per group on column slices of the quantized unfolded input, results concatenated along the
+ * channels).  a: [M][lda] with K valid columns (lda % 16 == 0); out: hw == 0 -> [M][ldc] with the N results in its first N columns
+ * (pass out + first channel); hw > 0 -> the image [B][ldc channels][hw], `out` pointing at the group's first channel plane.  bias NULL or [N]. */
+int sdnq_hip_scaled_mm_strided(int mm_dtype, const void* a, int64_t lda, const void* b, const float* sa, const float* sb,
+                               const void* bias, int bias_dtype, void* out, int64_t ldc, int out_dtype, int64_t m, int64_t n,
+                               int64_t k, int64_t hw, sdnq_stream_t stream);
+
+/* sdnq_hip_linear_float with an output row stride (ldc >= n elements): the float matmul of one conv group on views. */
+int sdnq_hip_linear_float_strided(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
+                                  int64_t n, int64_t k, int64_t ldx, int64_t ldc, sdnq_stream_t stream);
+
 /* fused variant for the quantized-matmul conv forwards: row scales xs[m] = amax_k |x_unfold[m][k]| / qmax straight from the
  * image, then the unfold writes the QUANTIZED operand xq [M][K] (int8 or fp8-e4m3fn bytes) -- the bf16 [M][K] matrix of
  * process_conv_input + quantize_int_mm_input / quantize_fp_mm_input (conv_int8.py:31, 64; quant_utils.py:265-273, 290-299)

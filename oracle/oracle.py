@@ -526,11 +526,40 @@ def im2col(x: np.ndarray, kernel, stride, padding, dilation) -> tuple[np.ndarray
     return np.ascontiguousarray(cols.reshape(B * Ho * Wo, C * kh * kw)), (B, Ho, Wo)
 
 
+def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str, small: bool) -> np.ndarray:
+    """groups > 1 on the unfolded rows [M, groups * K']: the float forward is F.conv*d(..., groups) on the dequantized weight
+    (layers/conv/forward.py:80-81); the int8 / fp8 matmuls quantize the WHOLE row with one scale and multiply per group
+    (conv_int8.py:64, 73-79; conv_fp8.py:56-60: int_mm per column slice, cat, .mul_(input_scale), addcmul(bias, ., scale))."""
+    d = mod.deq
+    Kg, N = mod.K, mod.N
+    Ng = N // groups
+    assert x2d.shape[1] == groups * Kg and N % groups == 0
+    x2d = _c(x2d, np.float32)
+    outs = []
+    if not d["use_quantized_matmul"] or small:
+        W = mod.dequantize(mod.result_tag)
+        for g in range(groups):
+            b = None if mod.bias is None else mod.bias[g * Ng:(g + 1) * Ng]
+            outs.append(linear_float(_c(x2d[:, g * Kg:(g + 1) * Kg], np.float32), _c(W[g * Ng:(g + 1) * Ng], np.float32), b, tag))
+        return np.concatenate(outs, axis=1)
+    mmd = d["quantized_matmul_dtype"]
+    assert mmd in ("int8", "float8_e4m3fn", "fp8") and mod.svd_up is None and mod.scale_tag == "f32"
+    mm = "int8" if mmd == "int8" else "fp8"
+    wq, ws, zp = _mm_weights(mod, mm)
+    assert zp is None
+    xq, xs, _ = rowquant(x2d, mm)
+    for g in range(groups):
+        b = None if mod.bias is None else mod.bias[g * Ng:(g + 1) * Ng]
+        outs.append(scaled_mm(mm, np.ascontiguousarray(xq[:, g * Kg:(g + 1) * Kg]), np.ascontiguousarray(wq[g * Ng:(g + 1) * Ng]), xs,
+                              np.ascontiguousarray(ws[g * Ng:(g + 1) * Ng]), b, tag))
+    return np.concatenate(outs, axis=1)
+
+
 def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.ndarray:
     """SDNQConv1d / SDNQConv2d forward (layers/conv/forward.py:80-81, conv_int8.py:94-123, conv_fp8.py): unfold, the Linear
     arithmetic on [M, K] rows, fold back to NCHW.  `conv` = {"nd", "kernel_size", "stride", "padding", "dilation",
     "padding_mode", "groups"} as in the fixtures' meta."""
-    assert conv["groups"] == 1
+    groups = int(conv["groups"])
     nd = conv["nd"]
     k, s, p, dl = (tuple(conv[f]) for f in ("kernel_size", "stride", "padding", "dilation"))
     small = x.size / x.shape[2] < 32  # conv_int8.py:96 (evaluated on the conv input, before unfolding)
@@ -542,10 +571,44 @@ def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.n
         x = x[:, :, None, :]
         k, s, p, dl = (1, k[0]), (1, s[0]), (0, p[0]), (1, dl[0])
     x2d, (B, Ho, Wo) = im2col(np.asarray(x, dtype=np.float32), k, s, p, dl)
-    y = forward(mod, x2d, tag, small_batch=small)
+    if groups == 1:
+        y = forward(mod, x2d, tag, small_batch=small)
+    else:
+        y = _grouped_conv_rows(mod, x2d, groups, tag, small)
     if nd == 1:
         return np.ascontiguousarray(y.reshape(B, Wo, mod.N).transpose(0, 2, 1))
     return np.ascontiguousarray(y.reshape(B, Ho, Wo, mod.N).transpose(0, 3, 1, 2))
+
+
+def _mm_weights(mod: OracleLinear, mm: str):
+    """The matmul operand of the int8 / fp8 forwards: (wq [N, K] int8 | e4m3 bytes, ws [N], zero-point term | None)
+    (linear_int8.py:38-50, 104-107; linear_fp8.py:36-38)."""
+    d = mod.deq
+    K, N = mod.K, mod.N
+    zp = None
+    if d["re_quantize_for_matmul"]:
+        wq, ws = mod.re_quantize_matmul()  # linear_int8.py:104-107
+    else:
+        vals, sc, zpv, group = mod._nk_values_scale()
+        assert group == K, "row-wise only without re-quantization"
+        ws = sc
+        info = dtype_info(d["weights_dtype"])
+        if mm == "int8":
+            if d["is_packed"]:
+                # unpack_int(..., dtype=int8): signed -> values; unsigned -> raw codes viewed as int8 (linear_int8.py:38-44)
+                wq = vals.astype(np.int32).astype(np.uint8).view(np.int8) if info["kind"] == "uint" else vals.astype(np.int8)
+                zp = zpv
+            elif info["kind"] == "uint":  # plain uint8: w ^ 0x80, zp += 128*scale (linear_int8.py:45-50)
+                wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+                zp = (zpv + np.float32(128.0) * sc).astype(np.float32) if zpv is not None else (sc * np.float32(128.0)).astype(np.float32)
+            else:
+                wq = vals.astype(np.int8)
+        else:
+            if d["is_packed"]:  # unpack_float(...).to(float8_e4m3fn) (linear_fp8.py:37)
+                wq = np.array([lib().orc_f32_to_e4m3fn(float(v)) for v in vals.reshape(-1)], dtype=np.uint8).reshape(N, K)
+            else:
+                wq = np.ascontiguousarray(mod.weight.reshape(K, N).T).view(np.uint8) if mod.transposed else mod.weight.reshape(N, K).view(np.uint8)
+    return wq, ws, zp
 
 
 def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool = False, small_batch=None):
@@ -571,29 +634,7 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
         return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
     mm = "int8" if mmd == "int8" else "fp8"
 
-    zp = None
-    if d["re_quantize_for_matmul"]:
-        wq, ws = mod.re_quantize_matmul()  # linear_int8.py:104-107
-    else:
-        vals, sc, zpv, group = mod._nk_values_scale()
-        assert group == K, "row-wise only without re-quantization"
-        ws = sc
-        info = dtype_info(d["weights_dtype"])
-        if mm == "int8":
-            if d["is_packed"]:
-                # unpack_int(..., dtype=int8): signed -> values; unsigned -> raw codes viewed as int8 (linear_int8.py:38-44)
-                wq = vals.astype(np.int32).astype(np.uint8).view(np.int8) if info["kind"] == "uint" else vals.astype(np.int8)
-                zp = zpv
-            elif info["kind"] == "uint":  # plain uint8: w ^ 0x80, zp += 128*scale (linear_int8.py:45-50)
-                wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
-                zp = (zpv + np.float32(128.0) * sc).astype(np.float32) if zpv is not None else (sc * np.float32(128.0)).astype(np.float32)
-            else:
-                wq = vals.astype(np.int8)
-        else:
-            if d["is_packed"]:  # unpack_float(...).to(float8_e4m3fn) (linear_fp8.py:37)
-                wq = np.array([lib().orc_f32_to_e4m3fn(float(v)) for v in vals.reshape(-1)], dtype=np.uint8).reshape(N, K)
-            else:
-                wq = np.ascontiguousarray(mod.weight.reshape(K, N).T).view(np.uint8) if mod.transposed else mod.weight.reshape(N, K).view(np.uint8)
+    wq, ws, zp = _mm_weights(mod, mm)
     inter["wq"], inter["ws"] = wq, ws
 
     if d["use_hadamard"]:

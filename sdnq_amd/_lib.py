@@ -30,6 +30,7 @@ EXPORTS = [
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
     "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
+    "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided",
 ]
 
 
@@ -140,6 +141,8 @@ def _declare(lib):
     lib.sdnq_hip_lowrank_down.argtypes = [vp, i32, i64, i64, i64, vp, i32, i32, vp, vp]
     lib.sdnq_hip_scaled_mm_lowrank.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_linear_float.argtypes = [vp, vp, vp, i32, vp, i64, i64, i64, i64, vp]
+    lib.sdnq_hip_linear_float_strided.argtypes = [vp, vp, vp, i32, vp, i64, i64, i64, i64, i64, vp]
+    lib.sdnq_hip_scaled_mm_strided.argtypes = [i32, vp, i64, vp, vp, vp, vp, i32, vp, i64, i32, i64, i64, i64, i64, vp]
     lib.sdnq_hip_linear_skinny.argtypes = [c.POINTER(SdnqWeight), i32, vp, vp, i32, vp, i64, i64, vp]
     lib.sdnq_hip_quantize_weight.argtypes = [vp, i32, i64, c.POINTER(SdnqWeight), c.c_float, c.c_float, vp]
     lib.sdnq_hip_linear_skinny_svd.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, i32, vp, i64, i64, vp]

@@ -7,8 +7,13 @@ arithmetic is the Linear one -- row quantization, int8 / fp8 MFMA scaled matmul 
 float GEMM -- and the ``[M, C_out]`` product is viewed back to NCHW (conv_int8.py:81-88).  The float branch uses this build's
 own GEMM instead of the library convolution the reference calls (``_conv_forward``): same sum, fp32 accumulation.
 
-Not built (raise): groups != 1 (the reference loops ``int_mm`` per group, conv_int8.py:73-79), Conv3d, fp16 matmul,
-Hadamard on conv layers.
+Grouped convs (``groups > 1``; conv_int8.py:73-79, conv_fp8.py:56-60): the unfolded input keeps ALL input channels in a row (one
+row scale over the whole row, as in the reference), and each group multiplies its column slice with its own output channels'
+weight rows -- one launch per group on views (``sdnq_hip_scaled_mm_strided`` / ``sdnq_hip_linear_float_strided``), written straight
+into its channel range of the output.  Built for the float forward and the plain int8 / fp8 matmuls; the reference's SVD, zero-point
+and uint8-matmul terms are not defined per group (its SVD product has the wrong shape there) and raise here.
+
+Not built (raise): Conv3d, fp16 matmul, Hadamard on conv layers.
 """
 from __future__ import annotations
 
@@ -27,8 +32,6 @@ def _pair(v, n):
 
 def _geometry(self, input: torch.Tensor):
     """-> (input [B, C, H, W] (explicitly padded for non-zero padding modes), kernel, stride, padding, dilation, nd)."""
-    if self.groups != 1:
-        raise NotImplementedError("SDNQ conv with groups != 1 is not built for MI355X")
     if self.sdnq_dequantizer.use_hadamard:
         raise NotImplementedError("Hadamard-rotated conv layers are not built for MI355X")
     if isinstance(self.padding, str):
@@ -64,9 +67,39 @@ def _unfold(self, input: torch.Tensor):
     return x2d, _folder(self, nd, b, ho, wo)
 
 
+def _group_slices(self, k_total: int):
+    """(K', N_g) of a grouped conv: columns g K' .. (g + 1) K' of the unfolded input meet output channels g N_g .. (g + 1) N_g."""
+    g = int(self.groups)
+    n = self.sdnq_dequantizer.out_features
+    if k_total % g or n % g:
+        raise RuntimeError(f"groups={g} does not divide {k_total} unfolded input columns / {n} output channels")
+    return k_total // g, n // g
+
+
+def _grouped_float_forward(self, x2d: torch.Tensor, fold):
+    """F.conv*d(input, dequant(W), bias, groups=g) (layers/conv/forward.py:80-81): one float matmul per group on column views."""
+    dq = self.sdnq_dequantizer
+    st = linear._state(self)
+    if x2d.dtype != dq.result_dtype:
+        raise RuntimeError(f"expected input dtype {dq.result_dtype} (the layer's result_dtype) but got {x2d.dtype}")
+    kg, ng = _group_slices(self, x2d.shape[1])
+    wd = ops.dequant(st.qw, dq.result_dtype, 0)  # [N, K']
+    out = torch.empty((x2d.shape[0], dq.out_features), device=x2d.device, dtype=x2d.dtype)
+    aligned = (kg * x2d.element_size()) % 16 == 0
+    for g in range(int(self.groups)):
+        xg = x2d[:, g * kg:(g + 1) * kg]
+        if not aligned:
+            xg = xg.contiguous()
+        bias = None if self.bias is None else self.bias[g * ng:(g + 1) * ng]
+        ops.linear_float_into(xg, wd[g * ng:(g + 1) * ng], bias, out, g * ng)
+    return fold(out)
+
+
 @torch.no_grad()
 def quantized_conv_forward(self, input: torch.Tensor) -> torch.Tensor:
     x2d, fold = _unfold(self, input)
+    if self.groups != 1:
+        return _grouped_float_forward(self, x2d, fold)
     return fold(linear._float_forward(self, x2d, linear._state(self)))
 
 
@@ -75,10 +108,11 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
     if dq.is_packed and not dq.re_quantize_for_matmul:
         raise NotImplementedError("packed conv weights with a direct quantized matmul have no valid layout in the reference")
     if input.numel() / input.shape[2] < 32:  # conv_int8.py:96-97 (the reference's criterion, not the row count)
-        x2d, fold = _unfold(self, input)
-        return fold(linear._float_forward(self, x2d, linear._state(self)))
+        return quantized_conv_forward(self, input)
     st = linear._state(self)
     wq, ws, zp = linear._prepare_mm_weights(self, st, mm)
+    if self.groups != 1:
+        return _grouped_matmul_forward(self, input, mm, st, wq, ws, zp)
     if FUSED_CONV_QUANT and st.svd_up is None and zp is None and st.qw.scale_dtype == torch.float32:
         # no SVD / zero-point terms: the float [M, K] matrix is never needed -- row scales straight from the image, then the
         # unfold writes the quantized operand (same values as im2col + rowquant)
@@ -93,6 +127,35 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
     return fold(linear._quantized_matmul_forward(self, x2d, mm, small_batch_branch=False, cache_input=False))
 
 
+def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) -> torch.Tensor:
+    """conv_int8.py:73-79 / conv_fp8.py:56-60: the whole unfolded row is quantized with ONE scale, every group multiplies its column
+    slice of the codes with its own weight rows, and the epilogue fma(acc * xs, ws, bias) is the ungrouped one."""
+    if st.svd_up is not None or zp is not None or st.qw.scale_dtype != torch.float32:
+        raise NotImplementedError("grouped conv with SVD / zero-point terms or 16-bit scales: the reference's per-group matmul has no "
+                                  "valid form for them (its SVD product does not match the grouped weight)")
+    x4, kernel, stride, padding, dilation, nd = _geometry(self, input)
+    if FUSED_CONV_QUANT and kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
+        xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
+    else:
+        x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
+        xq, xs = ops.rowquant(x2d, mm, 0)[:2]
+    kg, ng = _group_slices(self, xq.shape[1])
+    if kg % 16 or ng % 8:
+        raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
+    n = self.sdnq_dequantizer.out_features
+    wq2, ws1 = wq.reshape(n, kg), ws.reshape(-1)
+    pixels = ho * wo
+    nchw = pixels % 8 == 0 and input.dtype != torch.float32
+    out = torch.empty((b, n, pixels) if nchw else (b * pixels, n), device=input.device, dtype=input.dtype)
+    for g in range(int(self.groups)):
+        bias = None if self.bias is None else self.bias[g * ng:(g + 1) * ng]
+        ops.scaled_mm_into(mm, xq[:, g * kg:(g + 1) * kg], wq2[g * ng:(g + 1) * ng], xs, ws1[g * ng:(g + 1) * ng], bias, out, g * ng,
+                           pixels if nchw else 0)
+    if nchw:
+        return out.view(b, n, wo) if nd == 1 else out.view(b, n, ho, wo)
+    return _folder(self, nd, b, ho, wo)(out)
+
+
 @torch.no_grad()
 def quantized_conv_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _conv_matmul_forward(self, input, ops.MM_I8)
@@ -101,6 +164,10 @@ def quantized_conv_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tenso
 @torch.no_grad()
 def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     """layers/conv/conv_uint8.py:95-121: unfolded input through the asymmetric-activation int8 matmul."""
+    if self.groups != 1:
+        if input.numel() / input.shape[2] < 32:
+            return quantized_conv_forward(self, input)
+        raise NotImplementedError("the uint8 matmul of a grouped conv (activation zero-point terms per group) is not built")
     x2d, fold = _unfold(self, input)
     if input.numel() / input.shape[2] < 32:
         return fold(linear._float_forward(self, x2d, linear._state(self)))

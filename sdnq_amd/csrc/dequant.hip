@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void unpack_mm_kernel(const DeqParams p, uint8
 template <int T_ID, int MC>
 __global__ __launch_bounds__(256) void linear_float_kernel(const void* __restrict__ x, const void* __restrict__ w,
                                                            const void* __restrict__ bias, void* __restrict__ out, int64_t M,
-                                                           int64_t N, int64_t K, int64_t ldx) {
+                                                           int64_t N, int64_t K, int64_t ldx, int64_t ldc) {
     constexpr int VN = Vec16<T_ID>::n;
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void linear_float_kernel(const void* __restric
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0 && m0 + i < M) {
             if (bias) s += FT<T_ID>::load(bias, n);
-            FT<T_ID>::store(out, (m0 + i) * N + n, s);
+            FT<T_ID>::store(out, (m0 + i) * ldc + n, s);
         }
     }
 }
@@ -1107,27 +1107,33 @@ extern "C" int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, s
 }
 
 int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,
-                    int64_t ldx, hipStream_t s, void* const* outs = nullptr, int n_outs = 0, int64_t seg_n = 0);  // gemm.hip
+                    int64_t ldx, hipStream_t s, void* const* outs = nullptr, int n_outs = 0, int64_t seg_n = 0, int64_t ldc = 0);  // gemm.hip
 
-extern "C" int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
-                                     int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {
+extern "C" int sdnq_hip_linear_float_strided(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
+                                             int64_t n, int64_t k, int64_t ldx, int64_t ldc, sdnq_stream_t stream) {
     if (!x || !wd || !out) return SDNQ_ERR_NULL;
     if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
     const int eb = (dtype == SDNQ_F32) ? 4 : 2;
-    if (m <= 0 || n <= 0 || k <= 0 || ldx < k || ((k * eb) % 16) != 0) return SDNQ_ERR_SHAPE;
+    if (m <= 0 || n <= 0 || k <= 0 || ldx < k || ldc < n || ((k * eb) % 16) != 0) return SDNQ_ERR_SHAPE;
     if (((uintptr_t)x % 16) || ((uintptr_t)wd % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     // more than a few rows: the MFMA GEMM of gemm.hip (bf16 / f16 / f32 matrix cores); its stores are 8 channels wide
-    if (m > 32 && (n % 8) == 0 && ((uintptr_t)out % 16) == 0) return sdnq_float_gemm(x, wd, bias, dtype, out, m, n, k, ldx, s);
+    if (m > 32 && (n % 8) == 0 && ((uintptr_t)out % 16) == 0 && ((ldc * eb) % 16) == 0)
+        return sdnq_float_gemm(x, wd, bias, dtype, out, m, n, k, ldx, s, nullptr, 0, 0, ldc);
     constexpr int MC = 8;
     dim3 grid((unsigned)((n + 3) / 4), (unsigned)((m + MC - 1) / MC)), block(256);
     switch (dtype) {
-        case SDNQ_F32: hipLaunchKernelGGL((linear_float_kernel<SDNQ_F32, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx); break;
-        case SDNQ_BF16: hipLaunchKernelGGL((linear_float_kernel<SDNQ_BF16, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx); break;
-        default: hipLaunchKernelGGL((linear_float_kernel<SDNQ_F16, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx); break;
+        case SDNQ_F32: hipLaunchKernelGGL((linear_float_kernel<SDNQ_F32, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx, ldc); break;
+        case SDNQ_BF16: hipLaunchKernelGGL((linear_float_kernel<SDNQ_BF16, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx, ldc); break;
+        default: hipLaunchKernelGGL((linear_float_kernel<SDNQ_F16, MC>), grid, block, 0, s, x, wd, bias, out, m, n, k, ldx, ldc); break;
     }
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_linear_float(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
+                                     int64_t n, int64_t k, int64_t ldx, sdnq_stream_t stream) {
+    return sdnq_hip_linear_float_strided(x, wd, bias, dtype, out, m, n, k, ldx, n, stream);
 }
 
 extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, const void* svd_down,

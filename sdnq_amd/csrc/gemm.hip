@@ -64,6 +64,7 @@ struct GemmParams {
     const float* wcs;          // [N] f32(colsum(b)) * sb (uint8 matmul) or null
     int64_t M, N, K;   // K in BYTES of one operand row (== elements for int8 / fp8)
     int64_t lda, ldb;  // operand row strides in bytes (0: K)
+    int64_t ldc;       // output row stride in ELEMENTS (0: N); with out_hw > 0: channels per image of the conv output (0: N)
     int64_t out_hw;    // 0: out is [M][N].  > 0: conv output [B][N][out_hw] with m = b * out_hw + pixel (NCHW, conv_int8.py:81-87)
     int64_t ld_bias;
     int bias_ndim;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         tv.sb = p.sb + n0;
         tv.bias = p.bias;
         tv.bias0 = n0;
-        tv.out_ld = p.N;
+        tv.out_ld = p.ldc;
         tv.out = (uint8_t*)p.out + n0 * OUT_B;
         tv.n_lim = p.N - n0;
     }
@@ -1241,7 +1242,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     }
                 }
                 const int64_t img = gm / p.out_hw, px = gm - img * p.out_hw;
-                *(uint4*)((uint8_t*)p.out + ((img * p.N + gn) * p.out_hw + px) * OUT_B) = Vec16<OUT_T>::pack(o);
+                *(uint4*)((uint8_t*)p.out + ((img * p.ldc + gn) * p.out_hw + px) * OUT_B) = Vec16<OUT_T>::pack(o);
             }
             continue;  // next chunk
         }
@@ -1421,7 +1422,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h8[e] = *(const uint16_t*)(stage + (r8 + e) * OUT_ROW + n * 2);
                 const int64_t img = gm / p.out_hw, px = gm - img * p.out_hw;
-                *(uint4*)((uint8_t*)p.out + ((img * p.N + gn) * p.out_hw + px) * 2) = *(const uint4*)h8;
+                *(uint4*)((uint8_t*)p.out + ((img * p.ldc + gn) * p.out_hw + px) * 2) = *(const uint4*)h8;
             }
             continue;  // next chunk
         }
@@ -1461,6 +1462,7 @@ int launch_one(GemmParams p, hipStream_t s) {
     }
     if (p.lda == 0) p.lda = p.K;
     if (p.ldb == 0) p.ldb = is_w8a16<MM> ? p.K / 2 : p.K;
+    if (p.ldc == 0) p.ldc = p.N;
     p.tiles_m = (int)((p.M + BM - 1) / BM);
     p.tiles_n = (int)((p.N + BN - 1) / BN);
     {
@@ -1672,9 +1674,10 @@ extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b,
 
 // internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`
 int sdnq_float_gemm(const void* x, const void* w, const void* bias, int dtype, void* out, int64_t m, int64_t n, int64_t k,
-                    int64_t ldx, hipStream_t s, void* const* outs = nullptr, int n_outs = 0, int64_t seg_n = 0) {
+                    int64_t ldx, hipStream_t s, void* const* outs = nullptr, int n_outs = 0, int64_t seg_n = 0, int64_t ldc = 0) {
     const int eb = (dtype == SDNQ_F32) ? 4 : 2;
     GemmParams p{};
+    p.ldc = ldc;
     p.a = (const uint8_t*)x; p.b = (const uint8_t*)w; p.bias = bias; p.out = out;
     if (outs) {  // several output tensors, one per stacked layer (sdnq_hip_linear_float_multi)
         for (int i = 0; i < n_outs; ++i) p.out_seg[i] = outs[i];
@@ -1819,6 +1822,28 @@ extern "C" int sdnq_hip_scaled_mm_nchw(int mm_dtype, const void* a, const void* 
     GemmParams p{};
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
     p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias_dtype; p.out_hw = hw;
+    hipStream_t s = (hipStream_t)stream;
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);
+}
+
+// sdnq_hip_scaled_mm / sdnq_hip_scaled_mm_nchw on VIEWS: a is [M][lda] with K valid columns, out is [M][ldc] with N valid columns
+// (hw == 0) or the channel slice [B][ldc channels][hw] starting at `out` (hw > 0).  Used for the per-group matmuls of grouped convs
+// (conv_int8.py:73-79, conv_fp8.py:56-60: int_mm / scaled_mm per group on column slices of the quantized unfolded input).
+extern "C" int sdnq_hip_scaled_mm_strided(int mm_dtype, const void* a, int64_t lda, const void* b, const float* sa, const float* sb,
+                                          const void* bias, int bias_dtype, void* out, int64_t ldc, int out_dtype, int64_t m, int64_t n,
+                                          int64_t k, int64_t hw, sdnq_stream_t stream) {
+    int st = check_common(mm_dtype, a, b, sa, sb, out, out_dtype, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (lda < k || (lda % 16) != 0 || ldc < n) return SDNQ_ERR_SHAPE;
+    if (hw < 0 || (hw > 0 && ((hw % 8) != 0 || (m % hw) != 0))) return SDNQ_ERR_SHAPE;
+    if (hw > 0 && out_dtype == SDNQ_F32) return SDNQ_ERR_UNSUPPORTED;
+    if (hw == 0 && (ldc * (out_dtype == SDNQ_F32 ? 4 : 2)) % 16 != 0) return SDNQ_ERR_ALIGN;
+    if (!bias) bias_dtype = out_dtype;
+    if (bias_dtype < 0 || bias_dtype > 2) return SDNQ_ERR_DTYPE;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.M = m; p.N = n; p.K = k; p.lda = lda; p.ldc = ldc; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias_dtype; p.out_hw = hw;
     hipStream_t s = (hipStream_t)stream;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);

@@ -389,6 +389,40 @@ def scaled_mm_nchw(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Ten
     return out
 
 
+def scaled_mm_into(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out: torch.Tensor,
+                   chan0: int, pixels: int = 0) -> None:
+    """scaled_mm on views (sdnq_hip_scaled_mm_strided): `a` is a column slice [M, K] of a wider row-major matrix, the N = b_phys.shape[0]
+    output channels go to channels chan0 .. chan0 + N of `out` -- [M, C] row-major (pixels == 0) or the conv image [B, C, pixels].
+    One group of a grouped conv (conv_int8.py:73-79)."""
+    _require_cuda(a, b_phys, sa, sb, bias, out)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    assert a.stride(1) == 1 and b_phys.is_contiguous() and out.is_contiguous()
+    c_total = out.shape[1]
+    esz = out.element_size()
+    dst = out.data_ptr() + (chan0 * pixels * esz if pixels else chan0 * esz)
+    bias_dt = 0
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_dt = float_code(bias.dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_strided(mm, a.data_ptr(), a.stride(0), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                                 bias_dt, dst, c_total, float_code(out.dtype), m, n, k, pixels, _stream(a)), "scaled_mm_strided")
+
+
+def linear_float_into(x2d: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, chan0: int) -> None:
+    """linear_float on views (sdnq_hip_linear_float_strided): x2d a column slice [M, K], the N outputs go to columns chan0 .. chan0 + N of
+    the row-major `out` [M, C]."""
+    _require_cuda(x2d, w, bias, out)
+    m, k = x2d.shape
+    n = w.shape[0]
+    assert w.is_contiguous() and x2d.stride(1) == 1 and w.dtype == x2d.dtype == out.dtype and out.is_contiguous()
+    if bias is not None and bias.dtype != x2d.dtype:
+        bias = bias.to(x2d.dtype)
+    check(_lib.load().sdnq_hip_linear_float_strided(x2d.data_ptr(), w.data_ptr(), _ptr(bias), float_code(x2d.dtype),
+                                                    out.data_ptr() + chan0 * out.element_size(), m, n, k, x2d.stride(0), out.shape[1],
+                                                    _stream(x2d)), "linear_float_strided")
+
+
 def scaled_mm_lowrank(mm: int, a, b_phys, sa, sb, bias, t, svd_up_phys, rowsum, zp, out_dtype: torch.dtype, a_zp=None,
                       w_colsum_scaled=None):
     _require_cuda(a, b_phys)

@@ -324,6 +324,17 @@ CONV_CASES = [
          cfg=dict(weights_dtype="int4", group_size=16, quantized_matmul_dtype="uint8", use_quantized_matmul_conv=True)),
     dict(name="conv2d_uint8_int8mm_qmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),
+    # grouped convs (conv_int8.py:73-79, conv_fp8.py:56-60; the float forward is F.conv2d(..., groups))
+    dict(name="conv2d_g2_int8_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_g4_fp8_qmm_bf16_nobias", nd=2, cin=128, cout=128, k=3, conv=dict(padding=1, groups=4, bias=False), xs=[(1, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_g2_int4_g16_qmm_f16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, stride=2, groups=2), xs=[(1, 12, 12)], dtype="f16",
+         cfg=dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True)),
+    dict(name="conv2d_g2_int8_noqmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 7, 7)], dtype="bf16",
+         cfg=dict(weights_dtype="int8")),
+    dict(name="conv1d_g4_uint4_noqmm_f32", nd=1, cin=32, cout=32, k=3, conv=dict(padding=1, groups=4), xs=[(2, 20)], dtype="f32",
+         cfg=dict(weights_dtype="uint4")),
 ]
 
 
