@@ -160,6 +160,13 @@ int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const floa
                           int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
                           int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
+/* sdnq_hip_scaled_mm_lp plus the zero-point term of unsigned weights on bfloat16 tensors (linear_int8.py:65-69 with dequantize_fp32=False):
+ *     zero_bias = bf16(bf16(bf16(f32(rowsum[m])) * sa[m]) * zp[n]);  bias' = bf16(zero_bias + bias)  (bias: the [N] bias or the low-rank bias)
+ * zp_rowsum [M] int32 (sdnq_hip_rowquant_lp's rowsum) and zp [N] f32 holding bf16-representable values: both or neither; bias_ndim <= 1. */
+int sdnq_hip_scaled_mm_lp_zp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                             int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, const int32_t* zp_rowsum,
+                             const float* zp, void* out, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
+
 /* the same scaled matmul over the STACKED weights of layers that consume one activation (to_q / to_k / to_v of an attention block),
  * each layer's columns stored in its own contiguous tensor: b [n_outs * seg_n][K], sb / bias [n_outs * seg_n], outs[i] is
  * [M][seg_n] (seg_n % 8 == 0, n_outs <= 4, n == n_outs * seg_n).  One launch and one pass over the quantized activation instead

@@ -580,6 +580,11 @@ def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.n
     return np.ascontiguousarray(y.reshape(B, Ho, Wo, mod.N).transpose(0, 3, 1, 2))
 
 
+def info_is_plain_uint8(d: dict) -> bool:
+    """A raw (unpacked) unsigned 8-bit weight: the case whose zero point the int8 forward shifts by 128 * scale (linear_int8.py:45-50)."""
+    return (not d["is_packed"]) and dtype_info(d["weights_dtype"])["kind"] == "uint"
+
+
 def _mm_weights(mod: OracleLinear, mm: str):
     """The matmul operand of the int8 / fp8 forwards: (wq [N, K] int8 | e4m3 bytes, ws [N], zero-point term | None)
     (linear_int8.py:38-50, 104-107; linear_fp8.py:36-38)."""
@@ -647,11 +652,21 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
         b1 = None if bias is None else round_dtype(bias, mod.svd_tag)
         bias = lowrank_bias(t, up, b1, mod.svd_tag)
     lp = mod.scale_tag != "f32"
-    if lp and zp is not None:
-        raise NotImplementedError("zero-point matmul terms with 16-bit scales are not restated")
+    if lp and zp is not None and info_is_plain_uint8(d):
+        # `torch.add(zero_point, scale, alpha=128)` on 16-bit tensors (linear_int8.py:47-50): float32 op-math, rounded to the scale dtype
+        zp = round_dtype(zp, mod.scale_tag)
     xq, xs, rowsum = rowquant_lp(x2, mm, mod.scale_tag) if lp else rowquant(x2, mm)  # linear_int8.py:64
     inter["xq"], inter["xs"] = xq, xs
     if lp and mod.scale_tag == "bf16":
+        if zp is not None:
+            # linear_int8.py:65-69 on bfloat16 tensors: sum(int32).to(bf16).mul_(input_scale).mul(zero_point) [.add_(bias)], every
+            # step rounded to bfloat16
+            zs = round_dtype(round_dtype(rowsum.astype(np.float32), "bf16") * xs.reshape(-1), "bf16")
+            zero_bias = round_dtype(zs[:, None] * zp.astype(np.float32).reshape(1, -1), "bf16")
+            if bias is not None:
+                b2 = _c(bias, np.float32)
+                zero_bias = round_dtype(zero_bias + (b2.reshape(1, -1) if b2.ndim == 1 else b2), "bf16")
+            bias = zero_bias
         y = round_dtype(scaled_mm_lp(mm, xq, wq, xs, ws, bias, "bf16"), tag)
         return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
     if zp is not None:  # linear_int8.py:65-69

@@ -30,7 +30,7 @@ EXPORTS = [
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
     "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
-    "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided",
+    "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
 ]
 
 
@@ -152,6 +152,7 @@ def _declare(lib):
     lib.sdnq_hip_linear_w8a16.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
     lib.sdnq_hip_rowquant_lp.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]
     lib.sdnq_hip_scaled_mm_lp.argtypes = [i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, i32, vp, i64, i64, i64, vp]
+    lib.sdnq_hip_scaled_mm_lp_zp.argtypes = [i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp]
     lib.sdnq_hip_set_tile_override.argtypes = [i32]
     lib.sdnq_hip_set_tile_override.restype = None
     lib.sdnq_hip_scaled_mm_grouped.argtypes = [i32, vp, vp, vp, i64, i64, i32, vp, i32, i64, i64, vp]

@@ -914,6 +914,37 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
 #endif
         };
+#ifdef SDNQ_LAB_LUT4
+        // TIMING-ONLY lab build (wrong results; tools/lut4_lab.sh): what a fused 4-bit loader would add to this K loop.  Every weight
+        // fragment is treated as 8 bytes of packed codes + a 16-entry byte table of its (row, group) and expanded to the 16 int8 codes
+        // of the MFMA operand with the cheapest sequence found (nibble split, two v_perm per 4 codes, bit-3 blend; the even / odd
+        // interleave is assumed away by a k-permuted activation operand): 34 vector-ALU instructions per fragment, placed in the
+        // read / issue section of the phase (where the partner wave's MFMA section can hide them).  No table build, no table traffic.
+        v4i lut_t = *(const v4i*)(lds + VEC_OFF + (lane & 15) * 16);
+        auto lut_expand = [&](fragb_t& f) {
+            if constexpr (NPC == 1) {
+                v4i o;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const u32 x = (u32)f[d];
+                    const u32 cl = x & 0x0f0f0f0fu, chh = (x >> 4) & 0x0f0f0f0fu;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32 c = h ? chh : cl;
+                        const u32 sel = c & 0x07070707u;
+                        const u32 p0 = __builtin_amdgcn_perm((u32)lut_t[1], (u32)lut_t[0], sel);
+                        const u32 p1 = __builtin_amdgcn_perm((u32)lut_t[3], (u32)lut_t[2], sel);
+                        const u32 m = ((c >> 3) & 0x01010101u) * 255u;
+                        o[2 * d + h] = (int)((p1 & m) | (p0 & ~m));
+                    }
+                }
+                f = o;
+            }
+        };
+#define LUT_EXPAND(fb) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) lut_expand(fb[ks]); } while (0)
+#else
+#define LUT_EXPAND(fb) do { } while (0)
+#endif
         wait_vmcnt<8>();  // HA0(0), HB0(0) have landed: everything phase 0 reads
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger: group 1 sits out the first slot
@@ -927,6 +958,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             // ---- phase 0: B0 (A0 was read in the previous phase 3) -> acc[0][0..1]; refill HB1 for K tile t + 1
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) fb0[ks] = ldB(ks, PAR * HT_BYTES);
+            LUT_EXPAND(fb0);
             __builtin_amdgcn_sched_barrier(0);
             issue_ht(std::integral_constant<int, 3>{}, 6 + (PAR ^ 1), t + 1);
             phase_sync(true);
@@ -938,6 +970,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             // ---- phase 1: B1 -> acc[1][0..1]; refill HA1 for K tile t + 1
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) fb1[ks] = ldB(ks, (2 + PAR) * HT_BYTES);
+            LUT_EXPAND(fb1);
             __builtin_amdgcn_sched_barrier(0);
             issue_ht(std::integral_constant<int, 1>{}, 2 + (PAR ^ 1), t + 1);
             phase_sync(true);
@@ -987,6 +1020,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         }
 #endif
 #undef TS
+#undef LUT_EXPAND
+    } else if constexpr (LD == LD_HT + 100) {
     } else if constexpr (LD == LD_DMA) {
         // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
         // single raw barrier), refill the ring slot stage kt-1 occupied (an unconsumed re-fetch past the end of K), run the MFMAs.
@@ -1256,7 +1291,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
         float zsum = 0.0f, azp = 0.0f;
         if constexpr (is_lr<EPI>) {
-            if (p.zp_rowsum) zsum = (float)p.zp_rowsum[gm] * sa;  // .to(f32).mul_(input_scale), linear_int8.py:66
+            if (p.zp_rowsum) {  // sum(int32).to(scale dtype).mul_(input_scale), linear_int8.py:66 (LP: both steps rounded to bf16)
+                zsum = (float)p.zp_rowsum[gm];
+                if constexpr (LP) zsum = FT<SDNQ_BF16>::round(FT<SDNQ_BF16>::round(zsum) * sa);
+                else zsum *= sa;
+            }
             if (p.a_zp) azp = p.a_zp[gm];
         }
         float o[8];
@@ -1321,14 +1360,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         }
                         float zb = 0.0f;
                         bool hasz = false;
-                        if (p.zp) { zb = zsum * s_zpq[cn]; hasz = true; }
+                        if (p.zp) {
+                            zb = zsum * s_zpq[cn];
+                            if constexpr (LP) zb = FT<SDNQ_BF16>::round(zb);  // .mul(zero_point) on bf16 tensors
+                            hasz = true;
+                        }
                         if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
                             const float t2 = s_wcsq[cn] * azp;
                             zb = hasz ? zb + t2 : t2;
                             if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
                             hasz = true;
                         }
-                        if (hasz) { bv = has ? zb + bv : zb; has = true; }
+                        if (hasz) {
+                            bv = has ? zb + bv : zb;  // zero_bias.add_(bias), linear_int8.py:67-68
+                            if constexpr (LP) bv = FT<SDNQ_BF16>::round(bv);
+                            has = true;
+                        }
                         res = has ? fmaf(vv, sb4[e], bv) : vv * sb4[e];
                     }
                 }
@@ -1646,23 +1693,26 @@ int launch_lp(const GemmParams& p, hipStream_t s) {
     return launch_one<MM, SDNQ_BF16, EPI, 64, 64, 32, 32, 4, LD_PIPE, BKB, true>(p, s);
 }
 
-extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
-                                     int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
-                                     int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+extern "C" int sdnq_hip_scaled_mm_lp_zp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                        int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank,
+                                        const int32_t* zp_rowsum, const float* zp, void* out, int64_t m, int64_t n, int64_t k,
+                                        sdnq_stream_t stream) {
     int st = check_common(mm_dtype, a, b, sa, sb, out, SDNQ_BF16, m, n, k);
     if (st != SDNQ_OK) return st;
+    if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
+    if (zp && bias_ndim == 2) return SDNQ_ERR_SHAPE;
     if (bias_ndim < 0 || bias_ndim > 2 || (bias_ndim != 0 && !bias)) return SDNQ_ERR_NULL;
     if ((t == nullptr) != (svd_up == nullptr)) return SDNQ_ERR_NULL;
     if (t && (rank <= 0 || bias_ndim == 2)) return SDNQ_ERR_SHAPE;
     if (t && (((uintptr_t)t % 16) || ((uintptr_t)svd_up % 16))) return SDNQ_ERR_ALIGN;
     GemmParams p{};
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
-    p.lr_t = t; p.lr_up = svd_up; p.rank = rank;
+    p.lr_t = t; p.lr_up = svd_up; p.rank = rank; p.zp_rowsum = zp_rowsum; p.zp = zp;
     p.M = m; p.N = n; p.K = k; p.ld_bias = ld_bias; p.bias_ndim = bias_ndim; p.bias_dtype = SDNQ_BF16;
     hipStream_t s = (hipStream_t)stream;
 #define LPD(MMV)                                                              \
     do {                                                                      \
-        if (t) return launch_lp<MMV, EPI_LOWRANK>(p, s);                      \
+        if (t || zp) return launch_lp<MMV, EPI_LOWRANK>(p, s);                \
         if (bias_ndim == 0) return launch_lp<MMV, EPI_NONE>(p, s);            \
         if (bias_ndim == 1) return launch_lp<MMV, EPI_BIAS1D>(p, s);          \
         return launch_lp<MMV, EPI_BIAS2D>(p, s);                              \
@@ -1670,6 +1720,12 @@ extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b,
     if (mm_dtype == SDNQ_MM_I8) LPD(SDNQ_MM_I8);
     LPD(SDNQ_MM_FP8);
 #undef LPD
+}
+
+extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                     int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
+                                     int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+    return sdnq_hip_scaled_mm_lp_zp(mm_dtype, a, b, sa, sb, bias, bias_ndim, ld_bias, t, svd_up, rank, nullptr, nullptr, out, m, n, k, stream);
 }
 
 // internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`

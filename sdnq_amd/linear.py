@@ -313,6 +313,8 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
             zp = st.qw.keep[2]
             if not ent["is_packed"]:  # plain uint8: zero_point += 128 * scale (linear_int8.py:47-50)
                 zp = torch.add(zp, ws, alpha=128) if zp is not None else ws * 128
+                if st.qw.scale_dtype != torch.float32:  # the reference's add runs on 16-bit tensors: float32 op-math, one rounding
+                    zp = zp.to(st.qw.scale_dtype).float()
     if CACHE_WEIGHTS:
         st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, wq, ws, zp, None
     elif dq.re_quantize_for_matmul and not asymmetric:
@@ -582,20 +584,19 @@ def _lp_matmul_forward(self, input: torch.Tensor, st: _State, mm: int) -> torch.
     if input.dtype != sdt:
         raise NotImplementedError(f"16-bit scales ({sdt}) with {input.dtype} activations are not built (the layer's dtype must match)")
     wq, ws, zp = _prepare_mm_weights(self, st, mm)  # re-quantization rounds in the scale dtype (SdnqWeight.scale_dtype)
-    if zp is not None:
-        raise NotImplementedError("zero-point matmul terms with 16-bit scales (dequantize_fp32=False) are not built")
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
     bias = _attr(self, "bias")
     x2 = input.reshape(-1, k)
     if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
         x2 = x2.contiguous()
-    xq, xs, _, xrot = ops.rowquant_lp(x2, mm, had, want_xrot=has_svd)
+    xq, xs, rowsum, xrot = ops.rowquant_lp(x2, mm, had, want_rowsum=zp is not None, want_xrot=has_svd)
     t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
     if sdt == torch.bfloat16:
-        y = ops.scaled_mm_lp(mm, xq, wq, xs, ws, bias, t, st.svd_up if has_svd else None)
-    elif has_svd:
-        y = ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, st.svd_up, None, None, input.dtype)
+        # zero-point term of unsigned weights (linear_int8.py:65-69) on bf16 tensors: every step rounded, inside the epilogue
+        y = ops.scaled_mm_lp(mm, xq, wq, xs, ws, bias, t, st.svd_up if has_svd else None, rowsum, zp)
+    elif has_svd or zp is not None:  # float16 scales: float32 activation scale, so the float32 epilogue (zp holds f16-representable values)
+        y = ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, t, st.svd_up if has_svd else None, rowsum, zp, input.dtype)
     else:
         y = ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype)
     return y.view(*input.shape[:-1], n)

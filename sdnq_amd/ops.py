@@ -214,10 +214,12 @@ def rowquant_lp(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum
     return xq, xs, rowsum, xrot
 
 
-def scaled_mm_lp(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, t=None, svd_up=None):
-    """sdnq_hip_scaled_mm_lp: the scaled matmul of bfloat16-scale layers (accumulator, activation-scale product and result each
-    rounded to bf16); bias None | [N] | [M,N] bf16; t [M,R] / svd_up [N,R] bf16 add the low-rank bias.  Returns [M,N] bf16."""
-    _require_cuda(a, b_phys, sa, sb, bias, t, svd_up)
+def scaled_mm_lp(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, t=None, svd_up=None,
+                 rowsum=None, zp=None):
+    """sdnq_hip_scaled_mm_lp[_zp]: the scaled matmul of bfloat16-scale layers (accumulator, activation-scale product and result each
+    rounded to bf16); bias None | [N] | [M,N] bf16; t [M,R] / svd_up [N,R] bf16 add the low-rank bias; rowsum [M] i32 + zp [N] f32
+    (bf16-representable) the zero-point term of unsigned weights.  Returns [M,N] bf16."""
+    _require_cuda(a, b_phys, sa, sb, bias, t, svd_up, rowsum, zp)
     m, k = a.shape
     n = b_phys.shape[0]
     out = torch.empty((m, n), device=a.device, dtype=torch.bfloat16)
@@ -233,8 +235,12 @@ def scaled_mm_lp(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tenso
             raise _lib.SdnqHipError("scaled_mm_lp: low-rank factors must be bfloat16")
         t, svd_up = t.contiguous(), svd_up.contiguous()
         rank = t.shape[1]
-    check(_lib.load().sdnq_hip_scaled_mm_lp(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), bias_ndim,
-                                            ld_bias, _ptr(t), _ptr(svd_up), rank, out.data_ptr(), m, n, k, _stream(a)), "scaled_mm_lp")
+    if zp is not None:
+        zp = zp.reshape(-1).contiguous()
+        assert zp.dtype == torch.float32 and rowsum is not None and rowsum.dtype == torch.int32
+    check(_lib.load().sdnq_hip_scaled_mm_lp_zp(mm, a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), bias_ndim,
+                                               ld_bias, _ptr(t), _ptr(svd_up), rank, _ptr(rowsum if zp is not None else None), _ptr(zp),
+                                               out.data_ptr(), m, n, k, _stream(a)), "scaled_mm_lp")
     return out
 
 

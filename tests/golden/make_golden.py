@@ -211,6 +211,13 @@ CASES = [
          cfg=dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="int8_svd32_noqmm_f16_lpscale", K=256, N=64, Ms=[5, 40], dtype="f16",
          cfg=dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=False, dequantize_fp32=False)),
+    dict(name="uint8_int8mm_qmm_bf16_lpscale", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="uint8_int8mm_qmm_f16_lpscale_nobias", K=256, N=64, Ms=[40], dtype="f16", bias=False,
+         cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="uint8_svd32_int8mm_qmm_bf16_lpscale", K=256, N=128, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True,
+                  dequantize_fp32=False)),
     dict(name="fp8_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
 ]
@@ -333,7 +340,7 @@ CONV_CASES = [
          cfg=dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True)),
     dict(name="conv2d_g2_int8_noqmm_bf16", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 7, 7)], dtype="bf16",
          cfg=dict(weights_dtype="int8")),
-    dict(name="conv1d_g4_uint4_noqmm_f32", nd=1, cin=32, cout=32, k=3, conv=dict(padding=1, groups=4), xs=[(2, 20)], dtype="f32",
+    dict(name="conv1d_g4_uint4_noqmm_f32", nd=1, cin=64, cout=32, k=3, conv=dict(padding=1, groups=4), xs=[(2, 20)], dtype="f32",
          cfg=dict(weights_dtype="uint4")),
 ]
 
