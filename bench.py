@@ -773,6 +773,10 @@ def main():
         for l in layers:
             if hasattr(l[1], "sdnq_dequantizer"):
                 torch_ops.layer_handle(l[1])
+        if not args.no_link_projections:
+            # layers whose layer_matmul nodes share (xq, xs) after the graph's CSE become one grouped launch (the compiled-graph form of
+            # the eager path's linked projections; sdnq_amd.torch_ops.MergeLayerMatmuls)
+            torch_ops.enable_compile_grouping()
         step_mod = Step(layers)
         t_c = time.perf_counter()
         compiled = torch.compile(step_mod, mode="reduce-overhead", fullgraph=True)
@@ -834,9 +838,9 @@ def main():
         "config": {"workload": f"{args.workload}: {len(layers)} quantized {'Conv2d' if is_conv else 'Linear'} layers of one denoising step, bs=1 "
                                f"({sum(1 for l in layers if l[3] >= 32)} w8a8 GEMMs + {sum(1 for l in layers if l[3] < 32)} M=1 layers)",
                    "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
-                   "launch": ("torch.compile(mode='reduce-overhead'): one sdnq_hip::layer_forward op per layer, no activation cache / linked projections inside the graph"
+                   "launch": ("torch.compile(mode='reduce-overhead'): every plain layer rowquant + layer_matmul operators, layers on one quantized activation merged into grouped launches by the post-grad pass"
                               if compiled is not None else ("eager" if graph is None else "hipGraph replay")), "activations": "bf16",
-                   **({"compile_seconds": round(compile_s, 1)} if compiled is not None else {}),
+                   **({"compile_seconds": round(compile_s, 1), "compile_grouping": dict(__import__("sdnq_amd").torch_ops.merge_stats)} if compiled is not None else {}),
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
                    "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
                    "linked_projection_groups": linked,

@@ -21,7 +21,7 @@ inside a compiled graph.  Its fake implementation only needs the layer's out_fea
 from __future__ import annotations
 
 import weakref
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 from torch.library import custom_op
@@ -159,6 +159,207 @@ def layer_matmul(xq: torch.Tensor, xs: torch.Tensor, handle: int, out_dtype: tor
 @layer_matmul.register_fake
 def _(xq, xs, handle, out_dtype):
     return xq.new_empty((xq.shape[0], _layer(handle).sdnq_dequantizer.out_features), dtype=out_dtype)
+
+
+# ---- linked projections inside a compiled graph ------------------------------------------------------------------------------
+# Eagerly, layers that consume ONE tensor (to_q / to_k / to_v, every cross-attention to_k / to_v) share a launch through a run-time
+# guess that is checked by tensor identity (linear.ProjectionGroup) -- which proves nothing inside a compiled graph.  There the same
+# sharing is a DATAFLOW fact: after the graph's common-subexpression elimination those layers are `layer_matmul` nodes with the very
+# same (xq, xs) arguments.  `MergeLayerMatmuls` (an Inductor post-grad pass, installed by `enable_compile_grouping()`) rewrites every
+# such set into ONE `layer_matmul_group` node -- sdnq_hip_scaled_mm_grouped over the members' own weights, one pass over the quantized
+# activation -- whose flat result the members' outputs are sliced from (views, free in Inductor).  Bit-identical to the members alone.
+_group_cache: dict = {}
+
+
+def _matmul_group(handles, mm):
+    """(ProjectionGroup of the layers behind `handles`, ready for `mm`) or None when they cannot share a grouped launch."""
+    from . import linear as L
+    key = tuple(handles)
+    pg = _group_cache.get(key)
+    if pg is None or any(m is not _layers.get(h, lambda: None)() for m, h in zip(pg.mods, key)):
+        pg = L.ProjectionGroup([_layer(h) for h in key])
+        _group_cache[key] = pg
+    return pg if pg._operands(mm) else None
+
+
+@custom_op("sdnq_hip::layer_matmul_group", mutates_args=())
+def layer_matmul_group(xq: torch.Tensor, xs: torch.Tensor, handles: List[int], out_dtype: torch.dtype) -> torch.Tensor:
+    """layer_matmul of several layers on ONE quantized activation: a flat [M * sum(N_i)] buffer in which layer i's [M, N_i] output is
+    the contiguous block starting at element M * sum(N_j, j < i)."""
+    from . import linear as L
+    mm = ops.MM_I8 if xq.dtype == torch.int8 else ops.MM_FP8
+    pg = _matmul_group(handles, mm)
+    if pg is not None:
+        outs = ops.scaled_mm_grouped(mm, xq, xs, pg.gemm, out_dtype)
+        return outs[0]._base if outs[0]._base is not None else torch.cat([o.reshape(-1) for o in outs])
+    # the members stopped being groupable after tracing (a parameter moved / changed form): one launch each, same layout
+    m = xq.shape[0]
+    mods = [_layer(h) for h in handles]
+    widths = [mod.sdnq_dequantizer.out_features for mod in mods]
+    flat = torch.empty((m * sum(widths),), device=xq.device, dtype=out_dtype)
+    start = 0
+    for mod, n in zip(mods, widths):
+        wq, ws, zp = L._prepare_mm_weights(mod, L._state(mod), mm)
+        if zp is not None or L._state(mod).svd_up is not None:
+            raise _lib.SdnqHipError("sdnq_hip::layer_matmul_group: a member changed to a form with zero-point / low-rank terms after tracing")
+        ops.scaled_mm_into(mm, xq, wq.reshape(n, -1), xs, ws.reshape(-1), L._attr(mod, "bias"), flat[m * start:m * (start + n)].view(m, n), 0)
+        start += n
+    return flat
+
+
+@layer_matmul_group.register_fake
+def _(xq, xs, handles, out_dtype):
+    return xq.new_empty((xq.shape[0] * sum(_layer(h).sdnq_dequantizer.out_features for h in handles),), dtype=out_dtype)
+
+
+def _groupable(handles) -> bool:
+    """Static test at pass time: one K, a common width divisor that is a multiple of 64, all or none with a bias."""
+    import math
+    mods = [_layer(h) for h in handles]
+    dqs = [m.sdnq_dequantizer for m in mods]
+    if len({dq.in_features for dq in dqs}) != 1:
+        return False
+    g = 0
+    for dq in dqs:
+        g = math.gcd(g, dq.out_features)
+    if g % 64:
+        return False
+    has_bias = [getattr(m, "bias", None) is not None for m in mods]
+    return all(has_bias) or not any(has_bias)
+
+
+def merge_layer_matmuls(graph: "torch.fx.Graph") -> int:
+    """Rewrite sets of `sdnq_hip::layer_matmul` nodes that share (xq, xs, out_dtype) into one `layer_matmul_group` node + views.
+    Returns the number of launches removed.  Static shapes only (a symbolic row count leaves the graph untouched)."""
+    targets = (torch.ops.sdnq_hip.layer_matmul.default, torch.ops.sdnq_hip.layer_matmul)  # post-grad graphs hold the overload
+    sets: dict = {}
+    names = ("xq", "xs", "handle", "out_dtype")
+    import os
+    debug = os.environ.get("SDNQ_HIP_DEBUG_PASS", "0") == "1"
+
+    def operands(node):  # positional or keyword form (Inductor's passes may normalise a custom operator's call to keywords)
+        vals = dict(zip(names, node.args))
+        vals.update(node.kwargs)
+        return vals if set(vals) == set(names) else None
+
+    # (1) the row quantization of one value with one configuration is computed once: sdnq_hip::rowquant is a pure operator, but the
+    #     graph passes in front of this one leave the per-layer copies in place (measured: to_q / to_k / to_v each kept its own)
+    import operator
+    rq_targets = (torch.ops.sdnq_hip.rowquant.default, torch.ops.sdnq_hip.rowquant)
+    first_rq: dict = {}
+    for node in list(graph.nodes):
+        if node.op == "call_function" and node.target in rq_targets:
+            key = (tuple(node.args), tuple(sorted(node.kwargs.items())))
+            canon = first_rq.setdefault(key, node)
+            if canon is not node:
+                node.replace_all_uses_with(canon)
+                graph.erase_node(node)
+    for canon in first_rq.values():  # one getitem per output index
+        items: dict = {}
+        for user in list(canon.users):
+            if user.op == "call_function" and user.target is operator.getitem:
+                keep = items.setdefault(user.args[1], user)
+                if keep is not user:
+                    user.replace_all_uses_with(keep)
+                    graph.erase_node(user)
+    # (2) layer_matmul nodes on one (xq, xs) -> one grouped launch
+    for node in graph.nodes:
+        if node.op == "call_function" and node.target in targets:
+            v = operands(node)
+            if debug:
+                print("[sdnq merge pass]", node.name, node.args, node.kwargs)
+            if v is not None:
+                sets.setdefault((v["xq"], v["xs"], v["out_dtype"]), []).append(node)
+    removed = 0
+    for (xq, xs, out_dtype), nodes in sets.items():
+        if len(nodes) < 2 or not isinstance(xq, torch.fx.Node):
+            continue
+        val = xq.meta.get("val")
+        if val is None or not isinstance(val.shape[0], int):
+            if debug:
+                print("[sdnq merge pass] no static fake value on", xq, type(val))
+            continue
+        handles = [int(operands(n)["handle"]) for n in nodes]
+        try:
+            if not _groupable(handles):
+                continue
+        except _lib.SdnqHipError:
+            continue
+        # build the group's device-resident unit table NOW (compile time, the ordinary allocator): built lazily inside the first run
+        # it would be a live allocation in the CUDA-graph trees' private pool that is no output of the graph -- which they refuse
+        if val.device.type == "cuda":
+            try:
+                if _matmul_group(handles, ops.MM_I8 if val.dtype == torch.int8 else ops.MM_FP8) is None:
+                    continue
+            except _lib.SdnqHipError:
+                continue
+        m = int(val.shape[0])
+        widths = [_layer(h).sdnq_dequantizer.out_features for h in handles]
+        fake_mode = getattr(val, "fake_mode", None)
+        with graph.inserting_before(nodes[0]):
+            flat = graph.call_function(torch.ops.sdnq_hip.layer_matmul_group.default, (xq, xs, handles, out_dtype))
+            pieces, start = [], 0
+            for n in widths:
+                sl = graph.call_function(torch.ops.aten.slice.Tensor, (flat, 0, m * start, m * (start + n)))
+                pieces.append((sl, graph.call_function(torch.ops.aten.view.default, (sl, [m, n]))))
+                start += n
+        if fake_mode is not None:  # Inductor lowers from the nodes' fake values
+            with fake_mode:
+                fv = torch.ops.sdnq_hip.layer_matmul_group.default(val, xs.meta["val"], handles, out_dtype)
+                flat.meta["val"] = fv
+                start = 0
+                for (sl, vw), n in zip(pieces, widths):
+                    sv = torch.ops.aten.slice.Tensor(fv, 0, m * start, m * (start + n))
+                    sl.meta["val"] = sv
+                    vw.meta["val"] = torch.ops.aten.view.default(sv, [m, n])
+                    start += n
+        for node, (_, vw) in zip(nodes, pieces):
+            node.replace_all_uses_with(vw)
+            graph.erase_node(node)
+        removed += len(nodes) - 1
+    if removed:
+        graph.lint()
+    return removed
+
+
+merge_stats = {"graphs": 0, "launches_removed": 0}
+
+
+def enable_compile_grouping() -> None:
+    """Install `merge_layer_matmuls` as Inductor's post-grad custom pass (torch.compile of a model whose SDNQ layers trace as
+    rowquant + layer_matmul).  Idempotent; an already installed foreign pass is chained, not replaced."""
+    from torch._inductor import config
+    from torch._inductor.custom_graph_pass import CustomGraphPass
+    prev = config.post_grad_custom_post_pass
+    if isinstance(prev, _MergePass):
+        return
+
+    config.post_grad_custom_post_pass = _MergePass(prev)
+
+
+def _make_pass_class():
+    from torch._inductor.custom_graph_pass import CustomGraphPass
+
+    class MergePass(CustomGraphPass):
+        def __init__(self, prev=None):
+            self.prev = prev
+
+        def __call__(self, graph):
+            if self.prev is not None:
+                self.prev(graph)
+            merge_stats["graphs"] += 1
+            merge_stats["launches_removed"] += merge_layer_matmuls(graph)
+
+        def uuid(self):
+            return None  # the graphs hold per-process layer handles: never served from Inductor's on-disk cache
+
+    return MergePass
+
+
+try:
+    _MergePass = _make_pass_class()
+except Exception:  # noqa: BLE001  (a torch build without Inductor)
+    _MergePass = type("_MergePass", (), {})
 
 
 def layer_plan(module: torch.nn.Module):

@@ -154,3 +154,60 @@ def test_copies_of_a_layer_get_their_own_operator_handle():
     other = copy.copy(layer)
     other.__dict__["_sdnq_hip_handle"] = h
     assert torch_ops.layer_handle(other) != h and torch_ops._layer(h) is layer
+
+
+def test_merge_pass_links_projections_in_a_traced_graph_cpu():
+    """`merge_layer_matmuls` (the Inductor post-grad pass behind enable_compile_grouping): after common-subexpression elimination
+    to_q / to_k / to_v are layer_matmul nodes on the SAME (xq, xs) values and become ONE layer_matmul_group node whose flat result
+    the three outputs are sliced from; layers with their own input stay as they are.  CPU: graph surgery + fake-tensor shapes only."""
+    blk = _quantized_block("cpu", weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    x = torch.randn(2, 40, 128).to(torch.bfloat16)
+    gm, _ = torch._dynamo.export(blk, assume_static_by_default=True)(x)
+    for n in gm.graph.nodes:
+        if "val" not in n.meta and "example_value" in n.meta:
+            n.meta["val"] = n.meta["example_value"]
+    g = gm.graph  # six rowquant nodes: the pass itself merges the row quantizations of one value (Inductor's passes do not)
+
+    def count(op):
+        return sum(1 for n in g.nodes if n.op == "call_function" and n.target in (op, op.default))
+
+    assert count(torch.ops.sdnq_hip.rowquant) == 6 and count(torch.ops.sdnq_hip.layer_matmul) == 6
+    removed = torch_ops.merge_layer_matmuls(g)
+    assert removed == 2 and count(torch.ops.sdnq_hip.rowquant) == 4
+    assert count(torch.ops.sdnq_hip.layer_matmul) == 3 and count(torch.ops.sdnq_hip.layer_matmul_group) == 1
+    grp = next(n for n in g.nodes if n.op == "call_function" and n.target is torch.ops.sdnq_hip.layer_matmul_group.default)
+    assert [torch_ops._layer(h) for h in grp.args[2]] == [blk.to_q, blk.to_k, blk.to_v]
+    assert grp.meta["val"].shape == (80 * 3 * 128,) and grp.meta["val"].dtype == torch.bfloat16
+    views = [u for s in grp.users for u in s.users]
+    assert sorted(tuple(v.meta["val"].shape) for v in views) == [(80, 128)] * 3
+    g.lint()
+    gm.recompile()
+    # a second application finds nothing left to merge
+    assert torch_ops.merge_layer_matmuls(g) == 0
+
+
+@pytest.mark.gpu
+def test_compiled_block_with_grouping_equals_eager(gpu_device):
+    """enable_compile_grouping(): torch.compile (Inductor) of the block runs to_q / to_k / to_v as ONE grouped launch and still equals
+    the eager block within the rounding of Inductor's fused pointwise code; the operator alone is bit-identical to the members."""
+    blk = _quantized_block(gpu_device, weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    sdnq_amd.accelerate(blk)
+    x = torch.randn(2, 77, 128, device=gpu_device, dtype=torch.bfloat16)
+    with torch.no_grad():
+        h = blk.norm1(x)
+        xq, xs = torch.ops.sdnq_hip.rowquant(h, "int8", 0)
+        hs = [m._sdnq_hip_handle for m in (blk.to_q, blk.to_k, blk.to_v)]
+        flat = torch.ops.sdnq_hip.layer_matmul_group(xq, xs, hs, torch.bfloat16)
+        m = xq.shape[0]
+        for i, mod in enumerate((blk.to_q, blk.to_k, blk.to_v)):
+            alone = torch.ops.sdnq_hip.layer_matmul(xq, xs, mod._sdnq_hip_handle, torch.bfloat16)
+            assert torch.equal(flat[m * 128 * i:m * 128 * (i + 1)].view(m, 128), alone)
+        want = blk(x)
+        torch_ops.enable_compile_grouping()
+        before = dict(torch_ops.merge_stats)
+        try:
+            got = torch.compile(blk, fullgraph=True)(x)
+        except Exception as e:  # noqa: BLE001  (no Triton code generation available on the box)
+            pytest.skip(f"inductor backend unavailable here: {type(e).__name__}")
+        assert torch_ops.merge_stats["launches_removed"] - before["launches_removed"] == 2
+        assert (got.float() - want.float()).abs().max() <= 0.05 * want.float().abs().max()
