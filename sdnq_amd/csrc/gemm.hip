@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             static_assert(LR_BYTES + CH2 * O_ROW <= EPI_BYTES, "register-layout low-rank epilogue fits the staged epilogue's LDS budget");
             const bool hb = p.bias != nullptr;
             const bool is_bf = p.bias_dtype == SDNQ_BF16;
+            TRACE(5);
 #pragma nounroll
             for (int ch = 0; ch < ECH2; ++ch) {
                 if (ch > 0) __syncthreads();  // previous chunk copied out before its staging area is overwritten
@@ -1102,10 +1103,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 uint8_t* ostq = ostage + opq;
                 const float* sbq = (const float*)((const uint8_t*)s_sb + opq);
                 const float* biasq = (const float*)((const uint8_t*)s_bias + opq);
-                if ((wm * WM) / CH2 == ch) {  // wave-uniform: all of this wave's rows lie in one chunk (CH2 % WM == 0)
+                // Two chunks: chunk ch takes HALF of the row blocks of EVERY wave (j in [ch TM/2, (ch + 1) TM/2)), so all eight waves work in
+                // both chunks.  (Chunks of whole wave rows -- rows 0-127, then 128-255 -- left half of the workgroup idle in each: the
+                // epilogue of a 256x256 tile took 35 K cycles against 13 K of the plain one, tools/trace_gemm.py --lowrank, round 3.)
+                {
 #pragma unroll
                     for (int j = 0; j < TM; ++j) {
+                        if (ECH2 > 1 && (j * ECH2) / TM != ch) continue;  // wave-uniform; j is unrolled, so every copy runs in one chunk
                         const int tr = wm * WM + j * 32 + (lane & 31);  // tile row = this lane's output row
+                        // its row in the chunk's staging area: [wave row][row blocks of this chunk][32]
+                        const int sr = ECH2 == 1 ? tr : wm * (WM / ECH2) + (j % (TM / ECH2)) * 32 + (lane & 31);
                         int64_t gm = m0 + tr;
                         if (gm >= p.M) gm = p.M - 1;
                         const float sa = p.sa[gm];
@@ -1140,7 +1147,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                                     const float vv = acc_times_sa<LP>(MT::tof(acc[i][j], 4 * q + e), sa);
                                     r[e] = fmaf(vv, sb4[e], b2);
                                 }
-                                *(v2i*)(ostq + (tr - ch * CH2) * O_ROW + nl0 * OUT_B) = (v2i){(int)pack2<OUT_T>(r[0], r[1]), (int)pack2<OUT_T>(r[2], r[3])};
+                                *(v2i*)(ostq + sr * O_ROW + nl0 * OUT_B) = (v2i){(int)pack2<OUT_T>(r[0], r[1]), (int)pack2<OUT_T>(r[2], r[3])};
                             }
                             __builtin_amdgcn_sched_barrier(0);  // one sub-tile at a time (register pressure next to 128 accumulators)
                         }
@@ -1151,11 +1158,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma nounroll
                 for (int v = tid; v < CH2 * PPR2; v += NT) {
                     const int r = v / PPR2, c = v % PPR2;
-                    const int64_t gm = m0 + ch * CH2 + r, gn0 = n0 + c * EPP2;
+                    // staging row -> tile row (the inverse of `sr` above)
+                    const int trow = ECH2 == 1 ? r : (r / (WM / ECH2)) * WM + ch * (WM / ECH2) + r % (WM / ECH2);
+                    const int64_t gm = m0 + trow, gn0 = n0 + c * EPP2;
                     if (gm >= p.M || c * EPP2 >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
                     store16(out_piece(p, tv, gm, gn0, c * EPP2, OUT_B), *(const uint4*)(ostage + r * O_ROW + c * 16));
                 }
             }
+            TRACE(6);
             return;
         }
     }

@@ -12,7 +12,7 @@ shapes = [(4096, 640, 640), (1024, 1280, 1280), (1024, 1280, 5120), (77, 640, 20
 LOWRANK = "--lowrank" in sys.argv  # the SVD epilogue on FLUX shapes, next to the plain epilogue
 W8A16 = "--w8a16" in sys.argv      # the fused dequantize GEMM next to the int8 one
 if LOWRANK:
-    shapes = [(4608, 3072, 3072), (4608, 3072, 12288)]
+    shapes = [(4608, 3072, 3072), (4608, 12288, 3072)]
 names = ["entry", "issued", "stage0", "steady_end", "mainloop_end", "epi_compute", "stored"]
 for (m, n, k) in shapes:
     x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
