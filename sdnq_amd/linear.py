@@ -34,6 +34,8 @@ FUSED_DEQUANT_GEMM_MAX_FLOP = float(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
 
 
+UNSHARED_FAST_PATH = os.environ.get("SDNQ_HIP_UNSHARED_FAST_PATH", "1").lower() not in {"0", "false", "no"}
+UNSHARED_AFTER = 2  # steps in which nobody used a layer's parked quantized activation before the layer stops parking it
 CACHE_ACTIVATION_BYTES = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATION_MB", "256")) << 20  # bound on what the entries pin
 
 
@@ -66,7 +68,7 @@ class _ActivationCache:
     def __init__(self, size: int | None = None, max_bytes: int | None = None):
         self.size = size   # None: the module-level CACHE_ACTIVATIONS, read at use time (the switch can be flipped after import)
         self.max_bytes = max_bytes
-        self.entries = []  # most recent last: (tensor, key, params, result, pinned bytes)
+        self.entries = []  # most recent last: (tensor, key, params, result, pinned bytes, producing module | None, [was it ever hit])
 
     def get(self, t: torch.Tensor, params, key=None):
         if key is None:
@@ -77,31 +79,51 @@ class _ActivationCache:
             e = self.entries[i]
             if e[0] is t and e[1] == key and e[2] == params:
                 self.entries.append(self.entries.pop(i))
+                e[6][0] = True
                 return e[3]
         return None
 
-    def put(self, t: torch.Tensor, params, result, key=None, nbytes=None):
+    def put(self, t: torch.Tensor, params, result, key=None, nbytes=None, producer=None):
         if key is None:
             key = None if _no_identity_reuse[0] else tensor_key(t)
         if key is None:
             return
         if nbytes is None:
             nbytes = t.numel() * t.element_size() + sum(r.numel() * r.element_size() for r in result if isinstance(r, torch.Tensor) and r is not t)
-        self.entries.append((t, key, params, result, nbytes))
+        self.entries.append((t, key, params, result, nbytes, producer, [False]))
         cap = max(CACHE_ACTIVATIONS, 0) if self.size is None else self.size
         lim = CACHE_ACTIVATION_BYTES if self.max_bytes is None else self.max_bytes
         while len(self.entries) > cap or (len(self.entries) > 1 and sum(e[4] for e in self.entries) > lim):
-            self.entries.pop(0)
+            self._retire(self.entries.pop(0))
+
+    @staticmethod
+    def _retire(e):
+        """An entry leaves the cache: its producing layer learns whether anybody else ever asked for the quantized copy it parked.
+        A layer whose entries were never used (its input is its own: to_out, the feed-forward layers, ...) stops parking them after
+        UNSHARED_AFTER such steps -- the plain forward then skips the tensor key, the look-up and two of its three allocations (the
+        quantized activation lives in the stream's workspace); one use by another layer resets the count for good."""
+        mod = e[5]
+        if mod is not None:
+            d = mod.__dict__
+            d["_sdnq_unshared"] = -(1 << 30) if e[6][0] else d.get("_sdnq_unshared", 0) + 1
 
     def invalidate(self, t: torch.Tensor | None = None):
         """Drop the entries of `t` (every entry whose input shares t's storage), or everything."""
         if t is None:
-            self.entries.clear()
+            self.clear()
             return
         base = t.untyped_storage().data_ptr() if t.numel() else None
-        self.entries = [e for e in self.entries if e[0] is not t and (base is None or e[0].untyped_storage().data_ptr() != base)]
+        keep = []
+        for e in self.entries:
+            if e[0] is not t and (base is None or e[0].untyped_storage().data_ptr() != base):
+                keep.append(e)
+            else:
+                self._retire(e)
+        self.entries = keep
 
     def clear(self):
+        for e in self.entries:
+            self._retire(e)
         self.entries.clear()
 
 
@@ -529,8 +551,17 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     if not has_svd and zp is None and (had == 0 or k <= 5120):
         # plain w8a8 layer: on a cache miss the row quantization and the GEMM go through ONE binding call (an eager model is
         # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers
-        params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
         use_cache = cache_input and CACHE_ACTIVATIONS > 0
+        if (use_cache and UNSHARED_FAST_PATH and self.__dict__.get("_sdnq_unshared", 0) >= UNSHARED_AFTER and input.is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            # nobody ever used the quantized copy this layer parked (see _ActivationCache._retire): no key, no look-up, the quantized
+            # activation in the stream's workspace -- one allocation (the output) and one binding call
+            x2 = input if input.dim() == 2 else input.reshape(-1, k)
+            if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+                x2 = x2.contiguous()
+            y = ops.linear_w8a8_ws(mm, x2, wq, ws, bias, input.dtype, had)
+            return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
+        params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
         key = tensor_key(input) if (use_cache and not _no_identity_reuse[0]) else None  # one key for the look-up and the store
         hit = _act_cache.get(input, params, key) if key is not None else None
         if hit is None:
@@ -541,7 +572,7 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
                 raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
             y, xq, xs = ops.linear_w8a8(mm, x2, wq, ws, bias, input.dtype, had)
             if key is not None:
-                _act_cache.put(input, params, (x2, xq, xs, None, None), key, m * k * (input.element_size() + 1) + 4 * m)
+                _act_cache.put(input, params, (x2, xq, xs, None, None), key, m * k * (input.element_size() + 1) + 4 * m, self)
             return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         x2, xq, xs, rowsum, xrot = hit
         return ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype).view(*input.shape[:-1], n)

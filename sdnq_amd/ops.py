@@ -377,6 +377,23 @@ def linear_w8a8(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.Tens
     return out, xq, xs
 
 
+def linear_w8a8_ws(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype, hadamard_group: int = 0):
+    """linear_w8a8 with the quantized activation in the stream's persistent scratch buffer (not returned, not kept): ONE allocation
+    per call instead of three.  Same-stream launches are ordered, so the next layer overwriting the buffer is safe; a buffer replaced
+    by a larger one stays valid for the work already queued (the caching allocator does not hand a freed block to another stream).
+    Not for use while the stream is being captured into a graph (the buffer may be replaced later)."""
+    m, k = x2d.shape
+    n = b_phys.shape[0]
+    stream = _stream(x2d)
+    xq_bytes = (m * k + 255) & ~255
+    base = (_workspace(x2d.device, stream, xq_bytes + 4 * m + 512).data_ptr() + 255) & ~255  # the per-stream scratch buffer (below)
+    out = torch.empty((m, n), device=x2d.device, dtype=out_dtype)
+    check(_lib.load().sdnq_hip_linear_w8a8(mm, x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), hadamard_group, base,
+                                           base + xq_bytes, b_phys.data_ptr(), sb.data_ptr(), _ptr(bias), 0 if bias is None else float_code(bias.dtype),
+                                           out.data_ptr(), float_code(out_dtype), n, stream), "linear_w8a8")
+    return out
+
+
 def scaled_mm_nchw(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype,
                    batch: int, pixels: int) -> torch.Tensor:
     """Conv flavour of scaled_mm: rows m = (b, pixel); returns the channel-major image [batch, N, pixels] (the reference's

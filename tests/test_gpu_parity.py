@@ -419,6 +419,40 @@ def test_activation_cache_is_transparent(gpu_device):
         L.clear_activation_cache()
 
 
+@pytest.mark.gpu
+def test_unshared_layers_stop_parking_their_activation(gpu_device):
+    """A layer whose parked quantized activation nobody ever used learns that (two steps) and then runs the workspace path: no cache
+    entry, same bits; a layer whose entry IS used by a sibling never does; consecutive workspace layers of different sizes (the
+    workspace is overwritten and once replaced by a larger one) stay bit-identical to the cached path."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(11)
+    cfg = sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+
+    def make(k, n):
+        return sdnq_amd.sdnq_quantize_layer(torch.nn.Linear(k, n).to(torch.bfloat16).to(gpu_device), cfg)[0]
+
+    solo_a, solo_b, sib0, sib1 = make(640, 320), make(2048, 128), make(640, 256), make(640, 256)
+    xa = torch.randn(96, 640, device=gpu_device, dtype=torch.bfloat16)
+    xb = torch.randn(4, 300, 2048, device=gpu_device, dtype=torch.bfloat16)
+    xs = torch.randn(80, 640, device=gpu_device, dtype=torch.bfloat16)
+    L.clear_activation_cache()
+    ref = None
+    for step in range(4):
+        outs = [solo_a(xa).clone(), solo_b(xb).clone(), sib0(xs).clone(), sib1(xs).clone(), solo_a(xa * 1).clone()]
+        L.clear_activation_cache()  # what the root model's forward-pre-hook does at the start of a step
+        if ref is None:
+            ref = outs
+        for a, b in zip(outs, ref):
+            assert torch.equal(a, b), step
+    assert solo_a.__dict__["_sdnq_unshared"] >= L.UNSHARED_AFTER and solo_b.__dict__["_sdnq_unshared"] >= L.UNSHARED_AFTER
+    assert sib0.__dict__["_sdnq_unshared"] < 0  # its entry was used by sib1: never takes the workspace path
+    assert "_sdnq_unshared" not in sib1.__dict__  # always served from sib0's entry: never produced one
+    solo_a(xa), solo_b(xb)
+    assert len(L._act_cache.entries) == 0  # the workspace path parks nothing
+    L.clear_activation_cache()
+
+
 def _golden_dtype_entries():
     with open(os.path.join(GOLD, "dequant_dtypes.json")) as f:
         return sorted(json.load(f)["dtypes"].keys())

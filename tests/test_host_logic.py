@@ -141,3 +141,27 @@ def test_link_projections_wiring():
         assert len(blk.to_q.__dict__["_sdnq_group"][0].mods) == 3
     finally:
         L.LINK_PROJECTIONS = old
+
+
+def test_activation_cache_teaches_producers_whether_their_entry_was_used():
+    """_ActivationCache._retire: an entry that leaves the cache unused bumps its producer's `_sdnq_unshared`; one that was hit resets it
+    for good (CPU: the bookkeeping only)."""
+    import torch
+    from sdnq_amd.linear import _ActivationCache
+
+    class M:
+        pass
+
+    a, b = M(), M()
+    c = _ActivationCache(size=2, max_bytes=1 << 30)
+    t1, t2, t3 = torch.zeros(4), torch.zeros(4), torch.zeros(4)
+    c.put(t1, "p", ("r1",), producer=a)
+    c.put(t2, "p", ("r2",), producer=b)
+    assert c.get(t2, "p") == ("r2",)
+    c.put(t3, "p", ("r3",), producer=a)       # evicts t1's entry, never hit
+    assert a.__dict__["_sdnq_unshared"] == 1 and "_sdnq_unshared" not in b.__dict__
+    c.clear()                                  # t2's entry was hit, t3's was not
+    assert b.__dict__["_sdnq_unshared"] < 0 and a.__dict__["_sdnq_unshared"] == 2
+    c.put(t1, "p", ("r1",), producer=b)
+    c.invalidate(t1)
+    assert b.__dict__["_sdnq_unshared"] < 0   # stays negative: one use by another layer settles it
