@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--launch", choices=["graph", "eager", "compile"], default=None,
                    help="how a step is launched: one captured hipGraph (default), eager Python (= --no-graph), or torch.compile(mode='reduce-overhead') "
                         "over the layer list (every SDNQ layer one sdnq_hip::layer_forward op; Inductor's own CUDA-graph trees do the replay)")
+    p.add_argument("--activation-pool", type=int, default=0,
+                   help="sensitivity variant: distinct activations of one shape rotate through this many buffers (0 = one buffer per activation, "
+                        "every read cold from HBM; a model's activations were just written by their producer)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--fuse-projections", action="store_true",
@@ -105,16 +108,28 @@ def expand_layers(shape_list, scale=1.0):
     return seq
 
 
-def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0, tp_chunks=1):
+def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0, tp_chunks=1, activation_pool=0):
     """-> list of (name, module, x, M, K, N, bias). One module per layer instance (distinct weights, like a real UNet /
     DiT); one activation tensor per distinct input_key: layers that consume the same tensor in the real model (q/k/v
     projections, every cross-attention k/v) get the SAME tensor object here, all others get their own."""
     import sdnq_amd
     g = torch.Generator(device=device).manual_seed(seed)
-    layers, inputs = [], {}
+    layers, inputs, pools = [], {}, {}
     for (name, m, k, n, has_bias, key) in expand_layers(shape_list, scale):
         if key not in inputs:
-            inputs[key] = torch.randn(m, k, device=device, dtype=torch.bfloat16, generator=g)
+            if activation_pool > 0:
+                # sensitivity variant (--activation-pool P): distinct activations of one shape rotate through P buffers, each a SEPARATE
+                # tensor object over shared storage (identity-keyed reuse still sees distinct tensors).  In a model an activation was
+                # written by the producing kernel microseconds before the Linear reads it (L2 / MALL resident); the default -- one
+                # buffer per activation, 1.2 GB cycled per step -- reads every one of them cold from HBM.
+                pool = pools.setdefault((m, k), [])
+                if len(pool) < activation_pool:
+                    pool.append([torch.randn(m, k, device=device, dtype=torch.bfloat16, generator=g), 0])
+                slot = pool[sum(c for _, c in pool) % activation_pool] if len(pool) == activation_pool else pool[-1]
+                slot[1] += 1
+                inputs[key] = slot[0].view(m, k)
+            else:
+                inputs[key] = torch.randn(m, k, device=device, dtype=torch.bfloat16, generator=g)
         x = inputs[key]
         assert x.shape == (m, k), (name, key, x.shape, m, k)
         lin = torch.nn.Linear(k, n, bias=has_bias, device=device, dtype=torch.bfloat16)
@@ -733,7 +748,7 @@ def main():
         layers = build_conv_layers(shape_list, cfg_kwargs, device, seed=rank)
     else:
         layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
-                              tp_world=world if tp else 1, seed=0 if tp else rank, tp_chunks=args.tp_chunks)
+                              tp_world=world if tp else 1, seed=0 if tp else rank, tp_chunks=args.tp_chunks, activation_pool=args.activation_pool)
     if args.fuse_projections and not is_conv and not tp:
         layers = fuse_shared_input_layers(layers)
     linked = 0
@@ -842,6 +857,7 @@ def main():
                               if compiled is not None else ("eager" if graph is None else "hipGraph replay")), "activations": "bf16",
                    **({"compile_seconds": round(compile_s, 1), "compile_grouping": dict(__import__("sdnq_amd").torch_ops.merge_stats)} if compiled is not None else {}),
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
+                   **({"activation_pool": args.activation_pool, "activation_buffers": len({l[2].data_ptr() for l in layers})} if args.activation_pool else {}),
                    "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
                    "linked_projection_groups": linked,
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
