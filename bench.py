@@ -789,7 +789,7 @@ def main():
             if hasattr(l[1], "sdnq_dequantizer"):
                 torch_ops.layer_handle(l[1])
         if not args.no_link_projections:
-            # layers whose layer_matmul nodes share (xq, xs) after the graph's CSE become one grouped launch (the compiled-graph form of
+            # layers whose layer_matmul nodes share one quantized activation become one grouped launch (the compiled-graph form of
             # the eager path's linked projections; sdnq_amd.torch_ops.MergeLayerMatmuls)
             torch_ops.enable_compile_grouping()
         step_mod = Step(layers)

@@ -143,9 +143,9 @@ def layer_forward(input: torch.Tensor, handle: int) -> torch.Tensor:
 def layer_matmul(xq: torch.Tensor, xs: torch.Tensor, handle: int, out_dtype: torch.dtype) -> torch.Tensor:
     """The matmul half of a plain w8a8 layer on an activation that `sdnq_hip::rowquant` already quantized:
     y [M, N] = scaled_mm(xq, Wq, xs, ws, bias).  Under torch.compile a layer whose forward is exactly rowquant + scaled_mm is traced
-    as these two operators (``layer_plan``), so that the graph's own common-subexpression elimination merges the row quantization of
-    layers that consume one tensor (to_q / to_k / to_v, every cross-attention to_k / to_v) -- the dataflow-level, and therefore safe,
-    form of the eager path's identity-keyed activation cache."""
+    as these two operators (``layer_plan``), so that the row quantization of layers that consume one tensor (to_q / to_k / to_v, every
+    cross-attention to_k / to_v) is ONE graph value after `merge_layer_matmuls` (Inductor's own passes do not merge the copies) -- the
+    dataflow-level, and therefore safe, form of the eager path's identity-keyed activation cache."""
     from . import linear as L
     mod = _layer(handle)
     st = L._state(mod)

@@ -60,8 +60,7 @@ def test_fake_implementations_give_shapes_and_dtypes():
 
 def test_dynamo_traces_a_block_without_graph_breaks_cpu():
     """fullgraph tracing on CPU (no kernels run: export only traces with fake tensors).  Plain w8a8 layers trace as
-    sdnq_hip::rowquant + sdnq_hip::layer_matmul (so that layers sharing an input share its row quantization through the graph's
-    CSE), dequantize-mode layers as one sdnq_hip::layer_forward; nothing else of this package is in the graph."""
+    sdnq_hip::rowquant + sdnq_hip::layer_matmul (so that layers sharing an input can share its row quantization: merge_layer_matmuls), dequantize-mode layers as one sdnq_hip::layer_forward; nothing else of this package is in the graph."""
     blk = _quantized_block("cpu", weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
     assert sum(isinstance(m, sdnq_amd.SDNQLinear) for m in blk.modules()) == 6
     x = torch.randn(2, 40, 128).to(torch.bfloat16)
@@ -74,7 +73,7 @@ def test_dynamo_traces_a_block_without_graph_breaks_cpu():
     assert len(mm) == 6 and len(calls_of(gm, torch.ops.sdnq_hip.rowquant)) == 6 and not calls_of(gm, torch.ops.sdnq_hip.layer_forward)
     handles = {m.__dict__["_sdnq_hip_handle"] for m in blk.modules() if isinstance(m, sdnq_amd.SDNQLinear)}
     assert handles == {n.args[2] for n in mm}
-    # to_q / to_k / to_v quantize the SAME graph value: identical (pure) operator calls, which CSE merges
+    # to_q / to_k / to_v quantize the SAME graph value: identical (pure) operator calls, which merge_layer_matmuls merges
     rq_inputs = [n.args[0] for n in calls_of(gm, torch.ops.sdnq_hip.rowquant)]
     assert len(set(rq_inputs)) == 4
     deq = _quantized_block("cpu", weights_dtype="uint4", use_quantized_matmul=False)
@@ -92,7 +91,7 @@ def test_compiled_block_equals_eager(cfg, gpu_device):
     backend (same kernels in the same order), within bf16 rounding of the fused pointwise code through Inductor."""
     blk = _quantized_block(gpu_device, **cfg)
     sdnq_amd.accelerate(blk)
-    # plain w8a8 layers trace as rowquant + layer_matmul (the graph's CSE then shares one row quantization among q / k / v);
+    # plain w8a8 layers trace as rowquant + layer_matmul (the post-grad pass then shares one row quantization among q / k / v);
     # everything else as one layer_forward operator
     plans = {name: m.__dict__.get("_sdnq_hip_plan") for name, m in blk.named_modules() if hasattr(m, "sdnq_dequantizer")}
     assert all((p is not None) == bool(cfg.get("use_quantized_matmul")) for p in plans.values()), plans
