@@ -1771,7 +1771,12 @@ int launch_tiles_w8(const GemmParams& p, hipStream_t s) {
     if (force == 0 && fit128) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 128>(p, s);
     if (force == 2 && fit128) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
     if (force == 3 || (force < 0 && p.M <= 64) || !fit128) return launch_one<MM, OUT_T, EPI, 64, 64, 64, 32, 4, LD_DMA, 128>(p, s);
-    if (force == 4 || (force < 0 && tiles(128, 128) >= 160)) return launch_one<MM, OUT_T, EPI, 128, 128, 128, 32, 3, LD_DMA, 128>(p, s);
+    // (round 3 re-sweep on the buffer-load loaders, profiles/r03_w8a16_sweep.txt: 160-240 tiles of 128x128 lose to 64x128 -- 4096 x 640 x 640
+    //  12.7 vs 11.4 us, 1024 x 3840 x 1280 20.2 vs 19.2 -- from 480 tiles up they win: 4096 x 1920 x 640 17.2 vs 21.0)
+    static const int t128_min = [] { const char* e = getenv("SDNQ_HIP_W8_T128_MIN"); return e ? atoi(e) : 320; }();  // tuning aid
+    if (force == 4 || (force < 0 && tiles(128, 128) >= t128_min)) return launch_one<MM, OUT_T, EPI, 128, 128, 128, 32, 3, LD_DMA, 128>(p, s);
+    // (128x64 tiles of two 128x32 waves -- the conversion shared by four MFMAs at twice the workgroups -- and a 4-deep ring for the
+    //  128x128 tile measured 20-60 % slower than the above on every SDXL shape: too few waves to hide the DMA / LDS latency)
     return launch_one<MM, OUT_T, EPI, 64, 128, 64, 32, 3, LD_DMA, 128>(p, s);
 }
 

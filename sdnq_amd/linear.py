@@ -31,6 +31,10 @@ PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "0").lower() not 
 FUSED_SKINNY = os.environ.get("SDNQ_HIP_FUSED_SKINNY", "1").lower() not in {"0", "false", "no"}
 FUSED_DEQUANT_GEMM = os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM", "1").lower() not in {"0", "false", "no"}
 FUSED_DEQUANT_GEMM_MAX_FLOP = float(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_MAX_FLOP", "4e10"))
+# (tuning aid) back-to-back on warm operands the two-launch form wins on long rows (profiles/r03_w8a16_sweep.txt: 1024 x 1280 x 5120
+# fused 43.0 us vs 29.0 + ~8 us for dequantize + bf16 GEMM), but inside the step -- cold weights, the 13 MB float copy written and read
+# back -- a K limit of 2560 made the SDXL default-mode step SLOWER (13.63 vs 13.37 ms, same box): no limit by default
+FUSED_DEQUANT_GEMM_MAX_K = int(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_MAX_K", str(1 << 30)))
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
 
 
@@ -276,7 +280,7 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
             return y
     if (FUSED_DEQUANT_GEMM and m > 32 and st.svd_up is None and not dq.use_hadamard and dq.weights_dtype in ("int8", "uint8")
             and dq.group_size <= 0 and dq.kernel_positions == 1 and input.dtype in (torch.bfloat16, torch.float16) and k % 16 == 0 and n % 8 == 0
-            and st.wd is None and input.is_cuda and 2 * m * n * k <= FUSED_DEQUANT_GEMM_MAX_FLOP):
+            and st.wd is None and input.is_cuda and 2 * m * n * k <= FUSED_DEQUANT_GEMM_MAX_FLOP and k <= FUSED_DEQUANT_GEMM_MAX_K):
         # row-wise 8-bit weights, more than 32 rows, a small problem: ONE launch -- the weight goes from HBM to the matrix cores as
         # bytes and is dequantized (to the very values sdnq_hip_dequant would write) between LDS and the MFMA; no [N, K] float copy,
         # no second pass.  The in-loop conversion costs ~1.5x the K loop of the plain 16-bit GEMM (22 VALU per weight fragment on
