@@ -40,7 +40,7 @@ def is_hot_path_linear(module: torch.nn.Module) -> bool:
 def is_hot_path_conv(module: torch.nn.Module) -> bool:
     dq = getattr(module, "sdnq_dequantizer", None)
     return (dq is not None and getattr(dq, "layer_class_name", None) in ("Conv1d", "Conv2d", "SDNQConv1d", "SDNQConv2d")
-            and not getattr(dq, "use_codebook", False) and not getattr(dq, "use_hadamard", False) and getattr(module, "groups", 1) == 1
+            and not getattr(dq, "use_codebook", False) and not getattr(dq, "use_hadamard", False)
             and getattr(dq, "quantized_matmul_dtype", "int8") in ("int8", "uint8", "fp8", "float8_e4m3fn"))
 
 
@@ -62,7 +62,7 @@ def _clear_step_state(_module=None, _args=None):
 
 @torch.no_grad()
 def accelerate(model: torch.nn.Module) -> int:
-    """Route every quantized Linear (and Conv1d / Conv2d with groups = 1) of ``model`` through the HIP forwards.
+    """Route every quantized Linear (and Conv1d / Conv2d, any ``groups``) of ``model`` through the HIP forwards.
     Returns the number of re-pointed modules."""
     count = 0
     for module in model.modules():
@@ -254,7 +254,8 @@ def fuse_projections(model: torch.nn.Module) -> int:
 def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
                                 use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):
     for module in model.modules():
-        if not is_hot_path_linear(module):
+        conv = is_hot_path_conv(module)
+        if not (is_hot_path_linear(module) or conv):
             continue
         dq = adopt_dequantizer(module.sdnq_dequantizer)
         module.sdnq_dequantizer = dq
@@ -279,6 +280,12 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
             module.scale = torch.nn.Parameter(module.scale.to(want_sdt), requires_grad=False)
             if getattr(module, "zero_point", None) is not None:
                 module.zero_point = torch.nn.Parameter(module.zero_point.to(want_sdt), requires_grad=False)
+        if conv:
+            # conv layers: result dtype and scale dtype only -- the reference leaves their matmul switch alone here
+            # (`current_use_quantized_matmul = None` for everything that is not a Linear, loader.py:244-255)
+            module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
+            module.__dict__.pop("_sdnq_hip_state", None)
+            continue
         if use_quantized_matmul is not None and use_quantized_matmul != dq.use_quantized_matmul:
             n, k = dq.out_features, dq.in_features
             want = check_quantized_matmul_is_allowed(use_quantized_matmul, n, k)

@@ -331,6 +331,11 @@ CONV_CASES = [
          cfg=dict(weights_dtype="int4", group_size=16, quantized_matmul_dtype="uint8", use_quantized_matmul_conv=True)),
     dict(name="conv2d_uint8_int8mm_qmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 8, 8)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),
+    # dequantize_fp32=False on conv layers: scales in the model dtype (quantizer.py:147-156)
+    dict(name="conv2d_int8_qmm_bf16_lpscale", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(2, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True, dequantize_fp32=False)),
+    dict(name="conv2d_uint4_noqmm_f16_lpscale", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 6, 6)], dtype="f16",
+         cfg=dict(weights_dtype="uint4", dequantize_fp32=False)),
     # grouped convs (conv_int8.py:73-79, conv_fp8.py:56-60; the float forward is F.conv2d(..., groups))
     dict(name="conv2d_g2_int8_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
          cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),

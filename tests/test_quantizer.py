@@ -93,6 +93,15 @@ def test_apply_options_scale_dtype_rules():
     assert m[0].scale.dtype == torch.float16 and m[0].sdnq_dequantizer.result_dtype == torch.float16
     sdnq_amd.apply_sdnq_options_to_model(m, dequantize_fp32=True)
     assert m[0].scale.dtype == torch.float32 and m[0].zero_point.dtype == torch.float32
+    # conv layers follow the same scale-dtype rule (the reference applies it to every SDNQ layer, loader.py:262-283; round-2 advisor)
+    conv = sdnq_amd.sdnq_quantize_layer(torch.nn.Conv2d(64, 64, 3, padding=1, groups=2).to(torch.bfloat16),
+                                        sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))[0]
+    cm = torch.nn.Sequential(conv)
+    assert cm[0].scale.dtype == torch.float32
+    sdnq_amd.apply_sdnq_options_to_model(cm, dequantize_fp32=False)
+    assert cm[0].scale.dtype == torch.bfloat16 and cm[0].forward_func.__name__ == "quantized_conv_forward_int8_matmul"
+    sdnq_amd.apply_sdnq_options_to_model(cm, dequantize_fp32=True)
+    assert cm[0].scale.dtype == torch.float32
     # quantizer: dequantize_fp32=False quantizes against the rounded scale; 16-bit formats and float32 models keep float32
     lin = torch.nn.Linear(64, 64).to(torch.bfloat16)
     l8 = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", dequantize_fp32=False))[0]
