@@ -167,6 +167,8 @@ struct PrepParams {
 // heads: knp is a multiple of the 32 / 16 tokens it covers), the rest lay out V
 template <int T_ID>
 __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
+    SDNQ_KERNARGS_NOW("s"(p.q), "s"(p.k), "s"(p.v), "s"(p.qq), "s"(p.kq), "s"(p.qs), "s"(p.ks), "s"(p.vt), "s"(p.kpart), "s"(p.qheads), "s"(p.kheads), "s"(p.qn), "s"(p.kn),
+                      "s"(p.knp), "s"(p.nqb), "s"(p.nkb), "s"(p.d), "s"(p.d_src), "s"(p.log2g));
     __shared__ float smean[128];
     __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
     const int64_t b = blockIdx.x;
@@ -250,6 +252,10 @@ typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 // pipe while the VALU works on the scores of kb; V / k_scale of kb+1 and K of kb+2 are in flight meanwhile.
 template <int V_T, int OUT_T, int D, bool CAUSAL, bool HAS_MASK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+    // one batch of kernarg loads (SDNQ_KERNARGS_NOW, sdnq_dev.h)
+    SDNQ_KERNARGS_NOW("s"(p.qq), "s"(p.qs), "s"(p.kq), "s"(p.ks), "s"(p.vt), "s"(p.out), "s"(p.qh), "s"(p.kh), "s"(p.qn), "s"(p.kn), "s"(p.knp), "s"(p.qblocks), "s"(p.split),
+                      "s"(p.shared_kv), "s"(p.log2_sm_scale), "s"(p.ost.b), "s"(p.ost.h), "s"(p.ost.n), "s"(p.ost.heads), "s"(p.d_out), "s"(p.mask), "s"(p.mask_dtype),
+                      "s"(p.ms_z), "s"(p.ms_h), "s"(p.ms_q));
     constexpr int KK = D / 32;  // int8 MFMA K steps of Q.K^T; also the 32-channel blocks of O
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in SGPRs: block indices stay scalar
     const int ql = lane & 31, g = lane >> 5;

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void conv_pixel_amax_kernel(const void* __rest
 template <int T_ID, int MM, int CT>
 __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, const unsigned int* __restrict__ amap, float qmax,
                                                          uint8_t* __restrict__ xq, float* __restrict__ xs) {
+    SDNQ_KERNARGS_NOW("s"(p.x), "s"(p.out), "s"(p.B), "s"(p.C), "s"(p.H), "s"(p.W), "s"(p.KH), "s"(p.KW), "s"(p.SH), "s"(p.SW), "s"(p.PH), "s"(p.PW), "s"(p.DH),
+                      "s"(p.DW), "s"(p.HO), "s"(p.WO), "s"(p.M), "s"(p.K));  // one batch of kernarg loads (sdnq_dev.h)
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int P = p.KH * p.KW;
@@ -171,6 +173,8 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
 // explicit copy (float [M][K] matrix for the float / SVD / zero-point branches); T = element type, 2 or 4 bytes
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
+    SDNQ_KERNARGS_NOW("s"(p.x), "s"(p.out), "s"(p.B), "s"(p.C), "s"(p.H), "s"(p.W), "s"(p.KH), "s"(p.KW), "s"(p.SH), "s"(p.SW), "s"(p.PH), "s"(p.PW), "s"(p.DH),
+                      "s"(p.DW), "s"(p.HO), "s"(p.WO), "s"(p.M), "s"(p.K));
     typedef T O;
     constexpr int EPC = 16 / sizeof(O);  // elements per 16-byte chunk
     __shared__ O tile[64][64 + EPC];     // [k][m]

@@ -29,6 +29,11 @@ struct DeqParams {
     WeightFmt fmt;
 };
 
+// the scalar fields of a by-value DeqParams in one batch of kernarg loads (SDNQ_KERNARGS_NOW, sdnq_dev.h)
+#define SDNQ_DEQ_ARGS_NOW(p)                                                                                                              \
+    SDNQ_KERNARGS_NOW("s"((p).w), "s"((p).scale), "s"((p).zp), "s"((p).svd_up), "s"((p).svd_down), "s"((p).N), "s"((p).K), "s"((p).group_size), \
+                      "s"((p).G), "s"((p).rank), "s"((p).P), "s"((p).SG), "s"((p).sdt))
+
 // dequantize 16 elements (row n, columns k0..k0+15) to fp32: f32(w)*s or fma(f32(w), s, zp)
 __device__ __forceinline__ void dequant16(const DeqParams& p, int64_t n, int64_t k0, float (&v)[16]) {
     load16_values(p.w, n * p.K + k0, p.fmt, v);
@@ -179,6 +184,8 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
 // per-call path of SDNQ_HIP_CACHE_WEIGHTS=0 then reads the codes once.  Needs packed 4-bit storage, group_size % 64 == 0, P == 1.
 template <int MM, int NP>
 __global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws, int ws_known) {
+    SDNQ_DEQ_ARGS_NOW(p);
+    SDNQ_KERNARGS_NOW("s"(wq), "s"(ws), "s"(ws_known));
     // NP = passes of 1024 elements per row (K <= 1024 NP), compile time: every load of the row -- codes and group scales of all
     // passes -- is issued before the first use (unconditionally, from clamped addresses: a load under a condition gets its own
     // vmcnt(0)), so a row costs one memory round trip instead of one per pass
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(256) void linear_float_kernel(const void* __restric
 template <int T_ID, int MROWS>
 __global__ __launch_bounds__(256) void linear_skinny_kernel(const DeqParams p, const void* __restrict__ x, const void* __restrict__ bias,
                                                             void* __restrict__ out, int64_t M, int64_t ldx, int log2had) {
+    SDNQ_DEQ_ARGS_NOW(p);
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t m0 = (int64_t)blockIdx.y * MROWS;
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const DeqParams p, c
 template <int T_ID, int BITS, int MROWS>
 __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams p, const void* __restrict__ x, const void* __restrict__ bias,
                                                                  void* __restrict__ out, int64_t M, int64_t ldx, int log2had) {
+    SDNQ_DEQ_ARGS_NOW(p);
     const int lane = threadIdx.x & 63;
     const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= p.N) return;
@@ -531,6 +540,7 @@ __global__ __launch_bounds__(256) void linear_skinny_fast_kernel(const DeqParams
 template <int T_ID, int BITS, int MROWS>
 __global__ __launch_bounds__(256) void linear_skinny_had256_kernel(const DeqParams p, const void* __restrict__ x, const void* __restrict__ bias,
                                                                    void* __restrict__ out, int64_t M, int64_t ldx) {
+    SDNQ_DEQ_ARGS_NOW(p);
     static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
     constexpr int NG = 16;
     const int lane = threadIdx.x & 63;
@@ -707,6 +717,7 @@ __global__ __launch_bounds__(256) void skinny_svd_kernel(const DeqParams p, cons
 template <bool IS_BF16, int MR, int BITS>
 __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, const uint16_t* __restrict__ down_t, const void* __restrict__ x,
                                                            const void* __restrict__ bias, void* __restrict__ out, int64_t M, int64_t ldx) {
+    SDNQ_DEQ_ARGS_NOW(p);
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int T_ID = IS_BF16 ? SDNQ_BF16 : SDNQ_F16;
@@ -884,6 +895,7 @@ __device__ const uint4 g_lr_zero16 = {0u, 0u, 0u, 0u};  // source of chunks past
 template <bool IS_BF16>
 __global__ __launch_bounds__(256) void lowrank_down_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ down,
                                                            uint16_t* __restrict__ t, int64_t M, int64_t K, int64_t ldx, int R) {
+    SDNQ_KERNARGS_NOW("s"(x), "s"(down), "s"(t), "s"(M), "s"(K), "s"(ldx), "s"(R));
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     constexpr int NS = 4, XS = 16 * 256, STAGE = XS + 32 * 256;  // 12 KB per stage; 48 KB ring: three workgroups per CU

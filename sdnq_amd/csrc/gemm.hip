@@ -72,6 +72,12 @@ struct GemmParams {
     int rank;
     int tiles_m, tiles_n;
     int group_m;  // m-strips per rasterization group
+    // host-computed multipliers for the divisions of the tile mapping: q = umulhi(n, ceil(2^32 / d)) is exact for n * d <= 2^32 (0 stands for
+    // d = 1); `fastmap` says the grid is small enough.  A software 32-bit division is ~30 scalar instructions and the 64-bit one of the
+    // grouped launch ~150 -- code a wave executes once, at instruction-fetch speed (the prologue is fetched from the last-level cache on
+    // every launch of the bs = 1 steps), in front of its first LDS-DMA
+    uint32_t mg_per_group, mg_group_m, mg_tail, mg_unit;
+    int fastmap, fastunit;
     int swz;      // LDS chunk swizzle mask (7; 0 only for experiments)
     // several output tensors (linked projections: one GEMM over the stacked weights of to_q / to_k / to_v, each layer's output in
     // its own [M][seg_n] tensor): channel n goes to out_seg[n / seg_n]; seg_n % 8 == 0, so a 16-byte piece never straddles tensors
@@ -423,6 +429,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     float* s_zp = s_bias + BN;              // [BN] zero points (EPI_LOWRANK)
     float* s_wcs = s_zp + BN;               // [BN] scaled weight column sums (EPI_LOWRANK, uint8 matmul)
 
+    // Every parameter the prologue needs, fetched in ONE batch: left to itself the compiler issues the s_loads of the by-value struct
+    // where each field is first used, and the tile mapping -> TileView -> descriptor chain then waits for three or four DEPENDENT
+    // round trips to a cold scalar cache (~600-800 cycles each) before the first LDS-DMA can be issued.  The empty asm makes all of
+    // them live in SGPRs here, so the loads go out together behind a single s_waitcnt.
+#ifndef SDNQ_NO_KERNARG_BATCH
+    asm volatile("" ::"s"(p.a), "s"(p.b), "s"(p.sb), "s"(p.bias), "s"(p.out), "s"(p.units), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb),
+                 "s"(p.ldc), "s"(p.unit_n));
+    asm volatile("" ::"s"(p.tiles_m), "s"(p.tiles_n), "s"(p.group_m), "s"(p.swz), "s"(p.mg_per_group), "s"(p.mg_group_m), "s"(p.mg_tail),
+                 "s"(p.mg_unit), "s"(p.fastmap), "s"(p.fastunit), "s"(p.bias_dtype), "s"(p.seg_n), "s"(p.out_hw), "s"(p.sa));
+#endif
     TRACE(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -440,7 +456,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     int tile_m, tile_n;
-    {
+    auto fdiv = [](uint32_t n, uint32_t mg) -> uint32_t { return mg ? __umulhi(n, mg) : n; };
+    if (p.fastmap) {
+        const int per_group = p.group_m * p.tiles_n;
+        const int gid = (int)fdiv((uint32_t)bid, p.mg_per_group), first_m = gid * p.group_m;
+        const bool tail = (p.tiles_m - first_m) < p.group_m;
+        const int gsz = tail ? (p.tiles_m - first_m) : p.group_m;
+        const int in_g = bid - gid * per_group;
+        tile_n = (int)fdiv((uint32_t)in_g, tail ? p.mg_tail : p.mg_group_m);
+        tile_m = first_m + in_g - tile_n * gsz;
+    } else {
         const int per_group = p.group_m * p.tiles_n;
         const int gid = bid / per_group, first_m = gid * p.group_m;
         const int gsz = (p.tiles_m - first_m) < p.group_m ? (p.tiles_m - first_m) : p.group_m;
@@ -452,7 +477,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     const int K = (int)p.K;
     TileView tv;
     if (p.units != nullptr) {  // grouped launch: this tile lies inside ONE unit of one layer (BN divides unit_n); wave-uniform loads
-        const int64_t u = n0 / p.unit_n, d = n0 - u * p.unit_n;
+        const int64_t u = p.fastunit ? (int64_t)fdiv((uint32_t)n0, p.mg_unit) : n0 / p.unit_n, d = n0 - u * p.unit_n;
         const SdnqGemmUnit un = p.units[u];
         tv.b = (const uint8_t*)un.b + d * p.ldb;
         tv.sb = un.sb + d;
@@ -1530,6 +1555,14 @@ int launch_one(GemmParams p, hipStream_t s) {
         p.group_m = gm;
         static const int swz_env = [] { const char* e = getenv("SDNQ_HIP_SWZ"); return e ? atoi(e) : 7; }();
         p.swz = swz_env;
+        auto magic = [](uint64_t d) -> uint32_t { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + d - 1) / d); };
+        static const bool fast_env = [] { const char* e = getenv("SDNQ_HIP_FASTMAP"); return !e || atoi(e) != 0; }();  // A/B aid
+        const uint64_t nwg = (uint64_t)p.tiles_m * (uint64_t)p.tiles_n, per_group = (uint64_t)gm * (uint64_t)p.tiles_n;
+        const uint64_t tail = (uint64_t)(p.tiles_m % gm);
+        p.fastmap = fast_env && nwg * (per_group > (uint64_t)gm ? per_group : (uint64_t)gm) <= (1ull << 32);
+        p.mg_per_group = magic(per_group); p.mg_group_m = magic((uint64_t)gm); p.mg_tail = magic(tail ? tail : 1);
+        p.fastunit = fast_env && p.units != nullptr && p.unit_n > 0 && (uint64_t)p.N * (uint64_t)p.unit_n <= (1ull << 32);
+        p.mg_unit = magic(p.unit_n > 0 ? (uint64_t)p.unit_n : 1);
     }
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), LDS_BYTES, s, p);
     SDNQ_CHECK_LAUNCH();

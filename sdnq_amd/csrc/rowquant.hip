@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                                                        int32_t* __restrict__ rowsum, void* __restrict__ xrot,
                                                        const uint4* __restrict__ pf, int64_t pf_vecs, int row_blocks,
                                                        float* __restrict__ xzp) {
+    // every argument in one batch of scalar loads (SDNQ_KERNARGS_NOW, sdnq_dev.h): this kernel is 443 of the 905 launches of the SDXL step
+    SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(log2g), "s"(xq), "s"(xs), "s"(rowsum), "s"(xrot), "s"(pf), "s"(pf_vecs), "s"(row_blocks), "s"(xzp));
     if ((int)blockIdx.x >= row_blocks) {
         // software prefetch of the following GEMM's weight operand: these extra workgroups just stream it once so it
         // sits in the last-level cache (MALL) / L2 when the GEMM's LDS-DMA asks for it. 8 loads in flight per lane.
@@ -344,6 +346,7 @@ template <int T_ID, int MM, int NG, int WPR>
 __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, uint8_t* __restrict__ xq,
                                                               float* __restrict__ xs, int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
     static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
+    SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(xq), "s"(xs), "s"(rowsum), "s"(xrot));
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int64_t m = (int64_t)blockIdx.x * (4 / WPR) + wv / WPR;
     const int part = wv % WPR;

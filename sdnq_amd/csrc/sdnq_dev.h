@@ -253,3 +253,11 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     do {                                                 \
         if (hipGetLastError() != hipSuccess) return SDNQ_ERR_LAUNCH; \
     } while (0)
+
+// Kernel arguments fetched in ONE batch at kernel entry.  Left to itself the compiler issues the s_load of each argument (or field of a
+// by-value parameter struct) where it is first used, so a prologue waits for several DEPENDENT round trips to a scalar cache that is cold
+// at every launch of the bs = 1 steps (~600-800 cycles each; the GEMM: entry -> first LDS-DMA 3176 -> 1451 cycles, SDXL step 8.43 ->
+// 8.15 ms).  An empty asm with the values as scalar inputs makes them live here: the loads go out together behind one s_waitcnt.
+// (device pass only; at most 30 operands per statement)
+#define SDNQ_KA1(a) "s"(a)
+#define SDNQ_KERNARGS_NOW(...) asm volatile("" ::__VA_ARGS__)
