@@ -19,6 +19,11 @@ for f in $SRCS; do
   # attention.hip: keep the MFMA accumulators in VGPRs (the softmax rescales / reads them with VALU every block; in AGPR form
   # the compiler moved 80 registers per 32-key block through v_accvgpr_read/write)
   [ "$f" = attention ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
+  # rowquant.hip: kernarg preload -- the first 14 argument dwords of the row quantizer (everything its row loads need) arrive in
+  # SGPRs with the wave, so the loads go out without a scalar round trip first; the other arguments are fetched behind them
+  [ "$f" = rowquant ] && [ "${SDNQ_PRELOAD_ROWQUANT:-1}" != 0 ] && EXTRA="-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
+  # gemm.hip: the same for the GEMM kernel's 14 leading scalar arguments (tile mapping, operand descriptors, prologue DMAs)
+  [ "$f" = gemm ] && [ "${SDNQ_PRELOAD_GEMM:-1}" != 0 ] && EXTRA="-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
   H=$( (echo "$HDR_HASH $FLAGS $EXTRA"; cat "$HERE/$f.hip") | sha256sum | cut -d' ' -f1)
   ALL="$ALL $f:$H"
   if [ "${FORCE:-0}" != 1 ] && [ -f "$OBJ/$f.o" ] && [ "$(cat "$OBJ/$f.hash" 2>/dev/null)" = "$H" ]; then continue; fi

@@ -381,7 +381,23 @@ constexpr int HT_BYTES = 16384, HT_SLOTS = 8;
 // `int_mm_func(a, b, out_dtype=scale_a.dtype).mul_(scale_a)` then `.mul_(scale_b)` / addcmul): the accumulator is rounded to bf16,
 // the product with the activation scale is rounded to bf16, and the last fma (fp32 op-math) is rounded by the bf16 store.
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD, int BK, bool LP = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const GemmParams p) {
+// Kernel arguments: the 14 dwords everything in front of the first LDS-DMA needs come FIRST, as scalars -- a kernarg-preloading build
+// (-mllvm -amdgpu-kernarg-preload-count=14, build.sh) delivers them in SGPRs with the wave, so tile mapping, descriptors and the prologue
+// DMAs run without a scalar-cache round trip; the rest of the parameter struct is fetched in one batch behind them.  hk_flags: bits 0-7
+// group_m, 8-15 swz, 16 fastmap, 17 fastunit, 18 grouped launch.
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const uint8_t* hk_a, const uint8_t* hk_b, int hk_lda, int hk_ldb, int hk_M,
+                                                                          int hk_N, int hk_K, int hk_tiles_m, int hk_tiles_n, uint32_t hk_flags,
+                                                                          uint32_t hk_mg_per_group, uint32_t hk_mg_group_m, const GemmParams p_) {
+    const GemmParams& p = p_;  // the rest of the parameters stay where they are (kernarg memory: p.out_seg is indexed at run time)
+    struct Hot {
+        const uint8_t *a, *b;
+        int64_t lda, ldb, M, N, K;
+        int tiles_m, tiles_n, group_m, swz, fastmap, fastunit;
+        uint32_t mg_per_group, mg_group_m;
+        bool grouped;  // p.units != nullptr, known without the struct: the non-grouped path never waits for it
+    };
+    const Hot hk = {hk_a, hk_b, hk_lda, hk_ldb, hk_M, hk_N, hk_K, hk_tiles_m, hk_tiles_n, (int)(hk_flags & 0xffu), (int)((hk_flags >> 8) & 0xffu),
+                   (int)((hk_flags >> 16) & 1u), (int)((hk_flags >> 17) & 1u), hk_mg_per_group, hk_mg_group_m, ((hk_flags >> 18) & 1u) != 0};
     typedef MmaTraits<MM> MT;
     constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN, NW = WAVES_M * WAVES_N, NT = NW * 64;
     constexpr int MS = MT::MS;                 // MFMA output tile edge: 32, or 16 for MM_I8_16
@@ -434,10 +450,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // round trips to a cold scalar cache (~600-800 cycles each) before the first LDS-DMA can be issued.  The empty asm makes all of
     // them live in SGPRs here, so the loads go out together behind a single s_waitcnt.
 #ifndef SDNQ_NO_KERNARG_BATCH
-    asm volatile("" ::"s"(p.a), "s"(p.b), "s"(p.sb), "s"(p.bias), "s"(p.out), "s"(p.units), "s"(p.M), "s"(p.N), "s"(p.K), "s"(p.lda), "s"(p.ldb),
-                 "s"(p.ldc), "s"(p.unit_n));
-    asm volatile("" ::"s"(p.tiles_m), "s"(p.tiles_n), "s"(p.group_m), "s"(p.swz), "s"(p.mg_per_group), "s"(p.mg_group_m), "s"(p.mg_tail),
-                 "s"(p.mg_unit), "s"(p.fastmap), "s"(p.fastunit), "s"(p.bias_dtype), "s"(p.seg_n), "s"(p.out_hw), "s"(p.sa));
+    asm volatile("" ::"s"(hk_a), "s"(hk_b), "s"(hk_lda), "s"(hk_ldb), "s"(hk_M), "s"(hk_N), "s"(hk_K), "s"(hk_tiles_m), "s"(hk_tiles_n), "s"(hk_flags),
+                 "s"(hk_mg_per_group), "s"(hk_mg_group_m));
+#ifndef SDNQ_PRELOAD_GEMM  // without preload everything is fetched here; with it the struct's fields are requested below, behind the DMAs
+    asm volatile("" ::"s"(p_.sb), "s"(p_.bias), "s"(p_.out), "s"(p_.units), "s"(p_.ldc), "s"(p_.unit_n), "s"(p_.mg_tail), "s"(p_.mg_unit),
+                 "s"(p_.bias_dtype), "s"(p_.seg_n), "s"(p_.out_hw), "s"(p_.sa));
+#endif
 #endif
     TRACE(0);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -449,7 +467,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // ~32 workgroups resident on one XCD at a time cover a near-square GROUP_M x (32/GROUP_M) patch of tiles and
     // share both their A strips and their B slabs in that L2 (a 1 x 32 row of tiles would re-fetch every B slab from
     // MALL/HBM for each m-strip: measured 51% of wave cycles parked on vmcnt/barrier at 16384 x 8192 x 4096).
-    const int nwg = p.tiles_m * p.tiles_n;
+    const int nwg = hk.tiles_m * hk.tiles_n;
     int bid = blockIdx.x;
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
@@ -457,43 +475,40 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     }
     int tile_m, tile_n;
     auto fdiv = [](uint32_t n, uint32_t mg) -> uint32_t { return mg ? __umulhi(n, mg) : n; };
-    if (p.fastmap) {
-        const int per_group = p.group_m * p.tiles_n;
-        const int gid = (int)fdiv((uint32_t)bid, p.mg_per_group), first_m = gid * p.group_m;
-        const bool tail = (p.tiles_m - first_m) < p.group_m;
-        const int gsz = tail ? (p.tiles_m - first_m) : p.group_m;
+    if (hk.fastmap) {
+        const int per_group = hk.group_m * hk.tiles_n;
+        const int gid = (int)fdiv((uint32_t)bid, hk.mg_per_group), first_m = gid * hk.group_m;
+        const bool tail = (hk.tiles_m - first_m) < hk.group_m;
+        const int gsz = tail ? (hk.tiles_m - first_m) : hk.group_m;
         const int in_g = bid - gid * per_group;
-        tile_n = (int)fdiv((uint32_t)in_g, tail ? p.mg_tail : p.mg_group_m);
+        if (tail) tile_n = (int)fdiv((uint32_t)in_g, p.mg_tail);  // (a branch, not a select: only the last group waits for the struct)
+        else tile_n = (int)fdiv((uint32_t)in_g, hk.mg_group_m);
         tile_m = first_m + in_g - tile_n * gsz;
     } else {
-        const int per_group = p.group_m * p.tiles_n;
-        const int gid = bid / per_group, first_m = gid * p.group_m;
-        const int gsz = (p.tiles_m - first_m) < p.group_m ? (p.tiles_m - first_m) : p.group_m;
+        const int per_group = hk.group_m * hk.tiles_n;
+        const int gid = bid / per_group, first_m = gid * hk.group_m;
+        const int gsz = (hk.tiles_m - first_m) < hk.group_m ? (hk.tiles_m - first_m) : hk.group_m;
         const int in_g = bid - gid * per_group;
         tile_m = first_m + in_g % gsz;
         tile_n = in_g / gsz;
     }
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int K = (int)p.K;
+    const int K = (int)hk.K;
+    // Where the tile's weight rows are -- all the prologue DMAs need of the TileView.  The rest of it (scale / bias / output of the
+    // tile) is filled in AFTER the prologue DMAs are issued: those fields come out of the parameter struct, and a scalar load in front
+    // of the DMAs means a round trip to the (cold) scalar cache before the first byte is requested.
     TileView tv;
-    if (p.units != nullptr) {  // grouped launch: this tile lies inside ONE unit of one layer (BN divides unit_n); wave-uniform loads
-        const int64_t u = p.fastunit ? (int64_t)fdiv((uint32_t)n0, p.mg_unit) : n0 / p.unit_n, d = n0 - u * p.unit_n;
-        const SdnqGemmUnit un = p.units[u];
-        tv.b = (const uint8_t*)un.b + d * p.ldb;
-        tv.sb = un.sb + d;
-        tv.bias = un.bias;
-        tv.bias0 = d;
-        tv.out_ld = un.n_seg;
-        tv.out = (uint8_t*)p.out + (p.M * un.n_start + un.n_loc + d) * OUT_B;
-        tv.n_lim = p.unit_n - d;
+    SdnqGemmUnit un = {};
+    int64_t un_d = 0;
+    if (hk.grouped) {  // grouped launch: this tile lies inside ONE unit of one layer (BN divides unit_n); wave-uniform loads
+        const int64_t u = hk.fastunit ? (int64_t)fdiv((uint32_t)n0, p.mg_unit) : n0 / p.unit_n;
+        un_d = n0 - u * p.unit_n;
+        un = p.units[u];
+        tv.b = (const uint8_t*)un.b + un_d * hk.ldb;
+        tv.n_lim = p.unit_n - un_d;
     } else {
-        tv.b = p.b + n0 * p.ldb;
-        tv.sb = p.sb + n0;
-        tv.bias = p.bias;
-        tv.bias0 = n0;
-        tv.out_ld = p.ldc;
-        tv.out = (uint8_t*)p.out + n0 * OUT_B;
-        tv.n_lim = p.N - n0;
+        tv.b = hk.b + n0 * hk.ldb;
+        tv.n_lim = hk.N - n0;
     }
 
     // ---- LDS-DMA assignment: piece = 8 tile rows x 128 B; lane l -> row l/8, physical chunk l%8 ----------------
@@ -511,7 +526,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // row of this lane inside a DMA piece and the (swizzle-inverse) 16-byte chunk it fetches, per operand geometry
     auto r8_of = [&](bool isA) { return lane / (isA ? LPR : LPR_B); };
     auto chunk_of = [&](int r, bool isA) {
-        return (isA ? BK : BKW) == 128 ? ((lane & 7) ^ ((r >> 1) & p.swz)) : ((lane & 3) ^ ((r >> 2) & (p.swz & 3)));
+        return (isA ? BK : BKW) == 128 ? ((lane & 7) ^ ((r >> 1) & hk.swz)) : ((lane & 3) ^ ((r >> 2) & (hk.swz & 3)));
     };
     const bool full = REM == 0 || wave < REM;  // wave-uniform: this wave owns PPW pieces (else PPW - 1)
     // (operand, piece inside the operand) of this wave's piece slot i
@@ -529,7 +544,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     const int nk = (K + BK - 1) / BK;
     const int K_B = is_w8a16<MM> ? K / 2 : K;  // bytes of a B row
     const bool has_tail = (K % BK) != 0;
-    const uint8_t* baseA = p.a + m0 * p.lda;
+    const uint8_t* baseA = hk.a + m0 * hk.lda;
     auto rsA = SDNQ_MAKE_RSRC(baseA);
     auto rsB = SDNQ_MAKE_RSRC(tv.b);
 #pragma unroll
@@ -541,11 +556,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         // clamp: rows past the edge are computed on valid memory and never stored
         if (isA) {
             int64_t g = r;
-            if (m0 + g >= p.M) g = p.M - 1 - m0;
-            voff[i] = (int)(g * p.lda) + c * 16;
+            if (m0 + g >= hk.M) g = hk.M - 1 - m0;
+            voff[i] = (int)(g * hk.lda) + c * 16;
         } else {
             const int64_t g = r < tv.n_lim ? r : tv.n_lim - 1;
-            voff[i] = (int)(g * p.ldb) + c * 16;
+            voff[i] = (int)(g * hk.ldb) + c * 16;
         }
     }
     // logical K offset (bytes) of this lane's chunk inside a stage row (recomputed: 2 VALU, prologue only)
@@ -625,15 +640,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rho = (2 * wave + u) * 8 + (lane >> 3);  // row inside the half-tile
-            const int ck = ((lane & 7) ^ ((rho >> 1) & p.swz)) << 4;
+            const int ck = ((lane & 7) ^ ((rho >> 1) & hk.swz)) << 4;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int64_t ra = (rho >> 6) * 128 + h * 64 + (rho & 63);  // tile row of this half-tile row
-                if (m0 + ra >= p.M) ra = p.M - 1 - m0;
-                hvo[h][u] = (int)(ra * p.lda) + ck;
+                if (m0 + ra >= hk.M) ra = hk.M - 1 - m0;
+                hvo[h][u] = (int)(ra * hk.lda) + ck;
                 int64_t rb = (rho >> 5) * 64 + h * 32 + (rho & 31);
                 if (rb >= tv.n_lim) rb = tv.n_lim - 1;
-                hvo[2 + h][u] = (int)(rb * p.ldb) + ck;
+                hvo[2 + h][u] = (int)(rb * hk.ldb) + ck;
             }
         }
         issue_ht(std::integral_constant<int, 0>{}, 0, 0);
@@ -644,6 +659,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         issue_ht(std::integral_constant<int, 2>{}, 5, 1);
     }
     TRACE(1);
+#if defined(SDNQ_PRELOAD_GEMM) && !defined(SDNQ_NO_KERNARG_BATCH)
+    asm volatile("" ::"s"(p_.sb), "s"(p_.bias), "s"(p_.out), "s"(p_.ldc), "s"(p_.bias_dtype), "s"(p_.seg_n), "s"(p_.out_hw), "s"(p_.sa));
+#endif
+    if (hk.grouped) {
+        tv.sb = un.sb + un_d;
+        tv.bias = un.bias;
+        tv.bias0 = un_d;
+        tv.out_ld = un.n_seg;
+        tv.out = (uint8_t*)p.out + (hk.M * un.n_start + un.n_loc + un_d) * OUT_B;
+    } else {
+        tv.sb = p.sb + n0;
+        tv.bias = p.bias;
+        tv.bias0 = n0;
+        tv.out_ld = p.ldc;
+        tv.out = (uint8_t*)p.out + n0 * OUT_B;
+    }
 
     // per-output-channel epilogue vectors -> LDS once per workgroup (after the DMA prologue so its load latency hides
     // under it; visible after the first barrier of the K loop)
@@ -685,9 +716,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
+            for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, hk.swz);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
+            for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, hk.swz);
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -708,9 +739,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             const uint8_t* sA = lds + slot * STAGE_BYTES;
             const uint8_t* sB = sA + BM * BK;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[st][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
+            for (int j = 0; j < TM; ++j) fa[st][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, hk.swz);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
+            for (int i = 0; i < TN; ++i) fb[st][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, hk.swz);
         };
         auto mma_set = [&](auto setc) {
             constexpr int st = decltype(setc)::value;
@@ -775,9 +806,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
+                    for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, hk.swz);
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
+                    for (int j = 0; j < TM; ++j) fa[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, hk.swz);
                 }
             }
             if (half == 1) wait_ahead();  // own pieces of stage kt+1, read by half 0 in the next slot
@@ -820,9 +851,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, p.swz);
+                for (int i = 0; i < TN; ++i) fb[ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, hk.swz);
 #pragma unroll
-                for (int j = 0; j < TH; ++j) fa0[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, p.swz);
+                for (int j = 0; j < TH; ++j) fa0[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, hk.swz);
             }
             __builtin_amdgcn_sched_barrier(0);
             issue_range(kt + AHEAD, slot_r, std::integral_constant<int, A_PIECES>{}, std::integral_constant<int, PPW>{});  // weight rows
@@ -845,7 +876,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int j = 0; j < TH; ++j) fa1[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + (TH + j) * MS + frow, ks, fgrp, p.swz);
+                for (int j = 0; j < TH; ++j) fa1[ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + (TH + j) * MS + frow, ks, fgrp, hk.swz);
             __builtin_amdgcn_sched_barrier(0);
             issue_range(kt + AHEAD, slot_r, std::integral_constant<int, 0>{}, std::integral_constant<int, A_PIECES>{});  // activation rows
             slot_r = (slot_r + 1 == NS) ? 0 : slot_r + 1;
@@ -880,7 +911,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         // lane + immediates (slot, second row block): no address arithmetic inside the loop
         const uint8_t* ldsA = lds + (wm * 64 + frow) * 128;                  // slot 0 (HA0, parity 0)
         const uint8_t* ldsB = lds + 4 * HT_BYTES + (wn * 32 + frow) * 128;   // slot 4 (HB0, parity 0)
-        const int rswA = ((wm * 64 + frow) >> 1) & p.swz, rswB = ((wn * 32 + frow) >> 1) & p.swz;
+        const int rswA = ((wm * 64 + frow) >> 1) & hk.swz, rswB = ((wn * 32 + frow) >> 1) & hk.swz;
         // chunk offsets (swizzled) of this lane's 16-byte pieces: [k sub-step][piece of the fragment]
         constexpr int CPK = MT::KB / 16, NPC = (MM == SDNQ_MM_FP8) ? 2 : 1;  // chunks per sub-step; 16-byte reads per lane and fragment
         int coA[KS][NPC], coB[KS][NPC];
@@ -1083,7 +1114,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                 const int row = (is_t ? pc : pc - BM / 16) * 16 + (lane >> 2);
                 const int c = (lane & 3) ^ ((row >> 2) & 3);
                 int64_t g = (is_t ? m0 : n0) + row;
-                const int64_t lim = is_t ? p.M : p.N;
+                const int64_t lim = is_t ? hk.M : hk.N;
                 if (g >= lim) g = lim - 1;
                 const uint8_t* src = (const uint8_t*)(is_t ? p.lr_t : p.lr_up) + g * 64 + c * 16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds + pc * 1024), 16, 0, 0);
@@ -1139,7 +1170,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         // its row in the chunk's staging area: [wave row][row blocks of this chunk][32]
                         const int sr = ECH2 == 1 ? tr : wm * (WM / ECH2) + (j % (TM / ECH2)) * 32 + (lane & 31);
                         int64_t gm = m0 + tr;
-                        if (gm >= p.M) gm = p.M - 1;
+                        if (gm >= hk.M) gm = hk.M - 1;
                         const float sa = p.sa[gm];
                         const uint8_t* lt = ldsq + tr * 64;
                         const int tsw = (tr >> 2) & 3;
@@ -1186,7 +1217,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                     // staging row -> tile row (the inverse of `sr` above)
                     const int trow = ECH2 == 1 ? r : (r / (WM / ECH2)) * WM + ch * (WM / ECH2) + r % (WM / ECH2);
                     const int64_t gm = m0 + trow, gn0 = n0 + c * EPP2;
-                    if (gm >= p.M || c * EPP2 >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
+                    if (gm >= hk.M || c * EPP2 >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
                     store16(out_piece(p, tv, gm, gn0, c * EPP2, OUT_B), *(const uint4*)(ostage + r * O_ROW + c * 16));
                 }
             }
@@ -1232,8 +1263,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #pragma unroll
                     for (int e = 0; e < 16; ++e) lrt[e] = 0.0f;
                     int64_t gn = n0 + wn * WN + i * 32 + (lane & 31), gm = m0 + wm * WM + j * 32 + (lane & 31);
-                    if (gn >= p.N) gn = p.N - 1;
-                    if (gm >= p.M) gm = p.M - 1;
+                    if (gn >= hk.N) gn = hk.N - 1;
+                    if (gm >= hk.M) gm = hk.M - 1;
                     const uint16_t* up = (const uint16_t*)p.lr_up + gn * p.rank + (lane >> 5) * 8;
                     const uint16_t* tt = (const uint16_t*)p.lr_t + gm * p.rank + (lane >> 5) * 8;
                     // staged tiles (rank 32): row r of t at lds + r * 64, of svd_up at lds + (BM + r) * 64, chunk-swizzled
@@ -1295,7 +1326,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             for (int v = tid; v < (CH / 8) * BN; v += NT) {
                 const int n = v / (CH / 8), r8 = (v % (CH / 8)) * 8;
                 const int64_t gm = m0 + ch * CH + r8, gn = n0 + n;
-                if (gm >= p.M || gn >= p.N) continue;
+                if (gm >= hk.M || gn >= hk.N) continue;
                 const float sbn = is_float_mm<MM> ? 1.0f : s_sbq[n];
                 const float bn = (EPI == EPI_BIAS1D) ? s_biasq[n] : 0.0f;
                 float o[8];
@@ -1322,7 +1353,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int v = tid; v < CH * G8; v += NT) {
         const int r = v / G8, c8 = (v % G8) * 8;  // r: row inside the chunk
         const int64_t gm = m0 + ch * CH + r, gn0 = n0 + c8;
-        if (gm >= p.M || c8 >= tv.n_lim) continue;  // N % 8 == 0: a group of 8 never straddles N
+        if (gm >= hk.M || c8 >= tv.n_lim) continue;  // N % 8 == 0: a group of 8 never straddles N
         const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
         float zsum = 0.0f, azp = 0.0f;
         if constexpr (is_lr<EPI>) {
@@ -1403,7 +1434,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
                             const float t2 = s_wcsq[cn] * azp;
                             zb = hasz ? zb + t2 : t2;
-                            if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)p.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
+                            if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)hk.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
                             hasz = true;
                         }
                         if (hasz) {
@@ -1446,8 +1477,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int j = 0; j < TM; ++j) {
         const int ml = wm * WM + j * MS + frow - ch * CHR;        // row inside the chunk
         int64_t gm = m0 + wm * WM + j * MS + frow;
-        const bool m_ok = gm < p.M;
-        if (!m_ok) gm = p.M - 1;
+        const bool m_ok = gm < hk.M;
+        if (!m_ok) gm = hk.M - 1;
         const float sa = is_float_mm<MM> ? 1.0f : p.sa[gm];
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
@@ -1472,7 +1503,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                             res = fmaf(vv, sbn, s_bias[cn]);
                         } else {
                             int64_t gn = n0 + cn;
-                            if (gn >= p.N) gn = p.N - 1;
+                            if (gn >= hk.N) gn = hk.N - 1;
                             res = fmaf(vv, sbn, ldf_rt(p.bias, gm * p.ld_bias + gn, p.bias_dtype));  // EPI_BIAS2D
                         }
                     }
@@ -1499,7 +1530,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             for (int v = tid; v < (CHR / 8) * BN; v += NT) {
                 const int n = v / (CHR / 8), r8 = (v % (CHR / 8)) * 8;
                 const int64_t gm = m0 + ch * CHR + r8, gn = n0 + n;
-                if (gm >= p.M || gn >= p.N) continue;
+                if (gm >= hk.M || gn >= hk.N) continue;
                 uint16_t h8[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h8[e] = *(const uint16_t*)(stage + (r8 + e) * OUT_ROW + n * 2);
@@ -1516,7 +1547,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     for (int v = tid; v < CHR * PPR; v += NT) {
         const int r = v / PPR, c = v % PPR;
         const int64_t gm = m0 + ch * CHR + r, gn0 = n0 + c * EPP;
-        if (gm >= p.M || c * EPP >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
+        if (gm >= hk.M || c * EPP >= tv.n_lim) continue;  // N % 8 == 0: a piece never straddles N
         store16(out_piece(p, tv, gm, gn0, c * EPP, OUT_B), *(const uint4*)(stage + r * OUT_ROW + c * 16));
     }
     }
@@ -1552,6 +1583,7 @@ int launch_one(GemmParams p, hipStream_t s) {
         // near-square patch of ~32 concurrent tiles per XCD: rows*BM ~ cols*BN
         int gm = gm_env > 0 ? gm_env : (BM >= BN ? 6 : 8);
         if (gm > p.tiles_m) gm = p.tiles_m;
+        if (gm > 255) gm = 255;  // travels in 8 bits of hk_flags
         p.group_m = gm;
         static const int swz_env = [] { const char* e = getenv("SDNQ_HIP_SWZ"); return e ? atoi(e) : 7; }();
         p.swz = swz_env;
@@ -1564,7 +1596,11 @@ int launch_one(GemmParams p, hipStream_t s) {
         p.fastunit = fast_env && p.units != nullptr && p.unit_n > 0 && (uint64_t)p.N * (uint64_t)p.unit_n <= (1ull << 32);
         p.mg_unit = magic(p.unit_n > 0 ? (uint64_t)p.unit_n : 1);
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), LDS_BYTES, s, p);
+    if (p.M > 0x7fffffffll || p.N > 0x7fffffffll || p.K > 0x7fffffffll || p.lda > 0x7fffffffll || p.ldb > 0x7fffffffll) return SDNQ_ERR_SHAPE;
+    const uint32_t hk_flags = (uint32_t)(p.group_m & 0xff) | ((uint32_t)(p.swz & 0xff) << 8) | ((uint32_t)(p.fastmap != 0) << 16) |
+                              ((uint32_t)(p.fastunit != 0) << 17) | ((uint32_t)(p.units != nullptr) << 18);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), LDS_BYTES, s, p.a, p.b, (int)p.lda, (int)p.ldb, (int)p.M, (int)p.N, (int)p.K,
+                       p.tiles_m, p.tiles_n, hk_flags, p.mg_per_group, p.mg_group_m, p);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }

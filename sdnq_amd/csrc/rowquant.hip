@@ -126,13 +126,17 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, in
 // THAT dtype (`input.to(dtype=scale.dtype)`, linear_int8.py:15-22): scale = round_T(amax / qmax), q = rint(round_T(x / scale)).
 // Built for the two-phase path only (NP == 0): a compatibility mode, not the tuned one.
 template <int T_ID, int MM, bool HAD, int NP, int WPR = 1, bool LP = false>
-__global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx,
+// Argument order: what the row loads need first -- 14 dwords, the part a kernarg-preloading build (SDNQ_PRELOAD_ROWQUANT, build.sh)
+// delivers in SGPRs with the wave -- then the rest, fetched in one batch (SDNQ_KERNARGS_NOW, sdnq_dev.h).
+__global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, int row_blocks,
                                                        int log2g, uint8_t* __restrict__ xq, float* __restrict__ xs,
                                                        int32_t* __restrict__ rowsum, void* __restrict__ xrot,
-                                                       const uint4* __restrict__ pf, int64_t pf_vecs, int row_blocks,
-                                                       float* __restrict__ xzp) {
-    // every argument in one batch of scalar loads (SDNQ_KERNARGS_NOW, sdnq_dev.h): this kernel is 443 of the 905 launches of the SDXL step
-    SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(log2g), "s"(xq), "s"(xs), "s"(rowsum), "s"(xrot), "s"(pf), "s"(pf_vecs), "s"(row_blocks), "s"(xzp));
+                                                       const uint4* __restrict__ pf, int64_t pf_vecs, float* __restrict__ xzp) {
+    // this kernel is 443 of the 905 launches of the SDXL step
+    SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(row_blocks), "s"(log2g), "s"(xq), "s"(xs));
+#ifndef SDNQ_PRELOAD_ROWQUANT
+    SDNQ_KERNARGS_NOW("s"(rowsum), "s"(xrot), "s"(pf), "s"(pf_vecs), "s"(xzp));
+#endif
     if ((int)blockIdx.x >= row_blocks) {
         // software prefetch of the following GEMM's weight operand: these extra workgroups just stream it once so it
         // sits in the last-level cache (MALL) / L2 when the GEMM's LDS-DMA asks for it. 8 loads in flight per lane.
@@ -171,6 +175,12 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 const int64_t idx = k_part + (int64_t)p * 512 + lane * 8;
                 load8_raw<T_ID>(row, idx, idx < K, ra[p], rb[p]);
             }
+#ifdef SDNQ_PRELOAD_ROWQUANT
+            // the arguments that did not arrive preloaded: one batch of scalar loads, issued behind the row's loads (their round
+            // trip hides under the row's)
+            __builtin_amdgcn_sched_barrier(0);
+            SDNQ_KERNARGS_NOW("s"(rowsum), "s"(xrot), "s"(xzp));
+#endif
 #pragma unroll
             for (int p = 0; p < NP; ++p) unpack8<T_ID>(ra[p], rb[p], k_part + (int64_t)p * 512 + lane * 8 < K, v[p]);
         }
@@ -346,7 +356,10 @@ template <int T_ID, int MM, int NG, int WPR>
 __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, uint8_t* __restrict__ xq,
                                                               float* __restrict__ xs, int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
     static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
-    SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(xq), "s"(xs), "s"(rowsum), "s"(xrot));
+    SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(xq), "s"(xs), "s"(rowsum));  // the 14 dwords a preloading build delivers
+#ifndef SDNQ_PRELOAD_ROWQUANT
+    SDNQ_KERNARGS_NOW("s"(xrot));
+#endif
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int64_t m = (int64_t)blockIdx.x * (4 / WPR) + wv / WPR;
     const int part = wv % WPR;
@@ -546,11 +559,11 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     const int pf_blocks = (int)((pf_vecs + 256 * 8 - 1) / (256 * 8));
     dim3 grid((unsigned)(row_blocks + pf_blocks)), block(256);
 #define RQ_LAUNCH(T, MMV, H, NPV) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV>), grid, block, 0, s, x, m, k, ldx, row_blocks, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, xzp)
 #define RQ_LAUNCH2(T, MMV, H, NPV) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV, 2>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV, 2>), grid, block, 0, s, x, m, k, ldx, row_blocks, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, xzp)
 #define RQ_LAUNCH4(T, MMV, H, NPV) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV, 4>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, row_blocks, xzp)
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, NPV, 4>), grid, block, 0, s, x, m, k, ldx, row_blocks, log2g, (uint8_t*)xq, xs, rowsum, xrot, pf, pf_vecs, xzp)
 #define RQ_DISPATCH_NP(T, MMV, H)               \
     do {                                        \
         if (split4 && np <= 4) RQ_LAUNCH4(T, MMV, H, 1);      \
@@ -604,8 +617,8 @@ extern "C" int sdnq_hip_rowquant_lp(const void* x, int x_dtype, int64_t m, int64
     const int row_blocks = (int)((m + 3) / 4);
     dim3 grid((unsigned)row_blocks), block(256);
 #define RQLP(T, MMV, H) \
-    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, 0, 1, true>), grid, block, 0, s, x, m, k, ldx, log2g, (uint8_t*)xq, xs, rowsum, xrot, \
-                       (const uint4*)nullptr, (int64_t)0, row_blocks, (float*)nullptr)
+    hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, 0, 1, true>), grid, block, 0, s, x, m, k, ldx, row_blocks, log2g, (uint8_t*)xq, xs, rowsum, xrot, \
+                       (const uint4*)nullptr, (int64_t)0, (float*)nullptr)
 #define RQLP_H(T, MMV) do { if (log2g) RQLP(T, MMV, true); else RQLP(T, MMV, false); } while (0)
 #define RQLP_MM(T) do { if (mm_dtype == SDNQ_MM_I8) RQLP_H(T, SDNQ_MM_I8); else RQLP_H(T, SDNQ_MM_FP8); } while (0)
     if (x_dtype == SDNQ_BF16) RQLP_MM(SDNQ_BF16);
