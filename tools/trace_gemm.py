@@ -13,6 +13,8 @@ LOWRANK = "--lowrank" in sys.argv  # the SVD epilogue on FLUX shapes, next to th
 W8A16 = "--w8a16" in sys.argv      # the fused dequantize GEMM next to the int8 one
 if LOWRANK:
     shapes = [(4608, 3072, 3072), (4608, 12288, 3072)]
+if os.environ.get("SHAPES"):  # SHAPES="m,n,k;m,n,k"
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")]
 names = ["entry", "issued", "stage0", "steady_end", "mainloop_end", "epi_compute", "stored"]
 for (m, n, k) in shapes:
     x = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
