@@ -95,6 +95,8 @@ def source_hash() -> str:
             extra = "-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
         if f == "gemm" and os.environ.get("SDNQ_PRELOAD_GEMM", "1") != "0":
             extra = "-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
+        if f in ("dequant", "conv"):
+            extra = "-mllvm -amdgpu-kernarg-preload-count=14"
         g = hashlib.sha256((f"{hdr_hash} {flags} {extra}\n").encode())
         g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())
         parts += f" {f}:{g.hexdigest()}"

@@ -24,6 +24,8 @@ for f in $SRCS; do
   [ "$f" = rowquant ] && [ "${SDNQ_PRELOAD_ROWQUANT:-1}" != 0 ] && EXTRA="-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
   # gemm.hip: the same for the GEMM kernel's 14 leading scalar arguments (tile mapping, operand descriptors, prologue DMAs)
   [ "$f" = gemm ] && [ "${SDNQ_PRELOAD_GEMM:-1}" != 0 ] && EXTRA="-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
+  # dequant.hip / conv.hip: kernels with scalar arguments (lowrank_down, linear_float, conv_pixel_amax) get theirs preloaded as well
+  { [ "$f" = dequant ] || [ "$f" = conv ]; } && EXTRA="-mllvm -amdgpu-kernarg-preload-count=14"
   H=$( (echo "$HDR_HASH $FLAGS $EXTRA"; cat "$HERE/$f.hip") | sha256sum | cut -d' ' -f1)
   ALL="$ALL $f:$H"
   if [ "${FORCE:-0}" != 1 ] && [ -f "$OBJ/$f.o" ] && [ "$(cat "$OBJ/$f.hash" 2>/dev/null)" = "$H" ]; then continue; fi

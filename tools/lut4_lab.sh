@@ -13,6 +13,7 @@ for f in api rowquant gemm dequant quantize conv attention parallel; do
   [ $f = attention ] && X="-mllvm -amdgpu-mfma-vgpr-form"
   [ $f = rowquant ] && X="-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
   [ $f = gemm ] && X="-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
+  { [ $f = dequant ] || [ $f = conv ]; } && X="-mllvm -amdgpu-kernarg-preload-count=14"
   /opt/rocm/bin/hipcc $F $X -c $f.hip -o /tmp/lut4_$f.o & OBJS+=(/tmp/lut4_$f.o)
 done; wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wno-unused-command-line-argument -o "$ROOT/build/libsdnq_hip_lut4.so" "${OBJS[@]}"
