@@ -65,6 +65,19 @@ def test_argument_validation_without_gpu():
     assert lib.sdnq_hip_scaled_mm_lp(0, p, p, p, p, None, 0, 0, p, None, 32, p, 32, 32, 32, None) == -1     # t without svd_up
     assert lib.sdnq_hip_scaled_mm_lp(0, p, p, p, p, None, 0, 0, None, None, 0, p, 32, 32, 24, None) == -3   # K % 16
     assert lib.sdnq_hip_lowrank_down(p, 1, 4, 64, 64, p, 2, 32, p, None) == -2                         # activation / factor dtype mismatch
+    assert lib.sdnq_hip_scaled_mm_lp_zp(0, p, p, p, p, None, 0, 0, None, None, 0, p, None, p, 32, 32, 32, None) == -1   # rowsum without zero point
+    assert lib.sdnq_hip_scaled_mm_lp_zp(0, p, p, p, p, p, 2, 32, None, None, 0, p, p, p, 32, 32, 32, None) == -3        # zero point with a 2-D bias
+    # matmuls on views (grouped convs)
+    smm = lib.sdnq_hip_scaled_mm_strided
+    assert smm(0, p, 16, p, p, p, None, 0, p, 32, 1, 32, 32, 32, 0, None) == -3                    # lda < K
+    assert smm(0, p, 72, p, p, p, None, 0, p, 32, 1, 32, 32, 32, 0, None) == -3                    # lda % 16
+    assert smm(0, p, 64, p, p, p, None, 0, p, 16, 1, 32, 32, 32, 0, None) == -3                    # ldc < N
+    assert smm(0, p, 64, p, p, p, None, 0, p, 32, 1, 32, 32, 32, 12, None) == -3                   # hw % 8 / M % hw
+    assert smm(0, p, 64, p, p, p, None, 0, p, 32, 0, 32, 32, 32, 16, None) == -5                   # float32 output with the NCHW store
+    lfs = lib.sdnq_hip_linear_float_strided
+    assert lfs(None, p, None, 1, p, 40, 32, 32, 32, 32, None) == -1
+    assert lfs(p, p, None, 1, p, 40, 32, 32, 32, 16, None) == -3                                   # ldc < N
+    assert lfs(p, p, None, 1, p, 40, 32, 32, 16, 32, None) == -3                                   # ldx < K
 
 
 def test_attention_argument_validation_without_gpu():
