@@ -474,7 +474,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     int tile_m, tile_n;
-    auto fdiv = [](uint32_t n, uint32_t mg) -> uint32_t { return mg ? __umulhi(n, mg) : n; };
+    // (operands are wave-uniform; __umulhi is selected as a VECTOR multiply, so the quotient is pinned back to a scalar register --
+    // left in a VGPR, a tile coordinate / unit index turned the unit-table load into vector loads and every buffer descriptor derived
+    // from it into VGPRs, i.e. a readfirstlane "waterfall" loop around each LDS-DMA of the K loop)
+    auto fdiv = [](uint32_t n, uint32_t mg) -> uint32_t { return mg ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__umulhi(n, mg)) : n; };
     if (hk.fastmap) {
         const int per_group = hk.group_m * hk.tiles_n;
         const int gid = (int)fdiv((uint32_t)bid, hk.mg_per_group), first_m = gid * hk.group_m;
@@ -504,7 +507,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         const int64_t u = hk.fastunit ? (int64_t)fdiv((uint32_t)n0, p.mg_unit) : n0 / p.unit_n;
         un_d = n0 - u * p.unit_n;
         un = p.units[u];
-        tv.b = (const uint8_t*)un.b + un_d * hk.ldb;
+        // The unit-table entry is read with vector loads (global memory the compiler cannot prove read-only), so the weight pointer of
+        // this path lives in VGPRs -- and with it the merged value of both paths: every LDS-DMA of the weight operand then sat in a
+        // readfirstlane "waterfall" loop (6-24 of them per kernel, the K loop's included).  The value is wave-uniform: pin it to SGPRs.
+        const uint64_t bv = (uint64_t)((const uint8_t*)un.b + un_d * hk.ldb);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bv >> 32));
+        tv.b = (const uint8_t*)(((uint64_t)hi << 32) | lo);
         tv.n_lim = p.unit_n - un_d;
     } else {
         tv.b = hk.b + n0 * hk.ldb;
