@@ -544,7 +544,9 @@ __global__ __launch_bounds__(256) void linear_skinny_had256_kernel(const DeqPara
     static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
     constexpr int NG = 16;
     const int lane = threadIdx.x & 63;
-    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave's output channel is wave-uniform: pinned to a scalar register, so that the buffer descriptors derived from it live in SGPRs
+    // (left as a function of threadIdx.x they were VGPRs, and each of the 48 buffer loads sat in a readfirstlane waterfall loop)
+    const int64_t n = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (n >= p.N) return;
     float acc[MROWS];
 #pragma unroll

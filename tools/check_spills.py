@@ -47,6 +47,25 @@ def kernel_resources(lib):
     return out
 
 
+def waterfall_loops(lib):
+    """Number of readfirstlane "waterfall" loops in front of memory instructions, over the whole library: a buffer descriptor (or any
+    scalar operand of a memory instruction) that the compiler could not keep in SGPRs is fed through `v_readfirstlane ... v_cmp_eq ...
+    s_and_saveexec ... <memory instruction> ... s_cbranch_execnz`.  Every descriptor of this library is wave-uniform by construction, so
+    the expected count is 0 (round 3: 6-24 such loops per GEMM kernel, the K loop's LDS-DMAs included, went unnoticed for a while)."""
+    n = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
+        data = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(b"\x7fELF", data)]
+        for i, st in enumerate(starts):
+            co = os.path.join(tmp, f"co{i}.elf")
+            open(co, "wb").write(data[st:starts[i + 1] if i + 1 < len(starts) else len(data)])
+            r = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True)
+            n += len(re.findall(r"v_readfirstlane_b32[^\n]*\n(?:[^\n]*\n){0,6}?[^\n]*v_cmp_eq_u64[^\n]*\n(?:[^\n]*\n){0,4}?[^\n]*s_and_saveexec_b64", r.stdout))
+    return n
+
+
 def main():
     lib = next((a for a in sys.argv[1:] if not a.startswith("-")), os.path.join(ROOT, "sdnq_amd", "libsdnq_hip.so"))
     res = kernel_resources(lib)
@@ -61,6 +80,11 @@ def main():
     print(f"{len(res)} kernels, {len(bad)} with scratch memory / vector-register spills ({len(sg)} more keep spilled SGPRs in VGPR lanes)")
     for r in bad:
         print(f"  scratch {r[1]} B, vgpr spills {r[2]}, sgpr spills {r[3]}: {r[0][:200]}")
+    if "--waterfalls" in sys.argv:
+        wf = waterfall_loops(lib)
+        print(f"{wf} readfirstlane waterfall loops in front of memory instructions")
+        if wf:
+            return 1
     return 1 if bad else 0
 
 
