@@ -12,7 +12,9 @@ rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 bad = 0
 n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 for it in range(n_it):
-    cin, cout = 16 * rng.randint(2, 6), 16 * rng.randint(2, 6)
+    groups = rng.choice([1, 1, 2, 4])
+    # per group: input channels * taps a multiple of 16 and >= 32 channels where the quantized matmul is to be taken
+    cin, cout = groups * 16 * rng.randint(2, 4), groups * 16 * rng.randint(2, 4)
     ks = rng.choice([1, 3, 3, (3, 1), (1, 3), 5])
     stride = rng.choice([1, 1, 2, (2, 1)])
     pad = rng.choice([0, 1, 2])
@@ -21,7 +23,7 @@ for it in range(n_it):
     b = rng.choice([1, 2])
     dt = rng.choice([torch.bfloat16, torch.float16])
     tag = "bf16" if dt == torch.bfloat16 else "f16"
-    conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, bias=rng.random() < 0.7)
+    conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
     try:
         y_shape = conv(torch.zeros(b, cin, h, w)).shape
     except RuntimeError:
@@ -32,9 +34,9 @@ for it in range(n_it):
     x = torch.randn(b, cin, h, w).to(dt)
     y = mod(x.to(dev)).float().cpu().numpy()
     meta = {"nd": 2, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
-            "padding_mode": mod.padding_mode, "groups": 1}
+            "padding_mode": mod.padding_mode, "groups": groups}
     ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
     if y.shape != ref.shape or not np.array_equal(y, ref):
         bad += 1
-        print("MISMATCH", cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape, int((y != ref).sum()) if y.shape == ref.shape else -1)
+        print("MISMATCH", groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape, int((y != ref).sum()) if y.shape == ref.shape else -1)
 print("conv fuzz done, mismatches:", bad)
