@@ -236,7 +236,18 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                 if constexpr (HAD) {
                     if (xrot != nullptr) store8<T_ID>((char*)xrot + m * K * FT<T_ID>::bytes, idx, v[p]);
                 }
-                *(uint2*)(qrow + idx) = quant8<MM>(v[p], rd, isum, zpv, asym);
+                {
+                    const uint2 qv = quant8<MM>(v[p], rd, isum, zpv, asym);
+                    // write-through (sc0 sc1): the codes are read by the following GEMM from OTHER XCDs; left dirty in this XCD's L2 they cost
+                    // that GEMM a remote write-back per first touch (row quantization + GEMM pair 12.04 -> 11.19 us, SDXL step 8.08 -> 8.04 ms)
+#if !defined(SDNQ_RQ_STORE_PLAIN)
+                    typedef int v2i_t __attribute__((ext_vector_type(2)));
+                    const v2i_t w2 = {(int)qv.x, (int)qv.y};
+                    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(qrow + idx), "v"(w2) : "memory");
+#else
+                    *(uint2*)(qrow + idx) = qv;
+#endif
+                }
             }
         }
     } else {
@@ -310,6 +321,15 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
         }
         if (row_ok && lane == 0 && part == 0) rowsum[m] = isum;
     }
+}
+
+// 4-byte store of quantized codes, write-through (see rowquant_kernel: the consumer GEMM reads them from other XCDs)
+__device__ __forceinline__ void store_codes4(uint8_t* dst, u32 w) {
+#if !defined(SDNQ_RQ_STORE_PLAIN)
+    asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+#else
+    *(u32*)dst = w;
+#endif
 }
 
 // ---- group-256 Hadamard rotation on the matrix cores -------------------------------------------------------------------------------
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __rest
                     if (q != q) q = 0.0f;
                     c[e] = fminf(fmaxf(q, -448.0f), 448.0f);
                 }
-                *(u32*)(qrow + go) = pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]);
+                store_codes4(qrow + go, pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]));
                 continue;
             }
 #pragma unroll
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __rest
                 }
                 w |= byte << (8 * e);
             }
-            *(u32*)(qrow + go) = w;
+            store_codes4(qrow + go, w);
         }
     }
     if (rowsum != nullptr) {
