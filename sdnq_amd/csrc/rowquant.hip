@@ -548,7 +548,10 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
         ((uintptr_t)xq % 4) == 0 && (!xrot || ((uintptr_t)xrot % 8) == 0)) {
         // the default group size, 16-bit activations: rotation on the matrix cores (rowquant_had256_kernel)
         const int groups = (int)(k / 256);
-        const bool wide = groups > 16;  // the row split over four waves
+        static const int wide_min = [] { const char* e = getenv("SDNQ_HIP_RQH_WIDE_MIN"); return e ? atoi(e) : 16; }();  // tuning aid
+        // the row split over four waves: long rows, and FEW rows of >= 8 groups (512 x 3072: 4.9 -> 3.8 us; at 4608 rows the one-wave
+        // form is the faster one, 15.0 vs 15.9 us).  Every wave must keep at least one group.
+        const bool wide = groups > wide_min || (m <= 1024 && groups >= 8 && ((groups + 3) / 4) * 3 < groups);
         const int per = wide ? (groups + 3) / 4 : groups;
         dim3 grid((unsigned)(wide ? m : (m + 3) / 4)), block(256);
 #define RQH(T, MMV, NGV, W) hipLaunchKernelGGL((rowquant_had256_kernel<T, MMV, NGV, W>), grid, block, 0, s, x, m, k, ldx, (uint8_t*)xq, xs, rowsum, xrot)

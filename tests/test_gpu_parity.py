@@ -725,7 +725,7 @@ def test_sdxl_size_conv_int8_vs_oracle(gpu_device):
     assert np.array_equal(got, ref), int((got != ref).sum())
 
 
-@pytest.mark.parametrize("k", [6144, 12288, 15360])
+@pytest.mark.parametrize("k", [2048, 2304, 3072, 6144, 12288, 15360])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("mm_name", ["int8", "fp8"])
 def test_long_row_hadamard_rowquant_equals_rotate_then_quantize(k, dt, mm_name, gpu_device):
