@@ -372,8 +372,14 @@ __global__ __launch_bounds__(256) void hadamard256_kernel(const void* __restrict
     }
 }
 
+// element `hi` (0 / 1) of a dword of two 16-bit activations, as a float
+template <int T_ID> __device__ __forceinline__ float unpk(u32 w, int hi) {
+    if constexpr (T_ID == SDNQ_BF16) return __uint_as_float(hi ? (w & 0xffff0000u) : (w << 16));
+    else return f16_bits_to_f32((uint16_t)(hi ? (w >> 16) : (w & 0xffffu)));
+}
+
 template <int T_ID, int MM, int NG, int WPR>
-__global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, uint8_t* __restrict__ xq,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NG >= 16 || (NG >= 12 && WPR > 1)) ? 4 : 5))) void rowquant_had256_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, uint8_t* __restrict__ xq,
                                                               float* __restrict__ xs, int32_t* __restrict__ rowsum, void* __restrict__ xrot) {
     static_assert(T_ID == SDNQ_BF16 || T_ID == SDNQ_F16, "16-bit activations");
     SDNQ_KERNARGS_NOW("s"(x), "s"(M), "s"(K), "s"(ldx), "s"(xq), "s"(xs), "s"(rowsum));  // the 14 dwords a preloading build delivers
@@ -400,17 +406,19 @@ __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __rest
         const int gg = (g0 + g < ngroups) ? g0 + g : 0;
         raw[g] = *(const uint2*)(row + (int64_t)gg * 256);
     }
-    float v[NG][4];
+    // the rotated row is kept as it will be stored -- rounded to the activation dtype, two elements per register -- not as floats:
+    // 2 registers per group instead of 4 (+ the 2 of the raw load, dead by then), so a 12-group row (K = 3072) fits 8 waves per SIMD
+    // instead of 3 and a 4608-row launch is one round of workgroups instead of two
+    u32 pk[NG][2];
     float amax = 0.0f;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const v4f y = had256_group<T_ID>(raw[g], hf);
         const bool live = g0 + g < ngroups;  // wave-uniform
+        pk[g][0] = live ? pack2<T_ID>(y[0], y[1]) : 0u;
+        pk[g][1] = live ? pack2<T_ID>(y[2], y[3]) : 0u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[g][e] = live ? FT<T_ID>::round(y[e]) : 0.0f;
-            amax = fmaxf(amax, fabsf(v[g][e]));
-        }
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(unpk<T_ID>(pk[g][e >> 1], e & 1)));
     }
     amax = wave_max(amax);
     if constexpr (WPR > 1) {
@@ -425,62 +433,44 @@ __global__ __launch_bounds__(256) void rowquant_had256_kernel(const void* __rest
     rd.set(scale);
     uint8_t* qrow = xq + m * K + eoff;
     int isum = 0;
-    if (xrot != nullptr) {  // the rotated copy (needed by the SVD branch), before the values turn into quotients
+    if (xrot != nullptr) {  // the rotated copy (needed by the SVD branch)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g0 + g < ngroups && row_ok) {
-                const uint32_t lo = (uint32_t)FT<T_ID>::bits(v[g][0]) | ((uint32_t)FT<T_ID>::bits(v[g][1]) << 16);
-                const uint32_t hi = (uint32_t)FT<T_ID>::bits(v[g][2]) | ((uint32_t)FT<T_ID>::bits(v[g][3]) << 16);
-                *(uint2*)((uint16_t*)xrot + m * K + eoff + (int64_t)(g0 + g) * 256) = make_uint2(lo, hi);
-            }
+            if (g0 + g < ngroups && row_ok)
+                *(uint2*)((uint16_t*)xrot + m * K + eoff + (int64_t)(g0 + g) * 256) = make_uint2(pk[g][0], pk[g][1]);
         }
-    }
-    if (rd.fast) {  // wave-uniform: the quotients in place, one branch for the row instead of a select per element
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[g][e] = rd.fastdiv(v[g][e]);
-    } else {
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[g][e] = v[g][e] / scale;
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g0 + g < ngroups && row_ok) {
             const int64_t go = (int64_t)(g0 + g) * 256;
-            u32 w = 0;
+            float qd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ve = unpk<T_ID>(pk[g][e >> 1], e & 1);
+                qd[e] = rd.fast ? rd.fastdiv(ve) : ve / scale;  // rd.fast is wave-uniform
+            }
             if constexpr (MM == SDNQ_MM_FP8) {
                 float c[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float q = v[g][e];
+                    float q = qd[e];
                     if (q != q) q = 0.0f;
                     c[e] = fminf(fmaxf(q, -448.0f), 448.0f);
                 }
                 store_codes4(qrow + go, pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]));
-                continue;
-            }
+            } else {
+                u32 w = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u32 byte;
-                const float qd = v[g][e];
-                if constexpr (MM == SDNQ_MM_I8) {
-                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(qd);
+                for (int e = 0; e < 4; ++e) {
+                    float q = (scale == 0.0f) ? 0.0f : __builtin_rintf(qd[e]);
                     q = fminf(fmaxf(q, -128.0f), 127.0f);
                     const int qi = (int)q;
                     isum += qi;
-                    byte = (u32)qi & 0xffu;
-                } else {
-                    float q = qd;
-                    if (q != q) q = 0.0f;
-                    q = fminf(fmaxf(q, -448.0f), 448.0f);
-                    byte = f32_to_e4m3fn(q);
+                    w |= ((u32)qi & 0xffu) << (8 * e);
                 }
-                w |= byte << (8 * e);
+                store_codes4(qrow + go, w);
             }
-            store_codes4(qrow + go, w);
         }
     }
     if (rowsum != nullptr) {
@@ -555,7 +545,7 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
         const int per = wide ? (groups + 3) / 4 : groups;
         dim3 grid((unsigned)(wide ? m : (m + 3) / 4)), block(256);
 #define RQH(T, MMV, NGV, W) hipLaunchKernelGGL((rowquant_had256_kernel<T, MMV, NGV, W>), grid, block, 0, s, x, m, k, ldx, (uint8_t*)xq, xs, rowsum, xrot)
-#define RQH_NG(T, MMV, W) do { if (per <= 4) RQH(T, MMV, 4, W); else if (per <= 8) RQH(T, MMV, 8, W); else RQH(T, MMV, 16, W); } while (0)
+#define RQH_NG(T, MMV, W) do { if (per <= 4) RQH(T, MMV, 4, W); else if (per <= 8) RQH(T, MMV, 8, W); else if (per <= 12) RQH(T, MMV, 12, W); else RQH(T, MMV, 16, W); } while (0)
 #define RQH_W(T, MMV) do { if (wide) RQH_NG(T, MMV, 4); else RQH_NG(T, MMV, 1); } while (0)
 #define RQH_MM(T) do { if (mm_dtype == SDNQ_MM_I8) RQH_W(T, SDNQ_MM_I8); else RQH_W(T, SDNQ_MM_FP8); } while (0)
         if (x_dtype == SDNQ_BF16) RQH_MM(SDNQ_BF16);
