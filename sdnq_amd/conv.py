@@ -13,7 +13,11 @@ weight rows -- one launch per group on views (``sdnq_hip_scaled_mm_strided`` / `
 into its channel range of the output.  Built for the float forward and the plain int8 / fp8 matmuls; the reference's SVD, zero-point
 and uint8-matmul terms are not defined per group (its SVD product has the wrong shape there) and raise here.
 
-Not built (raise): Conv3d, fp16 matmul, Hadamard on conv layers.
+Hadamard-rotated conv weights (quant_utils.py:222-236; conv_int8.py:52-53): the rotation groups run along the flattened (C_in, kernel)
+axis, i.e. along the unfolded row -- the Linear kernels' Hadamard path as is (rotation fused into the row quantization; the float forward
+un-rotates the weight rows).
+
+Not built (raise): Conv3d, fp16 matmul, Hadamard on grouped conv layers.
 """
 from __future__ import annotations
 
@@ -32,8 +36,8 @@ def _pair(v, n):
 
 def _geometry(self, input: torch.Tensor):
     """-> (input [B, C, H, W] (explicitly padded for non-zero padding modes), kernel, stride, padding, dilation, nd)."""
-    if self.sdnq_dequantizer.use_hadamard:
-        raise NotImplementedError("Hadamard-rotated conv layers are not built for MI355X")
+    if self.sdnq_dequantizer.use_hadamard and self.groups != 1:
+        raise NotImplementedError("Hadamard-rotated grouped conv layers are not built for MI355X")
     if isinstance(self.padding, str):
         raise NotImplementedError("string padding modes ('same' / 'valid') are not supported by the reference's conv matmul either")
     nd = input.ndim - 2
@@ -113,7 +117,7 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
     wq, ws, zp = linear._prepare_mm_weights(self, st, mm)
     if self.groups != 1:
         return _grouped_matmul_forward(self, input, mm, st, wq, ws, zp)
-    if FUSED_CONV_QUANT and st.svd_up is None and zp is None and st.qw.scale_dtype == torch.float32:
+    if FUSED_CONV_QUANT and st.svd_up is None and zp is None and st.qw.scale_dtype == torch.float32 and not dq.use_hadamard:
         # no SVD / zero-point terms: the float [M, K] matrix is never needed -- row scales straight from the image, then the
         # unfold writes the quantized operand (same values as im2col + rowquant)
         x4, kernel, stride, padding, dilation, nd = _geometry(self, input)

@@ -40,7 +40,8 @@ def is_hot_path_linear(module: torch.nn.Module) -> bool:
 def is_hot_path_conv(module: torch.nn.Module) -> bool:
     dq = getattr(module, "sdnq_dequantizer", None)
     return (dq is not None and getattr(dq, "layer_class_name", None) in ("Conv1d", "Conv2d", "SDNQConv1d", "SDNQConv2d")
-            and not getattr(dq, "use_codebook", False) and not getattr(dq, "use_hadamard", False)
+            and not getattr(dq, "use_codebook", False)
+            and not (getattr(dq, "use_hadamard", False) and getattr(module, "groups", 1) != 1)
             and getattr(dq, "quantized_matmul_dtype", "int8") in ("int8", "uint8", "fp8", "float8_e4m3fn"))
 
 

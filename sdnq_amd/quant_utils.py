@@ -55,10 +55,15 @@ def rotate_hadamard(weight: torch.Tensor, group_size: int) -> torch.Tensor:
     return torch.matmul(weight.unflatten(-1, (-1, group_size)), h).flatten(-2, -1)
 
 
-def apply_hadamard(weight: torch.Tensor, group_size: int = 256):
-    use, g = get_hadamard_group_size(weight.shape[-1], group_size)
+def apply_hadamard(weight: torch.Tensor, group_size: int = 256, is_conv: bool = False):
+    """quant_utils.py:222-236.  Conv weights ([C_out, C_in, *kernel], or already flattened for the direct matmul): the group size is
+    chosen from dimension 1 and the groups run along the flattened (C_in, kernel) axis."""
+    use, g = get_hadamard_group_size(weight.shape[1] if is_conv else weight.shape[-1], group_size)
     if use:
-        weight = rotate_hadamard(weight, g)
+        if is_conv and weight.ndim > 2:
+            weight = rotate_hadamard(weight.flatten(1, -1), g).unflatten(-1, tuple(weight.shape[1:]))
+        else:
+            weight = rotate_hadamard(weight, g)
     return weight, use, g
 
 

@@ -191,9 +191,7 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
         weight = weight.flatten(1, -1)
 
     if use_hadamard:
-        if is_conv:
-            raise NotImplementedError("Hadamard rotation of conv weights is not built for MI355X")
-        weight, use_hadamard, hadamard_group_size = apply_hadamard(weight, hadamard_group_size)
+        weight, use_hadamard, hadamard_group_size = apply_hadamard(weight, hadamard_group_size, is_conv=is_conv)
     svd_up = svd_down = None
     if use_svd:
         weight, svd_up, svd_down = apply_svdquant(weight, rank=svd_rank, steps=svd_steps, dtype=torch_dtype)

@@ -347,6 +347,18 @@ CONV_CASES = [
          cfg=dict(weights_dtype="int8")),
     dict(name="conv1d_g4_uint4_noqmm_f32", nd=1, cin=64, cout=32, k=3, conv=dict(padding=1, groups=4), xs=[(2, 20)], dtype="f32",
          cfg=dict(weights_dtype="uint4")),
+    # Hadamard-rotated conv weights (quant_utils.py:222-236: the group divides C_in, groups run along the flattened (C_in, kernel) axis;
+    # the matmul forwards rotate the unfolded input, conv_int8.py:52-53 / conv_fp8.py:41-42; the float forward un-rotates the weight)
+    dict(name="conv2d_int8_had_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1), xs=[(2, 8, 8), (1, 4, 5)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True, use_hadamard=True)),
+    dict(name="conv2d_int4_g16_had32_qmm_f16", nd=2, cin=32, cout=48, k=3, conv=dict(padding=1, stride=2), xs=[(1, 12, 12)], dtype="f16",
+         cfg=dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True, use_hadamard=True)),
+    dict(name="conv2d_fp8_had_qmm_bf16", nd=2, cin=256, cout=64, k=1, conv=dict(), xs=[(1, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True, use_hadamard=True)),
+    dict(name="conv2d_uint4_had_noqmm_bf16", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 6, 6)], dtype="bf16",
+         cfg=dict(weights_dtype="uint4", use_hadamard=True)),
+    dict(name="conv1d_int8_had_noqmm_f32", nd=1, cin=64, cout=32, k=3, conv=dict(padding=1), xs=[(2, 20)], dtype="f32",
+         cfg=dict(weights_dtype="int8", use_hadamard=True, hadamard_group_size=16)),
 ]
 
 

@@ -579,13 +579,13 @@ def test_conv_forward_vs_golden_and_oracle(name, gpu_device):
         assert y.dtype == x.dtype and tuple(y.shape) == ref.shape and y.is_contiguous()
         got = to_f32_numpy(y)
         orc = O.conv_forward(omod, c.f32(f"x_{i}"), c.conv, c.tag)
-        exact = d["use_quantized_matmul"] and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up")
+        exact = d["use_quantized_matmul"] and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up") and not d["use_hadamard"]
         if exact:
             assert np.array_equal(got, ref), (name, i, "golden", int((got != ref).sum()))
             assert np.array_equal(got, orc), (name, i, "oracle")
         else:
-            assert_close_float(got, ref, c.tag, (name, i, "golden"))
-            assert_close_float(got, orc, c.tag, (name, i, "oracle"))
+            assert_close_float(got, ref, c.tag, (name, i, "golden"), hadamard=d["use_hadamard"])
+            assert_close_float(got, orc, c.tag, (name, i, "oracle"), hadamard=d["use_hadamard"])
 
 
 @pytest.mark.parametrize("name", [n for n in conv_case_names() if "svd" not in n])
@@ -596,13 +596,19 @@ def test_conv_dequant_and_hip_quantizer_vs_golden(name, gpu_device):
     if c.has("w_dequant"):
         wd = dq(mod.weight, mod.scale, mod.zero_point, None, None, skip_quantized_matmul=dq.use_quantized_matmul)
         assert tuple(wd.shape) == tuple(c.info("w_dequant")["shape"])
-        assert np.array_equal(to_f32_numpy(wd), c.f32("w_dequant")), (name, "dequant")
+        got, ref = to_f32_numpy(wd), c.f32("w_dequant")
+        if dq.use_hadamard:  # the un-rotation's summation order is the device's (as for the Linear cases)
+            assert np.all(np.abs(got - ref) <= 2 * np.maximum(np.abs(ref), 1e-30) * 2.0 ** -7 + 1e-6), (name, "dequant")
+        else:
+            assert np.array_equal(got, ref), (name, "dequant")
     if c.has("requant_weight"):
         wq, ws = dq.re_quantize_matmul(mod.weight, mod.scale, mod.zero_point)[:2]
         assert np.array_equal(bits_of(wq.contiguous()), c.raw("requant_weight").view(np.uint8).reshape(bits_of(wq.contiguous()).shape))
         assert np.array_equal(ws.float().cpu().numpy().reshape(-1), c.f32("requant_scale").reshape(-1))
     from sdnq_amd import quantizer as Q
     from tests.test_quantizer import _conv_quant_kwargs, check_conv_state_dict
+    if dq.use_hadamard:  # the rotation in front of the quantizer is a device matmul: codes may differ in the last step (CPU test: exact)
+        return
     dq2, tensors = Q.sdnq_quantize_layer_weight(c.torch_tensor("w_float", device=gpu_device), layer_class_name=c.deq["layer_class_name"],
                                                 **_conv_quant_kwargs(c))
     check_conv_state_dict(c, tensors, dq2, name)

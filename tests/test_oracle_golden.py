@@ -168,6 +168,8 @@ def test_conv_case_dequant_and_forward(name):
         ref = c.f32("w_dequant").reshape(c.N, c.K)
         if c.has("svd_up"):
             assert np.abs(W - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+        elif d["use_hadamard"] and c.tag == "f32":  # the un-rotation is an fp32 matmul: summation order is the library's
+            assert np.abs(W - ref).max() <= 1e-6 * np.abs(ref).max(), (name, "dequant")
         else:
             assert np.array_equal(W, ref), (name, "dequant")
     if c.has("requant_weight"):

@@ -154,8 +154,10 @@ def _conv_quant_kwargs(c):
 
 def check_conv_state_dict(c, tensors, dq, name):
     d = c.deq
-    for f in ("weights_dtype", "group_size", "use_quantized_matmul", "re_quantize_for_matmul", "is_packed"):
+    for f in ("weights_dtype", "group_size", "use_quantized_matmul", "re_quantize_for_matmul", "is_packed", "use_hadamard"):
         assert getattr(dq, f) == d[f], (name, f, getattr(dq, f), d[f])
+    if d["use_hadamard"]:
+        assert dq.hadamard_group_size == d["hadamard_group_size"], (name, dq.hadamard_group_size)
     assert list(dq.quantized_weight_shape) == d["quantized_weight_shape"]
     assert (None if dq.result_shape is None else list(dq.result_shape)) == d["result_shape"]
     for key in ("weight", "scale", "zero_point"):
