@@ -342,7 +342,7 @@ class OracleLinear:
         """Conv weights quantized along C_in keep one scale per (output channel, channel group, kernel position)
         (quantizer.py:120-123, 205-209); the flattened direct-matmul layout and Linear layers have P = 1."""
         d = self.deq
-        if not str(d.get("layer_class_name", "Linear")).endswith(("Conv1d", "Conv2d")) or self.transposed:
+        if not str(d.get("layer_class_name", "Linear")).endswith(("Conv1d", "Conv2d", "Conv3d")) or self.transposed:
             return 1
         return int(np.prod(d["original_shape"][2:]))
 
@@ -556,7 +556,7 @@ def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str
 
 
 def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.ndarray:
-    """SDNQConv1d / SDNQConv2d forward (layers/conv/forward.py:80-81, conv_int8.py:94-123, conv_fp8.py): unfold, the Linear
+    """SDNQConv1d / SDNQConv2d / SDNQConv3d forward (layers/conv/forward.py:80-81, conv_int8.py:94-123, conv_fp8.py): unfold, the Linear
     arithmetic on [M, K] rows, fold back to NCHW.  `conv` = {"nd", "kernel_size", "stride", "padding", "dilation",
     "padding_mode", "groups"} as in the fixtures' meta."""
     groups = int(conv["groups"])
@@ -567,14 +567,29 @@ def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.n
         pads = [(0, 0), (0, 0)] + [(int(q), int(q)) for q in p]
         x = np.pad(x, pads, mode={"reflect": "reflect", "replicate": "edge", "circular": "wrap"}[conv["padding_mode"]])
         p = (0,) * nd
+    Do = None
     if nd == 1:
         x = x[:, :, None, :]
         k, s, p, dl = (1, k[0]), (1, s[0]), (0, p[0]), (1, dl[0])
+    elif nd == 3:
+        # forward.py:59-73: Conv3d is padded explicitly (zeros too), then unfolded along depth, height and width; a row is ordered
+        # (C_in, kd, kh, kw).  Restated as: gather the kd depth taps of every output depth into the channel axis -- Z[(b, do), (c, kd)] =
+        # x[b, c, do * sd + kd * dd] -- and unfold Z in 2-D, which yields exactly that row order.
+        assert dl[0] == dl[1] == dl[2], "the reference's Conv3d unfold takes dilation[0] for every axis (forward.py:62-64)"
+        x = np.pad(x, [(0, 0), (0, 0)] + [(int(q), int(q)) for q in p])
+        B0, C, D = x.shape[:3]
+        Do = (D - dl[0] * (k[0] - 1) - 1) // s[0] + 1
+        taps = (np.arange(Do)[:, None] * s[0] + np.arange(k[0])[None, :] * dl[0])  # [Do, kd]
+        z = x[:, :, taps]  # [B, C, Do, kd, H, W]
+        x = np.ascontiguousarray(z.transpose(0, 2, 1, 3, 4, 5)).reshape(B0 * Do, C * k[0], x.shape[3], x.shape[4])
+        k, s, p, dl = k[1:], s[1:], (0, 0), dl[1:]
     x2d, (B, Ho, Wo) = im2col(np.asarray(x, dtype=np.float32), k, s, p, dl)
     if groups == 1:
         y = forward(mod, x2d, tag, small_batch=small)
     else:
         y = _grouped_conv_rows(mod, x2d, groups, tag, small)
+    if nd == 3:  # conv_int8.py:85-86
+        return np.ascontiguousarray(y.reshape(B // Do, Do, Ho, Wo, mod.N).transpose(0, 4, 1, 2, 3))
     if nd == 1:
         return np.ascontiguousarray(y.reshape(B, Wo, mod.N).transpose(0, 2, 1))
     return np.ascontiguousarray(y.reshape(B, Ho, Wo, mod.N).transpose(0, 3, 1, 2))

@@ -1,4 +1,4 @@
-"""Conv1d / Conv2d forwards of SDNQ-quantized layers as im2col + the Linear kernels.
+"""Conv1d / Conv2d / Conv3d forwards of SDNQ-quantized layers as im2col + the Linear kernels.
 
 Mirrors the reference's conv forwards (layers/conv/forward.py:80-81 ``quantized_conv_forward``,
 layers/conv/conv_int8.py:94-123 ``quantized_conv_forward_int8_matmul``, conv_fp8.py): the input is unfolded to
@@ -17,7 +17,9 @@ Hadamard-rotated conv weights (quant_utils.py:222-236; conv_int8.py:52-53): the 
 axis, i.e. along the unfolded row -- the Linear kernels' Hadamard path as is (rotation fused into the row quantization; the float forward
 un-rotates the weight rows).
 
-Not built (raise): Conv3d, fp16 matmul, Hadamard on grouped conv layers.
+Conv3d: see _geometry (depth taps gathered into the channel axis, then the 2-D path).
+
+Not built (raise): fp16 matmul, Hadamard on grouped conv layers, Conv3d with unequal dilations.
 """
 from __future__ import annotations
 
@@ -35,14 +37,19 @@ def _pair(v, n):
 
 
 def _geometry(self, input: torch.Tensor):
-    """-> (input [B, C, H, W] (explicitly padded for non-zero padding modes), kernel, stride, padding, dilation, nd)."""
+    """-> (input [B, C, H, W] (explicitly padded for non-zero padding modes), kernel, stride, padding, dilation, nd, depth_out).
+
+    Conv1d is the H = 1 case.  Conv3d (forward.py:43-51, 59-73: padded explicitly, unfolded along depth, height and width, rows ordered
+    (C_in, kd, kh, kw)) becomes a 2-D problem by gathering the kd depth taps of every output depth into the channel axis:
+    Z[(b, do), (c, kd)] = x[b, c, do * sd + kd * dd] -- one strided copy (kd times the input, what the reference's own unfold
+    materialises kd * kh * kw times) -- whose 2-D unfold has exactly the reference's row order; depth_out = D_out there, None otherwise."""
     if self.sdnq_dequantizer.use_hadamard and self.groups != 1:
         raise NotImplementedError("Hadamard-rotated grouped conv layers are not built for MI355X")
     if isinstance(self.padding, str):
         raise NotImplementedError("string padding modes ('same' / 'valid') are not supported by the reference's conv matmul either")
     nd = input.ndim - 2
-    if nd not in (1, 2):
-        raise NotImplementedError(f"{input.ndim}-D conv input: only Conv1d / Conv2d are built")
+    if nd not in (1, 2, 3):
+        raise NotImplementedError(f"{input.ndim}-D conv input: only Conv1d / Conv2d / Conv3d are built")
     stride, padding, dilation = _pair(self.stride, nd), _pair(self.padding, nd), _pair(self.dilation, nd)
     kernel = tuple(int(k) for k in self.sdnq_dequantizer.original_shape[2:])
     if self.padding_mode != "zeros":  # forward.py:57-59: explicit padding first, then an unpadded unfold
@@ -51,24 +58,40 @@ def _geometry(self, input: torch.Tensor):
     if nd == 1:  # forward.py:24-27, 66-67: Conv1d is the H = 1 case
         input = input.unsqueeze(2)
         kernel, stride, padding, dilation = (1, kernel[0]), (1, stride[0]), (0, padding[0]), (1, dilation[0])
-    return input, kernel, stride, padding, dilation, nd
+    depth_out = None
+    if nd == 3:
+        if not (dilation[0] == dilation[1] == dilation[2]):
+            raise NotImplementedError("Conv3d with unequal dilations: the reference's unfold sizes every axis with dilation[0] (forward.py:62-64)")
+        if padding[0]:  # height / width padding stays with the 2-D unfold
+            input = torch.nn.functional.pad(input, (0, 0, 0, 0, padding[0], padding[0]))
+        b, c, d, h, w = input.shape
+        span = dilation[0] * (kernel[0] - 1) + 1
+        depth_out = (d - span) // stride[0] + 1
+        z = input.unfold(2, span, stride[0])  # [B, C, D_out, H, W, span]
+        if dilation[0] > 1:
+            z = z[..., ::dilation[0]]
+        input = z.permute(0, 2, 1, 5, 3, 4).reshape(b * depth_out, c * kernel[0], h, w)  # (the copy)
+        kernel, stride, padding, dilation = kernel[1:], stride[1:], padding[1:], dilation[1:]
+    return input, kernel, stride, padding, dilation, nd, depth_out
 
 
-def _folder(self, nd: int, b: int, ho: int, wo: int):
+def _folder(self, nd: int, b: int, ho: int, wo: int, depth_out=None):
     n = self.sdnq_dequantizer.out_features
 
     def fold(y2d: torch.Tensor) -> torch.Tensor:
         if nd == 1:
             return y2d.view(b, wo, n).transpose(1, 2).contiguous()  # conv_int8.py:81-82
+        if nd == 3:
+            return y2d.view(b // depth_out, depth_out, ho, wo, n).permute(0, 4, 1, 2, 3).contiguous()  # conv_int8.py:85-87
         return y2d.view(b, ho, wo, n).permute(0, 3, 1, 2).contiguous()  # conv_int8.py:83-84, 87
     return fold
 
 
 def _unfold(self, input: torch.Tensor):
     """-> (x2d [M, K], fold) where fold(y2d [M, N]) gives the conv output in the reference's layout."""
-    input, kernel, stride, padding, dilation, nd = _geometry(self, input)
+    input, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
     x2d, (b, ho, wo) = ops.im2col(input, kernel, stride, padding, dilation)
-    return x2d, _folder(self, nd, b, ho, wo)
+    return x2d, _folder(self, nd, b, ho, wo, depth_out)
 
 
 def _group_slices(self, k_total: int):
@@ -120,14 +143,17 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
     if FUSED_CONV_QUANT and st.svd_up is None and zp is None and st.qw.scale_dtype == torch.float32 and not dq.use_hadamard:
         # no SVD / zero-point terms: the float [M, K] matrix is never needed -- row scales straight from the image, then the
         # unfold writes the quantized operand (same values as im2col + rowquant)
-        x4, kernel, stride, padding, dilation, nd = _geometry(self, input)
+        x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
         if kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
             xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
-            if (ho * wo) % 8 == 0 and input.dtype != torch.float32:  # channel-major store fused into the GEMM epilogue
+            if (ho * wo) % 8 == 0 and input.dtype != torch.float32 and nd != 3:  # channel-major store fused into the GEMM epilogue
                 y = ops.scaled_mm_nchw(mm, xq, wq, xs, ws, self.bias, input.dtype, b, ho * wo)
                 return y.view(b, -1, wo) if nd == 1 else y.view(b, -1, ho, wo)
-            return _folder(self, nd, b, ho, wo)(ops.scaled_mm(mm, xq, wq, xs, ws, self.bias, input.dtype))
-    x2d, fold = _unfold(self, input)
+            return _folder(self, nd, b, ho, wo, depth_out)(ops.scaled_mm(mm, xq, wq, xs, ws, self.bias, input.dtype))
+        x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
+        fold = _folder(self, nd, b, ho, wo, depth_out)
+    else:
+        x2d, fold = _unfold(self, input)
     return fold(linear._quantized_matmul_forward(self, x2d, mm, small_batch_branch=False, cache_input=False))
 
 
@@ -137,7 +163,7 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
     if st.svd_up is not None or zp is not None or st.qw.scale_dtype != torch.float32:
         raise NotImplementedError("grouped conv with SVD / zero-point terms or 16-bit scales: the reference's per-group matmul has no "
                                   "valid form for them (its SVD product does not match the grouped weight)")
-    x4, kernel, stride, padding, dilation, nd = _geometry(self, input)
+    x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
     if FUSED_CONV_QUANT and kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
         xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
     else:
@@ -149,7 +175,7 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
     n = self.sdnq_dequantizer.out_features
     wq2, ws1 = wq.reshape(n, kg), ws.reshape(-1)
     pixels = ho * wo
-    nchw = pixels % 8 == 0 and input.dtype != torch.float32
+    nchw = pixels % 8 == 0 and input.dtype != torch.float32 and nd != 3
     out = torch.empty((b, n, pixels) if nchw else (b * pixels, n), device=input.device, dtype=input.dtype)
     for g in range(int(self.groups)):
         bias = None if self.bias is None else self.bias[g * ng:(g + 1) * ng]
@@ -157,7 +183,7 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
                            pixels if nchw else 0)
     if nchw:
         return out.view(b, n, wo) if nd == 1 else out.view(b, n, ho, wo)
-    return _folder(self, nd, b, ho, wo)(out)
+    return _folder(self, nd, b, ho, wo, depth_out)(out)
 
 
 @torch.no_grad()

@@ -103,7 +103,7 @@ class SDNQDequantizer:
         if self.use_codebook:
             raise NotImplementedError("use_codebook (Lloyd-Max LUT) is outside the MI355X hot path (SURVEY 8a note)")
         if self.layer_class_name not in linear_types and self.layer_class_name not in conv_types:
-            raise NotImplementedError(f"{self.layer_class_name}: only Linear and Conv1d/Conv2d layers are built for MI355X")
+            raise NotImplementedError(f"{self.layer_class_name}: only Linear and Conv1d / Conv2d / Conv3d layers are built for MI355X")
         n, k, pos = self.out_features, self.in_features, self.kernel_positions
         group = self.group_size if self.group_size > 0 else k // pos
         return ops.make_quant_weight(self.weights_dtype, weight, scale, zero_point, svd_up, svd_down, n, k, group,

@@ -8,10 +8,10 @@ from .common import conv_transpose_types, conv_types, dtype_dict, embedding_type
 
 
 def get_forward_func(layer_class_name: str, quantized_matmul_dtype: str, use_quantized_matmul: bool) -> Callable:
-    if layer_class_name in embedding_types or layer_class_name in conv_transpose_types or layer_class_name in ("Conv3d", "SDNQConv3d"):
+    if layer_class_name in embedding_types or layer_class_name in conv_transpose_types:
         raise NotImplementedError(
-            f"{layer_class_name}: only Linear and Conv1d / Conv2d layers are built for MI355X (quant_embedding and transposed / "
-            "3-D convolutions are outside SURVEY 8)")
+            f"{layer_class_name}: only Linear and Conv1d / Conv2d / Conv3d layers are built for MI355X (quant_embedding and transposed "
+            "convolutions are outside SURVEY 8)")
     if layer_class_name in conv_types:  # forward.py:10-28
         from . import conv
         if use_quantized_matmul:

@@ -109,7 +109,11 @@ class SDNQConv2d(SDNQLayer, torch.nn.Conv2d):
     original_class: torch.nn.Conv2d
 
 
-torch.serialization.add_safe_globals([SDNQLayer, SDNQLinear, SDNQConv1d, SDNQConv2d])
+class SDNQConv3d(SDNQLayer, torch.nn.Conv3d):
+    original_class: torch.nn.Conv3d
+
+
+torch.serialization.add_safe_globals([SDNQLayer, SDNQLinear, SDNQConv1d, SDNQConv2d, SDNQConv3d])
 
 
 def get_sdnq_wrapper_class(original_layer: torch.nn.Module, forward_func: Callable) -> SDNQLayer:
@@ -120,5 +124,7 @@ def get_sdnq_wrapper_class(original_layer: torch.nn.Module, forward_func: Callab
         return SDNQConv1d(original_layer, forward_func)
     if name == "Conv2d":
         return SDNQConv2d(original_layer, forward_func)
-    # Conv3d / transposed conv / embedding wrappers are not built
+    if name == "Conv3d":
+        return SDNQConv3d(original_layer, forward_func)
+    # transposed conv / embedding wrappers are not built
     return SDNQLayer(original_layer, forward_func)

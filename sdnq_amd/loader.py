@@ -39,7 +39,7 @@ def is_hot_path_linear(module: torch.nn.Module) -> bool:
 
 def is_hot_path_conv(module: torch.nn.Module) -> bool:
     dq = getattr(module, "sdnq_dequantizer", None)
-    return (dq is not None and getattr(dq, "layer_class_name", None) in ("Conv1d", "Conv2d", "SDNQConv1d", "SDNQConv2d")
+    return (dq is not None and getattr(dq, "layer_class_name", None) in ("Conv1d", "Conv2d", "Conv3d", "SDNQConv1d", "SDNQConv2d", "SDNQConv3d")
             and not getattr(dq, "use_codebook", False)
             and not (getattr(dq, "use_hadamard", False) and getattr(module, "groups", 1) != 1)
             and getattr(dq, "quantized_matmul_dtype", "int8") in ("int8", "uint8", "fp8", "float8_e4m3fn"))
@@ -63,7 +63,7 @@ def _clear_step_state(_module=None, _args=None):
 
 @torch.no_grad()
 def accelerate(model: torch.nn.Module) -> int:
-    """Route every quantized Linear (and Conv1d / Conv2d, any ``groups``) of ``model`` through the HIP forwards.
+    """Route every quantized Linear (and Conv1d / Conv2d / Conv3d, any ``groups``) of ``model`` through the HIP forwards.
     Returns the number of re-pointed modules."""
     count = 0
     for module in model.modules():

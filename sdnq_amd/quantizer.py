@@ -166,9 +166,7 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
     """
     is_conv = layer_class_name in conv_types
     if layer_class_name not in linear_types and not is_conv:
-        raise NotImplementedError(f"{layer_class_name}: only Linear and Conv1d / Conv2d layers are built for MI355X")
-    if is_conv and weight.ndim not in (3, 4):
-        raise NotImplementedError("Conv3d weights are not built for MI355X")
+        raise NotImplementedError(f"{layer_class_name}: only Linear and Conv1d / Conv2d / Conv3d layers are built for MI355X")
     weight = weight.detach()
     original_shape, original_stride = weight.shape, weight.stride()
     torch_dtype = weight.dtype if torch_dtype is None else torch_dtype
@@ -285,7 +283,7 @@ def sdnq_quantize_layer(layer: torch.nn.Module, quantization_config: SDNQConfig,
     if torch_dtype is None:
         torch_dtype = layer.weight.dtype
     name = layer.__class__.__name__
-    if name not in linear_types and not (name in ("Conv1d", "Conv2d") and quantization_config.quant_conv):  # quantizer.py:429-435
+    if name not in linear_types and not (name in ("Conv1d", "Conv2d", "Conv3d") and quantization_config.quant_conv):  # quantizer.py:429-435
         quantization_config.modules_to_not_convert.append(param_name)
         return layer, quantization_config
     kw = quant_kwargs or _quant_kwargs(quantization_config, torch_dtype, param_name, name)
@@ -312,7 +310,7 @@ def apply_sdnq_to_module(model: torch.nn.Module, quantization_config: SDNQConfig
     for child_name, child in list(model.named_children()):
         pname = f"{full_param_name}.{child_name}" if full_param_name else child_name
         cname = child.__class__.__name__
-        if (cname == "Linear" or (cname in ("Conv1d", "Conv2d") and quantization_config.quant_conv)) and child.weight is not None:
+        if (cname == "Linear" or (cname in ("Conv1d", "Conv2d", "Conv3d") and quantization_config.quant_conv)) and child.weight is not None:
             wname = pname + ".weight"
             skip = any(s and s in wname for s in quantization_config.modules_to_not_convert)
             big = (child.weight.shape[-1 if cname == "Linear" else 1] >= quantization_config.minimum_allowed_channel_size

@@ -359,16 +359,31 @@ CONV_CASES = [
          cfg=dict(weights_dtype="uint4", use_hadamard=True)),
     dict(name="conv1d_int8_had_noqmm_f32", nd=1, cin=64, cout=32, k=3, conv=dict(padding=1), xs=[(2, 20)], dtype="f32",
          cfg=dict(weights_dtype="int8", use_hadamard=True, hadamard_group_size=16)),
+    # Conv3d (forward.py:43-51, 59-73: explicit padding, three unfolds, rows ordered (C_in, kd, kh, kw); conv_int8.py:85-86)
+    dict(name="conv3d_int8_qmm_bf16", nd=3, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(1, 4, 6, 6), (2, 3, 4, 5)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv3d_int8_qmm_s2_f16_nobias", nd=3, cin=32, cout=32, k=(1, 3, 3), conv=dict(padding=(0, 1, 1), stride=(1, 2, 2), bias=False),
+         xs=[(1, 3, 9, 8)], dtype="f16", cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv3d_int4_g16_qmm_bf16", nd=3, cin=32, cout=32, k=(3, 1, 1), conv=dict(padding=(1, 0, 0)), xs=[(1, 5, 6, 6)], dtype="bf16",
+         cfg=dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True)),
+    dict(name="conv3d_fp8_qmm_replicate_bf16", nd=3, cin=32, cout=48, k=3, conv=dict(padding=1, padding_mode="replicate"), xs=[(1, 4, 5, 6)],
+         dtype="bf16", cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True)),
+    dict(name="conv3d_uint4_noqmm_bf16", nd=3, cin=16, cout=32, k=3, conv=dict(padding=1), xs=[(1, 4, 5, 5)], dtype="bf16",
+         cfg=dict(weights_dtype="uint4")),
+    dict(name="conv3d_g2_int8_qmm_bf16", nd=3, cin=64, cout=64, k=(3, 3, 1), conv=dict(padding=(1, 1, 0), groups=2), xs=[(1, 4, 4, 6)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv3d_int8_noqmm_f32", nd=3, cin=32, cout=32, k=(2, 3, 3), conv=dict(padding=(0, 1, 1), stride=(2, 1, 1)), xs=[(2, 4, 5, 5)],
+         dtype="f32", cfg=dict(weights_dtype="int8")),
 ]
 
 
 def run_conv_case(case):
-    """Conv1d / Conv2d layers through the reference quantizer and conv forwards (layers/conv/*)."""
+    """Conv1d / Conv2d / Conv3d layers through the reference quantizer and conv forwards (layers/conv/*)."""
     name = case["name"]
     dtype = TORCH_DT[case["dtype"]]
     seed = zlib.crc32(name.encode()) % 1000
     g = torch.Generator().manual_seed(seed)
-    ctor = torch.nn.Conv2d if case["nd"] == 2 else torch.nn.Conv1d
+    ctor = {1: torch.nn.Conv1d, 2: torch.nn.Conv2d, 3: torch.nn.Conv3d}[case["nd"]]
     conv = ctor(case["cin"], case["cout"], case["k"], **case["conv"])
     with torch.no_grad():
         w = torch.randn(conv.weight.shape, generator=g) * 0.05

@@ -105,7 +105,7 @@ class ConvCase(Case):
         from sdnq_amd.layers import get_sdnq_wrapper_class
         from tests.modules_util import dequantizer_from_fields
         c = self.conv
-        ctor = torch.nn.Conv2d if c["nd"] == 2 else torch.nn.Conv1d
+        ctor = {1: torch.nn.Conv1d, 2: torch.nn.Conv2d, 3: torch.nn.Conv3d}[c["nd"]]
         skel = ctor(c["in_channels"], c["out_channels"], tuple(c["kernel_size"]), stride=tuple(c["stride"]), padding=tuple(c["padding"]),
                     dilation=tuple(c["dilation"]), groups=c["groups"], bias=c["bias"], padding_mode=c["padding_mode"])
         dq = dequantizer_from_fields(self.deq)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development aid: random-geometry sweep of the int8 Conv2d forward (use_quantized_matmul_conv) against the oracle (bit-exact)."""
+"""Development aid: random-geometry sweep of the int8 Conv2d / Conv3d forward (use_quantized_matmul_conv) against the oracle (bit-exact)."""
 import os, sys, random
 import numpy as np
 import torch
@@ -23,20 +23,30 @@ for it in range(n_it):
     b = rng.choice([1, 2])
     dt = rng.choice([torch.bfloat16, torch.float16])
     tag = "bf16" if dt == torch.bfloat16 else "f16"
-    conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
+    nd = rng.choice([2, 2, 3])
+    if nd == 3:
+        ks = rng.choice([1, 3, (3, 1, 1), (1, 3, 3), (2, 3, 3)])
+        stride = rng.choice([1, 1, 2, (1, 2, 2), (2, 1, 1)])
+        pad = rng.choice([0, 1, (1, 0, 0), (0, 1, 1)])
+        depth, h, w = rng.randint(2, 6), rng.randint(4, 10), rng.randint(4, 10)
+        conv = torch.nn.Conv3d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
+        shape = (b, cin, depth, h, w)
+    else:
+        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
+        shape = (b, cin, h, w)
     try:
-        y_shape = conv(torch.zeros(b, cin, h, w)).shape
+        y_shape = conv(torch.zeros(shape)).shape
     except RuntimeError:
         continue
     if min(y_shape[2:]) < 1:
         continue
     mod, _ = sdnq_amd.sdnq_quantize_layer(conv.to(dt).to(dev), sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))
-    x = torch.randn(b, cin, h, w).to(dt)
+    x = torch.randn(shape).to(dt)
     y = mod(x.to(dev)).float().cpu().numpy()
-    meta = {"nd": 2, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
+    meta = {"nd": nd, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
             "padding_mode": mod.padding_mode, "groups": groups}
     ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
     if y.shape != ref.shape or not np.array_equal(y, ref):
         bad += 1
-        print("MISMATCH", groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape, int((y != ref).sum()) if y.shape == ref.shape else -1)
+        print("MISMATCH", nd, groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape, int((y != ref).sum()) if y.shape == ref.shape else -1)
 print("conv fuzz done, mismatches:", bad)
