@@ -173,9 +173,14 @@ template <> struct MmaTraits<MM_F32> : FloatMma<MM_F32> {};
 // every lane turns the 8 codes of its weight row into the 8 bf16 / f16 values of its MFMA fragment between LDS and the matrix
 // core -- W = cast(fma(u, s, c)) with u the byte, c = -128 s (signed) or the zero point (unsigned): bit for bit the value
 // sdnq_hip_dequant writes -- and the activations are the plain 16-bit operand.  A stage row is BK bytes of A and BK / 2 of B.
-enum { MM_W8BF16 = 5, MM_W8F16 = 6 };
+// MM_W8*: signed codes (the int8 checkpoints), W = cast(f32(v) * s);  MM_W8*U: unsigned codes with a zero point, W = cast(fma(u, s, zp)).
+// Two instantiations, not a run-time switch: a branch inside the conversion splits the basic block the MFMAs live in and the
+// scheduler no longer overlaps one fragment's conversion with the previous fragment's MFMAs (measured: 14.3 against 13.1 ms per step).
+enum { MM_W8BF16 = 5, MM_W8F16 = 6, MM_W8BF16U = 8, MM_W8F16U = 9 };
 template <> struct MmaTraits<MM_W8BF16> : FloatMma<MM_W8BF16> {};
 template <> struct MmaTraits<MM_W8F16> : FloatMma<MM_W8F16> {};
+template <> struct MmaTraits<MM_W8BF16U> : FloatMma<MM_W8BF16U> {};
+template <> struct MmaTraits<MM_W8F16U> : FloatMma<MM_W8F16U> {};
 // int8 on v_mfma_i32_16x16x64_i8: 16 x 16 output tiles (4 accumulators per lane: lane l holds n = 4 (l >> 4) + 0..3 of m = l & 15 --
 // again a run of 4 output channels of one row), 64 bytes of K per instruction.  Same LDS image and loaders; what it buys is
 // tile shapes in multiples of 16: 64 x 80 tiles cut the 1024 x 1280 outputs of the SDXL attention / feed-forward projections into
@@ -188,8 +193,10 @@ template <> struct MmaTraits<MM_I8_16> {
     static __device__ __forceinline__ void zero(acc_t& c) { c = (v4i){0, 0, 0, 0}; }
     static __device__ __forceinline__ float tof(const acc_t& c, int i) { return (float)c[i]; }
 };
-template <int MM> constexpr bool is_float_mm = (MM >= MM_BF16 && MM <= 6);
-template <int MM> constexpr bool is_w8a16 = (MM == MM_W8BF16 || MM == MM_W8F16);
+template <int MM> constexpr bool is_w8a16 = (MM == MM_W8BF16 || MM == MM_W8F16 || MM == MM_W8BF16U || MM == MM_W8F16U);
+template <int MM> constexpr bool is_w8_bf16 = (MM == MM_W8BF16 || MM == MM_W8BF16U);
+template <int MM> constexpr bool is_w8_signed = (MM == MM_W8BF16 || MM == MM_W8F16);
+template <int MM> constexpr bool is_float_mm = ((MM >= MM_BF16 && MM <= 6) || is_w8a16<MM>);
 struct WRow { float s, c; };  // scale and additive constant of this lane's weight row (MM_W8*)
 
 // LDS byte offset of 16-byte chunk c (0..7) of tile row r; rows are 128 B, chunk XOR-swizzled.
@@ -261,25 +268,44 @@ template <int MM> struct FragOps {
         if constexpr (is_w8a16<MM>) return *(const v2i*)(s + lds_off<BKW>(r, ks, swz) + fgrp * 8);  // 8 codes = the lane's 8 k values
         else return *(const v4i*)(s + lds_off<BKW>(r, ks * CPK + fgrp, swz));
     }
-    // 8 stored bytes -> the 8 16-bit values of the MFMA fragment: v_cvt_f32_ubyteN (the byte extracts below) + fma + packed
-    // convert, ~22 VALU per fragment
+    // 8 stored bytes -> the 8 16-bit values of the MFMA fragment.  The K loop of the fused dequantize GEMM is bound by THIS VALU work,
+    // not by its MFMAs (two 32x32x16 = 64 matrix cycles per fragment of a 64-row wave tile against ~4 cycles per VALU instruction):
+    //   signed codes (MM_W8BF16 / MM_W8F16; the int8 checkpoints): v_cvt_f32_i32_sdwa sext(BYTE_n) + v_mul_f32 + packed convert = 20 VALU;
+    //   f32(v) * s is the reference's own expression (dequantizer.py:63), one rounding;
+    //   unsigned codes with a zero point: v_cvt_f32_ubyteN + fma(u, s, zp) + packed convert = 20 VALU.
+    // (Round 3: the signed codes used to take the unsigned route after an XOR with 0x80 -- u = v + 128, c = -128 s, same value after
+    // the single rounding of the fma -- 22 VALU.  v_pk_fma_f32 / v_pk_mul_f32 do not help: the compiler un-packs those that sit behind
+    // an MFMA, and forcing them packed with inline asm was slower, 13.9 against 13.4 ms per step: a packed fp32 instruction does not
+    // overlap the MFMA in flight.)
     static __device__ __forceinline__ v4i dequant8(const v2i& raw, const WRow& wr, u32 flip) {
-        const u32 w0 = (u32)raw[0] ^ flip, w1 = (u32)raw[1] ^ flip;  // flip = 0x80808080 for signed codes: u = w + 128
         float f[8];
-        f[0] = fmaf((float)(w0 & 0xffu), wr.s, wr.c); f[1] = fmaf((float)((w0 >> 8) & 0xffu), wr.s, wr.c);
-        f[2] = fmaf((float)((w0 >> 16) & 0xffu), wr.s, wr.c); f[3] = fmaf((float)(w0 >> 24), wr.s, wr.c);
-        f[4] = fmaf((float)(w1 & 0xffu), wr.s, wr.c); f[5] = fmaf((float)((w1 >> 8) & 0xffu), wr.s, wr.c);
-        f[6] = fmaf((float)((w1 >> 16) & 0xffu), wr.s, wr.c); f[7] = fmaf((float)(w1 >> 24), wr.s, wr.c);
-        const uint4 pk = (MM == MM_W8BF16) ? Vec16<SDNQ_BF16>::pack(f) : Vec16<SDNQ_F16>::pack(f);
+        if constexpr (is_w8_signed<MM>) {
+            const int w0 = raw[0], w1 = raw[1];
+            f[0] = (float)(int)(signed char)(w0 & 0xff) * wr.s; f[1] = (float)(int)(signed char)((w0 >> 8) & 0xff) * wr.s;
+            f[2] = (float)(int)(signed char)((w0 >> 16) & 0xff) * wr.s; f[3] = (float)(w0 >> 24) * wr.s;
+            f[4] = (float)(int)(signed char)(w1 & 0xff) * wr.s; f[5] = (float)(int)(signed char)((w1 >> 8) & 0xff) * wr.s;
+            f[6] = (float)(int)(signed char)((w1 >> 16) & 0xff) * wr.s; f[7] = (float)(w1 >> 24) * wr.s;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm("" : "+v"(f[e]));  // keeps the multiplies scalar (the SLP vectorizer would pair them: see above)
+        } else {
+            const u32 w0 = (u32)raw[0], w1 = (u32)raw[1];
+            f[0] = fmaf((float)(w0 & 0xffu), wr.s, wr.c); f[1] = fmaf((float)((w0 >> 8) & 0xffu), wr.s, wr.c);
+            f[2] = fmaf((float)((w0 >> 16) & 0xffu), wr.s, wr.c); f[3] = fmaf((float)(w0 >> 24), wr.s, wr.c);
+            f[4] = fmaf((float)(w1 & 0xffu), wr.s, wr.c); f[5] = fmaf((float)((w1 >> 8) & 0xffu), wr.s, wr.c);
+            f[6] = fmaf((float)((w1 >> 16) & 0xffu), wr.s, wr.c); f[7] = fmaf((float)(w1 >> 24), wr.s, wr.c);
+        }
+        const uint4 pk = is_w8_bf16<MM> ? Vec16<SDNQ_BF16>::pack(f) : Vec16<SDNQ_F16>::pack(f);
         return (v4i){(int)pk.x, (int)pk.y, (int)pk.z, (int)pk.w};
     }
-    static __device__ __forceinline__ void mma(typename MmaTraits<MM>::acc_t& c, const fragb_t& wb, const frag_t& x, const WRow& wr, u32 flip) {
-        v4i w;
-        if constexpr (is_w8a16<MM>) w = dequant8(wb, wr, flip);
-        else w = wb;
-        if constexpr (MM == MM_W8BF16) {
+    // the weight-side MFMA operand of a fragment: converted ONCE per fragment (the callers multiply it with every row tile of the wave)
+    static __device__ __forceinline__ v4i prep(const fragb_t& wb, const WRow& wr, u32 flip) {
+        if constexpr (is_w8a16<MM>) return dequant8(wb, wr, flip);
+        else return wb;
+    }
+    static __device__ __forceinline__ void mma(typename MmaTraits<MM>::acc_t& c, const v4i& w, const frag_t& x) {
+        if constexpr (is_w8_bf16<MM>) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, x), c, 0, 0, 0);
-        } else if constexpr (MM == MM_W8F16) {
+        } else if constexpr (is_w8a16<MM>) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, x), c, 0, 0, 0);
         } else if constexpr (MM == MM_I8_16) {
             c = __builtin_amdgcn_mfma_i32_16x16x64_i8(w, x, c, 0, 0, 0);
@@ -307,7 +333,8 @@ template <> struct FragOps<SDNQ_MM_FP8> {
     template <int BK> static __device__ __forceinline__ fragb_t loadb(const uint8_t* s, int r, int ks, int fgrp, int swz) {
         return load<BK>(s, r, ks, fgrp, swz);
     }
-    static __device__ __forceinline__ void mma(v16f& c, const frag_t& w, const frag_t& x, const WRow&, u32) {
+    static __device__ __forceinline__ const frag_t& prep(const fragb_t& wb, const WRow&, u32) { return wb; }
+    static __device__ __forceinline__ void mma(v16f& c, const frag_t& w, const frag_t& x) {
         c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w, x, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
 };
@@ -703,7 +730,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     WRow wrow[TN];
     u32 wflip = 0;
     if constexpr (is_w8a16<MM>) {
-        wflip = p.zp ? 0u : 0x80808080u;  // signed codes: u = w + 128, c = -128 s;  unsigned: c = zero point
+        wflip = p.zp ? 0u : 0x80808080u;  // (signedness is the kernel's MM; kept for the timing-lab builds)
         __syncthreads();  // s_sb / s_zp written by other threads (also waits for the prologue DMAs: once, before the loop)
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
@@ -732,8 +759,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
+                { const auto wfrag = FragOps<MM>::prep(fb[ks][i], wrow[i], wflip);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j], wrow[i], wflip);
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], wfrag, fa[ks][j]); }
     };
 
     if constexpr (LD == LD_PIPE) {
@@ -755,8 +783,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             constexpr int st = decltype(setc)::value;
 #pragma unroll
             for (int i = 0; i < TN; ++i)
+                { const auto wfrag = FragOps<MM>::prep(fb[st][i], wrow[i], wflip);
 #pragma unroll
-                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[st][i], fa[st][j], wrow[i], wflip);
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], wfrag, fa[st][j]); }
         };
         // stage 0 landed for every wave -> top up the ring (slot NS-1) -> first fragment set
         wait_ahead();
@@ -830,8 +859,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
+                    { const auto wfrag = FragOps<MM>::prep(fb[ks][i], wrow[i], wflip);
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa[ks][j], wrow[i], wflip);
+                for (int j = 0; j < TM; ++j) FragOps<MM>::mma(acc[i][j], wfrag, fa[ks][j]); }
             __builtin_amdgcn_s_setprio(0);
             if (half == 0) wait_ahead();  // own pieces of stage kt+1, read by this half right after the barrier
             __builtin_amdgcn_sched_barrier(0);
@@ -874,8 +904,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
+                    { const auto wfrag = FragOps<MM>::prep(fb[ks][i], wrow[i], wflip);
 #pragma unroll
-                    for (int j = 0; j < TH; ++j) FragOps<MM>::mma(acc[i][j], fb[ks][i], fa0[ks][j], wrow[i], wflip);
+                for (int j = 0; j < TH; ++j) FragOps<MM>::mma(acc[i][j], wfrag, fa0[ks][j]); }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -898,8 +929,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
+                    { const auto wfrag = FragOps<MM>::prep(fb[ks][i], wrow[i], wflip);
 #pragma unroll
-                    for (int j = 0; j < TH; ++j) FragOps<MM>::mma(acc[i][TH + j], fb[ks][i], fa1[ks][j], wrow[i], wflip);
+                for (int j = 0; j < TH; ++j) FragOps<MM>::mma(acc[i][TH + j], wfrag, fa1[ks][j]); }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1028,8 +1060,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             phase_sync(true);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
+                { const auto wfrag = FragOps<MM>::prep(fb0[ks], wrow[0], wflip);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[0][j], fb0[ks], fa0[ks][j], wrow[0], wflip);
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[0][j], wfrag, fa0[ks][j]); }
             phase_end(std::integral_constant<int, 0>{});
             // ---- phase 1: B1 -> acc[1][0..1]; refill HA1 for K tile t + 1
 #pragma unroll
@@ -1040,8 +1073,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             phase_sync(true);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
+                { const auto wfrag = FragOps<MM>::prep(fb1[ks], wrow[1], wflip);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[1][j], fb1[ks], fa0[ks][j], wrow[1], wflip);
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[1][j], wfrag, fa0[ks][j]); }
             phase_end(std::integral_constant<int, 1>{});
             // ---- phase 2: A1 -> acc[1][2..3]; refill HA0 for K tile t + 2
 #pragma unroll
@@ -1053,8 +1087,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             phase_sync(true);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
+                { const auto wfrag = FragOps<MM>::prep(fb1[ks], wrow[1], wflip);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[1][2 + j], fb1[ks], fa1[ks][j], wrow[1], wflip);
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[1][2 + j], wfrag, fa1[ks][j]); }
             phase_end(std::integral_constant<int, 2>{});
             // ---- phase 3: A0 of K tile t + 1 (its registers are free since phase 1; landed: it is the fifth-youngest half-tile) ->
             //      acc[0][2..3]; refill HB0 for K tile t + 2.  Reads per phase: 4 / 4 / 8 / 8 instead of 12 / 4 / 8 / 0.
@@ -1067,8 +1102,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             phase_sync(true);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
+                { const auto wfrag = FragOps<MM>::prep(fb0[ks], wrow[0], wflip);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[0][2 + j], fb0[ks], fa1[ks][j], wrow[0], wflip);
+                for (int j = 0; j < 2; ++j) FragOps<MM>::mma(acc[0][2 + j], wfrag, fa1[ks][j]); }
             phase_end(std::integral_constant<int, 3>{});
         };
 #pragma nounroll
@@ -1868,6 +1904,10 @@ extern "C" int sdnq_hip_linear_w8a16(const void* x, int x_dtype, const void* w, 
     p.M = m; p.N = n; p.K = k * 2; p.lda = ldx * 2; p.ldb = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = x_dtype;
     hipStream_t s = (hipStream_t)stream;
 #define W8(MMV, T) (bias ? launch_tiles_w8<MMV, T, EPI_BIAS1D>(p, s) : launch_tiles_w8<MMV, T, EPI_NONE>(p, s))
+    if (zero_point) {  // unsigned codes
+        if (x_dtype == SDNQ_BF16) return W8(MM_W8BF16U, SDNQ_BF16);
+        return W8(MM_W8F16U, SDNQ_F16);
+    }
     if (x_dtype == SDNQ_BF16) return W8(MM_W8BF16, SDNQ_BF16);
     return W8(MM_W8F16, SDNQ_F16);
 #undef W8
