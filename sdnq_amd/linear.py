@@ -283,7 +283,7 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
             and st.wd is None and input.is_cuda and 2 * m * n * k <= FUSED_DEQUANT_GEMM_MAX_FLOP and k <= FUSED_DEQUANT_GEMM_MAX_K):
         # row-wise 8-bit weights, more than 32 rows, a small problem: ONE launch -- the weight goes from HBM to the matrix cores as
         # bytes and is dequantized (to the very values sdnq_hip_dequant would write) between LDS and the MFMA; no [N, K] float copy,
-        # no second pass.  The in-loop conversion costs ~1.5x the K loop of the plain 16-bit GEMM (22 VALU per weight fragment on
+        # no second pass.  The in-loop conversion costs ~1.5x the K loop of the plain 16-bit GEMM (20 VALU per weight fragment on
         # wave tiles of 64 rows, ~1.25x on 128-row wave tiles), so it pays while the dequantize launch it removes (~6 us + the float
         # copy's traffic) is the larger cost: 1024 x 1280 x 1280: 14.9 vs 16.3 us, 1024 x 10240 x 1280: 47.4 vs 53 us;
         # 4096^3: 178 vs 159 us (tools/sweep_w8a16.py, profiles/r02_w8a16_sweep.txt)
