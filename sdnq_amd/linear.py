@@ -370,6 +370,7 @@ class ProjectionGroup:
         self.gemm = None   # ops.GemmGroup
         self.last = None   # (input tensor, its key, stream, outputs, indices not handed out yet)
         self.wasted = 0    # consecutive computes whose outputs were not all claimed
+        self.fallback = None  # smaller groups (lists of members) to form when THIS grouping turns out wrong (loader.link_projections)
         _groups.append(weakref.ref(self))
 
     def dissolve(self):
@@ -476,7 +477,13 @@ class ProjectionGroup:
         if self.last is not None and self.last[4]:
             self.wasted += 1
             if self.wasted >= 2:
+                fallback = self.fallback
                 self.dissolve()
+                if fallback:  # e.g. the model-wide key / value group -> the per-block to_k / to_v pairs it was made of
+                    from . import loader
+                    for mods in fallback:
+                        if all("_sdnq_group" not in m.__dict__ for m in mods):
+                            loader.link_layers(mods)
                 return False
         return True
 

@@ -146,7 +146,9 @@ def link_projections(model: torch.nn.Module) -> int:
       the same input width and configuration go into ONE model-wide group -- a UNet hands the same ``encoder_hidden_states``
       tensor to all of them (140 projections in SDXL), so the first one called in a step computes all of them in one launch.
     Whether the members really receive one tensor is checked at run time (``ProjectionGroup``): a group whose guess is wrong
-    dissolves itself.  Returns the number of groups."""
+    dissolves itself into the smaller groups it was made of (the model-wide group into per-block ``to_k / to_v`` pairs, a
+    ``to_q / to_k / to_v`` triple into the ``to_k / to_v`` pair), and those, if wrong too, into single layers.  Returns the number
+    of groups."""
     count = 0
     cross = {}  # (in_features, configuration) -> [to_k, to_v, to_k, to_v, ...] in module order
     for module in model.modules():
@@ -161,11 +163,14 @@ def link_projections(model: torch.nn.Module) -> int:
                 continue
             if q is not None and link_layers([q, k, v]):
                 count += 1
+                q.__dict__["_sdnq_group"][0].fallback = [[k, v]]  # a block whose query reads another tensor after all
             elif link_layers([k, v]):
                 count += 1
     for mods in cross.values():
         if link_layers(mods):
             count += 1
+            if len(mods) > 2:  # a wrong guess (per-block encoder states, skipped blocks) falls back to the per-block pairs
+                mods[0].__dict__["_sdnq_group"][0].fallback = [mods[i:i + 2] for i in range(0, len(mods), 2)]
         else:  # e.g. the dequantize + F.linear mode (at most four equal layers per group): per-block pairs
             for i in range(0, len(mods), 2):
                 count += bool(link_layers(mods[i:i + 2]))

@@ -1079,6 +1079,36 @@ def test_model_wide_cross_attention_group(gpu_device):
         L.LINK_PROJECTIONS = old
 
 
+def test_model_wide_group_falls_back_to_per_block_pairs(gpu_device):
+    """A model whose cross-attention blocks do NOT read one shared tensor (every block gets its own encoder states): the model-wide
+    guess is wrong, costs two wasted launches, and falls back to per-block to_k / to_v pairs -- which are right and stay."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(24)
+    cfg = sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    model = torch.nn.ModuleList([_attn_block(c, 512, False, gpu_device, cfg) for c in (320, 640, 320)])
+    texts = [torch.randn(1, 77, 512, device=gpu_device, dtype=torch.bfloat16) for _ in model]
+    old = L.LINK_PROJECTIONS
+    try:
+        L.LINK_PROJECTIONS = False
+        sdnq_amd.accelerate(model)
+        alone = [(b.to_k(t).clone(), b.to_v(t).clone()) for b, t in zip(model, texts)]
+        L.LINK_PROJECTIONS = True
+        sdnq_amd.accelerate(model)
+        wide = model[0].to_k.__dict__["_sdnq_group"][0]
+        assert len(wide.mods) == 6 and wide.fallback is not None
+        for step in range(4):
+            L.invalidate()
+            for i, (b, t) in enumerate(zip(model, texts)):
+                kk, vv = b.to_k(t), b.to_v(t)
+                assert torch.equal(kk, alone[i][0]) and torch.equal(vv, alone[i][1])
+        for b in model:
+            gk, gv = b.to_k.__dict__.get("_sdnq_group"), b.to_v.__dict__.get("_sdnq_group")
+            assert gk is not None and gk[0] is gv[0] and gk[0] is not wide and len(gk[0].mods) == 2 and gk[0].wasted == 0
+    finally:
+        L.LINK_PROJECTIONS = old
+
+
 def test_linked_group_dissolves_when_members_do_not_share_their_input(gpu_device):
     """A q / k / v group whose to_q is fed a different tensor than to_k / to_v (a cross-attention block that looked like
     self-attention): results stay correct from the first call, and after two computes that left outputs unclaimed the group
@@ -1100,6 +1130,23 @@ def test_linked_group_dissolves_when_members_do_not_share_their_input(gpu_device
             got = (blk.to_q(h), blk.to_k(e), blk.to_v(e))
             for a, b in zip(got, want):
                 assert torch.equal(a, b)
+        # the triple is gone; what it falls back to is the to_k / to_v pair (they DID share their input)
+        assert "_sdnq_group" not in blk.to_q.__dict__
+        gk, gv = blk.to_k.__dict__.get("_sdnq_group"), blk.to_v.__dict__.get("_sdnq_group")
+        assert gk is not None and gv is not None and gk[0] is gv[0] and len(gk[0].mods) == 2
+        for it in range(3):
+            got = (blk.to_q(h), blk.to_k(e), blk.to_v(e))
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+        assert gk[0].wasted == 0 and "_sdnq_group" in blk.to_k.__dict__
+        # a pair whose members do not share their input either ends as single layers
+        e2 = torch.randn(1, 64, 320, device=gpu_device, dtype=torch.bfloat16)
+        want_v2 = None
+        for it in range(4):
+            yk, yv = blk.to_k(e), blk.to_v(e2)
+            assert torch.equal(yk, want[1])
+            want_v2 = yv.clone() if want_v2 is None else want_v2
+            assert torch.equal(yv, want_v2)
         assert all("_sdnq_group" not in m.__dict__ for m in (blk.to_q, blk.to_k, blk.to_v))
     finally:
         L.LINK_PROJECTIONS = old
