@@ -146,8 +146,12 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
         x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
         if kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
             xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
-            if (ho * wo) % 8 == 0 and input.dtype != torch.float32 and nd != 3:  # channel-major store fused into the GEMM epilogue
-                y = ops.scaled_mm_nchw(mm, xq, wq, xs, ws, self.bias, input.dtype, b, ho * wo)
+            # channel-major store fused into the GEMM epilogue; Conv3d: the rows of one image are its D_out * H_out * W_out positions
+            imgs, px = (b, ho * wo) if nd != 3 else (b // depth_out, depth_out * ho * wo)
+            if px % 8 == 0 and input.dtype != torch.float32:
+                y = ops.scaled_mm_nchw(mm, xq, wq, xs, ws, self.bias, input.dtype, imgs, px)
+                if nd == 3:
+                    return y.view(imgs, -1, depth_out, ho, wo)
                 return y.view(b, -1, wo) if nd == 1 else y.view(b, -1, ho, wo)
             return _folder(self, nd, b, ho, wo, depth_out)(ops.scaled_mm(mm, xq, wq, xs, ws, self.bias, input.dtype))
         x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
@@ -174,14 +178,16 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
         raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
     n = self.sdnq_dequantizer.out_features
     wq2, ws1 = wq.reshape(n, kg), ws.reshape(-1)
-    pixels = ho * wo
-    nchw = pixels % 8 == 0 and input.dtype != torch.float32 and nd != 3
-    out = torch.empty((b, n, pixels) if nchw else (b * pixels, n), device=input.device, dtype=input.dtype)
+    imgs, pixels = (b, ho * wo) if nd != 3 else (b // depth_out, depth_out * ho * wo)  # Conv3d: an image = D_out * H_out * W_out rows
+    nchw = pixels % 8 == 0 and input.dtype != torch.float32
+    out = torch.empty((imgs, n, pixels) if nchw else (imgs * pixels, n), device=input.device, dtype=input.dtype)
     for g in range(int(self.groups)):
         bias = None if self.bias is None else self.bias[g * ng:(g + 1) * ng]
         ops.scaled_mm_into(mm, xq[:, g * kg:(g + 1) * kg], wq2[g * ng:(g + 1) * ng], xs, ws1[g * ng:(g + 1) * ng], bias, out, g * ng,
                            pixels if nchw else 0)
     if nchw:
+        if nd == 3:
+            return out.view(imgs, n, depth_out, ho, wo)
         return out.view(b, n, wo) if nd == 1 else out.view(b, n, ho, wo)
     return _folder(self, nd, b, ho, wo, depth_out)(out)
 
