@@ -894,29 +894,37 @@ __global__ __launch_bounds__(256) void skinny_svd32_kernel(const DeqParams p, co
 // per call at 4608 x 3072 whatever the software pipelining, 12 us even for 77 rows.  A register-staged coalesced variant lost to
 // the compiler's pessimistic s_waitcnt on loop-carried loads (47 us).
 __device__ const uint4 g_lr_zero16 = {0u, 0u, 0u, 0u};  // source of chunks past the end of K
-template <bool IS_BF16>
+// RT = activation row tiles of 16 per workgroup.  What bounds the kernel is the LDS-DMA rate of a CU (a stage moves 4 KB of activations
+// per row tile and ALWAYS 8 KB of factor rows), so the launcher picks RT by the largest number of bytes a CU has to move: 4608 rows are
+// 288 workgroups of one tile -- 32 CUs get two, 2 x 288 KB per K = 3072 -- or 144 workgroups of two tiles, 384 KB each: 8.5 -> 6 us.
+template <bool IS_BF16, int RT>
 __global__ __launch_bounds__(256) void lowrank_down_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ down,
                                                            uint16_t* __restrict__ t, int64_t M, int64_t K, int64_t ldx, int R) {
     SDNQ_KERNARGS_NOW("s"(x), "s"(down), "s"(t), "s"(M), "s"(K), "s"(ldx), "s"(R));
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    constexpr int NS = 4, XS = 16 * 256, STAGE = XS + 32 * 256;  // 12 KB per stage; 48 KB ring: three workgroups per CU
+    constexpr int NS = 4, XS = RT * 16 * 256, STAGE = XS + 32 * 256;  // 12 / 16 KB per stage; 48 / 64 KB ring
+    constexpr int NDMA = RT + 2;  // DMAs per wave and stage
     __shared__ __attribute__((aligned(1024))) uint8_t lds[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t m0 = (int64_t)blockIdx.x * 16;
+    const int64_t m0 = (int64_t)blockIdx.x * (16 * RT);
     const int n_tiles = (R + 31) / 32;
     const int64_t nst = (K + 127) / 128;
-    // DMA role of this lane: row 4 * wave + lane / 16 of the activation tile and of each half of the factor tile; physical chunk
+    // DMA role of this lane: row 4 * wave + lane / 16 of every activation tile and of each half of the factor tile; physical chunk
     // lane % 16 holds logical chunk (lane % 16) ^ row
     const int drow = wave * 4 + (lane >> 4);
     const int lchunk = (lane & 15) ^ drow;
     // fragment role: row lane & 15, logical chunk 4 * wave + lane / 16 of the stage
     const int frow = lane & 15;
     const int foff = frow * 256 + (((wave * 4 + (lane >> 4)) ^ frow) << 4);
-    int64_t gm = m0 + drow;
-    if (gm >= M) gm = M - 1;
-    const uint16_t* sx = x + gm * ldx + lchunk * 8;
+    const uint16_t* sx[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        int64_t gm = m0 + r * 16 + drow;
+        if (gm >= M) gm = M - 1;
+        sx[r] = x + gm * ldx + lchunk * 8;
+    }
     for (int nt = 0; nt < n_tiles; ++nt) {
         const int gn0 = nt * 32 + drow, gn1 = gn0 + 16;
         const uint16_t* sd0 = down + (int64_t)(gn0 < R ? gn0 : 0) * K + lchunk * 8;  // rows past R: valid memory, never stored
@@ -926,47 +934,63 @@ __global__ __launch_bounds__(256) void lowrank_down_kernel(const uint16_t* __res
             const int64_t k0 = st * 128;
             const bool ok = k0 + lchunk * 8 < K;
             const uintptr_t z = (uintptr_t)&g_lr_zero16;  // (integer selects: a pointer ternary became three divergent branches)
-            const uintptr_t px = ok ? (uintptr_t)(sx + k0) : z, p0 = ok ? (uintptr_t)(sd0 + k0) : z, p1 = ok ? (uintptr_t)(sd1 + k0) : z;
-            __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(base + wave * 1024), 16, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const uintptr_t px = ok ? (uintptr_t)(sx[r] + k0) : z;
+                __builtin_amdgcn_global_load_lds((gptr_t)px, (lptr_t)(base + r * 4096 + wave * 1024), 16, 0, 0);
+            }
+            const uintptr_t p0 = ok ? (uintptr_t)(sd0 + k0) : z, p1 = ok ? (uintptr_t)(sd1 + k0) : z;
             __builtin_amdgcn_global_load_lds((gptr_t)p0, (lptr_t)(base + XS + wave * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)p1, (lptr_t)(base + XS + 4096 + wave * 1024), 16, 0, 0);
         };
-        v4f a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        v4f acc[RT][2];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { acc[r][0] = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; acc[r][1] = (v4f){0.0f, 0.0f, 0.0f, 0.0f}; }
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0) issue(s0);
         for (int64_t st = 0; st < nst; ++st) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 3) : "memory");  // this wave's pieces of stage st have landed
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * NDMA) : "memory");  // this wave's pieces of stage st have landed
             // ... and everybody's; every wave is also done reading stage st - 1 (its fragments fed MFMAs already), whose slot is
             // refilled next.  Raw s_barrier: __syncthreads() would drain the DMAs in flight (s_waitcnt vmcnt(0)).
             __builtin_amdgcn_s_barrier();
             issue(st + NS - 1);
             const uint8_t* base = lds + (st % NS) * STAGE;
             // (ext-vector loads: an LDS read typed as the HIP uint4 struct makes the compiler drain the LDS-DMAs first, vmcnt(0))
-            const v4i fx = *(const v4i*)(base + foff);
+            v4i fx[RT];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) fx[r] = *(const v4i*)(base + r * 4096 + foff);
             const v4i f0 = *(const v4i*)(base + XS + foff);
             const v4i f1 = *(const v4i*)(base + XS + 4096 + foff);
-            if constexpr (IS_BF16) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, f0), __builtin_bit_cast(v8bf, fx), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, f1), __builtin_bit_cast(v8bf, fx), a1, 0, 0, 0);
-            } else {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f0), __builtin_bit_cast(v8h, fx), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f1), __builtin_bit_cast(v8h, fx), a1, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                if constexpr (IS_BF16) {
+                    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, f0), __builtin_bit_cast(v8bf, fx[r]), acc[r][0], 0, 0, 0);
+                    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, f1), __builtin_bit_cast(v8bf, fx[r]), acc[r][1], 0, 0, 0);
+                } else {
+                    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f0), __builtin_bit_cast(v8h, fx[r]), acc[r][0], 0, 0, 0);
+                    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f1), __builtin_bit_cast(v8h, fx[r]), acc[r][1], 0, 0, 0);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing zero DMAs target the ring the partial sums reuse
         __syncthreads();
-        float* part = (float*)lds;  // [4 waves][2 tiles][4 regs][64 lanes]
+        float* part = (float*)lds;  // [4 waves][RT row tiles][2 rank halves][4 regs][64 lanes]
+        constexpr int WSTRIDE = RT * 2 * 4 * 64;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { part[((wave * 2 + 0) * 4 + e) * 64 + lane] = a0[e]; part[((wave * 2 + 1) * 4 + e) * 64 + lane] = a1[e]; }
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[wave * WSTRIDE + ((r * 2 + h) * 4 + e) * 64 + lane] = acc[r][h][e];
         __syncthreads();
-        // accumulator layout: lane l of tile h holds n = 16 h + 4 (l >> 4) + e, m = l & 15.  512 outputs; consecutive threads take
-        // consecutive n of one row (64-byte runs of t)
+        // accumulator layout: lane l of (row tile r, rank half h) holds n = 16 h + 4 (l >> 4) + e, m = 16 r + (l & 15).  Consecutive
+        // threads take consecutive n of one row (64-byte runs of t)
 #pragma unroll
-        for (int o = tid; o < 512; o += 256) {
+        for (int o = tid; o < RT * 512; o += 256) {
             const int n = o & 31, m = o >> 5;
-            const int h = n >> 4, r = n & 15, l = (r >> 2) * 16 + m, e = r & 3;
-            const int idx = (h * 4 + e) * 64 + l;
-            const float sum = (part[idx] + part[512 + idx]) + (part[1024 + idx] + part[1536 + idx]);
+            const int r = m >> 4, ml = m & 15, h = n >> 4, q = n & 15, l = (q >> 2) * 16 + ml, e = q & 3;
+            const int idx = ((r * 2 + h) * 4 + e) * 64 + l;
+            const float sum = (part[idx] + part[WSTRIDE + idx]) + (part[2 * WSTRIDE + idx] + part[3 * WSTRIDE + idx]);
             const int gn = nt * 32 + n;
             if (m0 + m < M && gn < R) t[(m0 + m) * R + gn] = IS_BF16 ? f32_to_bf16_bits(sum) : f32_to_f16_bits(sum);
         }
@@ -1158,11 +1182,16 @@ extern "C" int sdnq_hip_lowrank_down(const void* x, int x_dtype, int64_t m, int6
     if (x_dtype != SDNQ_F32 && (k % 16) == 0 && rank > 0 && x && svd_down && t && ((uintptr_t)x % 16) == 0 &&
         ((uintptr_t)svd_down % 16) == 0 && ((ldx * 2) % 16) == 0) {
         hipStream_t s = (hipStream_t)stream;
-        dim3 grid((unsigned)((m + 15) / 16)), block(256);
-        if (x_dtype == SDNQ_BF16)
-            hipLaunchKernelGGL((lowrank_down_kernel<true>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)svd_down, (uint16_t*)t, m, k, ldx, rank);
-        else
-            hipLaunchKernelGGL((lowrank_down_kernel<false>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)svd_down, (uint16_t*)t, m, k, ldx, rank);
+        // row tiles per workgroup: whichever leaves the busiest CU fewer bytes to move (see the kernel; 3 : 4 = bytes per workgroup and stage)
+        static const int rt_env = [] { const char* e = getenv("SDNQ_HIP_LRD_RT"); return e ? atoi(e) : 0; }();  // tuning aid: 1 / 2
+        const int64_t wg1 = (m + 15) / 16, wg2 = (m + 31) / 32;
+        const int64_t cus = 256;
+        const bool two = rt_env ? rt_env == 2 : ((wg2 + cus - 1) / cus) * 4 < ((wg1 + cus - 1) / cus) * 3;
+        dim3 grid((unsigned)(two ? wg2 : wg1)), block(256);
+#define LRD(BF, RTV) hipLaunchKernelGGL((lowrank_down_kernel<BF, RTV>), grid, block, 0, s, (const uint16_t*)x, (const uint16_t*)svd_down, (uint16_t*)t, m, k, ldx, rank)
+        if (x_dtype == SDNQ_BF16) { if (two) LRD(true, 2); else LRD(true, 1); }
+        else { if (two) LRD(false, 2); else LRD(false, 1); }
+#undef LRD
         SDNQ_CHECK_LAUNCH();
         return SDNQ_OK;
     }
