@@ -1744,6 +1744,11 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
     if (p.M >= 2048 && tiles(256, 128) >= 150 && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
     if constexpr (PP_OK<MM, OUT_T, EPI>) {
+        //  * a few hundred rows against a wide N and a long K (the text stream of FLUX: 512 x 9216 / 12288 x 3072): ONE round of 256x128
+        //    tiles on the fine-grained ping-pong -- 22.8 vs 28.9 us and 24.9 vs 30.7 us against 64x128 tiles (profiles/r03_gemm_tile_resweep.txt);
+        //    with fewer tiles (N = 3072: 48) or more than one round the small tiles win
+        if (p.M < 2048 && p.K >= 2048 && tiles(256, 128) >= 128 && tiles(256, 128) <= 256 && fits(128))
+            return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
         //  * wide-N, few-row problems (the GEGLU projection 1024 x 10240 x 1280): 256x160 tiles cut N = 10240 into exactly 256
         //    workgroups of 8 waves (wave tile 32x160), 43 % of the LDS-fill bytes of 64x128 tiles: 27.6 -> 22.4 us
         if ((p.N % 160) == 0 && tiles(256, 160) >= 192 && tiles(256, 160) <= 512 && fits(160))
