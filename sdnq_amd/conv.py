@@ -122,7 +122,7 @@ def _grouped_float_forward(self, x2d: torch.Tensor, fold):
     return fold(out)
 
 
-@torch.no_grad()
+@linear._no_grad
 def quantized_conv_forward(self, input: torch.Tensor) -> torch.Tensor:
     x2d, fold = _unfold(self, input)
     if self.groups != 1:
@@ -192,12 +192,12 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
     return _folder(self, nd, b, ho, wo, depth_out)(out)
 
 
-@torch.no_grad()
+@linear._no_grad
 def quantized_conv_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _conv_matmul_forward(self, input, ops.MM_I8)
 
 
-@torch.no_grad()
+@linear._no_grad
 def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     """layers/conv/conv_uint8.py:95-121: unfolded input through the asymmetric-activation int8 matmul."""
     if self.groups != 1:
@@ -210,6 +210,6 @@ def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tens
     return fold(linear._uint8_matmul_forward(self, x2d, small_batch_branch=False, cache_input=False))
 
 
-@torch.no_grad()
+@linear._no_grad
 def quantized_conv_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _conv_matmul_forward(self, input, ops.MM_FP8)
