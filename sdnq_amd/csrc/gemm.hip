@@ -25,6 +25,8 @@
 //     are produced in the epilogue instead of materialising an [M][N] bias in HBM;
 //   * block -> tile map is XCD-aware: the 8 XCDs (private L2s) each walk a contiguous range of tiles.
 #include <atomic>
+#include <vector>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1664,6 +1666,29 @@ inline int forced_tile() {
     return f;
 }
 
+// Shape-keyed override for IN-STEP tuning (tools/tune_tiles_in_step.py): SDNQ_HIP_TILE_MAP="MxNxK=tile,MxNxK=tile,..." forces a tile
+// for exactly those problems and leaves every other launch of the step to the heuristics -- a tile is judged by what it does to the
+// step, not by a kernel replayed alone.
+inline int forced_tile_for(const GemmParams& p) {
+    struct Ent { int64_t m, n, k; int tile; };
+    static const std::vector<Ent> map = [] {
+        std::vector<Ent> v;
+        const char* e = getenv("SDNQ_HIP_TILE_MAP");
+        while (e && *e) {
+            Ent t{};
+            int used = 0;
+            if (sscanf(e, "%ldx%ldx%ld=%d%n", &t.m, &t.n, &t.k, &t.tile, &used) == 4) v.push_back(t);
+            else break;
+            e += used;
+            if (*e == ',') ++e;
+        }
+        return v;
+    }();
+    for (const Ent& t : map)
+        if (t.m == p.M && t.n == p.N && t.k == p.K) return t.tile;
+    return forced_tile();
+}
+
 // the half-tile ring addresses a tile's rows with 32-bit byte offsets from the tile's first row
 inline bool ht_ok(const GemmParams& p) {
     const int64_t lda = p.lda ? p.lda : p.K, ldb = p.ldb ? p.ldb : p.K;
@@ -1676,7 +1701,7 @@ template <int MM, int OUT_T, int EPI> constexpr bool PP_OK = !is_float_mm<MM> &&
 template <int MM, int OUT_T, int EPI>
 int launch_tiles(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
-    const int force = forced_tile();  // tuning aid
+    const int force = forced_tile_for(p);  // tuning aid
     if constexpr (EPI != EPI_BIAS2D && EPI != EPI_LOWRANK) {
         if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
     } else if (force == 0) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
@@ -1764,7 +1789,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
 
 // development override SDNQ_HIP_TILE with a grouped launch: refuse tiles that do not divide the unit
 inline bool force_tile_unfit(const GemmParams& p) {
-    const int force = forced_tile();
+    const int force = forced_tile_for(p);
     if (force < 0 || p.units == nullptr) return false;
     static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128, 256, 128, 256};
     return force < (int)(sizeof(bn_of) / sizeof(int)) ? (p.unit_n % bn_of[force]) != 0 : false;
