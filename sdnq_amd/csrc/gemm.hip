@@ -1909,7 +1909,7 @@ int launch_tiles_w8(const GemmParams& p, hipStream_t s) {
     // fragment -- 128x128 tiles of four waves with 128x32 wave tiles (one conversion per FOUR MFMAs) beat every 64-row wave tile
     // once there are enough tiles (4096^3: 178 us vs 211-224; 1024 x 10240 x 1280: 47 vs 50-54); 64x128 tiles (conversion per two
     // MFMAs) for the small problems, where tiles are few
-    const int force = forced_tile();  // tuning / test aid: 0 256x128, 1 64x128, 2 128x128 (64x32 waves), 3 64x64, 4 128x128 (128x32 waves)
+    const int force = forced_tile_for(p);  // tuning / test aid: 0 256x128, 1 64x128, 2 128x128 (64x32 waves), 3 64x64, 4 128x128 (128x32 waves); K of the map in BYTES (2 x elements)
     const bool fit128 = p.units == nullptr || (p.unit_n % 128) == 0;
     if (force == 0 && fit128) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 128>(p, s);
     if (force == 2 && fit128) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
@@ -1917,7 +1917,10 @@ int launch_tiles_w8(const GemmParams& p, hipStream_t s) {
     // (round 3 re-sweep on the buffer-load loaders, profiles/r03_w8a16_sweep.txt: 160-240 tiles of 128x128 lose to 64x128 -- 4096 x 640 x 640
     //  12.7 vs 11.4 us, 1024 x 3840 x 1280 20.2 vs 19.2 -- from 480 tiles up they win: 4096 x 1920 x 640 17.2 vs 21.0)
     static const int t128_min = [] { const char* e = getenv("SDNQ_HIP_W8_T128_MIN"); return e ? atoi(e) : 320; }();  // tuning aid
-    if (force == 4 || (force < 0 && tiles(128, 128) >= t128_min)) return launch_one<MM, OUT_T, EPI, 128, 128, 128, 32, 3, LD_DMA, 128>(p, s);
+    // (judged on the STEP, tools/tune_tiles_in_step.py + profiles/r03_tiles_in_step_dequant.txt: the GEGLU projection 1024 x 10240 x 1280 --
+    //  640 tiles of 128x128 -- is 0.32 ms per step faster on 64x128 tiles, 12.75 against 13.07 ms; the 4096-row problems are indifferent:
+    //  128-row wave tiles only for M >= 2048)
+    if (force == 4 || (force < 0 && tiles(128, 128) >= t128_min && p.M >= 2048)) return launch_one<MM, OUT_T, EPI, 128, 128, 128, 32, 3, LD_DMA, 128>(p, s);
     // (128x64 tiles of two 128x32 waves -- the conversion shared by four MFMAs at twice the workgroups -- and a 4-deep ring for the
     //  128x128 tile measured 20-60 % slower than the above on every SDXL shape: too few waves to hide the DMA / LDS latency)
     return launch_one<MM, OUT_T, EPI, 64, 128, 64, 32, 3, LD_DMA, 128>(p, s);
