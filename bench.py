@@ -13,12 +13,20 @@ number measures the GPU, not the Python launch loop (the reference's own harness
     ms_per_step = SDXL-UNet Linear step latency;  tokens/s = 16384 latent tokens / step latency
     roofline    = the int8 MFMA scaled-mm kernel alone: algorithmic ops of all its launches in one step divided by
                   their summed duration, measured with HIP events on the launch stream, vs the dense int8 MFMA peak
-    cpu_baseline= the CPU oracle (plain C + OpenMP restatement of the reference's eager path) on a bounded sample of
-                  the same layer list, on this box's host cores (rank 0, N=1 only)
+                  (per workload: the matmul that actually runs -- int8 / fp8 scaled-mm, or the bf16 fused dequantize GEMM of
+                  the reference's default mode -- against the dense peak of ITS dtype)
+    cpu_baseline= the reference's CPU-eager path restated with the torch CPU operators it issues (row-quantize, torch._int_mm,
+                  addcmul epilogue) on the host's physical cores, on a bounded sample of the same layer list; the C + OpenMP
+                  oracle ("port_c_oracle") beside it; for the headline also BASELINE configs[0] (cfg1) on CPU and GPU
+                  (rank 0, N=1 only)
 
-N > 1 (driver launches one rank per GPU via torch.distributed.run): default = one independent latent per GPU
-(replicas, weak scaling, no data-path collective).  ``--tp`` column-shards every Linear across the ranks and
-all-gathers the outputs over RCCL/xGMI (strong scaling; see DESIGN.md for why that is link/latency-bound at bs=1).
+N > 1: one rank per GPU.  The driver launches the ranks via torch.distributed.run; started plainly (`python bench.py --gpus N`, no
+WORLD_SIZE in the environment) this script re-executes itself under torch.distributed.run with N ranks, and exits non-zero when
+fewer than N GPUs are visible -- it never silently runs one.  Default = one independent latent per GPU (replicas, weak scaling,
+no data-path collective).  ``--tp`` column-shards every Linear across the ranks and all-gathers the outputs over RCCL/xGMI
+(strong scaling; see DESIGN.md for why that is link/latency-bound at bs=1).  ``--dry-run`` exercises the multi-rank plumbing
+(rendezvous, barriers, max-over-ranks, the one JSON line) on CPU over gloo with NO device work: the line says so and is not a
+measurement.
 """
 from __future__ import annotations
 
@@ -36,6 +44,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 INT8_MFMA_PEAK_TOPS = 5033.0  # dense: 1024 MAC/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz x 2 (MI355X_MICROARCH.md: i8 = 2x bf16 rate)
 FP8_MFMA_PEAK_TFLOPS = 5033.0
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 / f16: 512 MAC/clk/SIMD (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
+XGMI_LINK_GBPS = 153.0  # one xGMI link, one direction (guide); 7 links per GPU, point to point
 # measured ceilings of the same instructions in a register-resident loop on this part (tools/mfma_peak.hip,
 # profiles/r02_mfma_peak.txt): the issue rate is the datasheet's (one 32x32x32 i8 MFMA per 32 clocks per SIMD) but the part clocks
 # to its power budget -- 2.0-2.3 GHz with small-integer operands (4.1-4.8 POP/s, the round-1 probe), 1.63-1.74 GHz with
@@ -68,6 +78,8 @@ def parse():
     p.add_argument("--no-link-projections", action="store_true",
                    help="do not link attention projections that share their input (sdnq_amd.accelerate links them by default)")
     p.add_argument("--layers-scale", type=float, default=1.0, help="debug: fraction of each layer's repeat count")
+    p.add_argument("--dry-run", action="store_true",
+                   help="multi-rank plumbing only, on CPU over gloo, NO device work (for tests): the JSON line is marked as such")
     return p.parse_args()
 
 
@@ -287,6 +299,82 @@ def time_gemm_kernel(layers, mm_name, device):
         s.synchronize()
     dur_s = e0.elapsed_time(e1) / 1e3 / reps
     return {"launches": len(calls), "ops": total_ops, "bytes": total_bytes, "seconds": dur_s}
+
+
+def time_float_kernel(layers, device):
+    """Dominant-kernel roofline of the DEFAULT mode (use_quantized_matmul=False): every M >= 32 layer is ONE launch of the fused
+    dequantize GEMM (int8 weight bytes converted between LDS and the bf16 MFMA; no activation pre-pass exists), linked projections
+    one grouped launch -- so the kernel's launches are the step without its M < 32 layers.  Graph-replayed, HIP events on the
+    launch stream."""
+    from sdnq_amd import linear as L
+    big = [l for l in layers if l[3] >= 32 and hasattr(l[1], "sdnq_dequantizer")]
+    if not big:
+        return None
+    total_ops = sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in big)
+    # x (bf16) + W (1 B / weight) + y (bf16) + row scales + bias; a shared activation is counted once per launch that reads it
+    total_bytes, launches, seen_groups = 0, 0, set()
+    for (_, mod, x, m, k, n, b) in big:
+        group = mod.__dict__.get("_sdnq_group") if L.LINK_PROJECTIONS else None
+        gid = id(group[0]) if group is not None else None
+        total_bytes += n * k + 2 * m * n + 4 * n + (2 * n if b else 0)
+        if gid is None or gid not in seen_groups:
+            launches += 1
+            total_bytes += 2 * m * k
+            if gid is not None:
+                seen_groups.add(gid)
+    run_step(big)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream(device=device)
+    reps = 5
+    with torch.cuda.stream(s):
+        run_step(big)
+        s.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=s):
+            run_step(big)
+        graph.replay()
+        s.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(s)
+        s.synchronize()
+    return {"launches": launches, "ops": total_ops, "bytes": total_bytes, "seconds": e0.elapsed_time(e1) / 1e3 / reps}
+
+
+def time_all_gathers(layers, device, reps=3):
+    """--tp: the all-gathers of one step ALONE (same message sizes, same process group, no matmuls), back to back on the current
+    stream -> seconds per step and bytes RECEIVED per rank: what the xGMI links deliver, to be read against 153 GB/s per link."""
+    import torch.distributed as dist
+    msgs = []
+    for (_, mod, x, m, k, n, b) in layers:
+        if type(mod).__name__ != "ColumnShardedLinear":
+            continue
+        wmax = max(bb - aa for aa, bb in mod.bounds)
+        msgs.append((m, wmax, mod.world))
+    if not msgs:
+        return None
+    bufs = {}
+    for (m, w, world) in set(msgs):
+        bufs[(m, w, world)] = (torch.empty((m, w), device=device, dtype=torch.bfloat16), torch.empty((world * m, w), device=device, dtype=torch.bfloat16))
+
+    def run():
+        for key in msgs:
+            send, recv = bufs[key]
+            dist.all_gather_into_tensor(recv, send)
+    run()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / reps
+    recv_bytes = sum(2 * m * w * (world - 1) for (m, w, world) in msgs)
+    return {"gathers_per_step": len(msgs), "seconds_per_step": sec, "bytes_received_per_rank_per_step": recv_bytes,
+            "largest_message_bytes": max(2 * m * w for (m, w, _) in msgs)}
 
 
 def cpu_baseline(shape_list, mm_name, budget_s):
@@ -708,14 +796,81 @@ def cpu_baseline_attention(calls, budget_s):
             "sample": f"oracle (numpy) quantized attention, 2 heads x 1024 x 1024 x {d}, {n} passes, {sec:.1f}s (numpy / BLAS default threading)"}
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` started WITHOUT a launcher: re-execute this script under torch.distributed.run with N ranks on
+    this node (one per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  Fewer than N visible GPUs is an error, not a
+    1-GPU run."""
+    import subprocess
+    if not args.dry_run:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to run fewer ranks than asked", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """The multi-rank skeleton of the benchmark with NO device work (CPU, gloo): rendezvous, warm-up, barrier-bracketed timed region,
+    MAX over ranks, one JSON line from rank 0.  For tests of the launch contract only -- the line is marked as not a measurement."""
+    import torch.distributed as dist
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))  # ranks differ: the MAX over ranks must come out
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        tp = args.tp and distributed
+        print(json.dumps({"metric": "DRY RUN (no device work): launch-contract plumbing only", "value": 0.0, "unit": "GOP/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "dry-run (no device work, gloo on CPU) -- NOT a measurement",
+                          "config": {"workload": args.workload, "parallelism": (f"tp{world}" if tp else f"{world} independent replicas")},
+                          "dry_run": True}))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    launched = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)  # under torch.distributed.run, also with 1 rank
-    if args.gpus != world and distributed:
+    if args.gpus != world and (distributed or args.gpus > 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible "
+                         "(the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:
@@ -868,30 +1023,66 @@ def main():
         "step_latency_ms": round(ms_per_step, 4),
     }
 
+    gathers = None
+    if tp:
+        try:
+            gathers = time_all_gathers(layers, device)  # a collective: every rank takes part
+        except Exception as e:  # noqa: BLE001
+            result["tp"]["gather_timing_error"] = repr(e)
+        if gathers:
+            link_gbps = gathers["bytes_received_per_rank_per_step"] / gathers["seconds_per_step"] / 1e9
+            result["tp"].update({
+                "gathers_per_step": gathers["gathers_per_step"], "gather_bytes_received_per_rank_per_step": gathers["bytes_received_per_rank_per_step"],
+                "largest_gather_message_bytes": gathers["largest_message_bytes"],
+                "gathers_alone_ms_per_step": round(gathers["seconds_per_step"] * 1e3, 4), "gather_achieved_gbps_per_rank": round(link_gbps, 1),
+                "xgmi_link_gbps": XGMI_LINK_GBPS, "xgmi_links_used": world - 1,
+                "gather_frac_of_links": round(link_gbps / (XGMI_LINK_GBPS * max(1, world - 1)), 4),
+                "note": "bytes received per rank / time of the step's all-gathers run alone; a fully connected all-gather receives from "
+                        "W - 1 peers over W - 1 links at once, each bound by 153 GB/s"})
+
+    float_mode = not cfg_kwargs.get("use_quantized_matmul", cfg_kwargs.get("use_quantized_matmul_conv", False))
+    if float_mode:
+        result["dtype"] = "bf16"
+        result["config"]["workload"] = (f"{args.workload}: {len(layers)} quantized Linear layers of one denoising step, bs=1, the reference's DEFAULT mode "
+                                        f"({sum(1 for l in layers if l[3] >= 32)} int8-weight x bf16-activation GEMMs, weights dequantized inside the kernel, "
+                                        f"+ {sum(1 for l in layers if l[3] < 32)} M=1 layers)")
     if rank == 0:
         try:
-            gk = time_gemm_kernel(layers, mm_name, device)
+            gk = time_float_kernel(layers, device) if float_mode else time_gemm_kernel(layers, mm_name, device)
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_meta = None, None, None
         pmc_name = "r03_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
         if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             # (tools/pmc_shapes.py + tools/pmc_traffic.py; counters cannot be read inside this process)
             with open(pmc) as f:
-                traffic = round(json.load(f)["_all_gemm_kernel"]["hbm_bytes_per_launch"])
+                pj = json.load(f)
+            traffic = round(pj["_all_gemm_kernel"]["hbm_bytes_per_launch"])
             traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)"
+            traffic_meta = pj.get("_provenance", "collected in an earlier profiling session (see `git log -- profiles/" + pmc_name + "`), not by this run")
         if gk:
             ach = gk["ops"] / gk["seconds"] / 1e12
-            result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s" if mm_name == "int8" else "TFLOP/s",
-                                  "frac": round(ach / INT8_MFMA_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            if float_mode:
+                peak, unit, kernel = BF16_MFMA_PEAK_TFLOPS, "TFLOP/s", "gemm_kernel<MM_W8BF16> (bf16 MFMA; int8 weight bytes dequantized between LDS and the MFMA)"
+                peak_meas, peak_meas_src = BF16_MFMA_MEASURED_TFLOPS, "profiles/r02_mfma_peak.txt (bf16 register-resident MFMA loop, random operands)"
+            elif mm_name == "int8":
+                peak, unit, kernel = INT8_MFMA_PEAK_TOPS, "TOP/s", "gemm_kernel<MM_I8> (int8 MFMA scaled-mm)"
+                peak_meas, peak_meas_src = INT8_MFMA_MEASURED_TOPS, "profiles/r02_mfma_peak.txt (register-resident MFMA loop on random operand bytes, tools/mfma_peak.hip)"
+            else:
+                peak, unit, kernel = FP8_MFMA_PEAK_TFLOPS, "TFLOP/s", "gemm_kernel<MM_FP8> (fp8 e4m3 MFMA scaled-mm)"
+                peak_meas, peak_meas_src = None, None
+            result["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": unit,
+                                  "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                                  # the PMC figure is a constant read from a tracked profile (counters cannot be collected inside a timed run)
+                                  "traffic_measured_in_run": False if traffic is not None else None, "traffic_provenance": traffic_meta,
                                   "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]),
                                   "hbm_achieved_gbps": round(gk["bytes"] / gk["seconds"] / 1e9, 1), "hbm_peak_gbps": HBM_PEAK_GBPS,
-                                  "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": "gemm_kernel (int8 MFMA scaled-mm)",
+                                  "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": kernel,
                                   "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3),
-                                  "peak_measured": INT8_MFMA_MEASURED_TOPS, "frac_of_measured_peak": round(ach / INT8_MFMA_MEASURED_TOPS, 4),
-                                  "peak_measured_source": "profiles/r02_mfma_peak.txt (register-resident MFMA loop on random operand bytes, tools/mfma_peak.hip)",
+                                  "peak_measured": peak_meas, "frac_of_measured_peak": round(ach / peak_meas, 4) if peak_meas else None,
+                                  "peak_measured_source": peak_meas_src,
                                   "traffic_over_algorithmic": round(traffic / (gk["bytes"] / gk["launches"]), 3) if traffic else None}
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:

@@ -1059,7 +1059,10 @@ extern "C" int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* o
 // `ws_known` (row scales already in ws) is honoured by it and ignored -- the scales are simply recomputed -- by the general kernel
 static int launch_requant(const DeqParams& p, int mm_dtype, void* wq, float* ws, int ws_known, hipStream_t s) {
     dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
-    static const bool no_lut = [] { const char* e = getenv("SDNQ_HIP_REQUANT_LUT"); return e && atoi(e) == 0; }();  // test / tuning aid
+    // test / tuning aid, read per call (a re-quantization is a whole-weight pass: a getenv is nothing beside it) so that one
+    // process can A/B the table kernel against the general one (tests/test_gpu_parity.py)
+    const char* lut_env = getenv("SDNQ_HIP_REQUANT_LUT");
+    const bool no_lut = lut_env && atoi(lut_env) == 0;
     const bool lut = !no_lut && p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && p.P == 1 && (p.group_size % 64) == 0 && (p.K % 64) == 0 &&
                      !p.fmt.native_float;
     const int np = (int)((p.K + 1023) / 1024);

@@ -291,6 +291,7 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
             # (`current_use_quantized_matmul = None` for everything that is not a Linear, loader.py:244-255)
             module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
             module.__dict__.pop("_sdnq_hip_state", None)
+            _refresh_compile_plan(module)
             continue
         if use_quantized_matmul is not None and use_quantized_matmul != dq.use_quantized_matmul:
             n, k = dq.out_features, dq.in_features
@@ -302,7 +303,17 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
         module.forward_func = get_forward_func("Linear", dq.quantized_matmul_dtype, dq.use_quantized_matmul)
         module.__dict__.pop("_sdnq_hip_state", None)
         _unlink(module)  # the layer's layout / forward may have changed: its group (if any) dissolves, siblings run alone
+        _refresh_compile_plan(module)
     return model
+
+
+def _refresh_compile_plan(module) -> None:
+    """The operator plan SDNQLayer.forward follows under torch.compile (`_sdnq_hip_plan`, torch_ops.layer_plan) is derived from the
+    dequantizer's matmul switch / dtypes and the scale dtype: whatever changed those must re-derive it, or the compiled model keeps
+    computing the OLD mode while the eager forward_func runs the new one (advisor, round 3)."""
+    if "_sdnq_hip_handle" in module.__dict__:
+        from . import torch_ops
+        torch_ops.layer_handle(module)
 
 
 def _relayout(module, dq: SDNQDequantizer, want_qmm: bool):

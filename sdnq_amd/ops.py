@@ -381,12 +381,17 @@ def linear_w8a8_ws(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.T
     """linear_w8a8 with the quantized activation in the stream's persistent scratch buffer (not returned, not kept): ONE allocation
     per call instead of three.  Same-stream launches are ordered, so the next layer overwriting the buffer is safe; a buffer replaced
     by a larger one stays valid for the work already queued (the caching allocator does not hand a freed block to another stream).
-    Not for use while the stream is being captured into a graph (the buffer may be replaced later)."""
+    While the stream is being captured into a graph the scratch is a fresh tensor of the graph's pool instead (the shared buffer
+    may be replaced later)."""
     m, k = x2d.shape
     n = b_phys.shape[0]
     stream = _stream(x2d)
     xq_bytes = (m * k + 255) & ~255
-    base = (_workspace(x2d.device, stream, xq_bytes + 4 * m + 512).data_ptr() + 255) & ~255  # the per-stream scratch buffer (below)
+    if torch.cuda.is_current_stream_capturing():
+        scratch = torch.empty((xq_bytes + 4 * m + 512 + 255,), device=x2d.device, dtype=torch.uint8)
+    else:
+        scratch = _workspace(x2d.device, stream, xq_bytes + 4 * m + 512)  # the per-stream scratch buffer (below)
+    base = (scratch.data_ptr() + 255) & ~255
     out = torch.empty((m, n), device=x2d.device, dtype=out_dtype)
     check(_lib.load().sdnq_hip_linear_w8a8(mm, x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), hadamard_group, base,
                                            base + xq_bytes, b_phys.data_ptr(), sb.data_ptr(), _ptr(bias), 0 if bias is None else float_code(bias.dtype),
@@ -670,7 +675,10 @@ def linear_call(mm: int, x2d: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor, 
     check(lib.sdnq_hip_linear_workspace_bytes(ctypes.byref(a), ctypes.byref(need)), "linear_workspace_bytes")
     stream = _stream(x2d)
     if need.value > 0:
-        w = _workspace(dev, stream, need.value)
+        # while the stream is being captured the scratch must belong to the graph's memory pool: the shared per-stream buffer may be
+        # replaced (and freed) by a later, larger eager call while the captured graph still holds its address (advisor, round 3)
+        w = (torch.empty((need.value + 255,), device=dev, dtype=torch.uint8) if torch.cuda.is_current_stream_capturing()
+             else _workspace(dev, stream, need.value))
         base = (w.data_ptr() + 255) & ~255
         a.workspace, a.workspace_bytes = base, w.numel() - (base - w.data_ptr())
     check(lib.sdnq_hip_linear(ctypes.byref(a), stream), "linear")

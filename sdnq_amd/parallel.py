@@ -45,14 +45,26 @@ def shard_bounds(n: int, rank: int, world: int, multiple: int = 16) -> tuple[int
     return start, start + size
 
 
+def chunk_rows(m: int, chunks: int) -> list[tuple[int, int]]:
+    """Row ranges of the M-chunked gather pipeline: 32-row-aligned steps, and NO chunk shorter than 32 rows -- a shorter tail would
+    take the layer's small-batch (M < 32) float branch instead of the quantized matmul (linear_int8.py:102-103) and differ from
+    the unchunked layer; such a tail is merged into the chunk before it."""
+    step = (-(-m // max(1, chunks)) + 31) // 32 * 32
+    starts = list(range(0, m, step))
+    if len(starts) > 1 and m - starts[-1] < 32:
+        starts.pop()
+    return [(a, starts[i + 1] if i + 1 < len(starts) else m) for i, a in enumerate(starts)]
+
+
 class ColumnShardedLinear(torch.nn.Module):
     """Holds this rank's slab of a Linear; forward = local forward + all-gather along the channel axis.
 
     On GPU tensors the re-assembly [W, M, w] -> [M, N] is ONE HIP pass (``sdnq_hip_unshard_columns``; uneven shards included: the
     local slab is written into a padded gather buffer, no zeros / cat), and with ``chunks > 1`` the M rows are processed as a
     pipeline: the all-gather of chunk i runs on a side stream while the local matmul of chunk i + 1 runs on the caller's stream
-    (row-wise activation quantization, the matmul and its epilogue are all per activation row, so a chunked layer is bit-identical
-    to the unchunked one).  The gather itself stays the bound -- 2 M N / W bytes per rank over one 153 GB/s xGMI link -- the
+    (row-wise activation quantization, the matmul and its epilogue are all per activation row, so a chunked int8 layer is
+    bit-identical to the unchunked one -- `chunk_rows` never leaves a chunk below the 32-row small-batch threshold; fp8 / float
+    matmuls may pick another tile for a chunk's M, i.e. another fp32 summation order: equal within the usual float tolerance).  The gather itself stays the bound -- 2 M N / W bytes per rank over one 153 GB/s xGMI link -- the
     pipeline only hides the matmul under it.  CPU tensors (the gloo tests) take the torch path."""
 
     def __init__(self, local: torch.nn.Module, n_total: int, rank: int, world: int, group=None, chunks: int = 1):
@@ -115,10 +127,8 @@ class ColumnShardedLinear(torch.nn.Module):
             self._side = torch.cuda.Stream(device=x.device)
         side = self._side
         side.wait_stream(cur)  # `out` was allocated on the caller's stream
-        step = -(-m // chunks)
-        step = (step + 31) // 32 * 32
-        for m0 in range(0, m, step):
-            y = self.local(x2[m0:m0 + step])
+        for m0, m1 in chunk_rows(m, chunks):
+            y = self.local(x2[m0:m1])
             ev = torch.cuda.Event()
             ev.record(cur)
             with torch.cuda.stream(side):

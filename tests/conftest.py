@@ -1,4 +1,5 @@
 import os
+import re
 import sys
 
 import pytest
@@ -7,9 +8,44 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# On a GPU box a `-m gpu` test may skip only for one of these reasons; any other skip is turned into a FAILURE (round 3 shipped
+# a parity test whose 24 parameters all skipped on a wrong premise and nothing noticed).  Keep the list short and literal.
+ALLOWED_GPU_SKIPS = (
+    r"host-side packer only",          # uint1 / bool codecs: the load-time quantizer runs its torch mirror for them
+    r"needs two GPUs",                 # the 2-rank RCCL test on a 1-GPU box
+    r"inductor backend unavailable",   # torch.compile tests where Inductor's toolchain is missing
+)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with -m gpu on the GPU box")
+
+
+def _gpu_visible() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def skip_is_allowed(reason: str) -> bool:
+    return any(re.search(pat, reason) for pat in ALLOWED_GPU_SKIPS)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if not rep.skipped or item.get_closest_marker("gpu") is None or not _gpu_visible():
+        return
+    if hasattr(rep, "wasxfail"):
+        return
+    reason = rep.longrepr[2] if isinstance(rep.longrepr, tuple) else str(rep.longrepr)
+    if skip_is_allowed(reason):
+        return
+    rep.outcome = "failed"
+    rep.longrepr = f"unexpected skip of a GPU test on a GPU box (not in tests/conftest.py ALLOWED_GPU_SKIPS): {reason}"
 
 
 @pytest.fixture(scope="session")

@@ -11,7 +11,13 @@ this file.  The fixtures are DATA only: no reference source is stored.
     SDNQ_USE_CONTIGUOUS_MM=0   -> reproduces gfx950's transposed int8 layout
     SDNQ_ALLOW_FP8_MM=1        -> CPU takes torch._scaled_mm like the GPU does
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [table codecs hadamard dequant cases conv | <case name> ...]
+        python tests/golden/make_golden.py --verify        # stored tensors -> reference layer -> forward == stored y
+        python tests/golden/make_golden.py --regen-check   # regenerate everything into a temp dir, compare with the tracked files
+
+Every case is self-seeded: `torch.manual_seed(crc32(name))` at the top of run_case / run_conv_case pins the GLOBAL generator that
+`torch.svd_lowrank` (quant_utils.py:132, the SVD cases) draws from, so each fixture regenerates byte-identically on its own,
+whatever ran before it (round 3's SVD fixtures depended on the order of the session that wrote them).
 """
 import json
 import os
@@ -28,6 +34,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = HERE  # --regen-check points this at a temp dir
 REF_SRC = "/root/reference/src"
 
 
@@ -235,6 +242,7 @@ DEQUANT_DTYPES = (
 
 def run_case(case):
     name = case["name"]
+    torch.manual_seed(zlib.crc32(name.encode()))  # the global generator: torch.svd_lowrank's random projection (SVD cases)
     dtype = TORCH_DT[case["dtype"]]
     K, N = case["K"], case["N"]
     lin = make_linear(K, N, seed=zlib.crc32(name.encode()) % 1000, dtype=dtype, bias=case.get("bias", True))
@@ -297,8 +305,8 @@ def run_case(case):
                     xq, xs = quantize_fp_mm(x2.to(qdt), dim=-1)
                     put(f"xq_{M}", xq)
                     put(f"xs_{M}", xs.to(torch.float32) if xs.dtype == torch.float16 else xs)
-    np.savez_compressed(os.path.join(HERE, f"case_{name}.npz"), **out)
-    with open(os.path.join(HERE, f"case_{name}.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT_DIR, f"case_{name}.npz"), **out)
+    with open(os.path.join(OUT_DIR, f"case_{name}.json"), "w") as f:
         json.dump(meta, f, indent=1, default=str)
     print("wrote", name, {k: v.shape for k, v in out.items() if k.startswith("y_")})
 
@@ -380,6 +388,7 @@ CONV_CASES = [
 def run_conv_case(case):
     """Conv1d / Conv2d / Conv3d layers through the reference quantizer and conv forwards (layers/conv/*)."""
     name = case["name"]
+    torch.manual_seed(zlib.crc32(name.encode()))  # as run_case
     dtype = TORCH_DT[case["dtype"]]
     seed = zlib.crc32(name.encode()) % 1000
     g = torch.Generator().manual_seed(seed)
@@ -432,8 +441,8 @@ def run_conv_case(case):
             put(f"x_{i}", x)
             put(f"y_{i}", y)
             meta["inputs"].append(i)
-    np.savez_compressed(os.path.join(HERE, f"conv_{name}.npz"), **out)
-    with open(os.path.join(HERE, f"conv_{name}.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT_DIR, f"conv_{name}.npz"), **out)
+    with open(os.path.join(OUT_DIR, f"conv_{name}.json"), "w") as f:
         json.dump(meta, f, indent=1, default=str)
     print("wrote conv", name, {k: v.shape for k, v in out.items() if k.startswith("y_")}, meta["forward_func"])
 
@@ -458,8 +467,8 @@ def run_dequant_dtypes():
                     out[f"{key}.{k}"] = arr
                 ent["tensors"][k] = {"dtype": tag, "shape": (list(t.shape) if t is not None else None)}
             meta["dtypes"][key] = ent
-    np.savez_compressed(os.path.join(HERE, "dequant_dtypes.npz"), **out)
-    with open(os.path.join(HERE, "dequant_dtypes.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT_DIR, "dequant_dtypes.npz"), **out)
+    with open(os.path.join(OUT_DIR, "dequant_dtypes.json"), "w") as f:
         json.dump(meta, f, indent=1, default=str)
     print("wrote dequant_dtypes", len(meta["dtypes"]))
 
@@ -514,8 +523,8 @@ def run_codecs():
         out[f"{wd}.sweep_in"] = sweep[:480].numpy()
         out[f"{wd}.sweep_packed"] = to_np(pk)[0]
         out[f"{wd}.sweep_decoded"] = dec2.numpy()
-    np.savez_compressed(os.path.join(HERE, "codecs.npz"), **out)
-    with open(os.path.join(HERE, "codecs.json"), "w") as f:
+    np.savez_compressed(os.path.join(OUT_DIR, "codecs.npz"), **out)
+    with open(os.path.join(OUT_DIR, "codecs.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print("wrote codecs", len(meta))
 
@@ -532,7 +541,7 @@ def run_hadamard():
             y = rotate_hadamard(x, group_size=n)
             out[f"x_{dt}_{n}"] = to_np(x)[0]
             out[f"y_{dt}_{n}"] = to_np(y)[0]
-    np.savez_compressed(os.path.join(HERE, "hadamard.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "hadamard.npz"), **out)
     print("wrote hadamard")
 
 
@@ -541,14 +550,112 @@ def run_dtype_table():
     for k, v in dtype_dict.items():
         table[k] = {kk: (vv if isinstance(vv, (int, float, bool, str)) else str(vv).replace("torch.", ""))
                     for kk, vv in v.items()}
-    with open(os.path.join(HERE, "dtype_table.json"), "w") as f:
+    with open(os.path.join(OUT_DIR, "dtype_table.json"), "w") as f:
         json.dump(table, f, indent=0, sort_keys=True)
     print("wrote dtype_table", len(table))
 
 
-if __name__ == "__main__":
-    torch.set_num_threads(8)
-    only = sys.argv[1:] or None
+def from_np(arr, tag):
+    """Inverse of to_np."""
+    if arr is None or tag == "none":
+        return None
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    view = {"bf16": torch.bfloat16, "f16": torch.float16, "fp8e4m3": torch.float8_e4m3fn, "fp8e5m2": torch.float8_e5m2}
+    if tag in view:
+        return t.view(view[tag])
+    if tag == "bool":
+        return t.view(torch.bool)
+    return t
+
+
+def _restore(layer, z, meta):
+    """Overwrite a freshly quantized reference layer's tensors with the STORED ones (same logical shape and strides)."""
+    for k in ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias"):
+        info = meta["tensors"][k]
+        cur = getattr(layer, k, None)
+        if info["shape"] is None:
+            assert cur is None, (meta["name"], k)
+            continue
+        t = from_np(z[k], info["dtype"])
+        assert cur is not None and list(cur.shape) == info["shape"] and cur.dtype == t.dtype, (meta["name"], k, cur.shape, info)
+        assert list(cur.stride()) == info["stride"], (meta["name"], k, cur.stride(), info["stride"])
+        if list(cur.stride()) != list(t.stride()):  # transposed matmul layout: stored as contiguous logical values
+            t = torch.empty_strided(tuple(cur.shape), tuple(cur.stride()), dtype=t.dtype).copy_(t)
+        setattr(layer, k, torch.nn.Parameter(t, requires_grad=False))
+
+
+def verify():
+    """For every Linear / conv fixture: build the reference layer for the stored config (any weights), replace its tensors by the
+    stored ones, run the reference forward on the stored inputs and require the stored outputs bit for bit.  This is the provenance
+    check that does not depend on regenerating the (RNG-dependent) quantization itself."""
+    bad = 0
+    for case in CASES:
+        name = case["name"]
+        z = np.load(os.path.join(HERE, f"case_{name}.npz"))
+        with open(os.path.join(HERE, f"case_{name}.json")) as f:
+            meta = json.load(f)
+        dtype = TORCH_DT[case["dtype"]]
+        lin = make_linear(case["K"], case["N"], seed=1, dtype=dtype, bias=case.get("bias", True))
+        layer = sdnq_quantize_layer(lin, SDNQConfig(**case["cfg"]))[0]
+        assert deq_fields(layer.sdnq_dequantizer) == meta["deq"], name
+        _restore(layer, z, meta)
+        with torch.no_grad():
+            for M in case["Ms"]:
+                x = from_np(z[f"x_{M}"], meta["tensors"][f"x_{M}"]["dtype"])
+                y = layer(x)
+                ya, _ = to_np(y)
+                ok = np.array_equal(ya, z[f"y_{M}"])
+                bad += not ok
+                print("verify", name, M, "OK" if ok else f"MISMATCH {(ya != z[f'y_{M}']).sum()} elements")
+    for case in CONV_CASES:
+        name = case["name"]
+        z = np.load(os.path.join(HERE, f"conv_{name}.npz"))
+        with open(os.path.join(HERE, f"conv_{name}.json")) as f:
+            meta = json.load(f)
+        dtype = TORCH_DT[case["dtype"]]
+        ctor = {1: torch.nn.Conv1d, 2: torch.nn.Conv2d, 3: torch.nn.Conv3d}[case["nd"]]
+        conv = ctor(case["cin"], case["cout"], case["k"], **case["conv"]).to(dtype)
+        layer = sdnq_quantize_layer(conv, SDNQConfig(quant_conv=True, **case["cfg"]))[0]
+        assert deq_fields(layer.sdnq_dequantizer) == meta["deq"], name
+        _restore(layer, z, meta)
+        with torch.no_grad():
+            for i in meta["inputs"]:
+                x = from_np(z[f"x_{i}"], meta["tensors"][f"x_{i}"]["dtype"])
+                ya, _ = to_np(layer(x))
+                ok = np.array_equal(ya, z[f"y_{i}"])
+                bad += not ok
+                print("verify conv", name, i, "OK" if ok else "MISMATCH")
+    print("verify done, mismatching outputs:", bad)
+    return bad
+
+
+def regen_check():
+    """Regenerate every fixture into a temp dir and compare array by array with the tracked files."""
+    import tempfile
+    global OUT_DIR
+    OUT_DIR = tempfile.mkdtemp(prefix="sdnq_golden_")
+    generate(None)
+    bad = 0
+    for fn in sorted(os.listdir(OUT_DIR)):
+        a, b = os.path.join(OUT_DIR, fn), os.path.join(HERE, fn)
+        if not os.path.exists(b):
+            print("regen-check: not tracked:", fn)
+            bad += 1
+        elif fn.endswith(".npz"):
+            za, zb = np.load(a), np.load(b)
+            same = sorted(za.files) == sorted(zb.files) and all(
+                za[k].dtype == zb[k].dtype and za[k].shape == zb[k].shape and za[k].tobytes() == zb[k].tobytes() for k in za.files)
+            bad += not same
+            print("regen-check", fn, "identical" if same else "DIFFERS")
+        else:
+            same = open(a).read() == open(b).read()
+            bad += not same
+            print("regen-check", fn, "identical" if same else "DIFFERS")
+    print("regen-check done, differing files:", bad, "(temp dir", OUT_DIR + ")")
+    return bad
+
+
+def generate(only):
     if only is None or "table" in only:
         run_dtype_table()
     if only is None or "codecs" in only:
@@ -563,3 +670,12 @@ if __name__ == "__main__":
     for c in CONV_CASES:
         if only is None or "conv" in only or c["name"] in only:
             run_conv_case(c)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    if "--verify" in sys.argv[1:]:
+        sys.exit(1 if verify() else 0)
+    if "--regen-check" in sys.argv[1:]:
+        sys.exit(1 if regen_check() else 0)
+    generate(sys.argv[1:] or None)

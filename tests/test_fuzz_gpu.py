@@ -1,0 +1,29 @@
+"""Bounded slices (a few seconds each) of the random-shape sweeps in tools/fuzz_*.py under -m gpu: the driver's GPU run executes
+them, so a shape class the hand-picked parity cases miss still has a chance of being seen.  Every sweep is bit-exact against its
+checker (the oracle, or sdnq_hip_dequant's values + the float GEMM)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [101, 202])
+def test_fuzz_linear_w8a8_bit_exact(seed, gpu_device):
+    import fuzz_linear
+    assert fuzz_linear.run(seed, 24, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [303, 404])
+def test_fuzz_conv_int8_bit_exact(seed, gpu_device):
+    import fuzz_conv
+    assert fuzz_conv.run(seed, 24, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [505, 606])
+def test_fuzz_fused_dequantize_gemm_bit_exact(seed, gpu_device):
+    import fuzz_w8a16
+    assert fuzz_w8a16.run(seed, 30, verbose=False) == []

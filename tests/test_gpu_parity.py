@@ -154,13 +154,15 @@ def test_dequant_every_storage_dtype_bit_exact(gpu_device):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(48, 256, 512), (77, 640, 2048), (333, 80, 48), (1000, 336, 144), (4096, 640, 640),
-                                   (129, 1280, 1280), (64, 64, 64), (32, 32, 32), (257, 2576, 656)])
-@pytest.mark.parametrize("out_dt", [torch.bfloat16, torch.float16, torch.float32])
+_MM_I8_SHAPES = [(48, 256, 512), (77, 640, 2048), (333, 80, 48), (1000, 336, 144), (4096, 640, 640),
+                 (129, 1280, 1280), (64, 64, 64), (32, 32, 32), (257, 2576, 656)]
+
+
+# large shapes (M > 400) once, in bf16: the parameter list says so, nothing is skipped at run time
+@pytest.mark.parametrize("shape,out_dt", [(sh, dt) for dt in (torch.bfloat16, torch.float16, torch.float32) for sh in _MM_I8_SHAPES
+                                          if dt == torch.bfloat16 or sh[0] <= 400])
 def test_scaled_mm_int8_bit_exact_vs_oracle(shape, out_dt, gpu_device):
     m, n, k = shape
-    if out_dt != torch.bfloat16 and m > 400:
-        pytest.skip("large shapes once, in bf16")
     g = torch.Generator().manual_seed(m * 7 + n)
     a = torch.randint(-128, 128, (m, k), dtype=torch.int8, generator=g)
     b = torch.randint(-128, 128, (n, k), dtype=torch.int8, generator=g)
@@ -197,11 +199,11 @@ def test_scaled_mm_fp8_vs_oracle(shape, gpu_device):
         assert_close_float(to_f32_numpy(out), ref, tag, (shape, tag), f32_lim=1e-4)
 
 
-@pytest.mark.parametrize("m,k", [(100, 640), (33, 1280), (7, 5120), (64, 48), (40, 15360), (4096, 640)])
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
+# the two large shapes once, in bf16
+@pytest.mark.parametrize("m,k,dt", [(m, k, dt) for dt in (torch.bfloat16, torch.float16, torch.float32)
+                                    for m, k in [(100, 640), (33, 1280), (7, 5120), (64, 48), (40, 15360), (4096, 640)]
+                                    if dt == torch.bfloat16 or m * k <= 300000])
 def test_rowquant_bit_exact_vs_oracle(m, k, dt, gpu_device):
-    if dt != torch.bfloat16 and m * k > 300000:
-        pytest.skip("large once")
     g = torch.Generator().manual_seed(k + m)
     x = torch.randn(m, k, generator=g) * 3
     x[:, 5 % k] *= 20
@@ -323,6 +325,34 @@ def test_cfg1_4096_dequant_roundtrip_and_linear(gpu_device):
     y = layer(x.to(gpu_device))
     ref = O.linear_float(x.numpy(), wd.detach().cpu().numpy(), layer.bias.detach().cpu().numpy(), "f32")
     assert_close_float(to_f32_numpy(y), ref, "f32", "cfg1 linear")
+
+
+@pytest.mark.parametrize("m", [64, 4096])
+def test_cfg1_4096_fp32_full_size_vs_oracle(m, gpu_device):
+    """BASELINE configs[0] at the sizes bench.py's cpu_baseline.cfg1 TIMES on the GPU (M = 64 and M = 4096, fp32 activations:
+    sdnq_hip_dequant + the f32-MFMA float GEMM, or the fused path where the dispatcher takes it): every output row at M = 64, a
+    128-row slab + the last rows at M = 4096, against the oracle's quantized_linear_forward (layers/linear/forward.py:25-26)."""
+    import sdnq_amd
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4096, 4096, bias=True)
+    layer, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=False))
+    layer = layer.to(gpu_device)
+    assert not layer.sdnq_dequantizer.use_quantized_matmul
+    wd = (layer.weight.cpu().float() * layer.scale.cpu()).numpy()  # == dequant, checked bit-exactly by the M = 8 test above
+    bias = layer.bias.detach().cpu().numpy()
+    x = torch.randn(m, 4096, generator=torch.Generator().manual_seed(m))
+    y = layer(x.to(gpu_device))
+    assert y.dtype == torch.float32 and tuple(y.shape) == (m, 4096)
+    got = y.cpu().numpy()
+    slabs = [(0, 64)] if m == 64 else [(1920, 2048), (4064, 4096)]
+    for lo, hi in slabs:
+        ref = O.linear_float(x[lo:hi].numpy(), wd, bias, "f32")
+        assert_close_float(got[lo:hi], ref, "f32", ("cfg1", m, lo, hi))
+    # row independence at full size: the slab computed alone equals the same rows of the whole call (same tile path or not, the
+    # fp32 accumulation order over K may differ between tile choices, so compare within the float tolerance)
+    if m == 4096:
+        y2 = layer(x[1920:2048].to(gpu_device)).cpu().numpy()
+        assert_close_float(y2, got[1920:2048], "f32", "cfg1 slab alone")
 
 
 def test_operator_seam_and_errors(gpu_device):
@@ -1352,37 +1382,74 @@ def test_rowquant_division_shortcut_over_the_exponent_range(dt, gpu_device):
             assert np.array_equal(rs.cpu().numpy(), rowsum)
 
 
-@pytest.mark.parametrize("wd", ["int4", "uint4", "float4_e2m1fn", "float4_e3m0fn"])
-@pytest.mark.parametrize("mm_name", ["int8", "fp8"])
-@pytest.mark.parametrize("group", [64, 128, 32])
-def test_requant_table_path_equals_oracle_and_known_scales(wd, mm_name, group, gpu_device):
-    """4-bit weights in groups of a multiple of 64 are re-quantized through a 16-entry table per (row, group)
-    (requant_lut4_kernel); group 32 takes the general kernel.  Codes and row scales must equal the oracle's re_quantize_matmul bit
-    for bit, and a second call that is handed the row scales (sdnq_hip_requant_ws, the per-call mode of SDNQ_HIP_CACHE_WEIGHTS=0)
-    must reproduce the first."""
+def _requant_layer(wd, mm_name, group, n, k, gpu_device, seed=5):
+    """A 4-bit (or other) layer that MUST re-quantize for its matmul: a wrong premise fails the test instead of skipping it."""
     import sdnq_amd
-    from sdnq_amd import linear as L
-    from tests.modules_util import oracle_from_module
-    if wd not in sdnq_amd.common.dtype_dict:
-        pytest.skip(f"{wd} not in the dtype table")
-    torch.manual_seed(5)
-    n, k = 200, 640
+    assert wd in sdnq_amd.common.dtype_dict, wd
+    assert n % 16 == 0 and k % 16 == 0 and n >= 32 and k >= 32  # check_quantized_matmul_is_allowed (utils.py:93-98)
+    torch.manual_seed(seed)
     lin = torch.nn.Linear(k, n, bias=False).to(torch.bfloat16).to(gpu_device)
     lin.weight.data[:, 3] *= 9
     lin.weight.data[7] = 0  # a constant row: 0 / 0 -> code 0
     mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype=wd, group_size=group, use_quantized_matmul=True,
                                                                    quantized_matmul_dtype="int8" if mm_name == "int8" else "float8_e4m3fn"))
     dq = mod.sdnq_dequantizer
-    if not (dq.use_quantized_matmul and dq.re_quantize_for_matmul):
-        pytest.skip("configuration does not re-quantize")
-    mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
+    assert dq.use_quantized_matmul and dq.re_quantize_for_matmul, (wd, mm_name, group, n, k, "does not re-quantize")
+    return mod
+
+
+def _requant_ab(mod, mm, n, k, expect_table):
+    """requant through the dispatcher (table kernel where it applies), again with the general kernel forced, and a third time with
+    the row scales handed in (sdnq_hip_requant_ws, the per-call mode): all bit-identical, and equal to the oracle."""
+    from sdnq_amd import linear as L
+    from tests.modules_util import oracle_from_module
     st = L._state(mod)
+    assert "SDNQ_HIP_REQUANT_LUT" not in os.environ
     wq, ws = ops.requant(st.qw, mm)
+    os.environ["SDNQ_HIP_REQUANT_LUT"] = "0"
+    try:
+        wq_gen, ws_gen = ops.requant(st.qw, mm)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["SDNQ_HIP_REQUANT_LUT"]
+    assert torch.equal(ws, ws_gen), "table kernel row scales != general kernel"
+    assert np.array_equal(bits_of(wq), bits_of(wq_gen)), "table kernel codes != general kernel"
     wq2, ws2 = ops.requant(st.qw, mm, ws.clone())
-    assert torch.equal(ws, ws2) and np.array_equal(bits_of(wq), bits_of(wq2))
+    assert torch.equal(ws, ws2) and np.array_equal(bits_of(wq), bits_of(wq2)), "known-scale call differs"
+    # the known-scale path must USE the scales it is given where the table kernel runs: doubled scales halve the int8 codes
+    if expect_table and mm == ops.MM_I8:
+        wq3, ws3 = ops.requant(st.qw, mm, ws * 2)
+        assert torch.equal(ws3, ws * 2)
+        a, b = wq.view(torch.int8).int(), wq3.view(torch.int8).int()
+        assert ((a - 2 * b).abs() <= 1).all() and not torch.equal(a, b)
     rq, rs = oracle_from_module(mod).re_quantize_matmul()[:2]
     assert np.array_equal(ws.cpu().numpy().reshape(-1), np.asarray(rs, dtype=np.float32).reshape(-1))
     assert np.array_equal(bits_of(wq).reshape(n, k), np.ascontiguousarray(rq).view(np.uint8).reshape(n, k))
+    assert (bits_of(wq).reshape(n, k)[7] == 0).all()  # the constant row
+
+
+@pytest.mark.parametrize("wd", ["int4", "uint4", "float4_e2m1fn", "float4_e3m0fn"])
+@pytest.mark.parametrize("mm_name", ["int8", "fp8"])
+@pytest.mark.parametrize("group", [64, 128, 32])
+@pytest.mark.parametrize("k", [640, 3072])
+def test_requant_table_path_equals_oracle_and_known_scales(wd, mm_name, group, k, gpu_device):
+    """4-bit weights in groups of a multiple of 64 are re-quantized through a 16-entry table per (row, group)
+    (requant_lut4_kernel, NP = 1 / 3 passes per row here); group 32 takes the general kernel.  Codes and row scales must equal the
+    oracle's re_quantize_matmul (dequantizer.py:166-174, 204-239) bit for bit, the general kernel's (SDNQ_HIP_REQUANT_LUT=0) bit for
+    bit, and a call that is handed the row scales (sdnq_hip_requant_ws, the per-call mode of SDNQ_HIP_CACHE_WEIGHTS=0)."""
+    n = 208
+    mod = _requant_layer(wd, mm_name, group, n, k, gpu_device)
+    _requant_ab(mod, ops.MM_I8 if mm_name == "int8" else ops.MM_FP8, n, k, expect_table=group % 64 == 0)
+
+
+@pytest.mark.parametrize("k", [2048, 4096, 5120, 6144, 7168, 8192, 9216, 12288, 13312, 15360, 16384])
+@pytest.mark.parametrize("wd,mm_name,group", [("int4", "int8", 64), ("float4_e2m1fn", "fp8", 128), ("uint4", "int8", 128)])
+def test_requant_table_every_row_length_class(k, wd, mm_name, group, gpu_device):
+    """Every NP instantiation of requant_lut4_kernel (passes of 1024 elements per row: 2, 4, 5, 6, 8 (K = 7168: one pass of
+    clamped lanes; K = 8192), 12 (9216, 12288), 16 (13312, 15360 = FLUX proj_out, 16384)) against the oracle and the general kernel."""
+    n = 48
+    mod = _requant_layer(wd, mm_name, group, n, k, gpu_device, seed=k)
+    _requant_ab(mod, ops.MM_I8 if mm_name == "int8" else ops.MM_FP8, n, k, expect_table=True)
 
 
 @pytest.mark.parametrize("form", ["plain", "svd", "zp", "svd+zp", "had+svd", "uint8mm", "fp8+svd"])

@@ -165,3 +165,25 @@ def test_activation_cache_teaches_producers_whether_their_entry_was_used():
     c.put(t1, "p", ("r1",), producer=b)
     c.invalidate(t1)
     assert b.__dict__["_sdnq_unshared"] < 0   # stays negative: one use by another layer settles it
+
+
+def test_gpu_skip_allow_list_is_short_and_literal():
+    """tests/conftest.py turns any skip of a -m gpu test on a GPU box into a failure unless its reason is allow-listed."""
+    from tests import conftest as C
+    assert C.skip_is_allowed("uint1: host-side packer only")
+    assert C.skip_is_allowed("needs two GPUs (RCCL over xGMI); the gloo test covers the plumbing")
+    assert C.skip_is_allowed("inductor backend unavailable here: RuntimeError")
+    assert not C.skip_is_allowed("configuration does not re-quantize")
+    assert not C.skip_is_allowed("large shapes once, in bf16")
+    assert len(C.ALLOWED_GPU_SKIPS) <= 4
+
+
+def test_gather_pipeline_never_leaves_a_chunk_below_the_small_batch_threshold():
+    from sdnq_amd.parallel import chunk_rows
+    for m in (256, 257, 1000, 2305, 4096, 4608, 4609, 33, 64, 65):
+        for chunks in (1, 2, 3, 4, 8, 9, 16, 72):
+            r = chunk_rows(m, chunks)
+            assert r[0][0] == 0 and r[-1][1] == m and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert all(b - a >= min(32, m) for a, b in r), (m, chunks, r)
+            assert all(a % 32 == 0 for a, _ in r)
+    assert chunk_rows(2305, 9) == [(0, 288), (288, 576), (576, 864), (864, 1152), (1152, 1440), (1440, 1728), (1728, 2016), (2016, 2305)]

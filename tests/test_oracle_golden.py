@@ -189,3 +189,15 @@ def test_conv_case_dequant_and_forward(name):
             scale = float(np.abs(ref).max())
             lim = {"bf16": 2.0 ** -7, "f16": 2.0 ** -10, "f32": 2e-6}[c.tag]
             assert np.abs(y - ref).max() <= lim * scale, (name, i, float(np.abs(y - ref).max()), scale)
+
+
+def test_golden_fixtures_are_what_the_reference_computes():
+    """Provenance (build container only: the reference does not travel): `make_golden.py --verify` rebuilds the reference layer of
+    every Linear / conv fixture from the STORED tensors and requires the stored outputs from the reference's own forward."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src/sdnq"):
+        pytest.skip("the reference is not present on this box")
+    r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden.py"), "--verify"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatching outputs: 0" in r.stdout

@@ -210,3 +210,37 @@ def test_compiled_block_with_grouping_equals_eager(gpu_device):
             pytest.skip(f"inductor backend unavailable here: {type(e).__name__}")
         assert torch_ops.merge_stats["launches_removed"] - before["launches_removed"] == 2
         assert (got.float() - want.float()).abs().max() <= 0.05 * want.float().abs().max()
+
+
+def test_options_refresh_the_compile_plan_cpu():
+    """apply_sdnq_options_to_model may switch the matmul mode / scale dtype / matmul dtype of a layer; the operator plan that
+    SDNQLayer.forward follows under torch.compile must follow (a stale plan makes the compiled model compute the OLD mode)."""
+    from sdnq_amd import loader
+    blk = _quantized_block(torch.device("cpu"), weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    mods = [m for m in blk.modules() if hasattr(m, "sdnq_dequantizer")]
+    assert mods and all(m.__dict__.get("_sdnq_hip_plan") == ("q", "int8", 0) for m in mods)
+    loader.apply_sdnq_options_to_model(blk, use_quantized_matmul=False)
+    assert all(m.__dict__.get("_sdnq_hip_plan") is None for m in mods)          # float mode: one layer_forward operator
+    loader.apply_sdnq_options_to_model(blk, use_quantized_matmul=True)
+    assert all(m.__dict__.get("_sdnq_hip_plan") == ("q", "int8", 0) for m in mods)
+    loader.apply_sdnq_options_to_model(blk, dequantize_fp32=False)                # bf16 scales: the _lp forwards, not the fp32 epilogue
+    assert all(m.scale.dtype == torch.bfloat16 and m.__dict__.get("_sdnq_hip_plan") is None for m in mods)
+    loader.apply_sdnq_options_to_model(blk, dequantize_fp32=True, quantized_matmul_dtype="float8_e4m3fn")
+    assert all(m.__dict__.get("_sdnq_hip_plan") is not None and m.__dict__["_sdnq_hip_plan"][1] == "fp8" for m in mods)
+
+
+@pytest.mark.gpu
+def test_compile_after_options_follows_the_new_mode(gpu_device):
+    """The compiled model after apply_sdnq_options_to_model equals the eager model in the NEW mode (aot_eager: same kernels)."""
+    from sdnq_amd import loader
+    blk = _quantized_block(gpu_device, weights_dtype="int8", group_size=-1, use_quantized_matmul=True)
+    sdnq_amd.accelerate(blk)
+    x = torch.randn(2, 77, 128, device=gpu_device, dtype=torch.bfloat16)
+    with torch.no_grad():
+        qmm = blk(x)
+        loader.apply_sdnq_options_to_model(blk, use_quantized_matmul=False)
+        want = blk(x)
+        assert not torch.equal(want, qmm)  # the float mode really computes something else
+        torch._dynamo.reset()
+        got = torch.compile(blk, fullgraph=True, backend="aot_eager")(x)
+        assert torch.equal(got, want)

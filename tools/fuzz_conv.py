@@ -1,52 +1,65 @@
 #!/usr/bin/env python3
-"""Development aid: random-geometry sweep of the int8 Conv2d / Conv3d forward (use_quantized_matmul_conv) against the oracle (bit-exact)."""
+"""Random-geometry sweep of the int8 Conv2d / Conv3d forward (use_quantized_matmul_conv) against the oracle (bit-exact).
+`run(seed, iters)` is also driven, bounded, by tests/test_fuzz_gpu.py under -m gpu."""
 import os, sys, random
 import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import sdnq_amd
-from tests.modules_util import oracle_from_module
-from oracle import oracle as O
-dev = torch.device("cuda:0")
-rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-bad = 0
-n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-for it in range(n_it):
-    groups = rng.choice([1, 1, 2, 4])
-    # per group: input channels * taps a multiple of 16 and >= 32 channels where the quantized matmul is to be taken
-    cin, cout = groups * 16 * rng.randint(2, 4), groups * 16 * rng.randint(2, 4)
-    ks = rng.choice([1, 3, 3, (3, 1), (1, 3), 5])
-    stride = rng.choice([1, 1, 2, (2, 1)])
-    pad = rng.choice([0, 1, 2])
-    dil = rng.choice([1, 1, 2])
-    h, w = rng.randint(5, 20), rng.randint(5, 20)
-    b = rng.choice([1, 2])
-    dt = rng.choice([torch.bfloat16, torch.float16])
-    tag = "bf16" if dt == torch.bfloat16 else "f16"
-    nd = rng.choice([2, 2, 3])
-    if nd == 3:
-        ks = rng.choice([1, 3, (3, 1, 1), (1, 3, 3), (2, 3, 3)])
-        stride = rng.choice([1, 1, 2, (1, 2, 2), (2, 1, 1)])
-        pad = rng.choice([0, 1, (1, 0, 0), (0, 1, 1)])
-        depth, h, w = rng.randint(2, 6), rng.randint(4, 10), rng.randint(4, 10)
-        conv = torch.nn.Conv3d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
-        shape = (b, cin, depth, h, w)
-    else:
-        conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
-        shape = (b, cin, h, w)
-    try:
-        y_shape = conv(torch.zeros(shape)).shape
-    except RuntimeError:
-        continue
-    if min(y_shape[2:]) < 1:
-        continue
-    mod, _ = sdnq_amd.sdnq_quantize_layer(conv.to(dt).to(dev), sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))
-    x = torch.randn(shape).to(dt)
-    y = mod(x.to(dev)).float().cpu().numpy()
-    meta = {"nd": nd, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
-            "padding_mode": mod.padding_mode, "groups": groups}
-    ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
-    if y.shape != ref.shape or not np.array_equal(y, ref):
-        bad += 1
-        print("MISMATCH", nd, groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape, int((y != ref).sum()) if y.shape == ref.shape else -1)
-print("conv fuzz done, mismatches:", bad)
+
+
+def run(seed: int = 0, iters: int = 40, verbose: bool = True) -> list:
+    import sdnq_amd
+    from tests.modules_util import oracle_from_module
+    from oracle import oracle as O
+    dev = torch.device("cuda:0")
+    rng = random.Random(seed)
+    bad = []
+    done = 0
+    for it in range(iters):
+        groups = rng.choice([1, 1, 2, 4])
+        # per group: input channels * taps a multiple of 16 and >= 32 channels where the quantized matmul is to be taken
+        cin, cout = groups * 16 * rng.randint(2, 4), groups * 16 * rng.randint(2, 4)
+        ks = rng.choice([1, 3, 3, (3, 1), (1, 3), 5])
+        stride = rng.choice([1, 1, 2, (2, 1)])
+        pad = rng.choice([0, 1, 2])
+        dil = rng.choice([1, 1, 2])
+        h, w = rng.randint(5, 20), rng.randint(5, 20)
+        b = rng.choice([1, 2])
+        dt = rng.choice([torch.bfloat16, torch.float16])
+        tag = "bf16" if dt == torch.bfloat16 else "f16"
+        nd = rng.choice([2, 2, 3])
+        if nd == 3:
+            ks = rng.choice([1, 3, (3, 1, 1), (1, 3, 3), (2, 3, 3)])
+            stride = rng.choice([1, 1, 2, (1, 2, 2), (2, 1, 1)])
+            pad = rng.choice([0, 1, (1, 0, 0), (0, 1, 1)])
+            depth, h, w = rng.randint(2, 6), rng.randint(4, 10), rng.randint(4, 10)
+            conv = torch.nn.Conv3d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
+            shape = (b, cin, depth, h, w)
+        else:
+            conv = torch.nn.Conv2d(cin, cout, ks, stride=stride, padding=pad, dilation=dil, groups=groups, bias=rng.random() < 0.7)
+            shape = (b, cin, h, w)
+        try:
+            y_shape = conv(torch.zeros(shape)).shape
+        except RuntimeError:
+            continue
+        if min(y_shape[2:]) < 1:
+            continue
+        mod, _ = sdnq_amd.sdnq_quantize_layer(conv.to(dt).to(dev), sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))
+        x = torch.randn(shape).to(dt)
+        y = mod(x.to(dev)).float().cpu().numpy()
+        meta = {"nd": nd, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
+                "padding_mode": mod.padding_mode, "groups": groups}
+        ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
+        done += 1
+        if y.shape != ref.shape or not np.array_equal(y, ref):
+            bad.append((nd, groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape,
+                        int((y != ref).sum()) if y.shape == ref.shape else -1))
+            if verbose:
+                print("MISMATCH", *bad[-1])
+    if verbose:
+        print("conv fuzz done, mismatches:", len(bad), "of", done, "geometries")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40) else 0)

@@ -21,4 +21,14 @@ for k in fe:
     out[k[:110]] = {"launches": len(f), "fetch_bytes_per_launch_corrected": 2 * 1024 * sum(f) / len(f), "write_bytes_per_launch": 1024 * sum(w) / max(1, len(w))}
     tot_f += 2 * 1024 * sum(f); tot_w += 1024 * sum(w); n += len(f)
 out["_all_" + filt] = {"launches": n, "hbm_bytes_per_launch": (tot_f + tot_w) / max(1, n), "fetch_bytes_per_launch_corrected": tot_f / max(1, n), "write_bytes_per_launch": tot_w / max(1, n)}
+import datetime, os, subprocess
+def _git(*a):
+    try:
+        return subprocess.run(["git", *a], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except OSError:
+        return ""
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sdnq_amd", "libsdnq_hip.so.srchash")
+out["_provenance"] = {"collected_utc": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
+                      "library_srchash": open(lib).read().strip()[:16] if os.path.exists(lib) else None,
+                      "method": "two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_shapes.py; FETCH_SIZE doubled (gfx950 correction)"}
 print(json.dumps(out, indent=1))
