@@ -242,14 +242,13 @@ def _state(mod) -> _State:
                 break
         else:
             return st
+    from .support import require
+    require(mod)  # the predicate accelerate() decides with: an unbuilt configuration fails here, loudly, with the same sentence
     dq = mod.sdnq_dequantizer
     st = _State()
     st.key = _signature(mod)
     st.qw = dq.quant_weight(mod.weight, mod.scale, getattr(mod, "zero_point", None), getattr(mod, "svd_up", None),
                             getattr(mod, "svd_down", None))
-    if st.qw.scale_dtype != torch.float32 and st.qw.scale_dtype != dq.result_dtype:
-        raise NotImplementedError(f"scale dtype {st.qw.scale_dtype} differs from the layer's result dtype {dq.result_dtype}: 16-bit "
-                                  "scales are built for the layout apply_sdnq_options_to_model(dequantize_fp32=False) produces")
     st.mm = None
     st.mm_weight = st.mm_scale = st.mm_zp = st.mm_wcs = None
     st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]

@@ -33,16 +33,17 @@ def adopt_dequantizer(dq) -> SDNQDequantizer:
 
 
 def is_hot_path_linear(module: torch.nn.Module) -> bool:
+    """An SDNQ Linear the HIP forwards compute (support.unsupported_reason is the one predicate)."""
+    from .support import unsupported_reason
     dq = getattr(module, "sdnq_dequantizer", None)
-    return dq is not None and getattr(dq, "layer_class_name", None) in ("Linear", "SDNQLinear") and not getattr(dq, "use_codebook", False)
+    return dq is not None and getattr(dq, "layer_class_name", None) in ("Linear", "SDNQLinear") and unsupported_reason(module) is None
 
 
 def is_hot_path_conv(module: torch.nn.Module) -> bool:
+    from .support import unsupported_reason
     dq = getattr(module, "sdnq_dequantizer", None)
     return (dq is not None and getattr(dq, "layer_class_name", None) in ("Conv1d", "Conv2d", "Conv3d", "SDNQConv1d", "SDNQConv2d", "SDNQConv3d")
-            and not getattr(dq, "use_codebook", False)
-            and not (getattr(dq, "use_hadamard", False) and getattr(module, "groups", 1) != 1)
-            and getattr(dq, "quantized_matmul_dtype", "int8") in ("int8", "uint8", "fp8", "float8_e4m3fn"))
+            and unsupported_reason(module) is None)
 
 
 def _unlink(module: torch.nn.Module):
@@ -61,22 +62,55 @@ def _clear_step_state(_module=None, _args=None):
     linear.invalidate(None)
 
 
+class AccelerateResult(int):
+    """What `accelerate()` returns: an int (the number of re-pointed modules, as before) that also carries `.accelerated` and
+    `.skipped` -- [(qualified module name, reason)] of the SDNQ layers that were left on the forward they came with."""
+
+    def __new__(cls, accelerated: int, skipped):
+        r = super().__new__(cls, accelerated)
+        r.accelerated, r.skipped = int(accelerated), list(skipped)
+        return r
+
+    def __iter__(self):  # `n, skipped = accelerate(model)`
+        return iter((self.accelerated, self.skipped))
+
+
 @torch.no_grad()
-def accelerate(model: torch.nn.Module) -> int:
-    """Route every quantized Linear (and Conv1d / Conv2d / Conv3d, any ``groups``) of ``model`` through the HIP forwards.
-    Returns the number of re-pointed modules."""
-    count = 0
-    for module in model.modules():
-        if is_hot_path_linear(module) or is_hot_path_conv(module):
-            dq = adopt_dequantizer(module.sdnq_dequantizer)
-            module.sdnq_dequantizer = dq
-            module.forward_func = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
-            module.__dict__.pop("_sdnq_hip_state", None)
-            _unlink(module)
-            if is_hot_path_linear(module):
-                from . import torch_ops
-                torch_ops.layer_handle(module)  # torch.compile: the layer traces as one sdnq_hip::layer_forward op
-            count += 1
+def accelerate(model: torch.nn.Module) -> AccelerateResult:
+    """Route every quantized Linear (and Conv1d / Conv2d / Conv3d, any ``groups``) of ``model`` that the HIP forwards compute
+    through them.  NEVER turns a working model into a failing one: support is decided per module here, before anything is
+    re-pointed (`support.unsupported_reason`, the predicate the forwards themselves use); an SDNQ layer in a configuration this
+    package does not build keeps the ``forward_func`` it came with -- on a reference-built model that is the reference's own
+    working forward (its idiom for a missing kernel: fall back + log.warning, kernel_wrappers.py:80-88) -- and ONE
+    ``warnings.warn`` lists them.  Returns the number of re-pointed modules (an int with ``.accelerated`` / ``.skipped``,
+    unpackable as ``(accelerated, skipped)``)."""
+    from .support import unsupported_reason
+    count, skipped = 0, []
+    for name, module in model.named_modules():
+        if getattr(module, "sdnq_dequantizer", None) is None:
+            continue
+        why = unsupported_reason(module)
+        if why is None:
+            try:
+                dq = adopt_dequantizer(module.sdnq_dequantizer)
+                fwd = get_forward_func(dq.layer_class_name, dq.quantized_matmul_dtype, dq.use_quantized_matmul)
+            except (NotImplementedError, KeyError, AttributeError, TypeError) as e:  # a foreign record this package cannot read
+                why = f"{type(e).__name__}: {e}"
+        if why is not None:
+            skipped.append((name or type(module).__name__, why))
+            continue
+        module.sdnq_dequantizer = dq
+        module.forward_func = fwd
+        module.__dict__.pop("_sdnq_hip_state", None)
+        _unlink(module)
+        if is_hot_path_linear(module):
+            from . import torch_ops
+            torch_ops.layer_handle(module)  # torch.compile: the layer traces as one sdnq_hip::layer_forward op
+        count += 1
+    if skipped:
+        import warnings
+        warnings.warn(f"sdnq_amd.accelerate: {len(skipped)} SDNQ layer(s) are not computed by the MI355X kernels and keep the forward they "
+                      "came with: " + "; ".join(f"{n} ({w})" for n, w in skipped[:8]) + (" ..." if len(skipped) > 8 else ""), stacklevel=2)
     from . import linear
     if linear.LINK_PROJECTIONS:
         link_projections(model)
@@ -90,7 +124,7 @@ def accelerate(model: torch.nn.Module) -> int:
                 pass
     if count and not getattr(model, "_sdnq_hip_step_hook", None):
         model._sdnq_hip_step_hook = model.register_forward_pre_hook(_clear_step_state)
-    return count
+    return AccelerateResult(count, skipped)
 
 
 @torch.no_grad()
@@ -260,8 +294,13 @@ def fuse_projections(model: torch.nn.Module) -> int:
 def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
                                 use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):
     for module in model.modules():
-        conv = is_hot_path_conv(module)
-        if not (is_hot_path_linear(module) or conv):
+        # every SDNQ Linear / conv layer, whether or not the HIP forwards compute its (old or new) configuration: the options only
+        # re-type tensors and re-point forward_func; an unbuilt configuration then fails loudly at its forward (support.require)
+        cls = getattr(getattr(module, "sdnq_dequantizer", None), "layer_class_name", None)
+        if cls is None or getattr(module.sdnq_dequantizer, "use_codebook", False):
+            continue
+        conv = cls in ("Conv1d", "Conv2d", "Conv3d", "SDNQConv1d", "SDNQConv2d", "SDNQConv3d")
+        if not (conv or cls in ("Linear", "SDNQLinear")):
             continue
         dq = adopt_dequantizer(module.sdnq_dequantizer)
         module.sdnq_dequantizer = dq

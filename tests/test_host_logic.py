@@ -187,3 +187,48 @@ def test_gather_pipeline_never_leaves_a_chunk_below_the_small_batch_threshold():
             assert all(b - a >= min(32, m) for a, b in r), (m, chunks, r)
             assert all(a % 32 == 0 for a, _ in r)
     assert chunk_rows(2305, 9) == [(0, 288), (288, 576), (576, 864), (864, 1152), (1152, 1440), (1440, 1728), (1728, 2016), (2016, 2305)]
+
+
+def test_accelerate_never_breaks_a_working_model():
+    """accelerate() decides support per module BEFORE re-pointing (support.unsupported_reason): a layer in a configuration the HIP
+    path does not build keeps the forward it came with -- here a stand-in for the reference's working forward -- and is listed in
+    ONE warning and in the result's `.skipped`; supported layers are re-pointed.  The forwards use the same predicate."""
+    import warnings
+    import pytest
+    import sdnq_amd
+    from sdnq_amd import linear, support
+
+    def ref_forward(self, x):  # what a reference-built module would carry: a working forward of its own
+        return torch.nn.functional.linear(x, torch.zeros(self.sdnq_dequantizer.out_features, x.shape[-1], dtype=x.dtype), None) + 7
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.Linear(64, 64), torch.nn.Conv2d(64, 64, 3, padding=1, groups=2)).to(torch.bfloat16)
+    model[0] = sdnq_amd.sdnq_quantize_layer(model[0], sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
+    model[1] = sdnq_amd.sdnq_quantize_layer(model[1], sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
+    model[2] = sdnq_amd.sdnq_quantize_layer(model[2], sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True,
+                                                                          use_hadamard=True))[0]
+    # layer 1: the reference's 16-bit float matmul (linear_fp16.py) -- not built here; layer 2: Hadamard on a grouped conv -- not built
+    model[1].sdnq_dequantizer.quantized_matmul_dtype = "float16"
+    for i in (0, 1, 2):
+        model[i].forward_func = ref_forward
+    assert support.unsupported_reason(model[0]) is None
+    assert "float16" in support.unsupported_reason(model[1]) and "Hadamard" in support.unsupported_reason(model[2])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        res = sdnq_amd.accelerate(model)
+    assert len(w) == 1 and "keep the forward they came with" in str(w[0].message)
+    n, skipped = res
+    assert res == 1 and n == 1 and res.accelerated == 1 and [s[0] for s in skipped] == ["1", "2"]
+    assert model[0].forward_func is not ref_forward and model[1].forward_func is ref_forward and model[2].forward_func is ref_forward
+    # the skipped layer still computes (its own forward); before this round accelerate() re-pointed it at a forward that raises
+    y = model[1](torch.ones(3, 64, dtype=torch.bfloat16))
+    assert y.shape == (3, 64) and float(y[0, 0]) == 7.0
+    # a layer that reaches a HIP forward in an unbuilt configuration fails loudly, with the predicate's sentence
+    model[1].forward_func = linear.quantized_linear_forward_int8_matmul
+    with pytest.raises(NotImplementedError, match="float16"):
+        linear._state(model[1])
+    # nothing to warn about on a fully supported model
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert sdnq_amd.accelerate(torch.nn.Sequential(model[0])) == 1
+    assert not w
