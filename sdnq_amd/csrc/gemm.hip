@@ -1727,6 +1727,11 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 19) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
         if (force == 20 && (p.K % 128) == 0 && ht_ok(p)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
         if (force == 20) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+        // (round 4, profiles/r04_ring_depth_in_step.txt: 5- and 6-deep rings for the 64x128 tile -- the one-workgroup-per-CU problems of the
+        //  SDXL step, 160 tiles on 256 CUs -- judged on the step: 1024 x 1280 x 1280 +0.11 / +0.13 ms, 4096 x 640 x 640 +0.15 / +0.16 ms,
+        //  1024 x 1280 x 5120 +-0.00: more bytes in flight do not raise the per-CU fill rate, so the 27 B/clk is not latency x bytes-in-flight
+        //  (Little's law would have predicted a gain) but the rate at which a CU's LDS-DMA requests are served; the deeper prologue only
+        //  delays the first MFMA.  Not instantiated in the library.)
         // (64x80 tiles on v_mfma_i32_16x16x64_i8 -- MM_I8_16, instantiated by tools/micro/gemm_lab.hip only -- cut 1024 x 1280 outputs
         //  into exactly 256 workgroups with 25 % fewer LDS-fill bytes per CU, and measured SLOWER than 160 tiles of 64x128: 9.5 vs 7.9 us
         //  at K = 1280, 23.5 vs 19.0 us at K = 5120: four waves of 16x80 read six fragments per five 16-cycle MFMAs)

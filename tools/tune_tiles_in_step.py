@@ -14,6 +14,12 @@ SHAPES = SHAPES[workload]
 CANDS = {"sdxl_int8": [1, 3, 7, 9, 10, 13, 17, 19], "flux_int4_had": [1, 3, 19, 20]}.get(workload, [1, 2, 3, 4])  # launch_tiles / launch_tiles_w8 ids
 
 
+if os.environ.get("TUNE_SHAPES"):  # "MxNxK,MxNxK": only these problems
+    SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["TUNE_SHAPES"].split(",")]
+if os.environ.get("TUNE_CANDS"):   # "1,21,22": only these tile ids
+    CANDS = [int(v) for v in os.environ["TUNE_CANDS"].split(",")]
+
+
 def run(env_map):
     env = dict(os.environ)
     if env_map:
@@ -37,4 +43,8 @@ for (m, n, k) in SHAPES:
         ms = run(f"{m}x{n}x{k}={t}")
         line += f"  {t}: " + (f"{ms:.3f} ({ms - b:+.3f})" if ms else "fail")
     print(line, flush=True)
+if os.environ.get("TUNE_ALL"):  # every listed problem on one candidate at once
+    for t in CANDS:
+        ms = run(",".join(f"{m}x{n}x{k}={t}" for (m, n, k) in SHAPES))
+        print(f"all listed problems on tile {t}: " + (f"{ms:.3f} ({ms - b:+.3f})" if ms else "fail"), flush=True)
 print("heuristics again:", run(None), flush=True)
