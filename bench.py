@@ -221,7 +221,34 @@ def run_step(layers):
     out = None
     for (_, mod, x, *_rest) in layers:
         out = mod(x)
+    L.join_weight_pipeline()  # per-call mode: a weight prefetch nobody consumed re-joins the stream (no-op otherwise)
     return out
+
+
+def resident_weight_bytes(layers):
+    """Bytes the quantized layers keep resident in HBM: stored parameters + whatever the forwards cached on the module (the int8 / fp8
+    matmul operand of a re-quantized layer, row scales) + the per-call mode's two scratch buffers."""
+    from sdnq_amd import linear as L
+    seen, stored, cached = set(), 0, 0
+
+    def add(t):
+        if t is None or not isinstance(t, torch.Tensor):
+            return 0
+        key = (t.untyped_storage().data_ptr(), t.storage_offset(), t.numel())
+        if key in seen:
+            return 0
+        seen.add(key)
+        return t.numel() * t.element_size()
+    for (_, mod, *_r) in layers:
+        inner = getattr(mod, "local", mod)
+        for name in ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias"):
+            stored += add(getattr(inner, name, None))
+        st = inner.__dict__.get("_sdnq_hip_state")
+        if st is not None:
+            for name in ("mm_weight", "mm_scale", "mm_zp", "mm_wcs", "wd", "svd_down_t"):
+                cached += add(getattr(st, name, None))
+    return {"stored_parameters": stored, "cached_matmul_operands": cached, "per_call_scratch": L._weight_pipeline.scratch_bytes(),
+            "total": stored + cached + L._weight_pipeline.scratch_bytes()}
 
 
 def time_gemm_kernel(layers, mm_name, device):
@@ -230,6 +257,8 @@ def time_gemm_kernel(layers, mm_name, device):
     from sdnq_amd import ops
     mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
     calls, total_ops, total_bytes, seen_groups = [], 0, 0, set()
+    if not L.CACHE_WEIGHTS and L.PIPELINE_WEIGHTS:
+        return None  # per-call mode: every layer's operand lives in one of two scratch buffers, they cannot all be held at once
     for (_, mod, x, m, k, n, has_bias) in layers:
         if m < 32 or not hasattr(mod, "sdnq_dequantizer"):
             continue
@@ -1014,6 +1043,8 @@ def main():
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
                    **({"activation_pool": args.activation_pool, "activation_buffers": len({l[2].data_ptr() for l in layers})} if args.activation_pool else {}),
                    "requantized_weight_cache": L.CACHE_WEIGHTS, "fused_projections": bool(args.fuse_projections),
+                   "resident_weight_bytes": resident_weight_bytes(layers),
+                   **({"per_call_weight_pipeline": {"enabled": L.PIPELINE_WEIGHTS, **L._weight_pipeline.stats}} if not L.CACHE_WEIGHTS else {}),
                    "linked_projection_groups": linked,
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         **({"tp": {"ranks": world, "rank_devices": [f"cuda:{r}" for r in range(world)], "rccl_version": list(torch.cuda.nccl.version()),

@@ -324,6 +324,24 @@ int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, con
 int sdnq_hip_unshard_columns(const void* gathered, void* out, int elem_bytes, int64_t m0, int64_t m_rows, int64_t m,
                              int64_t wmax, int world, const int64_t* starts, sdnq_stream_t stream);
 
+/* Copy-free gather of a column-sharded Linear over PEER-MAPPED memory (round 4; SURVEY 8e: "have the GEMM write directly into a
+ * symmetric [M,N] buffer").  Every rank of the node owns an arena that all ranks have mapped through hipIpc handles (exchanged once, by
+ * the host side: sdnq_amd/parallel.py); a rank's output matrix [M][ldc] of gather number `seq` lives at a byte offset of ITS arena
+ * that it announces with sdnq_hip_push_post (a 64-bit word -- seq in the top 24 bits, offset / 256 below -- stored into slot `rank` of
+ * every rank's `post` array).  sdnq_hip_push_columns then copies this rank's slab y [rows][w] (row stride ldy elements) into columns
+ * [col0, col0 + w), rows [row0, row0 + rows) of EVERY rank's matrix (local stores for its own, P2P stores over xGMI for the peers'),
+ * stores `seq` into slot `rank` of every rank's `done` array and returns (stream-ordered) only when slot r of its OWN done array
+ * carries `seq` for every r: this rank's matrix is then complete.  No staging buffer, no collective, no re-assembly pass.
+ * arena / post / done: HOST arrays of `world` device pointers as mapped in THIS process (entry `rank` = the local one); post / done
+ * are u64 [world] arrays; ticket: device u32, zero; status: device i32, set to 1 when a rendezvous spin exceeded timeout_ms (the host
+ * side raises instead of hanging the GPU).  Not capturable into a hipGraph together with its peers' launches in a fixed order only if
+ * the arena offsets are the same at replay -- the host side runs it eagerly. */
+#define SDNQ_MAX_PUSH_RANKS 16
+int sdnq_hip_push_post(void* const* post, int world, int rank, uint64_t seq, uint64_t arena_offset, sdnq_stream_t stream);
+int sdnq_hip_push_columns(const void* y, int elem_bytes, int64_t rows, int64_t w, int64_t ldy, void* const* arena, void* const* post,
+                          void* const* done, int world, int rank, uint64_t seq, int64_t ldc, int64_t col0, int64_t row0, void* ticket,
+                          void* status, int timeout_ms, sdnq_stream_t stream);
+
 /* ---- 8(f) rank 3: convolution as GEMM -----------------------------------------------------------
  * replaces the F.unfold(...).transpose(1, 2) of process_conv_input (layers/conv/forward.py:30-76) for Conv1d (height = 1,
  * kh = 1) and Conv2d inputs x [batch][channels][height][width] of `dtype`: out [M][K] with rows m = (b, h_out, w_out),

@@ -35,7 +35,142 @@ __global__ __launch_bounds__(256) void unshard_columns_kernel(const UnshardParam
     *(uint4*)(p.out + (p.m0 + r_m) * p.n_bytes + cb) = v;
 }
 
+// ---- copy-free gather over peer-mapped memory (round 4) -----------------------------------------------------------------------------
+// Every rank owns an output matrix [M][N] inside an IPC-shared arena that all ranks of the node have mapped (hipIpc handles, exchanged
+// once).  Rank r PUSHES its slab y_r [rows][w] straight into columns [col0, col0 + w) of every rank's matrix -- its own with local
+// stores, the peers' with P2P stores over xGMI -- so the gather needs no staging buffer, no collective call and no re-assembly pass:
+// the one HBM read of y_r feeds W writes.  Rendezvous through two small peer-mapped u64 arrays per rank (each rank's arrays live in
+// ITS OWN arena, written remotely, read locally):
+//   post[s]  : rank s says "sequence number q of mine goes to byte offset o of MY arena" (one word: q in the top 24 bits, o / 256 below);
+//              the receiver chooses where it receives, so the ranks' allocators never have to agree
+//   done[s]  : rank s says "my slab of sequence q has landed in your matrix"
+// push_columns_kernel: every workgroup reads the W posts (spinning until they carry q -- they were posted before the layer's matmul),
+// copies its pieces to the W destinations, fences at system scope and takes a ticket; the LAST workgroup stores done[rank] = q into
+// every rank's array (release, system scope) and then waits until its own done[*] carry q: when the kernel ends, this rank's output
+// matrix is complete and every peer has been told about this rank's slab.  Spins are bounded by the wall clock (status word != 0 on
+// timeout: the host raises instead of hanging the GPU).
+struct PushParams {
+    const uint8_t* y;        // [rows][ldy_bytes]
+    int64_t rows, w_bytes, ldy_bytes;
+    int64_t ldc_bytes, col0_bytes, row0;   // destination geometry: row-major [*][ldc], first column / first row of the slab
+    uint8_t* arena[SDNQ_MAX_PUSH_RANKS];         // every rank's arena base as mapped HERE
+    unsigned long long* post[SDNQ_MAX_PUSH_RANKS];   // rank p's post array (u64 [world]) as mapped here
+    unsigned long long* done[SDNQ_MAX_PUSH_RANKS];   // rank p's done array
+    int world, rank;
+    unsigned long long seq;   // 24-bit sequence number of this gather
+    unsigned int* ticket;     // device-local counter (zero before and after the launch)
+    int* status;              // device-local: set to 1 on a rendezvous timeout
+    long long timeout_ticks;  // wall_clock64 ticks (100 MHz)
+};
+
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void push_columns_kernel(const PushParams p) {
+    __shared__ unsigned long long s_off[SDNQ_MAX_PUSH_RANKS];
+    __shared__ int s_fail, s_last;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_fail = 0; s_last = 0; }
+    __syncthreads();
+    const long long t0 = wall_clock64();
+    if (tid < p.world) {  // where does rank `tid` want sequence p.seq?  (its post array lives in ITS arena: a remote read for tid != rank)
+        unsigned long long v;
+        for (;;) {
+            v = ld_sys(p.post[tid] + p.rank);
+            if ((v >> 40) == p.seq) break;
+            if (wall_clock64() - t0 > p.timeout_ticks) { s_fail = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        s_off[tid] = (v & 0xffffffffffull) << 8;
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) *p.status = 1;
+    } else {
+        const int64_t pieces = p.w_bytes >> 4;
+        const int64_t total = p.rows * pieces;
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + tid; idx < total; idx += (int64_t)gridDim.x * 256) {
+            const int64_t r = idx / pieces, cb = (idx - r * pieces) << 4;
+            const uint4 v = *(const uint4*)(p.y + r * p.ldy_bytes + cb);
+            const int64_t dofs = (p.row0 + r) * p.ldc_bytes + p.col0_bytes + cb;
+#pragma unroll 1
+            for (int d = 0; d < p.world; ++d) {
+                const int q = (p.rank + d) % p.world;  // own matrix first, then the peers round-robin (every link busy at once)
+                *(uint4*)(p.arena[q] + s_off[q] + dofs) = v;
+            }
+        }
+    }
+    __threadfence_system();  // this workgroup's stores are visible system-wide before its ticket
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(p.ticket, 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) *p.ticket = 0;  // ready for the next launch (stream-ordered)
+    __threadfence_system();
+    if (tid < p.world) {
+        if (!s_fail) __hip_atomic_store(p.done[tid] + p.rank, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (;;) {  // every peer's slab has landed here
+            if (ld_sys(p.done[p.rank] + tid) == p.seq) break;
+            if (wall_clock64() - t0 > p.timeout_ticks) { *p.status = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
+struct PostParams {
+    unsigned long long* post[SDNQ_MAX_PUSH_RANKS];
+    int world, rank;
+    unsigned long long word;
+};
+
+__global__ void post_kernel(const PostParams p) {
+    const int t = threadIdx.x;
+    if (t < p.world) __hip_atomic_store(p.post[t] + p.rank, p.word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
+
+extern "C" int sdnq_hip_push_post(void* const* post, int world, int rank, uint64_t seq, uint64_t arena_offset, sdnq_stream_t stream) {
+    if (!post) return SDNQ_ERR_NULL;
+    if (world < 1 || world > SDNQ_MAX_PUSH_RANKS || rank < 0 || rank >= world) return SDNQ_ERR_SHAPE;
+    if ((arena_offset & 255) || (arena_offset >> 48) || (seq >> 24)) return SDNQ_ERR_ALIGN;
+    PostParams p{};
+    for (int r = 0; r < world; ++r) {
+        if (!post[r]) return SDNQ_ERR_NULL;
+        p.post[r] = (unsigned long long*)post[r];
+    }
+    p.world = world; p.rank = rank; p.word = (seq << 40) | (arena_offset >> 8);
+    hipLaunchKernelGGL(post_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_push_columns(const void* y, int elem_bytes, int64_t rows, int64_t w, int64_t ldy, void* const* arena,
+                                     void* const* post, void* const* done, int world, int rank, uint64_t seq, int64_t ldc,
+                                     int64_t col0, int64_t row0, void* ticket, void* status, int timeout_ms, sdnq_stream_t stream) {
+    if (!y || !arena || !post || !done || !ticket || !status) return SDNQ_ERR_NULL;
+    if (world < 1 || world > SDNQ_MAX_PUSH_RANKS || rank < 0 || rank >= world || (elem_bytes != 2 && elem_bytes != 4)) return SDNQ_ERR_SHAPE;
+    if (rows <= 0 || w <= 0 || ldy < w || ldc < col0 + w || col0 < 0 || row0 < 0 || (seq >> 24)) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)y % 16) || ((w * elem_bytes) % 16) || ((ldy * elem_bytes) % 16) || ((ldc * elem_bytes) % 16) || ((col0 * elem_bytes) % 16))
+        return SDNQ_ERR_ALIGN;
+    PushParams p{};
+    p.y = (const uint8_t*)y; p.rows = rows; p.w_bytes = w * elem_bytes; p.ldy_bytes = ldy * elem_bytes;
+    p.ldc_bytes = ldc * elem_bytes; p.col0_bytes = col0 * elem_bytes; p.row0 = row0;
+    for (int r = 0; r < world; ++r) {
+        if (!arena[r] || !post[r] || !done[r]) return SDNQ_ERR_NULL;
+        if ((uintptr_t)arena[r] % 256) return SDNQ_ERR_ALIGN;
+        p.arena[r] = (uint8_t*)arena[r]; p.post[r] = (unsigned long long*)post[r]; p.done[r] = (unsigned long long*)done[r];
+    }
+    p.world = world; p.rank = rank; p.seq = seq; p.ticket = (unsigned int*)ticket; p.status = (int*)status;
+    p.timeout_ticks = (long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ll;  // wall_clock64: 100 MHz
+    const int64_t total = rows * (p.w_bytes >> 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;  // grid-stride: enough workgroups to keep every link and HBM channel busy
+    hipLaunchKernelGGL(push_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
 
 extern "C" int sdnq_hip_unshard_columns(const void* gathered, void* out, int elem_bytes, int64_t m0, int64_t m_rows, int64_t m,
                                         int64_t wmax, int world, const int64_t* starts, sdnq_stream_t stream) {

@@ -27,6 +27,10 @@ from . import ops
 from .common import dtype_dict
 
 CACHE_WEIGHTS = os.environ.get("SDNQ_HIP_CACHE_WEIGHTS", "1").lower() not in {"0", "false", "no"}
+# per-call mode (CACHE_WEIGHTS off): re-quantize the NEXT layer's weights on a side stream under this layer's GEMM (_WeightPipeline).
+# Measured SLOWER than the inline re-quantization (profiles/r04_percall_pipeline.txt: FLUX int4 step 42.26 vs 40.96 ms, eager 44.2 vs
+# 41.3: the GEMM loses more than the hidden kernel costs): a tested opt-in, off by default
+PIPELINE_WEIGHTS = os.environ.get("SDNQ_HIP_PIPELINE_WEIGHTS", "0").lower() not in {"0", "false", "no"}
 PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "0").lower() not in {"0", "false", "no"}  # measured: no gain
 FUSED_SKINNY = os.environ.get("SDNQ_HIP_FUSED_SKINNY", "1").lower() not in {"0", "false", "no"}
 FUSED_DEQUANT_GEMM = os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM", "1").lower() not in {"0", "false", "no"}
@@ -153,6 +157,7 @@ _groups = []  # weak references to the live SharedInputGroups (invalidate() reac
 
 def clear_activation_cache():
     _act_cache.clear()
+    _weight_pipeline.start_step()
 
 
 def invalidate(tensor: torch.Tensor | None = None):
@@ -160,6 +165,8 @@ def invalidate(tensor: torch.Tensor | None = None):
     handed out); with no argument, from every tensor.  Needed only when a tensor's contents were changed WITHOUT bumping its
     autograd version counter, e.g. by another library's raw-pointer kernel."""
     _act_cache.invalidate(tensor)
+    if tensor is None:
+        _weight_pipeline.start_step()
     _groups[:] = [ref for ref in _groups if ref() is not None]
     for ref in _groups:
         g = ref()
@@ -323,6 +330,109 @@ def quantized_linear_forward(self, input: torch.Tensor) -> torch.Tensor:
     return _float_forward(self, input, _state(self))
 
 
+class _WeightPipeline:
+    """Per-call mode (SDNQ_HIP_CACHE_WEIGHTS=0: the stored codes are the only resident copy of a re-quantized layer's weights, 0.5625
+    B per weight for int4 in groups of 64 instead of 1.56 with the int8 copy) without paying the re-quantization on the critical
+    path: while layer i's row quantization and GEMM run on the caller's stream, layer i + 1's weights are re-quantized on a SIDE
+    stream into the other of TWO scratch buffers (each sized for the largest such layer seen) -- the table kernel is VALU / HBM work,
+    the GEMM it runs under is bound by the matrix pipe.  Which layer comes next is learned from the call sequence of the previous
+    step; a wrong guess costs one wasted launch (the layer then re-quantizes inline).  Same kernel, same bytes: bit-identical.
+
+    Hazards (slot = scratch buffer): layer i reads slot s_i in its GEMM on the caller's stream.  The prefetch for layer i + 1 writes
+    the other slot, last read by GEMM(i - 1): the side stream first waits for an event recorded on the caller's stream at the START of
+    layer i's forward (after GEMM(i - 1) was enqueued).  Layer i + 1's forward waits for the prefetch's event before its GEMM.  A
+    stray prefetch (wrong guess) is waited for before its slot is written again.  Works under hipGraph capture (fork / join by
+    events); `join()` re-joins a prefetch nobody consumed (end of a step)."""
+
+    def __init__(self):
+        self.order = {}       # id(module) -> weakref of the module that followed it in the last step
+        self.prev = None      # weakref of the previous per-call layer of this step
+        self.pending = None   # (id(module), mm, wq, ws, event, slot, stream key)
+        self.slot = 0         # slot the CURRENT layer uses
+        self.scratch = {}     # (device index, slot) -> uint8 buffer
+        self.side = {}        # device index -> side stream
+        self.stats = {"prefetched": 0, "inline": 0, "wasted": 0}
+
+    def _buffer(self, dev: torch.device, slot: int, nbytes: int) -> torch.Tensor:
+        key = (dev.index, slot)
+        buf = self.scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                # growing inside a capture would bake a buffer into the graph that a later eager call replaces: the warm-up step
+                # (eager, before capture) must have seen every layer
+                raise ops._lib.SdnqHipError("per-call weight pipeline: run one eager step before capturing a graph (scratch not sized yet)")
+            buf = torch.empty((nbytes + 255) // 256 * 256, device=dev, dtype=torch.uint8)
+            self.scratch[key] = buf
+        return buf
+
+    def scratch_bytes(self) -> int:
+        return sum(b.numel() for b in self.scratch.values())
+
+    def join(self):
+        """Re-join an unconsumed prefetch into the current stream (end of a step / before its slot is reused)."""
+        if self.pending is not None:
+            torch.cuda.current_stream(self.pending[2].device).wait_event(self.pending[4])
+            self.pending = None
+            self.stats["wasted"] += 1
+
+    def start_step(self):
+        self.join()
+        self.prev = None
+
+    def weights(self, mod, st, mm: int, known_ws):
+        """(wq, ws) of `mod` for this call -- from the prefetch launched during the previous layer, or re-quantized inline -- and
+        the prefetch for the layer expected next."""
+        import weakref
+        dev = st.qw.keep[0].device
+        cur = torch.cuda.current_stream(dev)
+        nbytes = st.qw.n * st.qw.k
+        p = self.pending
+        if p is not None and p[0] == id(mod) and p[1] == mm and p[6] == cur.cuda_stream:
+            cur.wait_event(p[4])
+            wq, ws, self.slot = p[2], p[3], p[5]
+            self.pending = None
+            self.stats["prefetched"] += 1
+        else:
+            self.join()  # a stray prefetch: its slot may be the one written next
+            self.slot ^= 1
+            wq, ws = ops.requant(st.qw, mm, known_ws, out=self._buffer(dev, self.slot, nbytes))
+            self.stats["inline"] += 1
+        # learn the order, then launch the next layer's re-quantization under this layer's GEMM
+        prev = self.prev() if self.prev is not None else None
+        if prev is not None:
+            self.order[id(prev)] = weakref.ref(mod)
+        self.prev = weakref.ref(mod)
+        nref = self.order.get(id(mod))
+        nxt = nref() if nref is not None else None
+        if nxt is not None and nxt is not mod:
+            nst = nxt.__dict__.get("_sdnq_hip_state")
+            ndq = getattr(nxt, "sdnq_dequantizer", None)
+            if (nst is not None and ndq is not None and ndq.re_quantize_for_matmul and nst.mm == (mm, False) and nst.mm_weight is None
+                    and nst.mm_scale is not None and nst.qw.keep[0].device == dev):
+                side = self.side.get(dev.index)
+                if side is None:
+                    side = self.side[dev.index] = torch.cuda.Stream(device=dev)
+                slot = self.slot ^ 1
+                out = self._buffer(dev, slot, nst.qw.n * nst.qw.k)
+                start = torch.cuda.Event()
+                start.record(cur)  # GEMM(i - 1), the last reader of that slot, is in front of this point
+                with torch.cuda.stream(side):
+                    side.wait_event(start)
+                    nwq, nws = ops.requant(nst.qw, mm, nst.mm_scale, out=out)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                self.pending = (id(nxt), mm, nwq, nws, done, slot, cur.cuda_stream)
+        return wq, ws
+
+
+_weight_pipeline = _WeightPipeline()
+
+
+def join_weight_pipeline():
+    """End of a step in the per-call mode: re-join a weight prefetch nobody consumed (required before a graph capture ends)."""
+    _weight_pipeline.join()
+
+
 def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
     """Weight operand of the quantized matmul: (wq [N,K], ws [N], zp [N] | None).  `asymmetric` (the uint8 matmul) only changes
     the re-quantizer: min / max range and a zero point per output row."""
@@ -337,7 +447,11 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
         # linear_int8.py:104-107; zero_point folded, none afterwards.  Per-call mode (SDNQ_HIP_CACHE_WEIGHTS=0): the N row scales of
         # the first call are kept (4 bytes per output channel), the [N][K] operand is not
         known = st.mm_scale if (st.mm == key and st.mm_weight is None) else None
-        wq, ws = ops.requant(st.qw, mm, known)
+        if not CACHE_WEIGHTS and PIPELINE_WEIGHTS and known is not None and st.qw.keep[0].is_cuda:
+            # (the first call of a layer derives its row scales inline; from the second on the layer takes part in the pipeline)
+            wq, ws = _weight_pipeline.weights(mod, st, mm, known)
+        else:
+            wq, ws = ops.requant(st.qw, mm, known)
     else:
         ws = st.qw.keep[1]  # row-wise scale [N]
         ent = dtype_dict[dq.weights_dtype]

@@ -75,6 +75,14 @@ class AccelerateResult(int):
         return iter((self.accelerated, self.skipped))
 
 
+def _end_step(_module=None, _args=None, _output=None):
+    """forward-hook of the root model: the per-call mode's weight prefetch re-joins the caller's stream (linear._WeightPipeline)."""
+    if torch.compiler.is_compiling():
+        return
+    from . import linear
+    linear.join_weight_pipeline()
+
+
 @torch.no_grad()
 def accelerate(model: torch.nn.Module) -> AccelerateResult:
     """Route every quantized Linear (and Conv1d / Conv2d / Conv3d, any ``groups``) of ``model`` that the HIP forwards compute
@@ -124,6 +132,7 @@ def accelerate(model: torch.nn.Module) -> AccelerateResult:
                 pass
     if count and not getattr(model, "_sdnq_hip_step_hook", None):
         model._sdnq_hip_step_hook = model.register_forward_pre_hook(_clear_step_state)
+        model._sdnq_hip_step_end_hook = model.register_forward_hook(_end_step)
     return AccelerateResult(count, skipped)
 
 

@@ -486,11 +486,17 @@ def dequant(qw: QuantWeight, out_dtype: torch.dtype, hadamard_group: int = 0, us
     return out
 
 
-def requant(qw: QuantWeight, mm: int, ws: torch.Tensor | None = None):
+def requant(qw: QuantWeight, mm: int, ws: torch.Tensor | None = None, out: torch.Tensor | None = None):
     """re_quantize_int_mm / re_quantize_fp_mm (dequantizer.py:166-174, 204-239): (wq [N, K] int8 | fp8, ws [N] f32).  `ws`: the row
-    scales of an earlier call on the same weights (sdnq_hip_requant_ws: the pass that derives them is skipped where the kernel can)."""
+    scales of an earlier call on the same weights (sdnq_hip_requant_ws: the pass that derives them is skipped where the kernel can).
+    `out`: caller-owned byte buffer of at least N * K bytes (16-byte aligned) the operand is written into (the per-call mode's
+    double-buffered scratch); the returned wq is a view of it.  Runs on torch's CURRENT stream."""
     dev = qw.keep[0].device
-    wq = torch.empty((qw.n, qw.k), device=dev, dtype=_MM_TORCH[mm])
+    if out is not None:
+        assert out.is_cuda and out.element_size() == 1 and out.numel() >= qw.n * qw.k and out.data_ptr() % 16 == 0
+        wq = out[: qw.n * qw.k].view(_MM_TORCH[mm]).view(qw.n, qw.k)
+    else:
+        wq = torch.empty((qw.n, qw.k), device=dev, dtype=_MM_TORCH[mm])
     known = ws is not None
     if not known:
         ws = torch.empty((qw.n,), device=dev, dtype=torch.float32)

@@ -24,8 +24,15 @@ slab) is kept for building sharded models from float checkpoints; with SVD it de
 
 Why the gather is not "in place": RCCL collectives move one contiguous buffer per rank, and rank r's columns of a row-major
 [M, N] matrix are M strided pieces, so the gathered [W, M, N/W] buffer needs one transposing copy: ``sdnq_hip_unshard_columns``
-(csrc/parallel.hip), one HBM-bound pass that also trims the padding of uneven shards.  A copy-free variant needs the GEMM epilogue
-to store straight into every peer's [M, N] buffer over xGMI (IPC-mapped peer memory): not built.
+(csrc/parallel.hip), one HBM-bound pass that also trims the padding of uneven shards.
+
+The COPY-FREE variant (round 4, ``PeerArena`` / ``column_shard_module(..., peer=arena)``): every rank owns an arena that all ranks
+of the node have mapped through IPC handles (exchanged once); rank r pushes its slab straight into columns [a_r, b_r) of EVERY
+rank's row-major [M, N] output with P2P stores over xGMI (``sdnq_hip_push_columns``): no staging buffer, no RCCL call, no
+re-assembly pass -- the one read of y_r feeds W writes.  The receiver chooses where it receives (a ring allocator over its arena that
+never reuses memory a live tensor still views) and announces the offset per gather through a peer-mapped mailbox, so the ranks'
+allocators never have to agree; completion is signalled through peer-mapped flags (no collective).  Falls back to the RCCL path
+when peer mapping is unavailable.
 """
 from __future__ import annotations
 
@@ -56,6 +63,135 @@ def chunk_rows(m: int, chunks: int) -> list[tuple[int, int]]:
     return [(a, starts[i + 1] if i + 1 < len(starts) else m) for i, a in enumerate(starts)]
 
 
+class _Region:
+    """A byte range of the arena exported through ``__cuda_array_interface__``: a tensor made from it (``torch.as_tensor``) has its OWN
+    storage object whose deleter drops this Python object -- so `weakref(region)` is dead exactly when no tensor, and no view of one,
+    still uses the range (every view shares that storage).  That is what lets the ring allocator reuse memory safely."""
+
+    def __init__(self, ptr: int, nbytes: int, owner):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
+        self._owner = owner  # keeps the arena allocation alive as long as any output tensor lives
+
+
+class PeerArena:
+    """The per-rank half of the copy-free gather: an IPC-shared arena (control words + a ring of output matrices) mapped by every rank
+    of `group` (one node), and the rendezvous protocol of ``sdnq_hip_push_post`` / ``sdnq_hip_push_columns`` (include/sdnq_hip.h).
+
+    Layout of a rank's arena: bytes [0, 128) post[16] u64, [128, 256) done[16] u64, data from byte 256.  `gather(y, n_total, col0)`
+    returns this rank's complete row-major [rows, n_total] matrix: a tensor over arena memory (no copy) that stays valid as long as it
+    (or any view of it) is referenced -- the ring never hands out a range that a live tensor still uses; when the ring is full of live
+    tensors it raises (size it with SDNQ_HIP_TP_ARENA_MB, default 2048).  All ranks must call gather() the same number of times in the
+    same order (SPMD), like any collective; a rank that does not show up trips the timeout (status word) instead of hanging the GPU."""
+
+    CTRL = 256
+
+    def __init__(self, rank: int, world: int, group=None, device=None, arena_bytes: int | None = None, timeout_ms: int = 2000):
+        import os
+        import torch.distributed as dist
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import _lib
+        if world > 16:
+            raise ValueError("PeerArena: at most 16 ranks (one node)")
+        self.rank, self.world, self.group, self.timeout_ms = rank, world, group, int(timeout_ms)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if arena_bytes is None:
+            arena_bytes = int(os.environ.get("SDNQ_HIP_TP_ARENA_MB", "2048")) << 20
+        self.size = (int(arena_bytes) + 255) // 256 * 256
+        self.buf = torch.zeros(self.CTRL + self.size, dtype=torch.uint8, device=self.device)
+        if self.buf.data_ptr() % 256:
+            raise _lib.SdnqHipError("PeerArena: allocation is not 256-byte aligned")
+        torch.cuda.synchronize(self.device)  # the zeroed control words are in memory before any peer maps them
+        # exchange the IPC handles (the reduce_tensor tuple is plain data: picklable through any backend's all_gather_object)
+        fn, args = reduce_tensor(self.buf)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (rank, args), group=group)
+        self.peers = [None] * world
+        for r, a in gathered:
+            self.peers[r] = self.buf if r == rank else fn(*a)
+        ptrs = [int(t.data_ptr()) for t in self.peers]
+        import ctypes
+        arr = ctypes.c_void_p * world
+        self._arena = arr(*[p for p in ptrs])
+        self._post = arr(*[p for p in ptrs])
+        self._done = arr(*[p + 128 for p in ptrs])
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.seq = 0
+        self.head = self.CTRL
+        self.live = []  # [(start, end, weakref(_Region))] in ring order
+        dist.barrier(group=group)  # every rank has mapped every arena before the first push
+
+    # ---- ring allocator over [CTRL, CTRL + size) ----------------------------------------------------------------------------------
+    def _alloc(self, nbytes: int):
+        import weakref
+        n = (nbytes + 255) // 256 * 256
+        if n > self.size:
+            raise RuntimeError(f"PeerArena: output of {nbytes} bytes exceeds the arena ({self.size} bytes; SDNQ_HIP_TP_ARENA_MB)")
+        if self.head + n > self.CTRL + self.size:
+            self.head = self.CTRL
+        start, end = self.head, self.head + n
+        keep = []
+        for (a, b, ref) in self.live:
+            if a < end and start < b:
+                if ref() is not None:
+                    raise RuntimeError("PeerArena: the ring is full of live output tensors; raise SDNQ_HIP_TP_ARENA_MB or drop references "
+                                       f"(need [{start}, {end}), [{a}, {b}) is still in use)")
+            else:
+                keep.append((a, b, ref))
+        region = _Region(self.buf.data_ptr() + start, n, self.buf)
+        keep.append((start, end, weakref.ref(region)))
+        self.live = keep
+        self.head = end
+        return start, region
+
+    def gather(self, y: torch.Tensor, n_total: int, col0: int) -> torch.Tensor:
+        """This rank's slab y [rows, w] goes to columns [col0, col0 + w) of every rank's [rows, n_total] output; returns this rank's."""
+        from . import _lib, ops
+        lib = _lib.load()
+        rows, w = y.shape
+        es = y.element_size()
+        if y.stride(1) != 1:
+            y = y.contiguous()
+        off, region = self._alloc(rows * n_total * es)
+        self.seq = (self.seq + 1) & 0xFFFFFF
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ops.check(lib.sdnq_hip_push_post(self._post, self.world, self.rank, self.seq, off, stream), "push_post")
+        ops.check(lib.sdnq_hip_push_columns(y.data_ptr(), es, rows, w, y.stride(0), self._arena, self._post, self._done, self.world, self.rank,
+                                            self.seq, n_total, col0, 0, self._ticket.data_ptr(), self._status.data_ptr(), self.timeout_ms,
+                                            stream), "push_columns")
+        out = torch.as_tensor(region, device=self.device).view(y.dtype)[: rows * n_total].view(rows, n_total)
+        return out
+
+    def post(self, rows: int, n_total: int, dtype: torch.dtype):
+        """Two-step form: announce the destination BEFORE the layer's matmul (the peers' pushes then never wait for it); returns a
+        token for `push`."""
+        from . import _lib, ops
+        es = torch.empty((), dtype=dtype).element_size()
+        off, region = self._alloc(rows * n_total * es)
+        self.seq = (self.seq + 1) & 0xFFFFFF
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ops.check(_lib.load().sdnq_hip_push_post(self._post, self.world, self.rank, self.seq, off, stream), "push_post")
+        return (self.seq, off, region, rows, n_total, dtype)
+
+    def push(self, token, y: torch.Tensor, col0: int) -> torch.Tensor:
+        from . import _lib, ops
+        seq, off, region, rows, n_total, dtype = token
+        assert y.shape[0] == rows and y.dtype == dtype
+        if y.stride(1) != 1:
+            y = y.contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ops.check(_lib.load().sdnq_hip_push_columns(y.data_ptr(), y.element_size(), rows, y.shape[1], y.stride(0), self._arena, self._post,
+                                                    self._done, self.world, self.rank, seq, n_total, col0, 0, self._ticket.data_ptr(),
+                                                    self._status.data_ptr(), self.timeout_ms, stream), "push_columns")
+        return torch.as_tensor(region, device=self.device).view(dtype)[: rows * n_total].view(rows, n_total)
+
+    def check(self):
+        """Synchronizes; raises if any rendezvous of this rank timed out (a peer that never arrived)."""
+        torch.cuda.synchronize(self.device)
+        if int(self._status.item()) != 0:
+            raise RuntimeError("PeerArena: a peer did not arrive within the timeout (ranks out of step, or a rank died)")
+
+
 class ColumnShardedLinear(torch.nn.Module):
     """Holds this rank's slab of a Linear; forward = local forward + all-gather along the channel axis.
 
@@ -67,10 +203,11 @@ class ColumnShardedLinear(torch.nn.Module):
     matmuls may pick another tile for a chunk's M, i.e. another fp32 summation order: equal within the usual float tolerance).  The gather itself stays the bound -- 2 M N / W bytes per rank over one 153 GB/s xGMI link -- the
     pipeline only hides the matmul under it.  CPU tensors (the gloo tests) take the torch path."""
 
-    def __init__(self, local: torch.nn.Module, n_total: int, rank: int, world: int, group=None, chunks: int = 1):
+    def __init__(self, local: torch.nn.Module, n_total: int, rank: int, world: int, group=None, chunks: int = 1, peer: "PeerArena | None" = None):
         super().__init__()
         self.local = local
         self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
+        self.peer = peer  # copy-free gather over peer-mapped memory instead of RCCL all-gather + re-assembly
         self.bounds = [shard_bounds(n_total, r, world) for r in range(world)]
         self.even = len({b - a for a, b in self.bounds}) == 1
         self.chunks = max(1, int(chunks))
@@ -115,6 +252,12 @@ class ColumnShardedLinear(torch.nn.Module):
         if not x.is_cuda or m == 0 or any((a * es) % 16 for a, _ in self.bounds):
             y_local = self.local(x)
             return self._forward_torch(y_local.reshape(-1, y_local.shape[-1]).contiguous(), m).view(*lead, self.n_total)
+        if self.peer is not None:
+            # destination announced first, so that no peer's push ever waits for it; then the local matmul; then the push into every
+            # rank's matrix (the kernel returns when this rank's matrix is complete)
+            token = self.peer.post(m, self.n_total, x.dtype)
+            y = self.local(x2)
+            return self.peer.push(token, y, self.bounds[self.rank][0]).view(*lead, self.n_total)
         out = torch.empty((m, self.n_total), device=x.device, dtype=x.dtype)
         chunks = min(self.chunks, max(1, m // 256))
         if chunks == 1:
@@ -206,13 +349,13 @@ def shard_quantized_module(mod: torch.nn.Module, a: int, b: int) -> torch.nn.Mod
 
 
 @torch.no_grad()
-def column_shard_module(mod: torch.nn.Module, rank: int, world: int, group=None, chunks: int = 1) -> ColumnShardedLinear:
+def column_shard_module(mod: torch.nn.Module, rank: int, world: int, group=None, chunks: int = 1, peer: "PeerArena | None" = None) -> ColumnShardedLinear:
     """Tensor-parallel shard of a PRE-QUANTIZED SDNQLinear (checkpoint layout untouched): this rank's slab (views of mod's
     parameters) + the RCCL all-gather of the outputs.  Bit-identical to `mod` for every storage format.  chunks > 1 pipelines the
     gather of one M chunk under the matmul of the next (ColumnShardedLinear)."""
     n = int(mod.sdnq_dequantizer.original_shape[0])
     a, b = shard_bounds(n, rank, world)
-    return ColumnShardedLinear(shard_quantized_module(mod, a, b), n, rank, world, group, chunks=chunks)
+    return ColumnShardedLinear(shard_quantized_module(mod, a, b), n, rank, world, group, chunks=chunks, peer=peer)
 
 
 @torch.no_grad()

@@ -1501,3 +1501,60 @@ def test_one_call_linear_equals_the_separate_calls(form, gpu_device):
     # one call on the pre-quantized activation (what sibling layers of a shared input do)
     got2, _ = ops.linear_call(mm, x, wq, ws, bias, dt, had, down, up, zp, asymmetric=asym, w_colsum_scaled=wcs, pre=inter)
     assert torch.equal(got2.view(torch.int16), want.view(torch.int16)), form
+
+
+def test_per_call_weight_pipeline_is_bit_identical(gpu_device, monkeypatch):
+    """SDNQ_HIP_CACHE_WEIGHTS=0 with the side-stream weight pipeline (linear._WeightPipeline: layer i + 1 re-quantized into the other
+    scratch buffer under layer i's GEMM): every step equals the cached mode bit for bit -- eagerly, with the layer order changed
+    under it (wrong guesses), and replayed from a captured graph."""
+    import sdnq_amd
+    from sdnq_amd import linear as L
+    torch.manual_seed(3)
+    dims = [(640, 208), (3072, 256), (1280, 1024), (2048, 64), (640, 640)]
+    mods, xs = [], []
+    for (k, n) in dims:
+        lin = torch.nn.Linear(k, n, bias=True).to(torch.bfloat16).to(gpu_device)
+        mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int4", group_size=64, use_quantized_matmul=True))
+        assert mod.sdnq_dequantizer.re_quantize_for_matmul
+        mods.append(mod)
+        xs.append(torch.randn(100, k, device=gpu_device, dtype=torch.bfloat16))
+    want = [m(x).clone() for m, x in zip(mods, xs)]  # cached mode
+    monkeypatch.setattr(L, "CACHE_WEIGHTS", False)
+    monkeypatch.setattr(L, "PIPELINE_WEIGHTS", True)
+    pipe = L._WeightPipeline()
+    monkeypatch.setattr(L, "_weight_pipeline", pipe)
+    for m in mods:
+        m.__dict__.pop("_sdnq_hip_state", None)
+
+    def step(order):
+        L.clear_activation_cache()
+        outs = {i: mods[i](xs[i]) for i in order}
+        L.join_weight_pipeline()
+        return outs
+
+    fwd = list(range(len(mods)))
+    for it in range(3):
+        outs = step(fwd)
+        for i in fwd:
+            assert torch.equal(outs[i], want[i]), (it, i)
+    assert pipe.stats["prefetched"] >= len(mods) - 1 and pipe.scratch_bytes() >= 2 * 3072 * 256
+    assert all(m.__dict__["_sdnq_hip_state"].mm_weight is None for m in mods)  # no int8 copy kept
+    for order in (fwd[::-1], [2, 0, 4], fwd):  # wrong guesses: stray prefetches are joined, results unchanged
+        outs = step(order)
+        for i in order:
+            assert torch.equal(outs[i], want[i]), (order, i)
+    assert pipe.stats["wasted"] >= 1
+    # graph capture: fork / join of the side stream by events
+    outs = step(fwd)
+    side = torch.cuda.Stream(device=gpu_device)
+    with torch.cuda.stream(side):
+        step(fwd)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            gouts = step(fwd)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for i in fwd:
+        assert torch.equal(gouts[i], want[i]), ("graph", i)

@@ -10,7 +10,7 @@ SHAPES = {"sdxl_int8": [(4096, 640, 640), (4096, 1920, 640), (4096, 5120, 640), 
                         (1024, 10240, 1280), (1024, 1280, 5120)]}
 SHAPES["sdxl_int8_dequant"] = [(m, n, 2 * k) for (m, n, k) in SHAPES["sdxl_int8"]]  # the fused dequantize GEMM counts K in bytes of the 16-bit rows
 SHAPES["flux_int4_had"] = [(4608, 3072, 3072), (4608, 3072, 12288), (4608, 3072, 15360), (512, 3072, 3072), (512, 3072, 12288)]
-SHAPES = SHAPES[workload]
+SHAPES = SHAPES.get(workload, [])
 CANDS = {"sdxl_int8": [1, 3, 7, 9, 10, 13, 17, 19], "flux_int4_had": [1, 3, 19, 20]}.get(workload, [1, 2, 3, 4])  # launch_tiles / launch_tiles_w8 ids
 
 
