@@ -64,6 +64,9 @@ def parse():
                             "sdxl_attn_int8", "flux_attn_int8", "sdxl_unet_all"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--tp-chunks", type=int, default=2, help="with --tp: M chunks per layer (gather of chunk i on a side stream under the matmul of chunk i + 1; 1 = plain)")
+    p.add_argument("--tp-gather", choices=["rccl", "peer"], default="rccl",
+                   help="with --tp: RCCL all-gather + re-assembly pass (default), or the copy-free gather -- every rank pushes its slab into every "
+                        "rank's [M, N] output over peer-mapped memory (sdnq_amd.parallel.PeerArena, sdnq_hip_push_columns)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--launch", choices=["graph", "eager", "compile"], default=None,
                    help="how a step is launched: one captured hipGraph (default), eager Python (= --no-graph), or torch.compile(mode='reduce-overhead') "
@@ -120,7 +123,7 @@ def expand_layers(shape_list, scale=1.0):
     return seq
 
 
-def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0, tp_chunks=1, activation_pool=0):
+def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=1, seed=0, tp_chunks=1, activation_pool=0, tp_peer=None):
     """-> list of (name, module, x, M, K, N, bias). One module per layer instance (distinct weights, like a real UNet /
     DiT); one activation tensor per distinct input_key: layers that consume the same tensor in the real model (q/k/v
     projections, every cross-attention k/v) get the SAME tensor object here, all others get their own."""
@@ -155,7 +158,7 @@ def build_layers(shape_list, cfg_kwargs, device, scale=1.0, tp_rank=0, tp_world=
             # tensor parallel: every rank holds the same quantized "checkpoint" layer and takes its slab of output channels
             # (views of the stored tensors, sdnq_amd.parallel.column_shard_module); M = 1 embedding layers stay replicated
             from sdnq_amd.parallel import column_shard_module
-            mod = column_shard_module(mod, tp_rank, tp_world, chunks=tp_chunks)
+            mod = column_shard_module(mod, tp_rank, tp_world, chunks=tp_chunks, peer=tp_peer)
         layers.append((name, mod, x, m, k, n, has_bias))
     return layers
 
@@ -928,11 +931,16 @@ def main():
     shape_list, cfg_kwargs, mm_name, tokens = workload_config(args.workload)
     tp = args.tp and distributed
     is_conv = args.workload.startswith("sdxl_conv")
+    tp_peer = None
     if is_conv:
         layers = build_conv_layers(shape_list, cfg_kwargs, device, seed=rank)
     else:
+        if tp and args.tp_gather == "peer":
+            from sdnq_amd.parallel import PeerArena
+            tp_peer = PeerArena(rank, world, device=device)
         layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank if tp else 0,
-                              tp_world=world if tp else 1, seed=0 if tp else rank, tp_chunks=args.tp_chunks, activation_pool=args.activation_pool)
+                              tp_world=world if tp else 1, seed=0 if tp else rank, tp_chunks=args.tp_chunks, activation_pool=args.activation_pool,
+                              tp_peer=tp_peer)
     if args.fuse_projections and not is_conv and not tp:
         layers = fuse_shared_input_layers(layers)
     linked = 0
@@ -1023,6 +1031,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if tp_peer is not None:
+        tp_peer.check()  # a rendezvous that timed out (a rank out of step) is an error, not a number
     ms_per_step = elapsed / args.steps * 1e3
     replicas = 1 if tp or not distributed else world
     total_ops = ops_per_step * args.steps * replicas
@@ -1049,7 +1059,10 @@ def main():
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         **({"tp": {"ranks": world, "rank_devices": [f"cuda:{r}" for r in range(world)], "rccl_version": list(torch.cuda.nccl.version()),
                    "sharded_layers": sum(1 for l in layers if type(l[1]).__name__ == "ColumnShardedLinear"),
-                   "collective": "all_gather_into_tensor of [M, N/W] bf16 per layer + sdnq_hip_unshard_columns", "m_chunks": args.tp_chunks}} if tp else {}),
+                   "collective": ("copy-free: sdnq_hip_push_columns -- P2P stores of [M, N/W] bf16 into every rank's [M, N] output over IPC-mapped "
+                                  "arenas, mailbox rendezvous, no RCCL call per layer" if args.tp_gather == "peer"
+                                  else "all_gather_into_tensor of [M, N/W] bf16 per layer + sdnq_hip_unshard_columns"),
+                   "gather": args.tp_gather, "m_chunks": args.tp_chunks if args.tp_gather == "rccl" else 1}} if tp else {}),
         "tokens_per_s": round(tokens * replicas / (ms_per_step / 1e3), 1),
         "step_latency_ms": round(ms_per_step, 4),
     }

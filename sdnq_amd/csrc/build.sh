@@ -8,7 +8,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${1:-$HERE/../libsdnq_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="${SDNQ_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
-OBJ="$HERE/../../build/obj"
+OBJ="${SDNQ_OBJ_DIR:-$HERE/../../build/obj}"  # (a second object directory lets an A/B build with other flags coexist)
 mkdir -p "$OBJ"
 SRCS="api rowquant gemm dequant quantize conv attention parallel"
 HDR_HASH=$(cat "$HERE"/*.h "$HERE/../../include/sdnq_hip.h" | sha256sum | cut -d' ' -f1)

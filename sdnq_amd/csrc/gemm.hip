@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // GEMM).  The 256-row tiles (128 accumulator registers per lane) also measured 2 % faster this way.  So the raw
     // accumulators (and the low-rank tile) are staged as 32-bit values and a small loop finishes them.
     if constexpr (is_lr<EPI> && OUT_T != SDNQ_F32) {
-        if (EPI == EPI_LRFAST || (lr_lds && p.zp == nullptr && p.a_zp == nullptr)) {
+        if (EPI == EPI_LRFAST || (lr_lds && p.zp == nullptr && p.a_zp == nullptr && p.bias_dtype == OUT_T)) {
             // ======== SVD-only layers (no zero-point terms; FLUX int8 + SVD): finish in the MFMA register layout ========
             // Every lane owns outputs m = wm*WM + j*32 + (lane & 31), n = wn*WN + i*32 + (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Per
             // sub-tile: two MFMAs on the staged factor tiles give the low-rank values of exactly those outputs; bias2d = cast_svd(bias +
@@ -1192,7 +1192,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
             uint8_t* ostage = lds + LR_BYTES;
             static_assert(LR_BYTES + CH2 * O_ROW <= EPI_BYTES, "register-layout low-rank epilogue fits the staged epilogue's LDS budget");
             const bool hb = p.bias != nullptr;
-            const bool is_bf = p.bias_dtype == SDNQ_BF16;
+            // the svd dtype is the OUTPUT dtype here (the launcher sends other combinations to the general path): a compile-time constant.
+            // As a run-time flag every bias2d rounding sat behind two scalar branches (s_and / s_cbranch around the f16 and around the
+            // bf16 convert, per ELEMENT: ~6 scalar + 4 vector instructions where 2 vector ones do) -- the epilogue of a 256x256 tile
+            // was 24 K cycles against 13 K of the plain one (round 3 trace)
+            constexpr bool is_bf = (OUT_T == SDNQ_BF16);
             TRACE(5);
 #pragma nounroll
             for (int ch = 0; ch < ECH2; ++ch) {
@@ -1241,13 +1245,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                             for (int q = 0; q < 4; ++q) {
                                 const int nl0 = wn * WN + i * 32 + 8 * q + 4 * fgrp;
                                 const v4f sb4 = *(const v4f*)(sbq + nl0), b4 = *(const v4f*)(biasq + nl0);
-                                float r[4];
+                                float r[4], lv[4], b2[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) lv[e] = hb ? lrt[4 * q + e] + b4[e] : lrt[4 * q + e];
+                                if constexpr (is_bf) {  // cast_svd on pairs: one packed convert per two values, then the halves back to f32
+                                    const u32 p01 = pack2<SDNQ_BF16>(lv[0], lv[1]), p23 = pack2<SDNQ_BF16>(lv[2], lv[3]);
+                                    b2[0] = __uint_as_float(p01 << 16); b2[1] = __uint_as_float(p01 & 0xffff0000u);
+                                    b2[2] = __uint_as_float(p23 << 16); b2[3] = __uint_as_float(p23 & 0xffff0000u);
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) b2[e] = FT<SDNQ_F16>::round(lv[e]);
+                                }
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    const float lv = hb ? lrt[4 * q + e] + b4[e] : lrt[4 * q + e];
-                                    const float b2 = is_bf ? FT<SDNQ_BF16>::round(lv) : FT<SDNQ_F16>::round(lv);
                                     const float vv = acc_times_sa<LP>(MT::tof(acc[i][j], 4 * q + e), sa);
-                                    r[e] = fmaf(vv, sb4[e], b2);
+                                    r[e] = fmaf(vv, sb4[e], b2[e]);
                                 }
                                 *(v2i*)(ostq + sr * O_ROW + nl0 * OUT_B) = (v2i){(int)pack2<OUT_T>(r[0], r[1]), (int)pack2<OUT_T>(r[2], r[3])};
                             }
@@ -1756,7 +1768,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     if constexpr (EPI == EPI_LOWRANK) {
         // low-rank layers reach the 256x256 tiles through EPI_LRFAST only (see the enum)
         if constexpr (OUT_T != SDNQ_F32) {
-            if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256) && p.lr_t != nullptr && p.rank == 32 && p.bias_dtype != SDNQ_F32 &&
+            if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256) && p.lr_t != nullptr && p.rank == 32 && p.bias_dtype == OUT_T &&
                 p.zp == nullptr && p.a_zp == nullptr) {
                 if (ht_ok(p)) return launch_one<MM, OUT_T, EPI_LRFAST, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
                 return launch_one<MM, OUT_T, EPI_LRFAST, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);

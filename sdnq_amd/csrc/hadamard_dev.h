@@ -225,6 +225,34 @@ __device__ __forceinline__ v4f had256_group(const uint2& raw, const float (&hf)[
         d1 = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(v4h, raw), hh, d1, 0, 0, 0);
     }
     v4f y = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifndef SDNQ_HAD256_F32_STAGE2
+    if constexpr (T_ID == SDNQ_BF16) {
+        // Second stage on the bf16 matrix rate (round 4).  The fp32 intermediate is split EXACTLY into three bfloat16 terms by
+        // truncation -- d1 = h1 + h2 + h3 with 8 significant bits each (24 in all) -- and multiplied with the same +-1/4 operand: every
+        // product is exact and the fp32 accumulation adds the same real numbers as the four v_mfma_f32_16x16x4_f32 did (those cost
+        // 4 x 32 matrix cycles per group; three 16x16x16 bf16 MFMAs cost 3 x 16).  The accumulator registers are
+        // still, unmoved, the A operand: lane l holds rows k = 4 (l >> 4) + e of column l & 15, which is what both bf16 forms want.
+        const v4s hb = {(short)f32_to_bf16_bits(hf[0]), (short)f32_to_bf16_bits(hf[1]), (short)f32_to_bf16_bits(hf[2]), (short)f32_to_bf16_bits(hf[3])};
+        u32 b1[4], r1[4], r2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            b1[e] = __float_as_uint(d1[e]);
+            const float f1 = d1[e] - __uint_as_float(b1[e] & 0xffff0000u);  // exact: the low 16 bits of the significand
+            r1[e] = __float_as_uint(f1);
+            r2[e] = __float_as_uint(f1 - __uint_as_float(r1[e] & 0xffff0000u));  // exact: at most 8 significant bits are left
+        }
+        // v_perm: the HIGH halves (= the truncated bf16) of two dwords side by side
+        const u32 a0 = __builtin_amdgcn_perm(b1[1], b1[0], 0x07060302u), a1 = __builtin_amdgcn_perm(b1[3], b1[2], 0x07060302u);
+        const u32 a2 = __builtin_amdgcn_perm(r1[1], r1[0], 0x07060302u), a3 = __builtin_amdgcn_perm(r1[3], r1[2], 0x07060302u);
+        const u32 a4 = __builtin_amdgcn_perm(r2[1], r2[0], 0x07060302u), a5 = __builtin_amdgcn_perm(r2[3], r2[2], 0x07060302u);
+        // three 16x16x16 MFMAs, smallest term first (the form stage 1 uses; the 16x16x32 form on [h1 | h2] measured wrong results in
+        // accumulator registers 0 and 1 -- its operand layout is not the one assumed -- and is not worth another 15 cycles)
+        y = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(v4s, make_uint2(a4, a5)), hb, y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(v4s, make_uint2(a2, a3)), hb, y, 0, 0, 0);
+        y = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(v4s, make_uint2(a0, a1)), hb, y, 0, 0, 0);
+        return y;
+    }
+#endif
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) y = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[sidx], hf[sidx], y, 0, 0, 0);
     return y;

@@ -74,10 +74,10 @@ __global__ __launch_bounds__(256) void push_columns_kernel(const PushParams p) {
     if (tid == 0) { s_fail = 0; s_last = 0; }
     __syncthreads();
     const long long t0 = wall_clock64();
-    if (tid < p.world) {  // where does rank `tid` want sequence p.seq?  (its post array lives in ITS arena: a remote read for tid != rank)
+    if (tid < p.world) {  // where does rank `tid` want sequence p.seq?  (it stored the word into slot `tid` of MY post array: a local read)
         unsigned long long v;
         for (;;) {
-            v = ld_sys(p.post[tid] + p.rank);
+            v = ld_sys(p.post[p.rank] + tid);
             if ((v >> 40) == p.seq) break;
             if (wall_clock64() - t0 > p.timeout_ticks) { s_fail = 1; break; }
             __builtin_amdgcn_s_sleep(8);

@@ -123,25 +123,28 @@ class PeerArena:
 
     # ---- ring allocator over [CTRL, CTRL + size) ----------------------------------------------------------------------------------
     def _alloc(self, nbytes: int):
+        """Next free range of the ring: dead ranges in the way are recycled, LIVE ones (a tensor or a view of one still references
+        them) are stepped over; raises only when one full turn of the ring finds no room."""
         import weakref
         n = (nbytes + 255) // 256 * 256
         if n > self.size:
             raise RuntimeError(f"PeerArena: output of {nbytes} bytes exceeds the arena ({self.size} bytes; SDNQ_HIP_TP_ARENA_MB)")
-        if self.head + n > self.CTRL + self.size:
-            self.head = self.CTRL
-        start, end = self.head, self.head + n
-        keep = []
-        for (a, b, ref) in self.live:
-            if a < end and start < b:
-                if ref() is not None:
+        self.live = [e for e in self.live if e[2]() is not None]  # only live ranges matter
+        lo, hi = self.CTRL, self.CTRL + self.size
+        start, wraps = self.head, 0
+        while True:
+            if start + n > hi:
+                start, wraps = lo, wraps + 1
+                if wraps > 1:
                     raise RuntimeError("PeerArena: the ring is full of live output tensors; raise SDNQ_HIP_TP_ARENA_MB or drop references "
-                                       f"(need [{start}, {end}), [{a}, {b}) is still in use)")
-            else:
-                keep.append((a, b, ref))
+                                       f"({sum(b - a for a, b, _ in self.live)} of {self.size} bytes are in use, {n} needed)")
+            clash = max((b for (a, b, _) in self.live if a < start + n and start < b), default=None)
+            if clash is None:
+                break
+            start = clash  # step over the live range
         region = _Region(self.buf.data_ptr() + start, n, self.buf)
-        keep.append((start, end, weakref.ref(region)))
-        self.live = keep
-        self.head = end
+        self.live.append((start, start + n, weakref.ref(region)))
+        self.head = start + n
         return start, region
 
     def gather(self, y: torch.Tensor, n_total: int, col0: int) -> torch.Tensor:

@@ -232,3 +232,31 @@ def test_accelerate_never_breaks_a_working_model():
         warnings.simplefilter("always")
         assert sdnq_amd.accelerate(torch.nn.Sequential(model[0])) == 1
     assert not w
+
+
+def test_peer_arena_ring_steps_over_live_ranges_and_recycles_dead_ones():
+    """PeerArena's allocator (the copy-free gather's receive ring), without a GPU: a range is reused only when no tensor made from it
+    is alive; live ranges are stepped over; a ring full of live tensors raises."""
+    import pytest
+    from sdnq_amd import parallel as P
+
+    class FakeBuf:
+        def data_ptr(self):
+            return 1 << 20
+    a = P.PeerArena.__new__(P.PeerArena)
+    a.size, a.CTRL, a.head, a.live, a.buf = 10240, 256, 256, [], FakeBuf()
+    off0, keep = a._alloc(2000)
+    assert off0 == 256
+    seen = set()
+    for _ in range(20):
+        off, r = a._alloc(3000)
+        assert off >= 256 + 2048 and off + 3072 <= 256 + 10240  # never on the live range, never past the end
+        seen.add(off)
+        del r
+    assert len(seen) == 2  # the dead ranges are recycled
+    held = [a._alloc(3000)[1] for _ in range(2)]
+    with pytest.raises(RuntimeError, match="full of live output tensors"):
+        for _ in range(5):
+            held.append(a._alloc(3000)[1])
+    del held, keep
+    assert a._alloc(9000)[0] == 256  # everything died: the whole ring is free again
