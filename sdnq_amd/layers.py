@@ -93,8 +93,10 @@ class SDNQLayer(torch.nn.Module):
 
 
 def _traceable(layer) -> bool:
+    """Layers that trace as sdnq_hip:: operators under torch.compile: Linear (one or two operators, torch_ops.layer_plan) and the conv
+    layers (one opaque layer_forward operator each -- round 4: a compiled UNet has no graph breaks at its 49 quantized convs)."""
     dq = layer.__dict__.get("sdnq_dequantizer")
-    return dq is not None and dq.layer_class_name in ("Linear", "SDNQLinear")
+    return dq is not None and dq.layer_class_name in ("Linear", "SDNQLinear", "Conv1d", "Conv2d", "Conv3d", "SDNQConv1d", "SDNQConv2d", "SDNQConv3d")
 
 
 class SDNQLinear(SDNQLayer, torch.nn.Linear):

@@ -111,9 +111,8 @@ def accelerate(model: torch.nn.Module) -> AccelerateResult:
         module.forward_func = fwd
         module.__dict__.pop("_sdnq_hip_state", None)
         _unlink(module)
-        if is_hot_path_linear(module):
-            from . import torch_ops
-            torch_ops.layer_handle(module)  # torch.compile: the layer traces as one sdnq_hip::layer_forward op
+        from . import torch_ops
+        torch_ops.layer_handle(module)  # torch.compile: the layer (Linear or conv) traces as sdnq_hip:: operators, no graph break
         count += 1
     if skipped:
         import warnings

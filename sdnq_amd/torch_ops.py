@@ -388,5 +388,13 @@ def _(input, handle):
     mod = _layer(handle)
     dq = mod.sdnq_dequantizer
     if dq.is_conv:
-        raise NotImplementedError("sdnq_hip::layer_forward traces Linear layers; conv layers run eagerly (graph break)")
+        # Conv1d / Conv2d / Conv3d: output geometry from the module's own attributes (the arithmetic of torch.nn.functional.conv*d;
+        # non-zero padding modes pad explicitly by `padding` first, which gives the same extents)
+        nd = input.ndim - 2
+        t = lambda v: (int(v),) * nd if isinstance(v, int) else tuple(int(e) for e in v)  # noqa: E731
+        if isinstance(mod.padding, str):
+            raise NotImplementedError("sdnq_hip::layer_forward: string padding modes are not built")
+        ks, st, pd, dl = tuple(int(k) for k in dq.original_shape[2:]), t(mod.stride), t(mod.padding), t(mod.dilation)
+        spatial = [(int(input.shape[2 + i]) + 2 * pd[i] - dl[i] * (ks[i] - 1) - 1) // st[i] + 1 for i in range(nd)]
+        return input.new_empty((input.shape[0], dq.out_features, *spatial))
     return input.new_empty((*input.shape[:-1], dq.out_features))

@@ -244,3 +244,65 @@ def test_compile_after_options_follows_the_new_mode(gpu_device):
         torch._dynamo.reset()
         got = torch.compile(blk, fullgraph=True, backend="aot_eager")(x)
         assert torch.equal(got, want)
+
+
+class ConvBlock(torch.nn.Module):
+    """A ResNet-style block of a UNet: two 3x3 convs, a strided down-sampling conv, a 1x1 skip, a Conv1d and a grouped conv."""
+
+    def __init__(self, c=32):
+        super().__init__()
+        self.conv1, self.conv2 = torch.nn.Conv2d(c, 2 * c, 3, padding=1), torch.nn.Conv2d(2 * c, 2 * c, 3, padding=1)
+        self.skip = torch.nn.Conv2d(c, 2 * c, 1)
+        self.down = torch.nn.Conv2d(2 * c, 2 * c, 3, stride=2, padding=1)
+        self.grouped = torch.nn.Conv2d(2 * c, 2 * c, 3, padding=1, groups=2)
+        self.c1d = torch.nn.Conv1d(2 * c, c, 3, padding=2, dilation=2)
+
+    def forward(self, x):
+        h = self.conv2(torch.nn.functional.silu(self.conv1(x))) + self.skip(x)
+        h = self.grouped(self.down(h))
+        return self.c1d(h.flatten(2))
+
+
+def _quantized_conv_block(device):
+    torch.manual_seed(0)
+    blk = ConvBlock().to(torch.bfloat16).to(device)
+    blk, _ = sdnq_amd.apply_sdnq_to_module(blk, sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True,
+                                                                    minimum_allowed_numel=256, minimum_allowed_channel_size=16))
+    return blk
+
+
+def test_dynamo_traces_conv_layers_without_graph_breaks_cpu():
+    """Round 4: quantized Conv1d / Conv2d / Conv3d layers trace as ONE sdnq_hip::layer_forward operator each (fake implementation =
+    the conv output geometry), so a compiled UNet has no graph break at its quantized convs."""
+    blk = _quantized_conv_block("cpu")
+    convs = [m for m in blk.modules() if hasattr(m, "sdnq_dequantizer")]
+    assert len(convs) == 6 and all(m.__dict__.get("_sdnq_hip_handle") is not None for m in convs)
+    x = torch.randn(2, 32, 12, 10).to(torch.bfloat16)
+    gm, _ = torch._dynamo.export(blk)(x)  # raises on any graph break
+    calls = [n for n in gm.graph.nodes if n.op == "call_function" and n.target in (torch.ops.sdnq_hip.layer_forward, torch.ops.sdnq_hip.layer_forward.default)]
+    assert len(calls) == 6
+    # the fake implementation's shapes are the real convs' shapes
+    want = ConvBlock().to(torch.bfloat16)(x).shape
+    meta = calls[-1].meta.get("val", calls[-1].meta.get("example_value"))
+    assert tuple(meta.shape) == tuple(want) == (2, 32, 30)
+    conv3 = sdnq_amd.sdnq_quantize_layer(torch.nn.Conv3d(16, 32, (3, 3, 1), stride=(1, 2, 1), padding=(1, 0, 0)).to(torch.bfloat16),
+                                         sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))[0]
+    fake = torch.ops.sdnq_hip.layer_forward.default
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        y = fake(torch.empty(2, 16, 5, 9, 4, dtype=torch.bfloat16), conv3.__dict__["_sdnq_hip_handle"])
+    assert tuple(y.shape) == (2, 32, 5, 4, 4)
+
+
+@pytest.mark.gpu
+def test_compiled_conv_block_equals_eager(gpu_device):
+    """torch.compile(fullgraph=True) of a block of quantized convs (plain, strided, 1x1, grouped, Conv1d with dilation): the
+    aot_eager result is bit-identical to the eager one (same kernels behind the operator)."""
+    blk = _quantized_conv_block(gpu_device)
+    sdnq_amd.accelerate(blk)
+    x = torch.randn(2, 32, 24, 16, device=gpu_device, dtype=torch.bfloat16)
+    with torch.no_grad():
+        want = blk(x)
+        torch._dynamo.reset()
+        got = torch.compile(blk, fullgraph=True, backend="aot_eager")(x)
+    assert got.shape == want.shape and torch.equal(got, want)
