@@ -1096,7 +1096,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
         traffic, traffic_src, traffic_meta = None, None, None
-        pmc_name = "r03_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
+        pmc_name = "r04_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
         if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes

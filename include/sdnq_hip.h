@@ -420,6 +420,16 @@ int sdnq_hip_scaled_mm_strided(int mm_dtype, const void* a, int64_t lda, const v
                                const void* bias, int bias_dtype, void* out, int64_t ldc, int out_dtype, int64_t m, int64_t n,
                                int64_t k, int64_t hw, sdnq_stream_t stream);
 
+/* sdnq_hip_scaled_mm_lowrank's zero-point terms on VIEWS: one group of a grouped conv whose weights are unsigned (zero-point term
+ * f32(rowsum) * sa * zp[n], conv_int8.py:65-69 -- rowsum taken over the WHOLE unfolded row, as the reference does) or whose matmul is
+ * the uint8 one (activation zero point: + colsum(w) * ws * xzp + K * (xzp * wzp), conv_uint8.py:58-66 -- K again the whole row:
+ * zp_k).  a: [M][lda] with K valid columns; out: [M][ldc] with N valid columns; everything per channel (sb, bias, zp,
+ * w_colsum_scaled) points at this group's first channel. */
+int sdnq_hip_scaled_mm_lowrank_strided(int mm_dtype, const void* a, int64_t lda, const void* b, const float* sa, const float* sb,
+                                       const void* bias, int bias_dtype, const int32_t* zp_rowsum, const float* zp, const float* a_zp,
+                                       const float* w_colsum_scaled, int64_t zp_k, void* out, int64_t ldc, int out_dtype, int64_t m,
+                                       int64_t n, int64_t k, sdnq_stream_t stream);
+
 /* sdnq_hip_linear_float with an output row stride (ldc >= n elements): the float matmul of one conv group on views. */
 int sdnq_hip_linear_float_strided(const void* x, const void* wd, const void* bias, int dtype, void* out, int64_t m,
                                   int64_t n, int64_t k, int64_t ldx, int64_t ldc, sdnq_stream_t stream);

@@ -543,15 +543,43 @@ def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str
             outs.append(linear_float(_c(x2d[:, g * Kg:(g + 1) * Kg], np.float32), _c(W[g * Ng:(g + 1) * Ng], np.float32), b, tag))
         return np.concatenate(outs, axis=1)
     mmd = d["quantized_matmul_dtype"]
-    assert mmd in ("int8", "float8_e4m3fn", "fp8") and mod.svd_up is None and mod.scale_tag == "f32"
-    mm = "int8" if mmd == "int8" else "fp8"
-    wq, ws, zp = _mm_weights(mod, mm)
-    assert zp is None
-    xq, xs, _ = rowquant(x2d, mm)
+    assert mmd in ("int8", "uint8", "float8_e4m3fn", "fp8") and mod.svd_up is None and mod.scale_tag == "f32"
+    f = np.float32
+    K_row = groups * Kg  # input.shape[-1] of the reference: the WHOLE unfolded row
+    if mmd == "uint8":
+        # conv_uint8.py:58-79: asymmetric activations over the whole row; zero_bias from whole-row statistics, colsum over the group's own K
+        if d["re_quantize_for_matmul"]:
+            wq, ws, zp = mod.re_quantize_matmul()
+        else:
+            assert not d["is_packed"]
+            vals, ws, zpv, _group = mod._nk_values_scale()
+            wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+            zp = (zpv + f(128.0) * ws).astype(f)
+        xq, xs, xzp = rowquant_asym(x2d)
+        xzp = xzp[:, None]
+        rowsum = xq.astype(np.int32).sum(-1)
+        colsum = wq.reshape(N, Kg).astype(np.int32).sum(-1)
+        bias2d = ((rowsum.astype(f) * xs.reshape(-1)).astype(f)[:, None] * zp[None, :]).astype(f)
+        bias2d = (bias2d + ((colsum.astype(f) * ws).astype(f)[None, :] * xzp).astype(f)).astype(f)
+        bias2d = (bias2d + f(K_row) * (xzp * zp[None, :]).astype(f)).astype(f)
+        if mod.bias is not None:
+            bias2d = (bias2d + mod.bias.astype(f)[None, :]).astype(f)
+        mm = "int8"
+    else:
+        mm = "int8" if mmd == "int8" else "fp8"
+        wq, ws, zp = _mm_weights(mod, mm)
+        xq, xs, rowsum = rowquant(x2d, mm)
+        bias2d = None
+        if zp is not None:  # conv_int8.py:65-69: the row sum runs over the whole unfolded row, every group gets the same zero_bias row term
+            bias2d = ((rowsum.astype(f) * xs.reshape(-1)).astype(f)[:, None] * zp.astype(f)[None, :]).astype(f)
+            if mod.bias is not None:
+                bias2d = (bias2d + mod.bias.astype(f)[None, :]).astype(f)
+    wq = wq.reshape(N, Kg)
     for g in range(groups):
-        b = None if mod.bias is None else mod.bias[g * Ng:(g + 1) * Ng]
-        outs.append(scaled_mm(mm, np.ascontiguousarray(xq[:, g * Kg:(g + 1) * Kg]), np.ascontiguousarray(wq[g * Ng:(g + 1) * Ng]), xs,
-                              np.ascontiguousarray(ws[g * Ng:(g + 1) * Ng]), b, tag))
+        sl = slice(g * Ng, (g + 1) * Ng)
+        b = (None if mod.bias is None else mod.bias[sl]) if bias2d is None else np.ascontiguousarray(bias2d[:, sl])
+        outs.append(scaled_mm(mm, np.ascontiguousarray(xq[:, g * Kg:(g + 1) * Kg]), np.ascontiguousarray(wq[sl]), xs,
+                              np.ascontiguousarray(ws[sl]), b, tag))
     return np.concatenate(outs, axis=1)
 
 

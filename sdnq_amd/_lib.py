@@ -31,7 +31,7 @@ EXPORTS = [
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
     "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
-    "sdnq_hip_push_post", "sdnq_hip_push_columns",
+    "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided",
 ]
 
 
@@ -137,6 +137,7 @@ def _declare(lib):
     lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_unshard_columns.argtypes = [vp, vp, i32, i64, i64, i64, i64, i32, c.POINTER(c.c_int64), vp]
+    lib.sdnq_hip_scaled_mm_lowrank_strided.argtypes = [i32, vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp, i64, i32, i64, i64, i64, vp]
     pvp = c.POINTER(c.c_void_p)
     lib.sdnq_hip_push_post.argtypes = [pvp, i32, i32, c.c_uint64, c.c_uint64, vp]
     lib.sdnq_hip_push_columns.argtypes = [vp, i32, i64, i64, i64, pvp, pvp, pvp, i32, i32, c.c_uint64, i64, i64, i64, vp, vp, i32, vp]

@@ -10,8 +10,10 @@ own GEMM instead of the library convolution the reference calls (``_conv_forward
 Grouped convs (``groups > 1``; conv_int8.py:73-79, conv_fp8.py:56-60): the unfolded input keeps ALL input channels in a row (one
 row scale over the whole row, as in the reference), and each group multiplies its column slice with its own output channels'
 weight rows -- one launch per group on views (``sdnq_hip_scaled_mm_strided`` / ``sdnq_hip_linear_float_strided``), written straight
-into its channel range of the output.  Built for the float forward and the plain int8 / fp8 matmuls; the reference's SVD, zero-point
-and uint8-matmul terms are not defined per group (its SVD product has the wrong shape there) and raise here.
+into its channel range of the output.  Built for the float forward, the plain int8 / fp8 matmuls and (round 4) the zero-point terms of
+unsigned weights and of the uint8 matmul, computed from whole-row statistics exactly as the reference does
+(``sdnq_hip_scaled_mm_lowrank_strided``); the reference's SVD term is not defined per group (its product has the wrong shape there)
+and raises here.
 
 Hadamard-rotated conv weights (quant_utils.py:222-236; conv_int8.py:52-53): the rotation groups run along the flattened (C_in, kernel)
 axis, i.e. along the unfolded row -- the Linear kernels' Hadamard path as is (rotation fused into the row quantization; the float forward
@@ -164,10 +166,12 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
 def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) -> torch.Tensor:
     """conv_int8.py:73-79 / conv_fp8.py:56-60: the whole unfolded row is quantized with ONE scale, every group multiplies its column
     slice of the codes with its own weight rows, and the epilogue fma(acc * xs, ws, bias) is the ungrouped one."""
-    if st.svd_up is not None or zp is not None or st.qw.scale_dtype != torch.float32:
-        raise NotImplementedError("grouped conv with SVD / zero-point terms or 16-bit scales: the reference's per-group matmul has no "
+    if st.svd_up is not None or st.qw.scale_dtype != torch.float32:
+        raise NotImplementedError("grouped conv with SVD or 16-bit scales: the reference's per-group matmul has no "
                                   "valid form for them (its SVD product does not match the grouped weight)")
     x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
+    if zp is not None:
+        return _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, wq, ws, zp, asymmetric=False)
     if FUSED_CONV_QUANT and kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
         xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
     else:
@@ -192,6 +196,30 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
     return _folder(self, nd, b, ho, wo, depth_out)(out)
 
 
+def _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, wq, ws, zp, asymmetric: bool, wcs=None):
+    """Grouped conv whose epilogue carries zero-point terms (round 4).  As the reference computes it: the WHOLE unfolded row is
+    quantized with one scale (and, for the uint8 matmul, one zero point), `zero_bias` is built from whole-row statistics --
+    rowsum(xq) * xs * zp[n] (conv_int8.py:65-69) [+ colsum(w[n]) * ws[n] * xzp + K_row * (xzp * zp[n]), conv_uint8.py:58-66] [+ bias]
+    -- and every group multiplies its column slice of the codes with its own weight rows; result = addcmul(zero_bias, acc * xs, ws)
+    (conv_int8.py:73-79 / conv_uint8.py:70-79).  One launch per group on views, the general GEMM epilogue does the terms."""
+    x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
+    res = ops.rowquant(x2d, ops.MM_I8, 0, want_rowsum=True, asymmetric=asymmetric)
+    xq, xs, rowsum = res[0], res[1], res[2]
+    xzp = res[4] if asymmetric else None
+    kg, ng = _group_slices(self, xq.shape[1])
+    if kg % 16 or ng % 8:
+        raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
+    n = self.sdnq_dequantizer.out_features
+    wq2, ws1, zp1 = wq.reshape(n, kg), ws.reshape(-1), zp.reshape(-1)
+    wcs1 = None if wcs is None else wcs.reshape(-1)
+    out = torch.empty((x2d.shape[0], n), device=x2d.device, dtype=x2d.dtype)
+    for g in range(int(self.groups)):
+        sl = slice(g * ng, (g + 1) * ng)
+        ops.scaled_mm_zp_into(ops.MM_I8, xq[:, g * kg:(g + 1) * kg], wq2[sl], xs, ws1[sl], None if self.bias is None else self.bias[sl], rowsum,
+                              zp1[sl], xzp, None if wcs1 is None else wcs1[sl], xq.shape[1], out, g * ng)
+    return _folder(self, nd, b, ho, wo, depth_out)(out)
+
+
 @linear._no_grad
 def quantized_conv_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _conv_matmul_forward(self, input, ops.MM_I8)
@@ -203,7 +231,14 @@ def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tens
     if self.groups != 1:
         if input.numel() / input.shape[2] < 32:
             return quantized_conv_forward(self, input)
-        raise NotImplementedError("the uint8 matmul of a grouped conv (activation zero-point terms per group) is not built")
+        st = linear._state(self)
+        if st.svd_up is not None or st.qw.scale_dtype != torch.float32:
+            raise NotImplementedError("grouped conv with SVD or 16-bit scales is not built")
+        wq, ws, zp = linear._prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)
+        kg = wq.numel() // self.sdnq_dequantizer.out_features
+        wcs = wq.reshape(-1, kg).to(torch.int32).sum(dim=1).to(torch.float32).mul_(ws.reshape(-1))  # f32(colsum over the group's own K) * ws
+        x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
+        return _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, wq, ws, zp, asymmetric=True, wcs=wcs)
     x2d, fold = _unfold(self, input)
     if input.numel() / input.shape[2] < 32:
         return fold(linear._float_forward(self, x2d, linear._state(self)))

@@ -69,6 +69,7 @@ struct GemmParams {
     int64_t ldc;       // output row stride in ELEMENTS (0: N); with out_hw > 0: channels per image of the conv output (0: N)
     int64_t out_hw;    // 0: out is [M][N].  > 0: conv output [B][N][out_hw] with m = b * out_hw + pixel (NCHW, conv_int8.py:81-87)
     int64_t ld_bias;
+    int64_t zp_k;      // K of the uint8 matmul's K * (xzp * wzp) term when it is not this launch's K (one group of a grouped conv: the whole unfolded row); 0: K
     int bias_ndim;
     int bias_dtype;  // SdnqFloat of bias (and of lr_t / lr_up, which share the svd dtype)
     int rank;
@@ -1492,7 +1493,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
                             const float t2 = s_wcsq[cn] * azp;
                             zb = hasz ? zb + t2 : t2;
-                            if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)hk.K, zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
+                            if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)(p.zp_k ? p.zp_k : hk.K), zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
                             hasz = true;
                         }
                         if (hasz) {
@@ -2085,6 +2086,30 @@ extern "C" int sdnq_hip_scaled_mm_strided(int mm_dtype, const void* a, int64_t l
     hipStream_t s = (hipStream_t)stream;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, s);
+}
+
+// sdnq_hip_scaled_mm_lowrank on VIEWS (one group of a grouped conv whose epilogue carries zero-point / activation-zero-point terms,
+// conv_int8.py:65-79, conv_uint8.py:58-79): a is [M][lda] with K valid columns, out [M][ldc] with N valid columns; zp_k = the K of the
+// reference's K * (xzp * wzp) term (the WHOLE unfolded row, all groups), 0: k.
+extern "C" int sdnq_hip_scaled_mm_lowrank_strided(int mm_dtype, const void* a, int64_t lda, const void* b, const float* sa, const float* sb,
+                                                  const void* bias, int bias_dtype, const int32_t* zp_rowsum, const float* zp, const float* a_zp,
+                                                  const float* w_colsum_scaled, int64_t zp_k, void* out, int64_t ldc, int out_dtype, int64_t m,
+                                                  int64_t n, int64_t k, sdnq_stream_t stream) {
+    int st = check_common(mm_dtype, a, b, sa, sb, out, out_dtype, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (lda < k || (lda % 16) != 0 || ldc < n || zp_k < 0) return SDNQ_ERR_SHAPE;
+    if ((ldc * (out_dtype == SDNQ_F32 ? 4 : 2)) % 16 != 0) return SDNQ_ERR_ALIGN;
+    if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
+    if ((a_zp == nullptr) != (w_colsum_scaled == nullptr)) return SDNQ_ERR_NULL;
+    const int bt = bias ? bias_dtype : out_dtype;
+    if (bt < 0 || bt > 2) return SDNQ_ERR_DTYPE;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.zp_rowsum = zp_rowsum; p.zp = zp; p.a_zp = a_zp; p.wcs = w_colsum_scaled; p.zp_k = zp_k;
+    p.M = m; p.N = n; p.K = k; p.lda = lda; p.ldc = ldc; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bt;
+    hipStream_t s = (hipStream_t)stream;
+    if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, EPI_LOWRANK, out_dtype, s);
+    return dispatch_epi<SDNQ_MM_FP8>(p, EPI_LOWRANK, out_dtype, s);
 }
 
 extern "C" int sdnq_hip_scaled_mm_lowrank(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb,

@@ -437,6 +437,26 @@ def scaled_mm_into(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Ten
                                                  bias_dt, dst, c_total, float_code(out.dtype), m, n, k, pixels, _stream(a)), "scaled_mm_strided")
 
 
+def scaled_mm_zp_into(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, rowsum, zp, a_zp, w_colsum_scaled,
+                      zp_k: int, out: torch.Tensor, chan0: int) -> None:
+    """scaled_mm with the zero-point / activation-zero-point epilogue terms on views (sdnq_hip_scaled_mm_lowrank_strided): one group of a
+    grouped conv with unsigned weights or the uint8 matmul (conv_int8.py:65-79, conv_uint8.py:58-79).  `rowsum` / `a_zp` are per ROW
+    of the whole unfolded input, `sb / bias / zp / w_colsum_scaled` this group's channels, `zp_k` the whole row's K; the N results go to
+    columns chan0 .. chan0 + N of the row-major `out` [M, C]."""
+    _require_cuda(a, b_phys, sa, sb, bias, rowsum, zp, a_zp, w_colsum_scaled, out)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    assert a.stride(1) == 1 and b_phys.is_contiguous() and out.is_contiguous() and out.dim() == 2
+    bias_dt = 0
+    if bias is not None:
+        bias = bias.contiguous()
+        bias_dt = float_code(bias.dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_lowrank_strided(mm, a.data_ptr(), a.stride(0), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                                         bias_dt, _ptr(rowsum), _ptr(zp), _ptr(a_zp), _ptr(w_colsum_scaled), int(zp_k),
+                                                         out.data_ptr() + chan0 * out.element_size(), out.shape[1], float_code(out.dtype), m, n, k,
+                                                         _stream(a)), "scaled_mm_lowrank_strided")
+
+
 def linear_float_into(x2d: torch.Tensor, w: torch.Tensor, bias, out: torch.Tensor, chan0: int) -> None:
     """linear_float on views (sdnq_hip_linear_float_strided): x2d a column slice [M, K], the N outputs go to columns chan0 .. chan0 + N of
     the row-major `out` [M, C]."""

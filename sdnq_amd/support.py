@@ -72,10 +72,6 @@ def unsupported_reason(module) -> str | None:
                 return "grouped conv with SVD: the reference's per-group matmul has no valid form for it (its SVD product does not match the grouped weight)"
             if lp:
                 return "grouped conv matmul with 16-bit scales is not built"
-            if uint8_mm:
-                return "the uint8 matmul of a grouped conv (activation zero-point terms per group) is not built"
-            if dq.is_unsigned and not dq.re_quantize_for_matmul:
-                return "grouped conv matmul with a weight zero-point term is not built"
     return None
 
 

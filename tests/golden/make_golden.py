@@ -355,6 +355,14 @@ CONV_CASES = [
          cfg=dict(weights_dtype="int8")),
     dict(name="conv1d_g4_uint4_noqmm_f32", nd=1, cin=64, cout=32, k=3, conv=dict(padding=1, groups=4), xs=[(2, 20)], dtype="f32",
          cfg=dict(weights_dtype="uint4")),
+    # grouped convs whose epilogue carries zero-point terms (round 4): unsigned weights through the int8 matmul (conv_int8.py:45-50, 65-79)
+    # and the uint8 matmul (conv_uint8.py:58-79) -- whole-row statistics, per-group matmuls
+    dict(name="conv2d_g2_uint8_int8mm_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_g2_uint8_uint8mm_qmm_bf16", nd=2, cin=64, cout=96, k=3, conv=dict(padding=1, stride=2, groups=2), xs=[(1, 12, 12)], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", use_quantized_matmul_conv=True)),
+    dict(name="conv1d_g4_int4_g16_uint8mm_qmm_f16_nobias", nd=1, cin=128, cout=64, k=3, conv=dict(padding=1, groups=4, bias=False), xs=[(2, 40)], dtype="f16",
+         cfg=dict(weights_dtype="int4", group_size=16, quantized_matmul_dtype="uint8", use_quantized_matmul_conv=True)),
     # Hadamard-rotated conv weights (quant_utils.py:222-236: the group divides C_in, groups run along the flattened (C_in, kernel) axis;
     # the matmul forwards rotate the unfolded input, conv_int8.py:52-53 / conv_fp8.py:41-42; the float forward un-rotates the weight)
     dict(name="conv2d_int8_had_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1), xs=[(2, 8, 8), (1, 4, 5)], dtype="bf16",

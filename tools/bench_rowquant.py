@@ -16,7 +16,7 @@ def timed(fn, reps=20):
         for _ in range(3): g.replay()
         e1.record(s); s.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (3 * reps)
-for (m, k) in [(4608, 15360), (4608, 12288), (4096, 12288), (512, 12288), (4608, 3072), (4608, 6144), (1024, 10240)]:
+for (m, k) in [(16384, 4096), (4608, 15360), (4608, 12288), (4096, 12288), (512, 12288), (4608, 3072), (4608, 6144), (1024, 10240)]:
     x = torch.randn(m, k, device=dev).to(torch.bfloat16)
     for had in (0, 256):
         os.environ.pop("SDNQ_HIP_RQ_SPLIT", None)
