@@ -423,8 +423,10 @@ int sdnq_hip_scaled_mm_strided(int mm_dtype, const void* a, int64_t lda, const v
 /* sdnq_hip_scaled_mm_lowrank's zero-point terms on VIEWS: one group of a grouped conv whose weights are unsigned (zero-point term
  * f32(rowsum) * sa * zp[n], conv_int8.py:65-69 -- rowsum taken over the WHOLE unfolded row, as the reference does) or whose matmul is
  * the uint8 one (activation zero point: + colsum(w) * ws * xzp + K * (xzp * wzp), conv_uint8.py:58-66 -- K again the whole row:
- * zp_k).  a: [M][lda] with K valid columns; out: [M][ldc] with N valid columns; everything per channel (sb, bias, zp,
- * w_colsum_scaled) points at this group's first channel. */
+ * zp_k).  zp_k > 0: linear form, fma(xzp * wzp, K, .) as torch's add_(., alpha=K) computes it (linear_uint8.py:66); zp_k < 0: K = -zp_k in
+ * the conv forwards' order, (xzp * K) * wzp added without fusion (conv_uint8.py:66: input_zero_point.mul_(K) in place first); 0: this
+ * launch's k, linear form.  a: [M][lda] with K valid columns; out: [M][ldc] with N valid columns; everything per channel (sb, bias, zp,
+ * w_colsum_scaled) points at this group's first channel.  Also the entry point of the UNGROUPED uint8 conv matmul (lda = k, ldc = n). */
 int sdnq_hip_scaled_mm_lowrank_strided(int mm_dtype, const void* a, int64_t lda, const void* b, const float* sa, const float* sb,
                                        const void* bias, int bias_dtype, const int32_t* zp_rowsum, const float* zp, const float* a_zp,
                                        const float* w_colsum_scaled, int64_t zp_k, void* out, int64_t ldc, int out_dtype, int64_t m,

@@ -561,7 +561,8 @@ def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str
         colsum = wq.reshape(N, Kg).astype(np.int32).sum(-1)
         bias2d = ((rowsum.astype(f) * xs.reshape(-1)).astype(f)[:, None] * zp[None, :]).astype(f)
         bias2d = (bias2d + ((colsum.astype(f) * ws).astype(f)[None, :] * xzp).astype(f)).astype(f)
-        bias2d = (bias2d + f(K_row) * (xzp * zp[None, :]).astype(f)).astype(f)
+        # conv_uint8.py:66: input_zero_point.mul_(K) in place (one rounding), .mul(zero_point) (one rounding), then a plain add
+        bias2d = (bias2d + ((xzp * f(K_row)).astype(f) * zp[None, :]).astype(f)).astype(f)
         if mod.bias is not None:
             bias2d = (bias2d + mod.bias.astype(f)[None, :]).astype(f)
         mm = "int8"
@@ -613,7 +614,7 @@ def conv_forward(mod: OracleLinear, x: np.ndarray, conv: dict, tag: str) -> np.n
         k, s, p, dl = k[1:], s[1:], (0, 0), dl[1:]
     x2d, (B, Ho, Wo) = im2col(np.asarray(x, dtype=np.float32), k, s, p, dl)
     if groups == 1:
-        y = forward(mod, x2d, tag, small_batch=small)
+        y = forward(mod, x2d, tag, small_batch=small, conv_form=True)
     else:
         y = _grouped_conv_rows(mod, x2d, groups, tag, small)
     if nd == 3:  # conv_int8.py:85-86
@@ -659,7 +660,7 @@ def _mm_weights(mod: OracleLinear, mm: str):
     return wq, ws, zp
 
 
-def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool = False, small_batch=None):
+def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool = False, small_batch=None, conv_form: bool = False):
     """SDNQLinear.forward: dispatch of get_forward_func (forward.py:39-57) + the four Linear forwards.
     small_batch: override of the M < 32 branch predicate (the conv forwards evaluate it on the un-folded input)."""
     d = mod.deq
@@ -678,7 +679,7 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
         return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
 
     if mmd == "uint8":
-        y = _forward_uint8(mod, x2, tag)
+        y = _forward_uint8(mod, x2, tag, conv_form=conv_form)
         return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
     mm = "int8" if mmd == "int8" else "fp8"
 
@@ -722,7 +723,13 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
     return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
 
 
-def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
+def _fma_scalar(a: np.ndarray, k, c: np.ndarray) -> np.ndarray:
+    """fl32(a * k + c) with ONE rounding: the product of two float32 values is exact in float64, the float64 sum then carries at
+    most one extra rounding far below float32 precision."""
+    return (a.astype(np.float64) * np.float64(k) + c.astype(np.float64)).astype(np.float32)
+
+
+def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: bool = False) -> np.ndarray:
     """quantized_linear_forward_uint8_matmul (layers/linear/linear_uint8.py:27-131): asymmetric int8 activations."""
     d = mod.deq
     K, N = mod.K, mod.N
@@ -731,10 +738,13 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
     if d["re_quantize_for_matmul"]:  # linear_uint8.py:109-111: int8 codes + per-row scale and zero point, no xor
         wq, sc, zp = mod.re_quantize_matmul()
     else:
-        assert not d["is_packed"], "row-wise uint8 is the only weight format that reaches the uint8 matmul without re-quantization"
+        assert not d["is_packed"], "packed weights that reach the uint8 matmul without re-quantization are not restated here"
         vals, sc, zpv, group = mod._nk_values_scale()
-        wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
-        zp = (zpv + f(128.0) * sc).astype(f)
+        if dtype_info(d["weights_dtype"])["kind"] == "uint":  # linear_uint8.py:45-50: w ^ 0x80, zero_point + 128 * scale
+            wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+            zp = (zpv + f(128.0) * sc).astype(f) if zpv is not None else (sc * f(128.0)).astype(f)
+        else:  # signed row-wise int8 through the uint8 matmul: no weight zero point, only the activation's (linear_uint8.py:67-68)
+            wq, zp = vals.astype(np.int8), None
     if d["use_hadamard"]:
         x2 = rotate_hadamard(x2, d["hadamard_group_size"], tag)
     bias = mod.bias
@@ -746,9 +756,20 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str) -> np.ndarray:
     xzp = xzp[:, None]
     rowsum = q.astype(np.int32).sum(-1)
     colsum = wq.astype(np.int32).sum(-1)  # sum over K of the weight, per output channel
+    if zp is None:
+        zero_bias = ((colsum.astype(f) * sc).astype(f)[None, :] * xzp).astype(f)
+        if bias is not None:
+            zero_bias = (zero_bias + bias.astype(f)).astype(f)
+        return scaled_mm("int8", q, wq, xs, sc, zero_bias, tag)
     zero_bias = ((rowsum.astype(f) * xs).astype(f)[:, None] * zp[None, :]).astype(f)
     zero_bias = (zero_bias + ((colsum.astype(f) * sc).astype(f)[None, :] * xzp).astype(f)).astype(f)
-    zero_bias = (zero_bias + f(K) * (xzp * zp[None, :]).astype(f)).astype(f)
+    # zero_bias.add_(mul(xzp, zp), alpha=K) (linear_uint8.py:66): torch's CPU add-with-alpha is ONE fused multiply-add per element
+    # (vec::fmadd), not a rounded product followed by a rounded sum -- found by tools/fuzz_modes.py in round 4 (57 of 245 760 outputs of a
+    # 640 x 384 x 368 layer differed from the reference with two roundings; the small fixtures never showed it)
+    if conv_form:  # conv_uint8.py:66: input_zero_point.mul_(K) in place, .mul(zero_point), a plain add_
+        zero_bias = (zero_bias + ((xzp * f(K)).astype(f) * zp[None, :]).astype(f)).astype(f)
+    else:
+        zero_bias = _fma_scalar((xzp * zp[None, :]).astype(f), f(K), zero_bias)
     if bias is not None:
         zero_bias = (zero_bias + bias.astype(f)).astype(f)
     return scaled_mm("int8", q, wq, xs, sc, zero_bias, tag)

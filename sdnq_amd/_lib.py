@@ -75,7 +75,7 @@ _lib = None
 
 
 _SRCS = ("api", "rowquant", "gemm", "dequant", "quantize", "conv", "attention", "parallel")
-_FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-command-line-argument"
+_FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-command-line-argument"
 
 
 def source_hash() -> str:
@@ -88,7 +88,7 @@ def source_hash() -> str:
         h.update(open(os.path.join(_CSRC, f), "rb").read())
     h.update(open(os.path.join(_HERE, "..", "include", "sdnq_hip.h"), "rb").read())
     hdr_hash = h.hexdigest()
-    flags = os.environ.get("SDNQ_EXTRA_FLAGS", "") + _FLAGS
+    flags = os.environ.get("SDNQ_EXTRA_FLAGS", "") + _FLAGS.replace("-ffp-contract=off", "-ffp-contract=" + os.environ.get("SDNQ_FP_CONTRACT", "off"))
     parts = ""
     for f in _SRCS:
         extra = "-mllvm -amdgpu-mfma-vgpr-form" if f == "attention" else ""

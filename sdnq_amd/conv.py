@@ -210,13 +210,15 @@ def _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd,
     if kg % 16 or ng % 8:
         raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
     n = self.sdnq_dequantizer.out_features
-    wq2, ws1, zp1 = wq.reshape(n, kg), ws.reshape(-1), zp.reshape(-1)
+    wq2, ws1, zp1 = wq.reshape(n, kg), ws.reshape(-1), None if zp is None else zp.reshape(-1)  # (signed weights in the uint8 matmul: no weight zero point)
     wcs1 = None if wcs is None else wcs.reshape(-1)
     out = torch.empty((x2d.shape[0], n), device=x2d.device, dtype=x2d.dtype)
     for g in range(int(self.groups)):
         sl = slice(g * ng, (g + 1) * ng)
-        ops.scaled_mm_zp_into(ops.MM_I8, xq[:, g * kg:(g + 1) * kg], wq2[sl], xs, ws1[sl], None if self.bias is None else self.bias[sl], rowsum,
-                              zp1[sl], xzp, None if wcs1 is None else wcs1[sl], xq.shape[1], out, g * ng)
+        # zp_k: the whole row's K; negative = the conv forwards' rounding order of the K * xzp * wzp term (conv_uint8.py:66)
+        ops.scaled_mm_zp_into(ops.MM_I8, xq[:, g * kg:(g + 1) * kg], wq2[sl], xs, ws1[sl], None if self.bias is None else self.bias[sl],
+                              None if zp1 is None else rowsum, None if zp1 is None else zp1[sl], xzp, None if wcs1 is None else wcs1[sl],
+                              -xq.shape[1], out, g * ng)
     return _folder(self, nd, b, ho, wo, depth_out)(out)
 
 
@@ -242,7 +244,7 @@ def quantized_conv_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Tens
     x2d, fold = _unfold(self, input)
     if input.numel() / input.shape[2] < 32:
         return fold(linear._float_forward(self, x2d, linear._state(self)))
-    return fold(linear._uint8_matmul_forward(self, x2d, small_batch_branch=False, cache_input=False))
+    return fold(linear._uint8_matmul_forward(self, x2d, small_batch_branch=False, cache_input=False, conv_form=True))
 
 
 @linear._no_grad

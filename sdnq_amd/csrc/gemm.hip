@@ -69,7 +69,8 @@ struct GemmParams {
     int64_t ldc;       // output row stride in ELEMENTS (0: N); with out_hw > 0: channels per image of the conv output (0: N)
     int64_t out_hw;    // 0: out is [M][N].  > 0: conv output [B][N][out_hw] with m = b * out_hw + pixel (NCHW, conv_int8.py:81-87)
     int64_t ld_bias;
-    int64_t zp_k;      // K of the uint8 matmul's K * (xzp * wzp) term when it is not this launch's K (one group of a grouped conv: the whole unfolded row); 0: K
+    int64_t zp_k;      // K of the uint8 matmul's K * (xzp * wzp) term when it is not this launch's K (one group of a grouped conv: the whole unfolded row); 0: K;
+                       // < 0: -K in the CONV forwards' rounding order, (xzp * K) * wzp added unfused (conv_uint8.py:66)
     int bias_ndim;
     int bias_dtype;  // SdnqFloat of bias (and of lr_t / lr_up, which share the svd dtype)
     int rank;
@@ -583,8 +584,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     const int K_B = is_w8a16<MM> ? K / 2 : K;  // bytes of a B row
     const bool has_tail = (K % BK) != 0;
     const uint8_t* baseA = hk.a + m0 * hk.lda;
-    auto rsA = SDNQ_MAKE_RSRC(baseA);
-    auto rsB = SDNQ_MAKE_RSRC(tv.b);
+    // Descriptors with the operands' TRUE extents from the tile's first row (the valid rows' bytes; clamped to the 31-bit field for
+    // matrices beyond 2 GiB, whose stages are whole anyway): a DMA lane that runs past the end of the matrix reads zeros.  Round 4: with
+    // K shorter than one stage (K = 32 on a 128-byte stage) the ring's filler fetches -- whole stages that nobody consumes, issued to keep
+    // the counted vmcnt a constant -- read up to 96 bytes past the last row, and a tiny operand at the end of a mapped segment took the
+    // GPU down with a memory access fault (found by tools/fuzz_modes.py; every shipped model has K >= 320).
+    const int64_t extA = (hk.M - 1 - m0) * hk.lda + K, extB = (tv.n_lim - 1) * hk.ldb + (is_w8a16<MM> ? K / 2 : K);
+    auto rsA = SDNQ_MAKE_RSRC_N(baseA, extA < 0x7fffffffll ? extA : 0x7fffffffll);
+    auto rsB = SDNQ_MAKE_RSRC_N(tv.b, extB < 0x7fffffffll ? extB : 0x7fffffffll);
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         bool isA;
@@ -1493,7 +1500,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                         if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
                             const float t2 = s_wcsq[cn] * azp;
                             zb = hasz ? zb + t2 : t2;
-                            if (p.zp) zb = fmaf(azp * s_zpq[cn], (float)(p.zp_k ? p.zp_k : hk.K), zb);  // add_(mul(xzp, wzp), alpha=K): fused on CPU eager
+                            if (p.zp) {
+                                if (p.zp_k < 0)  // conv form (conv_uint8.py:66): input_zero_point.mul_(K) in place, .mul(zero_point), a plain add_: three roundings
+                                    zb = __fadd_rn(zb, __fmul_rn(__fmul_rn(azp, (float)(-p.zp_k)), s_zpq[cn]));
+                                else  // linear form (linear_uint8.py:66): add_(mul(xzp, wzp), alpha=K) is ONE fused multiply-add on the CPU
+                                    zb = fmaf(azp * s_zpq[cn], (float)(p.zp_k ? p.zp_k : hk.K), zb);
+                            }
                             hasz = true;
                         }
                         if (hasz) {
@@ -2090,14 +2102,14 @@ extern "C" int sdnq_hip_scaled_mm_strided(int mm_dtype, const void* a, int64_t l
 
 // sdnq_hip_scaled_mm_lowrank on VIEWS (one group of a grouped conv whose epilogue carries zero-point / activation-zero-point terms,
 // conv_int8.py:65-79, conv_uint8.py:58-79): a is [M][lda] with K valid columns, out [M][ldc] with N valid columns; zp_k = the K of the
-// reference's K * (xzp * wzp) term (the WHOLE unfolded row, all groups), 0: k.
+// reference's K * (xzp * wzp) term (the WHOLE unfolded row, all groups), 0: k; negative: -K with the conv forwards' rounding order.
 extern "C" int sdnq_hip_scaled_mm_lowrank_strided(int mm_dtype, const void* a, int64_t lda, const void* b, const float* sa, const float* sb,
                                                   const void* bias, int bias_dtype, const int32_t* zp_rowsum, const float* zp, const float* a_zp,
                                                   const float* w_colsum_scaled, int64_t zp_k, void* out, int64_t ldc, int out_dtype, int64_t m,
                                                   int64_t n, int64_t k, sdnq_stream_t stream) {
     int st = check_common(mm_dtype, a, b, sa, sb, out, out_dtype, m, n, k);
     if (st != SDNQ_OK) return st;
-    if (lda < k || (lda % 16) != 0 || ldc < n || zp_k < 0) return SDNQ_ERR_SHAPE;
+    if (lda < k || (lda % 16) != 0 || ldc < n) return SDNQ_ERR_SHAPE;
     if ((ldc * (out_dtype == SDNQ_F32 ? 4 : 2)) % 16 != 0) return SDNQ_ERR_ALIGN;
     if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
     if ((a_zp == nullptr) != (w_colsum_scaled == nullptr)) return SDNQ_ERR_NULL;

@@ -22,6 +22,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* sdnq_lds_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SDNQ_MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, 0x7fffffff, 0x00020000)
+// the same with a byte extent: a lane whose offset reaches past it reads zeros instead of memory that may not be mapped
+#define SDNQ_MAKE_RSRC_N(ptr, nbytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(nbytes), 0x00020000)
 #define SDNQ_DMA16(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sdnq_lds_ptr_t)(dst), 16, voff, soff, 0, 0)
 #define SDNQ_DMA4(rs, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sdnq_lds_ptr_t)(dst), 4, voff, soff, 0, 0)
 #define SDNQ_BUF_LOAD16(rs, voff, soff) __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0))
@@ -32,6 +34,7 @@ typedef __attribute__((address_space(3))) void* sdnq_lds_ptr_t;
 #define SDNQ_BUF_STORE16_NT(rs, v, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rs, voff, soff, 2)
 #else
 #define SDNQ_MAKE_RSRC(ptr) ((const void*)(ptr))
+#define SDNQ_MAKE_RSRC_N(ptr, nbytes) ((void)(nbytes), (const void*)(ptr))
 #define SDNQ_DMA16(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
 #define SDNQ_DMA4(rs, dst, voff, soff) ((void)(rs), (void)(dst), (void)(voff), (void)(soff))
 #define SDNQ_BUF_LOAD16(rs, voff, soff) ((void)(rs), (void)(voff), (void)(soff), (v4i){0, 0, 0, 0})

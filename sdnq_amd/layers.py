@@ -28,7 +28,7 @@ class SDNQLayer(torch.nn.Module):
 
     # per-object runtime state that must not travel with a copy: the operator handle names THIS module, the projection group and the
     # kernel-ready tensor cache point at the original's siblings / parameters
-    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_hip_plan", "_sdnq_group", "_sdnq_hip_state", "_sdnq_unshared")
+    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_hip_plan", "_sdnq_group", "_sdnq_hip_state", "_sdnq_unshared", "_sdnq_compile_groups")
 
     def __deepcopy__(self, memo):
         import copy

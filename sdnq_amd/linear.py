@@ -782,7 +782,7 @@ def quantized_linear_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tens
     return _quantized_matmul_forward(self, input, ops.MM_FP8)
 
 
-def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = True, cache_input: bool = True) -> torch.Tensor:
+def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = True, cache_input: bool = True, conv_form: bool = False) -> torch.Tensor:
     """Asymmetric-activation int8 matmul (layers/linear/linear_uint8.py:106-131): activations get a per-row zero point,
     the three cross terms of (x - xzp)(w - wzp) are added in the GEMM epilogue instead of a materialised [M,N] bias."""
     dq = self.sdnq_dequantizer
@@ -803,6 +803,13 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     has_svd = st.svd_up is not None
     x2, xq, xs, rowsum, xrot, xzp = _rowquant_cached(input, k, ops.MM_I8, had, zp is not None, has_svd,
                                                      wq if PREFETCH_WEIGHTS else None, asymmetric=True, cache=cache_input)
+    if conv_form and not has_svd:
+        # the conv forwards build K * xzp * wzp as (xzp * K) * wzp with a plain add (conv_uint8.py:66), the Linear forward as ONE fused
+        # multiply-add (linear_uint8.py:66): same value up to the last bit, and the last bit is part of the contract
+        y = torch.empty((xq.shape[0], n), device=xq.device, dtype=input.dtype)
+        ops.scaled_mm_zp_into(ops.MM_I8, xq, wq, xs, ws.reshape(-1), self.bias, None if zp is None else rowsum, None if zp is None else zp.reshape(-1),
+                              xzp, wcs.reshape(-1), -k, y, 0)
+        return y.view(*input.shape[:-1], n)
     t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
     y = ops.scaled_mm_lowrank(ops.MM_I8, xq, wq, xs, ws, self.bias, t, st.svd_up, rowsum, zp, input.dtype, a_zp=xzp,
                               w_colsum_scaled=wcs)

@@ -44,6 +44,9 @@ def unsupported_reason(module) -> str | None:
                 "apply_sdnq_options_to_model(dequantize_fp32=False) produces")
     if qmm and not mm["is_integer"] and mm["num_bits"] != 8:
         return f"quantized_matmul_dtype='{dq.quantized_matmul_dtype}' (16-bit float matmul) is outside the MI355X hot path (SURVEY 8a note)"
+    w = dtype_dict[dq.weights_dtype]
+    if lp and w["num_bits"] > 8:
+        return "16-bit scales with formats wider than 8 bits are not built (the codes are not exact in the scale dtype)"
     uint8_mm = qmm and mm["is_integer"] and mm["is_unsigned"]
     if uint8_mm and lp:
         return "the uint8 matmul with 16-bit scales (dequantize_fp32=False) is not built"
@@ -61,6 +64,8 @@ def unsupported_reason(module) -> str | None:
             return "Conv3d with unequal dilations: the reference's unfold sizes every axis with dilation[0] (forward.py:62-64)"
     if qmm and dq.is_packed and not dq.re_quantize_for_matmul:
         return "packed conv weights with a direct quantized matmul have no valid layout in the reference"
+    if uint8_mm and getattr(module, "svd_up", None) is not None:
+        return "the uint8 conv matmul with SVD factors is not built (its K * xzp * wzp term is rounded in the conv forwards' own order)"
     if groups != 1:
         if dq.use_hadamard:
             return "Hadamard-rotated grouped conv layers are not built for MI355X"

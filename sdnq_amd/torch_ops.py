@@ -168,17 +168,20 @@ def _(xq, xs, handle, out_dtype):
 # same (xq, xs) arguments.  `MergeLayerMatmuls` (an Inductor post-grad pass, installed by `enable_compile_grouping()`) rewrites every
 # such set into ONE `layer_matmul_group` node -- sdnq_hip_scaled_mm_grouped over the members' own weights, one pass over the quantized
 # activation -- whose flat result the members' outputs are sliced from (views, free in Inductor).  Bit-identical to the members alone.
-_group_cache: dict = {}
 
 
 def _matmul_group(handles, mm):
     """(ProjectionGroup of the layers behind `handles`, ready for `mm`) or None when they cannot share a grouped launch."""
     from . import linear as L
     key = tuple(handles)
-    pg = _group_cache.get(key)
+    # the group lives on its FIRST member (module.__dict__), not in a module-level table: a table would hold the members -- and their
+    # quantized weights on the GPU -- alive for the life of the process (model-switching hosts; advisor, round 3).  Member -> group ->
+    # members is a reference cycle the garbage collector frees together with the model.
+    cache = _layer(key[0]).__dict__.setdefault("_sdnq_compile_groups", {})
+    pg = cache.get(key)
     if pg is None or any(m is not _layers.get(h, lambda: None)() for m, h in zip(pg.mods, key)):
         pg = L.ProjectionGroup([_layer(h) for h in key])
-        _group_cache[key] = pg
+        cache[key] = pg
     return pg if pg._operands(mm) else None
 
 

@@ -205,6 +205,11 @@ CASES = [
     dict(name="int4_svd_had_uint8mm_qmm_f16", K=512, N=64, Ms=[40], dtype="f16",
          cfg=dict(weights_dtype="int4", quantized_matmul_dtype="uint8", use_svd=True, svd_rank=16, use_hadamard=True,
                   use_quantized_matmul=True)),
+    # the uint8 matmul at a size where the single rounding of `zero_bias.add_(mul(xzp, zp), alpha=K)` (linear_uint8.py:66: one fused
+    # multiply-add per element on the CPU) shows: round 4's configuration fuzzer found the oracle wrong here (two roundings) while every
+    # smaller fixture agreed
+    dict(name="uint8_uint8mm_qmm_bf16_k384", K=384, N=64, Ms=[257], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", group_size=-1, use_quantized_matmul=True)),
     # dequantize_fp32=False: scales / zero points in the model dtype (quantizer.py:147-156), arithmetic in that dtype
     dict(name="int8_rowwise_qmm_bf16_lpscale", K=512, N=256, Ms=[4, 48, 77], dtype="bf16",
          cfg=dict(weights_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
@@ -363,6 +368,8 @@ CONV_CASES = [
          cfg=dict(weights_dtype="uint8", use_quantized_matmul_conv=True)),
     dict(name="conv1d_g4_int4_g16_uint8mm_qmm_f16_nobias", nd=1, cin=128, cout=64, k=3, conv=dict(padding=1, groups=4, bias=False), xs=[(2, 40)], dtype="f16",
          cfg=dict(weights_dtype="int4", group_size=16, quantized_matmul_dtype="uint8", use_quantized_matmul_conv=True)),
+    dict(name="conv2d_uint8_uint8mm_qmm_bf16_24x24", nd=2, cin=64, cout=96, k=3, conv=dict(padding=1), xs=[(1, 24, 24)], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", use_quantized_matmul_conv=True)),
     # Hadamard-rotated conv weights (quant_utils.py:222-236: the group divides C_in, groups run along the flattened (C_in, kernel) axis;
     # the matmul forwards rotate the unfolded input, conv_int8.py:52-53 / conv_fp8.py:41-42; the float forward un-rotates the weight)
     dict(name="conv2d_int8_had_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1), xs=[(2, 8, 8), (1, 4, 5)], dtype="bf16",

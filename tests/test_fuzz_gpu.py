@@ -27,3 +27,12 @@ def test_fuzz_conv_int8_bit_exact(seed, gpu_device):
 def test_fuzz_fused_dequantize_gemm_bit_exact(seed, gpu_device):
     import fuzz_w8a16
     assert fuzz_w8a16.run(seed, 30, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_configuration_space_vs_oracle(seed, gpu_device):
+    """Storage dtype x group size x matmul dtype x Hadamard x SVD x scale dtype x odd shapes (tools/fuzz_modes.py).  Round 4: this
+    sweep found a GPU memory fault at K < one LDS stage, epilogue terms the compiler had fused where torch rounds twice, and an
+    oracle line that rounded twice where torch fuses."""
+    import fuzz_modes
+    assert fuzz_modes.run(seed, 60, verbose=False) == []

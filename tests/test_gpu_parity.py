@@ -617,7 +617,7 @@ def test_conv_forward_vs_golden_and_oracle(name, gpu_device):
         assert y.dtype == x.dtype and tuple(y.shape) == ref.shape and y.is_contiguous()
         got = to_f32_numpy(y)
         orc = O.conv_forward(omod, c.f32(f"x_{i}"), c.conv, c.tag)
-        exact = d["use_quantized_matmul"] and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up") and not d["use_hadamard"]
+        exact = d["use_quantized_matmul"] and d["quantized_matmul_dtype"] in ("int8", "uint8") and not c.has("svd_up") and not d["use_hadamard"]
         if exact:
             assert np.array_equal(got, ref), (name, i, "golden", int((got != ref).sum()))
             assert np.array_equal(got, orc), (name, i, "oracle")
@@ -1558,3 +1558,41 @@ def test_per_call_weight_pipeline_is_bit_identical(gpu_device, monkeypatch):
     torch.cuda.synchronize()
     for i in fwd:
         assert torch.equal(gouts[i], want[i]), ("graph", i)
+
+
+@pytest.mark.parametrize("mm_name", ["int8", "fp8"])
+def test_scaled_mm_k_shorter_than_a_stage_at_the_end_of_an_allocation(mm_name, gpu_device):
+    """K of 16 ... 112 bytes is less than one 128-byte LDS stage: the ring's filler fetches (whole stages nobody consumes) used to read
+    up to 112 bytes past the last operand row -- round 4's configuration fuzzer took the GPU down with a memory access fault on a
+    K = 32 layer whose operands ended an allocation.  The operands here are the LAST bytes of their own 2 MiB blocks; results against
+    the oracle (bit-exact for int8)."""
+    mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
+    g = torch.Generator().manual_seed(7)
+
+    def at_end_of_block(t: torch.Tensor) -> torch.Tensor:
+        blk = torch.empty(2 << 20, dtype=torch.uint8, device=gpu_device)  # one whole small-pool segment of the caching allocator
+        nb = t.numel() * t.element_size()
+        nb16 = (nb + 15) // 16 * 16
+        dst = blk[(2 << 20) - nb16:(2 << 20) - nb16 + nb].view(t.dtype).view(t.shape)
+        dst.copy_(t)
+        dst._keep = blk
+        return dst
+
+    for (m, n, k) in [(32, 208, 32), (33, 64, 16), (100, 128, 48), (64, 64, 64), (257, 336, 96), (129, 64, 112), (40, 32, 80)]:
+        if mm_name == "int8":
+            a = torch.randint(-128, 128, (m, k), dtype=torch.int8, generator=g)
+            b = torch.randint(-128, 128, (n, k), dtype=torch.int8, generator=g)
+            a_np, b_np = a.numpy(), b.numpy()
+        else:
+            a = (torch.randn(m, k, generator=g) * 50).clamp(-448, 448).to(torch.float8_e4m3fn)
+            b = (torch.randn(n, k, generator=g) * 50).clamp(-448, 448).to(torch.float8_e4m3fn)
+            a_np, b_np = a.view(torch.uint8).numpy(), b.view(torch.uint8).numpy()
+        sa, sb = torch.rand(m, generator=g) * 0.02 + 1e-4, torch.rand(n, generator=g) * 0.02 + 1e-4
+        bias = torch.randn(n, generator=g).to(torch.bfloat16)
+        out = ops.scaled_mm(mm, at_end_of_block(a), at_end_of_block(b), sa.to(gpu_device), sb.to(gpu_device), bias.to(gpu_device), torch.bfloat16)
+        torch.cuda.synchronize()
+        ref = O.scaled_mm(mm_name, a_np, b_np, sa.numpy(), sb.numpy(), bias.float().numpy(), "bf16")
+        if mm_name == "int8":
+            assert np.array_equal(to_f32_numpy(out), ref), (m, n, k)
+        else:
+            assert_close_float(to_f32_numpy(out), ref, "bf16", (m, n, k))
