@@ -135,7 +135,11 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
                 for (int u = 0; u < CPT; ++u) v[u] = (inb && c0 + u < p.C) ? v[u] : 0.0f;
                 if (all_fast) {  // wave-uniform
 #pragma unroll
-                    for (int u = 0; u < CPT; ++u) v[u] = rd.fastdiv(v[u]);
+                    for (int u = 0; u < CPT; ++u) {
+                        const float x0 = v[u];
+                        v[u] = rd.fastdiv(x0);
+                        if constexpr (MM == SDNQ_MM_FP8) v[u] = (x0 == 0.0f) ? x0 : v[u];  // -0.0 keeps its sign (fp8 code 0x80), see rowquant.hip: quant8
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < CPT; ++u) v[u] = v[u] / scale;

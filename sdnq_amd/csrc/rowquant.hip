@@ -80,6 +80,10 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, in
         float c[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            // -0.0 / scale is -0.0 and its fp8 code 0x80: the three-instruction division returns +0 there (its correction term
+            // x - scale * q0 is +0, and -0 + +0 = +0), so a zero numerator passes through (round 4, tools/fuzz_ops.py: f16 activations
+            // that underflow to -0.0; the int8 codes have no signed zero)
+            if (LP_T == SDNQ_F32 && d.fast && v[e] == 0.0f) qv[e] = v[e];
             float q = FT<LP_T>::round(qv[e]);
             if (q != q) q = 0.0f;
             c[e] = fminf(fmaxf(q, -448.0f), 448.0f);

@@ -36,3 +36,12 @@ def test_fuzz_configuration_space_vs_oracle(seed, gpu_device):
     oracle line that rounded twice where torch fuses."""
     import fuzz_modes
     assert fuzz_modes.run(seed, 60, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_operators_vs_oracle(seed, gpu_device):
+    """scaled_mm (odd shapes, every bias form / output dtype), row quantization (odd K, padded rows, asymmetric), dequantize of every
+    storage dtype, quantized attention (tools/fuzz_ops.py).  Round 4: this sweep found the lost sign of a -0.0 activation in the fp8
+    row quantizer."""
+    import fuzz_ops
+    assert fuzz_ops.run(seed, 40, verbose=False) == []

@@ -1596,3 +1596,18 @@ def test_scaled_mm_k_shorter_than_a_stage_at_the_end_of_an_allocation(mm_name, g
             assert np.array_equal(to_f32_numpy(out), ref), (m, n, k)
         else:
             assert_close_float(to_f32_numpy(out), ref, "bf16", (m, n, k))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+def test_rowquant_fp8_keeps_the_sign_of_zero(dt, gpu_device):
+    """-0.0 / scale = -0.0 -> fp8 code 0x80 in the reference (torch.div + .to(float8_e4m3fn)); the three-instruction division used to
+    return +0 (code 0x00).  Found by tools/fuzz_ops.py on f16 activations that underflow to -0.0."""
+    x = torch.randn(40, 640, generator=torch.Generator().manual_seed(3)).to(dt)
+    x[:, 5::7] = -0.0
+    x[:, 6::7] = 0.0
+    x[3] = -0.0  # a whole row of negative zeros: scale 0, 0/0 -> NaN -> nan_to_num -> +0
+    xq, xs, _, _ = ops.rowquant(x.to(gpu_device), ops.MM_FP8)
+    q, s, _ = O.rowquant(x.float().numpy(), "fp8")
+    assert np.array_equal(xs.cpu().numpy().reshape(-1), s.reshape(-1))
+    assert np.array_equal(bits_of(xq), q.view(np.uint8))
+    assert (bits_of(xq)[0, 5::7] == 0x80).all() and (bits_of(xq)[0, 6::7] == 0x00).all()
