@@ -21,6 +21,7 @@ def test_fuzz_linear_w8a8_bit_exact(seed, gpu_device):
 def test_fuzz_conv_int8_bit_exact(seed, gpu_device):
     import fuzz_conv
     assert fuzz_conv.run(seed, 24, verbose=False) == []
+    assert fuzz_conv.run(seed + 1, 30, verbose=False, variety=True) == []  # unsigned weights, uint8 / fp8 matmuls, 4-bit, float mode, groups
 
 
 @pytest.mark.parametrize("seed", [505, 606])
@@ -45,3 +46,18 @@ def test_fuzz_operators_vs_oracle(seed, gpu_device):
     row quantizer."""
     import fuzz_ops
     assert fuzz_ops.run(seed, 40, verbose=False) == []
+
+
+def test_fuzz_large_problems_every_tile_agrees_with_the_small_tiles(gpu_device):
+    """Large ragged problems through the tile heuristics (256x256 half-tile ring, 256x128, 256x160, 128x128) == the same problem on
+    forced 64x128 tiles, bit for bit for int8, incl. the low-rank and zero-point epilogues (tools/fuzz_tiles.py)."""
+    import fuzz_tiles
+    assert fuzz_tiles.run(31, 16, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_fuzz_host_side_reuse_never_serves_stale_results(seed, gpu_device):
+    """Random call / in-place edit / invalidate / step-boundary sequences over shared tensors: the activation cache, the linked
+    projection groups and the per-module weight state always equal a computation on a fresh clone (tools/fuzz_host_state.py)."""
+    import fuzz_host_state
+    assert fuzz_host_state.run(seed, 250, verbose=False) == []

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(seed: int = 0, iters: int = 40, verbose: bool = True) -> list:
+def run(seed: int = 0, iters: int = 40, verbose: bool = True, variety: bool = False) -> list:
     import sdnq_amd
     from tests.modules_util import oracle_from_module
     from oracle import oracle as O
@@ -44,15 +44,36 @@ def run(seed: int = 0, iters: int = 40, verbose: bool = True) -> list:
             continue
         if min(y_shape[2:]) < 1:
             continue
-        mod, _ = sdnq_amd.sdnq_quantize_layer(conv.to(dt).to(dev), sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))
+        # configuration: mostly the int8 matmul on int8 weights (bit-exact), sometimes unsigned weights (zero-point terms), the uint8
+        # (asymmetric-activation) matmul, fp8, re-quantized 4-bit weights or the float mode
+        cfgname = rng.choice(["int8", "int8", "int8", "uint8w", "uint8mm", "fp8", "int4g16", "float"]) if variety else "int8"
+        cfg = {"int8": dict(weights_dtype="int8", use_quantized_matmul_conv=True),
+               "uint8w": dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True),
+               "uint8mm": dict(weights_dtype="uint8", use_quantized_matmul_conv=True),
+               "fp8": dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True),
+               "int4g16": dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True),
+               "float": dict(weights_dtype="uint4")}[cfgname]
+        try:
+            mod, _ = sdnq_amd.sdnq_quantize_layer(conv.to(dt).to(dev), sdnq_amd.SDNQConfig(quant_conv=True, **cfg))
+        except (NotImplementedError, ValueError):
+            continue
+        from sdnq_amd import support
+        if not hasattr(mod, "sdnq_dequantizer") or support.unsupported_reason(mod) is not None:
+            continue
         x = torch.randn(shape).to(dt)
         y = mod(x.to(dev)).float().cpu().numpy()
         meta = {"nd": nd, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
                 "padding_mode": mod.padding_mode, "groups": groups}
         ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
         done += 1
+        d = mod.sdnq_dequantizer
+        exact = d.use_quantized_matmul and str(d.quantized_matmul_dtype) in ("int8", "uint8") and x.numel() / x.shape[2] >= 32
+        if not exact and y.shape == ref.shape:  # float / fp8 matmuls: the float tolerance of the parity tests
+            scale = float(np.abs(ref).max()) or 1.0
+            if float(np.abs(y - ref).max()) / scale <= {"bf16": 2 * 2.0 ** -8, "f16": 2 * 2.0 ** -11}[tag]:
+                continue
         if y.shape != ref.shape or not np.array_equal(y, ref):
-            bad.append((nd, groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape,
+            bad.append((cfgname, nd, groups, mod.forward_func.__name__, cin, cout, ks, stride, pad, dil, h, w, b, tag, y.shape, ref.shape,
                         int((y != ref).sum()) if y.shape == ref.shape else -1))
             if verbose:
                 print("MISMATCH", *bad[-1])
@@ -62,4 +83,4 @@ def run(seed: int = 0, iters: int = 40, verbose: bool = True) -> list:
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40) else 0)
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 40, variety="--variety" in sys.argv) else 0)
