@@ -564,8 +564,14 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     // very long rows (5120 < K <= 16384: FLUX's 12288 / 15360-wide activations): four waves per row hold a quarter each in registers
     // -- ONE pass over HBM instead of the two-phase fallback's two (4608 x 15360: 66 us per launch on the two-phase path)
     const bool long4 = np > 10 && np <= 32 && !(prefetch && prefetch_bytes > 0) && split_env != 1;
-    const bool split4 = long4 || (can_split && np <= 12 && (split_env == 4 || (split_env == 0 && np >= 7)));
-    const bool split2 = can_split && !split4 && np <= 10 && split_env != 1;
+    // Two waves per row (1024 x 1280 rows: 3.2 us against 3.6 replayed alone) LOSE inside the step -- judged there, same box, two runs
+    // each: SDXL int8 step 8.097 / 8.099 ms with them, 7.967 / 7.966 without, fp8 step 8.16 -> 8.11, FLUX int8 + SVD neutral
+    // (profiles/r04_rowquant_split_in_step.txt): twice the workgroups to launch and drain in front of a GEMM that waits for the last of
+    // them.  Four waves per row for K >= 3584 still pay (all splits off: 8.005).  SDNQ_HIP_RQ_SPLIT2=1 brings the two-wave rows back.
+    static const int split2_env = [] { const char* e = getenv("SDNQ_HIP_RQ_SPLIT2"); return e ? atoi(e) : 0; }();
+    static const int split4_np = [] { const char* e = getenv("SDNQ_HIP_RQ_SPLIT4_NP"); return e ? atoi(e) : 7; }();    // tuning aid: four-wave rows from this many 512-element passes
+    const bool split4 = long4 || (can_split && np <= 12 && (split_env == 4 || (split_env == 0 && np >= split4_np)));
+    const bool split2 = can_split && !split4 && np <= 10 && split_env != 1 && split2_env != 0;
     const int row_blocks = split4 ? (int)m : (split2 ? (int)((m + 1) / 2) : (int)((m + 3) / 4));
     const uint4* pf = (const uint4*)prefetch;
     int64_t pf_vecs = 0;
