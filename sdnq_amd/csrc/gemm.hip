@@ -1752,6 +1752,8 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 19) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
         if (force == 20 && (p.K % 128) == 0 && ht_ok(p)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
         if (force == 20) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+        // (round 4 lab, not instantiated: 128x160 tiles -- N = 320 in two exact columns, 256 tiles at M = 16384 -- equal the 64x128 tile on
+        //  the conv step, 64x320 tiles are slower; profiles/r04_conv_tiles_in_step.txt)
         // (round 4, profiles/r04_ring_depth_in_step.txt: 5- and 6-deep rings for the 64x128 tile -- the one-workgroup-per-CU problems of the
         //  SDXL step, 160 tiles on 256 CUs -- judged on the step: 1024 x 1280 x 1280 +0.11 / +0.13 ms, 4096 x 640 x 640 +0.15 / +0.16 ms,
         //  1024 x 1280 x 5120 +-0.00: more bytes in flight do not raise the per-CU fill rate, so the 27 B/clk is not latency x bytes-in-flight
@@ -1797,7 +1799,11 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     }
     //  * tall problems that cannot fill the chip with 256x256 tiles (conv GEMMs 16384 x 320 x 2880..8640, 4096 x 5120 x 640):
     //    256x128 tiles, 8 waves of 64x64, two co-resident workgroups per CU -- +10..26 % over 64x128 there, slower elsewhere
-    if (p.M >= 2048 && tiles(256, 128) >= 150 && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
+    //    (round 4, judged on the conv step: with 150..229 such tiles -- the N = 320 convs, 192 tiles on 256 CUs -- the chip is a quarter idle
+    //     and 64x128 tiles win: 16384 x 320 x 2880 -0.08 ms over its 7 launches, x 640 / x 5760 / x 8640 -0.01..-0.03 each;
+    //     profiles/r04_conv_tiles_in_step.txt.  From 230 tiles on -- 4096 x 1920: 240, 4096 x 5120: 640 -- the tall tile stays.)
+    static const int tall_min = [] { const char* e = getenv("SDNQ_HIP_TALL_MIN_TILES"); return e ? atoi(e) : 230; }();  // tuning aid
+    if (p.M >= 2048 && tiles(256, 128) >= tall_min && fits(128)) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
     if constexpr (PP_OK<MM, OUT_T, EPI>) {
         //  * a few hundred rows against a wide N and a long K (the text stream of FLUX: 512 x 9216 / 12288 x 3072): ONE round of 256x128
         //    tiles on the fine-grained ping-pong -- 22.8 vs 28.9 us and 24.9 vs 30.7 us against 64x128 tiles (profiles/r03_gemm_tile_resweep.txt);
