@@ -706,7 +706,16 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     // measured (tools/bench_attention.py): splitting pays at head_dim 64 (SDXL 10 x 4096^2: 90 -> 78 us); at head_dim 128 the
     // unsplit kernel with K / V shared through LDS is faster (FLUX 24 x 4608^2: 333 -> 309 us), at 64 sharing does not pay
     const bool want_shared = head_dim == 128 && kv_len >= 2048 && !is_causal && !mask;
-    p.split = force_split ? force_split : ((!want_shared && tiles > 1024 && tiles < 4096 && kv_len >= 2048) ? 2 : 1);
+    // round 4, judged on the step (sdxl_attn_int8, one box: round-3 rule -- 2 parts for 1024 < tiles < 4096 and >= 2048 keys -- 3.35-3.42 ms;
+    // target 2048: 3.20; 4096: 3.155; 8192: 3.164; 4 parts forced everywhere: 3.235): the smallest number of parts that puts at least
+    // `split_target` waves on the chip, every part keeping >= 4 key blocks (the 77-key cross-attention stays whole)
+    static const int split_target = [] { const char* e = getenv("SDNQ_HIP_ATTN_SPLIT_TARGET"); return e ? atoi(e) : 4096; }();  // tuning aid
+    int auto_split = 1;
+    if (!want_shared) {
+        const int64_t kblocks = (kv_len + 31) / 32;
+        while (auto_split < 4 && tiles * auto_split < split_target && kblocks >= 4 * (auto_split * 2)) auto_split *= 2;
+    }
+    p.split = force_split ? force_split : auto_split;
     if (p.split != 1 && p.split != 2 && p.split != 4) return SDNQ_ERR_SHAPE;
     static const int force_shared = [] { const char* e = getenv("SDNQ_HIP_ATTN_SHARED"); return e ? atoi(e) : -1; }();  // tuning aid
     p.shared_kv = (p.split == 1 && !is_causal && !mask && kv_len >= 64) ? (force_shared < 0 ? (want_shared ? 1 : 0) : force_shared) : 0;
