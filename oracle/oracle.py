@@ -313,6 +313,11 @@ class OracleLinear:
         self.N, self.K = N, K
         self.result_tag = {"bfloat16": "bf16", "float16": "f16", "float32": "f32"}[deq["result_dtype"]]
         self.bias_tag = bias_tag or self.result_tag
+        if scale_tag != "f32" and dtype_info(deq["weights_dtype"])["bits"] > 8:
+            # the reference carries the dequantize of a 9..16-bit code in the 16-bit scale dtype (the codes themselves are rounded there);
+            # that arithmetic is not restated (tools/fuzz_oracle_vs_reference.py: int12 + bf16 scales differed from the reference), and
+            # the HIP path names the configuration unsupported (sdnq_amd.support)
+            raise NotImplementedError("16-bit scales with storage formats wider than 8 bits are not restated")
 
     # -- layout facts -------------------------------------------------------------------------
     @property
@@ -531,6 +536,9 @@ def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str
     (layers/conv/forward.py:80-81); the int8 / fp8 matmuls quantize the WHOLE row with one scale and multiply per group
     (conv_int8.py:64, 73-79; conv_fp8.py:56-60: int_mm per column slice, cat, .mul_(input_scale), addcmul(bias, ., scale))."""
     d = mod.deq
+    if d["use_hadamard"]:
+        # the reference rotates a grouped conv's rows too; that form is not restated (and sdnq_amd.support names it unsupported)
+        raise NotImplementedError("Hadamard-rotated grouped conv layers are not restated")
     Kg, N = mod.K, mod.N
     Ng = N // groups
     assert x2d.shape[1] == groups * Kg and N % groups == 0
@@ -735,6 +743,8 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: bool 
     K, N = mod.K, mod.N
     M = x2.shape[0]
     f = np.float32
+    if mod.scale_tag != "f32":  # (every weight form: tools/fuzz_oracle_vs_reference.py found the plain-uint8 form slipping through)
+        raise NotImplementedError("uint8 matmul with 16-bit scales is not restated")
     if d["re_quantize_for_matmul"]:  # linear_uint8.py:109-111: int8 codes + per-row scale and zero point, no xor
         wq, sc, zp = mod.re_quantize_matmul()
     else:

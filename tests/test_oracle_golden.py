@@ -203,3 +203,17 @@ def test_golden_fixtures_are_what_the_reference_computes():
     r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden.py"), "--verify"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatching outputs: 0" in r.stdout
+
+
+@pytest.mark.parametrize("tool,args,ok", [("fuzz_oracle_vs_reference.py", ["7", "60"], "0 mismatches"), ("fuzz_quantizer_vs_reference.py", ["7", "80"], "0 mismatches")])
+def test_random_sweeps_against_the_imported_reference(tool, args, ok):
+    """Build container only: beyond the committed fixtures, the ORACLE's forwards and the host-side load-time QUANTIZER are swept
+    against the imported reference over random configurations and shapes (round 4: 630 forwards / 300 layers clean after the oracle
+    stopped restating forms it had never been pinned on)."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src/sdnq"):
+        pytest.skip("the reference is not present on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and ok in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
