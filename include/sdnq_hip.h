@@ -469,11 +469,17 @@ int sdnq_hip_linear_skinny_svd(const SdnqWeight* w, const void* svd_down_t, cons
  *   the channel sums of 32 token splits; K minus its token mean when smooth_k), qq / kq int8 codes + qs / ks f32 per-token scales (quantize_int_mm, quant_utils.py:265-273;
  *   qs [batch*q_heads][q_len], ks [batch*kv_heads][kv_len rounded up to 32], padding never read as a value),
  *   vt = V transposed to [batch*kv_heads][head_dim][kv_len rounded up to 32] (zero padded) in the value dtype.
+ *   qq == NULL and qs == NULL: K and V only (q is not read) -- for sdnq_hip_attn_fwd_q16.  Launches: one, or two when smooth_k meets more
+ *   than 256 keys ({V layout, [Q rows,] channel sums of K} then {K rows}).
  * sdnq_hip_attn_fwd <- sdnq_attn_kernel (triton_atten.py:143-335): out [batch][q_heads][q_len][head_dim] of out_dtype
  *   (the value dtype or f32).  mask: NULL, or the attention mask of get_attn_inputs (triton_atten.py:520-527) addressed as
  *   mask[b * mask_stride_b + h * mask_stride_h + q * mask_stride_q + key] (element strides, 0 where it broadcasts, keys
  *   contiguous); mask_dtype -1 = int8 / bool (0 = masked out, :290-291), else SdnqFloat = additive mask, added to the base-2
- *   logits as is (:292-293).  A query with no visible key returns 0 (l_i stays 1, :232). */
+ *   logits as is (:292-293).  A query with no visible key returns 0 (l_i stays 1, :232).
+ * sdnq_hip_attn_fwd_q16: the same forward with Q still in the value dtype (q [batch][q_heads][q_len][head_dim], element strides q_strides
+ *   or NULL = contiguous): each wave quantizes its 32 queries per token (the quantize_int_mm arithmetic of sdnq_hip_attn_prepare, same
+ *   codes and scales, so the output is bit-identical to prepare + fwd) -- a query is read by one tile only, so the separate pass over Q
+ *   (16-bit read, 8-bit write, 8-bit read) becomes one 16-bit read.  Not with a Hadamard rotation (prepare rotates Q). */
 int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads,
                           int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, int hadamard_group,
                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, void* qq, float* qs,
@@ -483,6 +489,27 @@ int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const flo
                       int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, const int64_t* out_strides,
                       int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
                       sdnq_stream_t stream);
+int sdnq_hip_attn_fwd_q16(const void* q, const int64_t* q_strides, const void* kq, const float* ks, const void* vt, int v_dtype,
+                          float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                          int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, const int64_t* out_strides,
+                          int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                          sdnq_stream_t stream);
+
+/* sdnq_hip_attn <- sdnq_triton_atten (triton_atten.py:540-618) as ONE call: quantize_attn + sdnq_atten_fwd with the arguments of the three
+ * entry points above (q / k / v of `dtype` = bf16 / f16 with element strides or NULL, smooth_k, hadamard_group, sm_scale, is_causal, mask, out).
+ * Route, chosen here:
+ *   kv_len <= 128 and no rotation (cross-attention onto text tokens): a SINGLE launch -- every workgroup builds its head's smoothed,
+ *     quantized K, the V operand and the key scales in LDS and quantizes its own queries; no workspace (workspace_bytes() returns 0);
+ *   otherwise sdnq_hip_attn_prepare (K, V; Q too under a rotation) into `workspace` + sdnq_hip_attn_fwd(_q16).
+ * Results equal the three-call sequence bit for bit.  workspace: sdnq_hip_attn_workspace_bytes(...) bytes (< 0: SdnqStatus), 256-byte
+ * aligned, owned by the caller until the stream has run the call. */
+int64_t sdnq_hip_attn_workspace_bytes(int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                                      int hadamard_group);
+int sdnq_hip_attn(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len,
+                  int64_t kv_len, int64_t head_dim, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                  int smooth_k, int hadamard_group, float sm_scale, int is_causal, const void* mask, int mask_dtype,
+                  int64_t mask_stride_b, int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
+                  const int64_t* out_strides, void* workspace, int64_t workspace_bytes, sdnq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -9,12 +9,14 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 
 import torch
 
 from . import _lib, ops
 
 _DISABLED = {None, "none", "no", "disabled"}
+_Q16 = os.environ.get("SDNQ_HIP_ATTN_Q16", "1") != "0"
 
 
 def _rows16(t: torch.Tensor) -> torch.Tensor:
@@ -28,11 +30,16 @@ def _strides(t: torch.Tensor):
     return (ctypes.c_int64 * 3)(*t.stride()[:3])
 
 
-def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True, hadamard_group: int = 0):
+def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True, hadamard_group: int = 0,
+                  with_query: bool = True):
     """quantize_attn (triton_atten.py:443-487) for matmul_dtype="int8", pv_matmul_dtype=None.
     Returns (q_q int8 [Z,H,QN,D], q_scale f32 [Z,H,QN], k_q, k_scale f32 [Z,KH,KNp], v_f) with KNp = KN rounded up to 32.
     k_q [Z,KH,KNp/32,D/32,64,16] int8 and v_f [Z,KH,KNp/32,D/32,2,64,8] are the K / V operands in MFMA-fragment order (see
-    ``unpack_k_fragments`` / ``unpack_v_fragments``); tokens past KN are zero."""
+    ``unpack_k_fragments`` / ``unpack_v_fragments``); tokens past KN are zero.
+    ``with_query=False``: K and V only -- (query as the kernels will read it, None, k_q, k_scale, v_f) -- for ``atten_fwd``'s
+    quantize-in-the-forward-kernel route (same codes and scales, one pass over Q less; not with a Hadamard rotation)."""
+    if not with_query and hadamard_group:
+        raise ValueError("the Hadamard rotation of Q runs in the prepare pass: with_query=False needs hadamard_group=0")
     if not query.is_cuda:
         raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
     z, qh, qn, d = query.shape
@@ -42,7 +49,7 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     knp = (kn + 31) // 32 * 32
     d_src, d = d, (64 if d <= 64 else 128)  # head dims below 64 / 128 are zero-padded inside the kernels
     # one allocation for the five operands + the K-mean workspace (an eager host pays per allocation), 256-byte aligned slices
-    shapes = (((z, qh, qn, d), torch.int8), ((z, qh, qn), torch.float32), ((z, kh, knp // 32, d // 32, 64, 16), torch.int8),
+    shapes = (((z, qh, qn if with_query else 0, d), torch.int8), ((z, qh, qn if with_query else 0), torch.float32), ((z, kh, knp // 32, d // 32, 64, 16), torch.int8),
               ((z, kh, knp), torch.float32), ((z, kh, knp // 32, d // 32, 2, 64, 8), value.dtype),
               ((z, kh, 32, d), torch.float32))  # last: channel sums of 32 token splits
     sizes = [-(-(math.prod(shp) * dt.itemsize) // 256) * 256 for shp, dt in shapes]
@@ -54,9 +61,11 @@ def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, s
     qq, qs, kq, ks, vt, kmean = parts
     ops.check(_lib.load().sdnq_hip_attn_prepare(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype),
                                                 z, qh, kh, qn, kn, d_src, 1 if smooth_k else 0, hadamard_group, _strides(query), _strides(key),
-                                                _strides(value), qq.data_ptr(), qs.data_ptr(),
+                                                _strides(value), qq.data_ptr() if with_query else None, qs.data_ptr() if with_query else None,
                                                 kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), kmean.data_ptr(),
                                                 ops._stream(query)), "attn_prepare")
+    if not with_query:
+        return query, None, kq, ks, vt
     return qq, qs, kq, ks, vt
 
 
@@ -97,7 +106,8 @@ def prepare_mask(attn_mask: torch.Tensor, qn: int, kn: int) -> torch.Tensor:
 def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype,
               attn_mask: torch.Tensor | None = None, token_major: bool = False, head_dim: int | None = None) -> torch.Tensor:
     """sdnq_atten_fwd (triton_atten.py:338-385) on the quantized operands of ``quantize_attn``; ``attn_mask`` as ``prepare_mask``
-    returns it (4-D, contiguous; size-1 dimensions broadcast, triton_atten.py:371-378)."""
+    returns it (4-D, contiguous; size-1 dimensions broadcast, triton_atten.py:371-378).  ``qs is None``: ``qq`` is the query in the
+    value dtype (``quantize_attn(with_query=False)``) and the forward kernel quantizes it."""
     z, qh, qn, d = qq.shape
     kh = kq.shape[1]
     d = head_dim or d  # qq holds the padded head dim; the output has the tensors' own
@@ -110,11 +120,14 @@ def atten_fwd(qq, qs, kq, ks, vt, kn: int, sm_scale: float, is_causal: bool, out
         mptr = attn_mask.data_ptr()
         mdt = -1 if attn_mask.dtype == torch.int8 else ops.float_code(attn_mask.dtype)
         ms = tuple(attn_mask.stride(i) if attn_mask.shape[i] != 1 else 0 for i in range(3))
-    ops.check(_lib.load().sdnq_hip_attn_fwd(qq.data_ptr(), qs.data_ptr(), kq.data_ptr(), ks.data_ptr(), vt.data_ptr(),
-                                            ops.float_code(vt.dtype), float(sm_scale), 1 if is_causal else 0, mptr, mdt, *ms,
-                                            out.data_ptr(), ops.float_code(out_dtype), _strides(out), z, qh, kh, qn, kn, d,
-                                            ops._stream(qq)),
-              "attn_fwd")
+    tail = (kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), ops.float_code(vt.dtype), float(sm_scale), 1 if is_causal else 0, mptr, mdt, *ms,
+            out.data_ptr(), ops.float_code(out_dtype), _strides(out), z, qh, kh, qn, kn, d, ops._stream(qq))
+    if qs is None:
+        if qq.dtype != vt.dtype:
+            raise ValueError("query and value dtypes differ")
+        ops.check(_lib.load().sdnq_hip_attn_fwd_q16(qq.data_ptr(), _strides(qq), *tail), "attn_fwd_q16")
+    else:
+        ops.check(_lib.load().sdnq_hip_attn_fwd(qq.data_ptr(), qs.data_ptr(), *tail), "attn_fwd")
     return out
 
 
@@ -151,12 +164,37 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
         dp = 64 if d <= 64 else 128
         use_hadamard, group = get_hadamard_group_size(dp, min(hadamard_group_size, dp))
         group = group if use_hadamard else 0
-    qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k, hadamard_group=group)
+    if not query.is_cuda or (attn_mask is not None and not attn_mask.is_cuda):
+        raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
     if attn_mask is not None:
-        if not attn_mask.is_cuda:
-            raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
         attn_mask = prepare_mask(attn_mask, query.shape[2], key.shape[2])
     # like torch's SDPA, the output takes the memory layout of the query: a [Z,N,H,D]-backed query (the transposed view a
     # diffusers / transformers attention processor passes) gets a [Z,N,H,D]-backed output
     token_major = query.shape[1] > 1 and query.shape[2] > 1 and query.stride(2) > query.stride(1) and query.stride(-1) == 1
-    return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask, token_major=token_major, head_dim=d)
+    if not _Q16:  # SDNQ_HIP_ATTN_Q16=0 (A/B aid): the three-step sequence with the separate pass over Q
+        qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k, hadamard_group=group)
+        return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask, token_major=token_major, head_dim=d)
+    # one C call (sdnq_hip_attn): a single launch for up to 128 keys, else K / V prepared into a workspace and Q quantized by the
+    # forward kernel (under a rotation: in the prepare pass)
+    z, qh, qn, _ = query.shape
+    kh, kn = key.shape[1], key.shape[2]
+    query, key, value = _rows16(query), _rows16(key), _rows16(value)
+    lib = _lib.load()
+    nbytes = lib.sdnq_hip_attn_workspace_bytes(z, qh, kh, qn, kn, d, group)
+    if nbytes < 0:
+        ops.check(int(nbytes), "attn_workspace_bytes")
+    ws = torch.empty((nbytes,), device=query.device, dtype=torch.uint8) if nbytes else None
+    if token_major:
+        out = torch.empty((z, qn, qh, d), device=query.device, dtype=out_dtype).transpose(1, 2)
+    else:
+        out = torch.empty((z, qh, qn, d), device=query.device, dtype=out_dtype)
+    mptr, mdt, ms = None, 0, (0, 0, 0)
+    if attn_mask is not None:
+        mptr = attn_mask.data_ptr()
+        mdt = -1 if attn_mask.dtype == torch.int8 else ops.float_code(attn_mask.dtype)
+        ms = tuple(attn_mask.stride(i) if attn_mask.shape[i] != 1 else 0 for i in range(3))
+    ops.check(lib.sdnq_hip_attn(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype), z, qh, kh, qn, kn, d,
+                                _strides(query), _strides(key), _strides(value), 1 if smooth_k else 0, group, float(sm_scale),
+                                1 if is_causal else 0, mptr, mdt, *ms, out.data_ptr(), ops.float_code(out_dtype), _strides(out),
+                                ws.data_ptr() if ws is not None else None, nbytes, ops._stream(query)), "attn")
+    return out

@@ -28,9 +28,23 @@ namespace {
 
 // element strides of a [batch][heads][tokens][head_dim] tensor whose head_dim is contiguous (e.g. the transposed view of a
 // [batch][tokens][heads * head_dim] projection output); `heads` splits a linear batch*heads index
+// a 64-bit integer division is ~150 instructions on this ISA, a 32-bit one ~30 -- and the quotients of these kernels (head and row indices)
+// fit 32 bits in every call but the > 2^31-element ones; the prepare kernel runs four of them per thread around 60 instructions of work
+__device__ __forceinline__ void divmod(int64_t a, int64_t b, int64_t& q, int64_t& r) {
+    if ((((uint64_t)a | (uint64_t)b) >> 32) == 0) {
+        const uint32_t x = (uint32_t)a, y = (uint32_t)b;
+        q = x / y; r = x % y;
+    } else {
+        q = a / b; r = a % b;
+    }
+}
 struct Strides {
     int64_t b, h, n, heads;
-    __device__ __forceinline__ int64_t at(int64_t head_lin, int64_t tok) const { return (head_lin / heads) * b + (head_lin % heads) * h + tok * n; }
+    __device__ __forceinline__ int64_t at(int64_t head_lin, int64_t tok) const {
+        int64_t zb, hh;
+        divmod(head_lin, heads, zb, hh);
+        return zb * b + hh * h + tok * n;
+    }
 };
 
 // ---- K channel sums over the tokens of one (batch, head), split over KMEAN_SPLITS workgroups ----------------------------
@@ -38,17 +52,17 @@ struct Strides {
 constexpr int KMEAN_SPLITS = 32;
 
 template <int T_ID>
-__global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict__ k, const Strides ks, float* __restrict__ part, int64_t kn, int d,
-                                                         int d_src) {
-    __shared__ float red[256 * 8];
+__device__ __forceinline__ void attn_kmean_block(const void* __restrict__ k, const Strides ks, float* __restrict__ part, int64_t kn, int d, int d_src,
+                                                 int64_t block, float* red /* 256 * 8 floats of LDS */) {
     const int lpr = d / 8, rpp = 256 / lpr;  // lanes per token row, rows per pass
-    const int tid = threadIdx.x, c8 = (tid % lpr) * 8, r0 = tid / lpr;
-    const int64_t head = blockIdx.x / KMEAN_SPLITS, split = blockIdx.x % KMEAN_SPLITS;
+    const int tid = threadIdx.x, lsh = d == 64 ? 3 : 4, c8 = (tid & (lpr - 1)) * 8, r0 = tid >> lsh;  // d is 64 or 128
+    const int64_t head = block / KMEAN_SPLITS, split = block % KMEAN_SPLITS;  // (KMEAN_SPLITS is a power of two: shifts)
     const int64_t per = (kn + KMEAN_SPLITS - 1) / KMEAN_SPLITS, lo = split * per, hi = lo + per < kn ? lo + per : kn;
+    const uint16_t* khead = (const uint16_t*)k + ks.at(head, 0);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t r = lo + r0; r < hi; r += rpp) {
         float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (c8 < d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)k + ks.at(head, r) + c8), v);  // channels past d_src: zero padding
+        if (c8 < d_src) Vec16<T_ID>::unpack(*(const uint4*)(khead + r * ks.n + c8), v);  // channels past d_src: zero padding
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
     }
@@ -59,8 +73,103 @@ __global__ __launch_bounds__(256) void attn_kmean_kernel(const void* __restrict_
         float s = 0.0f;
         const int lane_of = tid / 8, e = tid % 8;
         for (int r = 0; r < rpp; ++r) s += red[(r * lpr + lane_of) * 8 + e];
-        part[(int64_t)blockIdx.x * d + tid] = s;
+        part[block * d + tid] = s;
     }
+}
+
+typedef float pv2f __attribute__((ext_vector_type(2)));
+// Short launches of these kernels are latency chains of ONE wave per SIMD (~10 cycles per dependent vector instruction: the whole per-token
+// quantization of a 128-query tile costs 2 us at 13 instructions per element), so the per-element work is kept to packed fp32 math:
+//   x / scale, correctly rounded, for two values in three packed instructions (RowDiv::fastdiv, sdnq_dev.h) ...
+__device__ __forceinline__ pv2f fastdiv2(pv2f x, const RowDiv& d) {
+    const pv2f r2 = {d.rcp, d.rcp}, ns = {-d.scale, -d.scale};
+    const pv2f q0 = x * r2;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(ns, q0, x), r2, q0);
+}
+//   ... and rint + int8 packing without a conversion: |q| <= 128, so q + 1.5 * 2^23 is exact up to the round-to-nearest-even that rint would do
+//   and leaves rint(q) as a two's complement byte in the low mantissa bits; two byte-permutes and one shift-or per four values
+__device__ __forceinline__ u32 pack4_rne_i8(pv2f a, pv2f b) {
+    const pv2f magic = {12582912.0f, 12582912.0f};
+    a += magic;
+    b += magic;
+    const u32 t0 = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x0c0c0400u);
+    const u32 t1 = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x0c0c0400u);
+    return t0 | (t1 << 16);
+}
+
+// ---- channel means of ONE head's K by one 256-thread workgroup (short key sequences: no separate channel-sum section) --------
+// Thread tid owns channels [8 (tid % lpr), + 8) of the rows tid / lpr, + 256 / lpr, ...: `acc` = its sums in row order.  xw: 4 * 128 floats,
+// smean: 128 floats of LDS.  One summation order for every caller (the prepare kernel's inline form and the single-launch attention), so
+// both routes produce the same K codes.
+__device__ __forceinline__ void attn_means_reduce(float (&acc)[8], int64_t kn, int d, float* xw, float* smean) {
+    const int lpr = d / 8, tid = threadIdx.x, c8 = (tid & (lpr - 1)) * 8;  // d is 64 or 128
+    // the lanes of a wave that hold the same channels are lpr apart (lane exchange on the VALU / swizzle paths, hadamard_dev.h)
+    if (lpr == 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += lane_xor(acc[e], 8);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += lane_xor(acc[e], 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += lane_xor(acc[e], 32);
+    if ((tid & 63) < lpr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xw[(tid >> 6) * 128 + c8 + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < d) smean[tid] = ((xw[tid] + xw[128 + tid]) + (xw[256 + tid] + xw[384 + tid])) / (float)kn;  // k.mean(dim=2), triton_atten.py:459
+    __syncthreads();
+}
+template <int T_ID>
+__device__ __forceinline__ void attn_head_means(const void* __restrict__ k, const Strides kst, int64_t head, int64_t kn, int d, int d_src, float* xw, float* smean) {
+    const int lpr = d / 8, lsh = d == 64 ? 3 : 4, rpp = 256 >> lsh, tid = threadIdx.x, c8 = (tid & (lpr - 1)) * 8;  // d is 64 or 128
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint16_t* khead = (const uint16_t*)k + kst.at(head, 0);
+    for (int64_t r = tid >> lsh; r < kn; r += rpp) {
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c8 < d_src) Vec16<T_ID>::unpack(*(const uint4*)(khead + r * kst.n + c8), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    attn_means_reduce(acc, kn, d, xw, smean);
+}
+
+// per-token symmetric int8 of one row spread over lpr lanes (8 channels each): codes of this lane's 8 channels, the row's scale
+__device__ __forceinline__ float attn_quant8(const float (&v)[8], int lpr, u32 (&o)[2]) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    amax = fmaxf(amax, lane_xor(amax, 1));
+    amax = fmaxf(amax, lane_xor(amax, 2));
+    amax = fmaxf(amax, lane_xor(amax, 4));
+    if (lpr == 16) amax = fmaxf(amax, lane_xor(amax, 8));
+    const float scale = amax / 127.0f;
+    RowDiv rd;  // the correctly rounded 3-instruction division (sdnq_dev.h) when every row of the wave has an ordinary scale
+    rd.set(scale);
+    if (__all(rd.fast)) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+            o[w] = pack4_rne_i8(fastdiv2((pv2f){v[4 * w], v[4 * w + 1]}, rd), fastdiv2((pv2f){v[4 * w + 2], v[4 * w + 3]}, rd));
+        return scale;
+    }
+    // a zero row (scale 0: 0 / 0 must become code 0), a non-finite one or an extreme scale somewhere in the wave: the plain sequence
+    o[0] = o[1] = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float q = __builtin_rintf(v[e] / scale);
+        if (q != q) q = 0.0f;
+        q = fminf(fmaxf(q, -128.0f), 127.0f);
+        o[e >> 2] |= ((u32)(int)q & 0xffu) << (8 * (e & 3));
+    }
+    return scale;
+}
+// byte offset of the 8 codes (key n, channels [c8, c8 + 8)) inside one head's K operand in MFMA-fragment order: one 1-KiB tile per (32-key
+// block, 32-channel step), lane (g, rho) holds the 16 bytes [32 kk + 16 g, +16) of key pi(rho) (pi = swap bits 2 and 3, see
+// attn_fwd_kernel) -> every fragment load of the forward kernel is one fully coalesced 1-KiB access
+__device__ __forceinline__ int64_t attn_kfrag_offset(int64_t n, int c8, int d) {
+    const int kk = c8 >> 5, g = (c8 >> 4) & 1, half = (c8 >> 3) & 1, nl = (int)(n & 31);
+    const int rho = (nl & 0x13) | ((nl & 4) << 1) | ((nl & 8) >> 1);
+    return ((n / 32) * (d / 32) + kk) * 1024 + (g * 32 + rho) * 16 + half * 8;
 }
 
 // ---- per-token int8 quantization of [heads][n_src][d] (d / 8 lanes per token), optional mean subtraction ------------------
@@ -70,12 +179,13 @@ template <int T_ID>
 __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, const Strides xst, const float* mean, int8_t* __restrict__ xq, float* __restrict__ xs,
                                                  int64_t heads, int64_t n_src, int64_t n_dst, int d, bool frag_major, int64_t block,
                                                  int log2g, int d_src) {
-    const int lpr = d / 8;
+    const int lpr = d / 8, lsh = d == 64 ? 3 : 4;  // d is 64 or 128
     const int64_t t = block * 256 + threadIdx.x;
-    const int64_t row = t / lpr;
-    const int c8 = (int)(t % lpr) * 8;
+    const int64_t row = t >> lsh;
+    const int c8 = (int)(t & (lpr - 1)) * 8;
     const bool live = row < heads * n_dst;
-    const int64_t head = live ? row / n_dst : 0, n = live ? row % n_dst : 0;
+    int64_t head = 0, n = 0;
+    if (live) divmod(row, n_dst, head, n);
     const bool real = live && n < n_src;
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (real && c8 < d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + xst.at(head, n) + c8), v);  // 8 elements per 16-byte load; head dims
@@ -95,28 +205,11 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
     }
-    float amax = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
-    for (int m = 1; m < lpr; m <<= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
-    const float scale = amax / 127.0f;
-    u32 o[2] = {0, 0};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        float q = __builtin_rintf(v[e] / scale);
-        if (q != q) q = 0.0f;
-        q = fminf(fmaxf(q, -128.0f), 127.0f);
-        o[e >> 2] |= ((u32)(int)q & 0xffu) << (8 * (e & 3));
-    }
+    u32 o[2];
+    const float scale = attn_quant8(v, lpr, o);
     if (live) {
-        if (frag_major) {
-            // K operand in MFMA-fragment order: one 1-KiB tile per (32-key block, 32-channel step), lane (g, rho) holds the 16
-            // bytes [32 kk + 16 g, +16) of key pi(rho) (pi = swap bits 2 and 3, see attn_fwd_kernel) -> every fragment load of
-            // the forward kernel is one fully coalesced 1-KiB access.  n_dst is a multiple of 32.
-            const int kk = c8 >> 5, g = (c8 >> 4) & 1, half = (c8 >> 3) & 1, nl = (int)(n & 31);
-            const int rho = (nl & 0x13) | ((nl & 4) << 1) | ((nl & 8) >> 1);
-            const int64_t tile = (head * (n_dst / 32) + n / 32) * (d / 32) + kk;
-            *(uint2*)(xq + tile * 1024 + (g * 32 + rho) * 16 + half * 8) = make_uint2(o[0], o[1]);
+        if (frag_major) {  // K operand in MFMA-fragment order (n_dst is a multiple of 32)
+            *(uint2*)(xq + head * n_dst * d + attn_kfrag_offset(n, c8, d)) = make_uint2(o[0], o[1]);
         } else {
             *(uint2*)(xq + row * d + c8) = make_uint2(o[0], o[1]);
         }
@@ -127,15 +220,18 @@ __device__ __forceinline__ void attn_quant_block(const void* __restrict__ x, con
 // ---- V [heads][kn][d] -> PV operand in MFMA-fragment order (knp = kn rounded up to 32, zero padded) -----------------------
 // one 1-KiB tile per (32-key block kb, 32-channel block dd, 16-key step c): lane (g, ql) holds the 8 keys
 // kb*32 + 16c + 8g + 0..7 of channel 32dd + ql, i.e. exactly the first operand of PV MFMA (dd, c) of attn_fwd_kernel.
+template <int PITCH>
 __device__ __forceinline__ void attn_vt_block(const uint16_t* __restrict__ v, const Strides vst, uint16_t* __restrict__ vt, int64_t kn, int64_t knp, int d,
-                                              int64_t head, int64_t kb, uint16_t (*tile)[128 + 2], int d_src) {
+                                              int64_t head, int64_t kb, uint16_t (*tile)[PITCH], int d_src) {
     const int64_t key0 = kb * 32;
     const int lpr = d / 8, kkn = d / 32;
     uint16_t* dst = vt + (head * (knp / 32) + kb) * (int64_t)(kkn * 2 * 512);
+    const int lsh = d == 64 ? 3 : 4;  // d is 64 or 128
+    const uint16_t* vhead = v + vst.at(head, 0);
     for (int t = threadIdx.x; t < 32 * lpr; t += 256) {
-        const int kr = t / lpr, c8 = (t % lpr) * 8;
+        const int kr = t >> lsh, c8 = (t & (lpr - 1)) * 8;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (key0 + kr < kn && c8 < d_src) val = *(const uint4*)(v + vst.at(head, key0 + kr) + c8);
+        if (key0 + kr < kn && c8 < d_src) val = *(const uint4*)(vhead + (key0 + kr) * vst.n + c8);
         const uint16_t* h = (const uint16_t*)&val;
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[kr][c8 + e] = h[e];
@@ -158,17 +254,20 @@ struct PrepParams {
     uint16_t* vt;
     Strides qst, kst, vst;
     const float* kpart;  // [kheads][KMEAN_SPLITS][d] channel sums (smooth_k) or nullptr
-    int64_t qheads, kheads, qn, kn, knp, nqb, nkb;
+    float* kpart_out;    // the same table, written by the channel-sum section of a launch
+    int64_t qheads, kheads, qn, kn, knp, nqb, nkb, nvb, nmb;  // workgroups per section: Q rows, K rows, V tiles, K channel sums
     int d, d_src, log2g;  // d: head dim padded to 64 / 128, d_src: the tensors' head dim; log2g: log2 of the Hadamard group (0 = none)
     bool smooth_inline;  // K means computed inside the K workgroups (short key sequences)
 };
 
-// one launch for the three operands: workgroups [0, nqb) quantize Q, [nqb, nqb + nkb) quantize K (a workgroup never straddles
-// heads: knp is a multiple of the 32 / 16 tokens it covers), the rest lay out V
+// one launch, four kinds of workgroup: [0, nqb) quantize Q, the next nkb quantize K (a workgroup never straddles heads: knp is a
+// multiple of the 32 / 16 tokens it covers), the next nvb lay out V, the last nmb sum K's channels over a token split.  Any count may be 0:
+// with smooth_k over a long key sequence the K rows wait for the channel sums, so the host launches {Q, V, sums} and then {K}
+// (round 4; before, the sums were a launch of their own -- 4.7 us of latency for 5 MB -- and everything else waited for it).
 template <int T_ID>
 __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
-    SDNQ_KERNARGS_NOW("s"(p.q), "s"(p.k), "s"(p.v), "s"(p.qq), "s"(p.kq), "s"(p.qs), "s"(p.ks), "s"(p.vt), "s"(p.kpart), "s"(p.qheads), "s"(p.kheads), "s"(p.qn), "s"(p.kn),
-                      "s"(p.knp), "s"(p.nqb), "s"(p.nkb), "s"(p.d), "s"(p.d_src), "s"(p.log2g));
+    SDNQ_KERNARGS_NOW("s"(p.q), "s"(p.k), "s"(p.v), "s"(p.qq), "s"(p.kq), "s"(p.qs), "s"(p.ks), "s"(p.vt), "s"(p.kpart), "s"(p.kpart_out), "s"(p.qheads), "s"(p.kheads), "s"(p.qn), "s"(p.kn),
+                      "s"(p.knp), "s"(p.nqb), "s"(p.nkb), "s"(p.nvb), "s"(p.nmb), "s"(p.d), "s"(p.d_src), "s"(p.log2g));
     __shared__ float smean[128];
     __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
     const int64_t b = blockIdx.x;
@@ -180,28 +279,13 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
         if (p.smooth_inline) {
             // short key sequences (cross-attention onto text tokens): every K workgroup sums its head's channels itself
             // instead of a separate attn_kmean_kernel launch
-            const int lpr = p.d / 8, rpp = 256 / lpr, tid = threadIdx.x, c8 = (tid % lpr) * 8;
-            const int64_t head = kb * rpp / p.knp;
-            float* red = (float*)&tile[0][0];  // 256 * 8 floats <= sizeof(tile)
-            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int64_t r = tid / lpr; r < p.kn; r += rpp) {
-                float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (c8 < p.d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)p.k + p.kst.at(head, r) + c8), v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += v[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) red[tid * 8 + e] = acc[e];
-            __syncthreads();
-            if (tid < p.d) {
-                float sum = 0.0f;
-                for (int r = 0; r < rpp; ++r) sum += red[(r * lpr + tid / 8) * 8 + tid % 8];
-                smean[tid] = sum / (float)p.kn;
-            }
-            __syncthreads();
+            int64_t head, rem;
+            divmod(kb * (256 / (p.d / 8)), p.knp, head, rem);
+            attn_head_means<T_ID>(p.k, p.kst, head, p.kn, p.d, p.d_src, (float*)&tile[0][0], smean);
             mean = smean;
         } else if (p.kpart != nullptr) {
-            const int64_t head = kb * (256 / (p.d / 8)) / p.knp;
+            int64_t head, rem;
+            divmod(kb * (256 / (p.d / 8)), p.knp, head, rem);
             if ((int)threadIdx.x < p.d) {
                 const float* pp = p.kpart + head * KMEAN_SPLITS * p.d + threadIdx.x;
                 float s = 0.0f;
@@ -212,9 +296,12 @@ __global__ __launch_bounds__(256) void attn_prepare_kernel(const PrepParams p) {
             mean = smean;
         }
         attn_quant_block<T_ID>(p.k, p.kst, mean, p.kq, p.ks, p.kheads, p.kn, p.knp, p.d, true, kb, p.log2g, p.d_src);
+    } else if (b < p.nqb + p.nkb + p.nvb) {
+        int64_t vhead, vblk;
+        divmod(b - p.nqb - p.nkb, p.knp >> 5, vhead, vblk);
+        attn_vt_block((const uint16_t*)p.v, p.vst, p.vt, p.kn, p.knp, p.d, vhead, vblk, tile, p.d_src);
     } else {
-        const int64_t vb = b - p.nqb - p.nkb, nb = p.knp / 32;
-        attn_vt_block((const uint16_t*)p.v, p.vst, p.vt, p.kn, p.knp, p.d, vb / nb, vb % nb, tile, p.d_src);
+        attn_kmean_block<T_ID>(p.k, p.kst, p.kpart_out, p.kn, p.d, p.d_src, b - p.nqb - p.nkb - p.nvb, (float*)&tile[0][0]);  // 256 * 8 floats <= sizeof(tile)
     }
 }
 
@@ -230,6 +317,17 @@ struct AttnParams {
     const void* mask;  // attention mask [*, *, q, key] (key stride 1) or nullptr
     int mask_dtype;    // -1: int8 / bool (0 = masked out), else SdnqFloat of an additive mask
     int64_t ms_z, ms_h, ms_q;  // element strides (0 for broadcast dimensions)
+    // Q in the tensor dtype, quantized per token by the wave that owns the 32 queries (sdnq_hip_attn_fwd_q16); nullptr: qq / qs hold it.
+    // A query is read by one tile only, so quantizing it ahead costs a 16-bit read, an 8-bit write and an 8-bit read where this is one 16-bit read.
+    const void* q_src;
+    Strides qst;
+    int d_src;
+    // K and V in the tensor dtype too (sdnq_hip_attn, at most 128 keys: cross-attention onto text tokens): every workgroup builds its head's
+    // quantized K, the V operand and the key scales in LDS -- the whole attention is ONE launch
+    const void* k_src;
+    const void* v_src;
+    Strides kst, vst;
+    int smooth;
 };
 
 __device__ __forceinline__ float ldf_mask(const void* p, int64_t i, int dt) {
@@ -255,7 +353,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     // one batch of kernarg loads (SDNQ_KERNARGS_NOW, sdnq_dev.h)
     SDNQ_KERNARGS_NOW("s"(p.qq), "s"(p.qs), "s"(p.kq), "s"(p.ks), "s"(p.vt), "s"(p.out), "s"(p.qh), "s"(p.kh), "s"(p.qn), "s"(p.kn), "s"(p.knp), "s"(p.qblocks), "s"(p.split),
                       "s"(p.shared_kv), "s"(p.log2_sm_scale), "s"(p.ost.b), "s"(p.ost.h), "s"(p.ost.n), "s"(p.ost.heads), "s"(p.d_out), "s"(p.mask), "s"(p.mask_dtype),
-                      "s"(p.ms_z), "s"(p.ms_h), "s"(p.ms_q));
+                      "s"(p.ms_z), "s"(p.ms_h), "s"(p.ms_q), "s"(p.q_src), "s"(p.qst.b), "s"(p.qst.h), "s"(p.qst.n), "s"(p.qst.heads), "s"(p.d_src), "s"(p.k_src), "s"(p.v_src));
     constexpr int KK = D / 32;  // int8 MFMA K steps of Q.K^T; also the 32-channel blocks of O
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index in SGPRs: block indices stay scalar
     const int ql = lane & 31, g = lane >> 5;
@@ -274,18 +372,106 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int wtile = p.split == 4 ? 0 : (p.split == 2 ? wave >> 1 : wave);  // query tile of this wave inside the workgroup
     const int64_t q0 = ((int64_t)qblk * (4 / p.split) + wtile) * 32;
     const bool active = q0 < p.qn;  // wave-uniform
-    if (!active && p.split == 1 && !p.shared_kv) return;  // (shared K / V: every wave is needed for the loads and barriers)
-    const int64_t z = head_lin / p.qh, h = head_lin % p.qh;
+    const bool inline_kv = p.k_src != nullptr;  // (then split == 1 and no shared_kv streaming)
+    if (!active && p.split == 1 && !p.shared_kv && !inline_kv) return;  // (shared / inline K / V: every wave is needed for the loads and barriers)
+    int64_t z, h;
+    divmod(head_lin, p.qh, z, h);
     const int64_t mz = z, mh = h;  // attention-mask batch / head index (strides are 0 where the mask broadcasts)
-    const int64_t kv_lin = z * p.kh + (h * p.kh) / p.qh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
+    int64_t kvh, kvr;
+    divmod(h * p.kh, p.qh, kvh, kvr);
+    const int64_t kv_lin = z * p.kh + kvh;  // offset_k of triton_atten.py:212 (grouped-query mapping)
 
     const int64_t qi = q0 + ql, qrow = qi < p.qn ? qi : p.qn - 1;
-    auto rsQ = SDNQ_MAKE_RSRC(p.qq + head_lin * p.qn * D);  // (buffer form: see the K / V loads below)
-    v4i qf[KK];
+    // inline K / V: thread tid owns channels [8 (tid % LPR), + 8) of the keys tid / LPR + i * RPP.  ALL loads of K and V are issued here, in
+    // front of the Q loads, so the kernel has ONE memory round trip in front of its arithmetic
+    constexpr int LPR = D / 8, RPP = 256 / LPR, NR = 128 / RPP;
+    const int ic8 = ((int)threadIdx.x % LPR) * 8, ir0 = (int)threadIdx.x / LPR;
+    uint4 kraw[NR], vraw[NR];
+    if (inline_kv) {
+        const uint16_t* kh = (const uint16_t*)p.k_src + p.kst.at(kv_lin, 0) + ic8;
+        const uint16_t* vh = (const uint16_t*)p.v_src + p.vst.at(kv_lin, 0) + ic8;
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) qf[kk] = SDNQ_BUF_LOAD16(rsQ, (int)qrow * D + 16 * g, 32 * kk);
-    // ((acc * q_scale) * k_scale) * log2_sm_scale of triton_atten.py:278 as acc * (k_scale * (q_scale * log2_sm_scale))
-    const float qsl = p.qs[head_lin * p.qn + qrow] * p.log2_sm_scale;
+        for (int i = 0; i < NR; ++i) {
+            const int64_t r = ir0 + i * RPP;
+            kraw[i] = vraw[i] = make_uint4(0, 0, 0, 0);
+            if (ic8 < p.d_src && r < p.kn) {
+                kraw[i] = *(const uint4*)(kh + r * p.kst.n);
+                vraw[i] = *(const uint4*)(vh + r * p.vst.n);
+            }
+        }
+    }
+    v4i qf[KK];
+    float qsl;
+    if (p.q_src != nullptr) {
+        // per-token symmetric int8 of this lane's query (quantize_int_mm, quant_utils.py:265-273; the arithmetic of attn_quant8): the lane
+        // holds channels [32 kk + 16 g, + 16) of every K step, its partner lane ^ 32 the other half of the row
+        const uint16_t* qp = (const uint16_t*)p.q_src + p.qst.at(head_lin, qrow);
+        uint4 raw[KK][2];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int c8 = 32 * kk + 16 * g + 8 * hf;
+                raw[kk][hf] = make_uint4(0, 0, 0, 0);
+                if (c8 < p.d_src) raw[kk][hf] = *(const uint4*)(qp + c8);  // channels past the tensors' head dim: zero padding
+            }
+        // |x| of bf16 / f16 values orders like the unsigned integer of its low 15 bits: the row maximum on packed 16-bit integers
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        us2 mx = {0, 0};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const u32 w[4] = {raw[kk][hf].x, raw[kk][hf].y, raw[kk][hf].z, raw[kk][hf].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = __builtin_elementwise_max(mx, __builtin_bit_cast(us2, w[i] & 0x7fff7fffu));
+            }
+        u32 ab = mx[0] > mx[1] ? mx[0] : mx[1];
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(ab, ab, false, false);
+            ab = sw[0] > sw[1] ? sw[0] : sw[1];
+        }
+        const float amax = V_T == SDNQ_BF16 ? __uint_as_float(ab << 16) : f16_bits_to_f32((uint16_t)ab);
+        const float scale = amax / 127.0f;
+        RowDiv dv;
+        dv.set(scale);
+        if (__all(dv.fast)) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                float v[16];
+                Vec16<V_T>::unpack(raw[kk][0], v);
+                Vec16<V_T>::unpack(raw[kk][1], v + 8);
+                u32 o4[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    o4[w] = pack4_rne_i8(fastdiv2((pv2f){v[4 * w], v[4 * w + 1]}, dv), fastdiv2((pv2f){v[4 * w + 2], v[4 * w + 3]}, dv));
+                qf[kk] = (v4i){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
+            }
+        } else {  // a zero row (0 / 0 -> code 0), a non-finite one or an extreme scale somewhere in the wave
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                float v[16];
+                Vec16<V_T>::unpack(raw[kk][0], v);
+                Vec16<V_T>::unpack(raw[kk][1], v + 8);
+                u32 o4[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float qv = __builtin_rintf(v[e] / scale);
+                    if (qv != qv) qv = 0.0f;
+                    qv = fminf(fmaxf(qv, -128.0f), 127.0f);
+                    o4[e >> 2] |= ((u32)(int)qv & 0xffu) << (8 * (e & 3));
+                }
+                qf[kk] = (v4i){(int)o4[0], (int)o4[1], (int)o4[2], (int)o4[3]};
+            }
+        }
+        qsl = scale * p.log2_sm_scale;
+    } else {
+        auto rsQ = SDNQ_MAKE_RSRC(p.qq + head_lin * p.qn * D);  // (buffer form: see the K / V loads below)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[kk] = SDNQ_BUF_LOAD16(rsQ, (int)qrow * D + 16 * g, 32 * kk);
+        // ((acc * q_scale) * k_scale) * log2_sm_scale of triton_atten.py:278 as acc * (k_scale * (q_scale * log2_sm_scale))
+        qsl = p.qs[head_lin * p.qn + qrow] * p.log2_sm_scale;
+    }
 
     v16f o[KK];
 #pragma unroll
@@ -469,7 +655,92 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     // whose loads all hit one block in L1 was 22 % faster).
     constexpr int STG_K = 2 * KK * 1024, STG_V = 4 * KK * 1024, STG_BYTES = STG_K + STG_V + 256;
     constexpr int COMB_BYTES = 3 * (KK * 16 + 2) * 64 * 4;
-    __shared__ __attribute__((aligned(16))) uint8_t smem[2 * STG_BYTES > COMB_BYTES ? 2 * STG_BYTES : COMB_BYTES];
+    // inline K / V (<= 128 keys = 4 blocks): [K tiles 4 KK KiB][V tiles 8 KK KiB][128 key scales][4 x 128 partial channel sums][128 means]
+    constexpr int IN_V = 4 * KK * 1024, IN_S = 12 * KK * 1024, IN_XW = IN_S + 512, IN_MEAN = IN_XW + 2048, IN_BYTES = IN_MEAN + 512;
+    constexpr int STREAM_BYTES = 2 * STG_BYTES > COMB_BYTES ? 2 * STG_BYTES : COMB_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[STREAM_BYTES > IN_BYTES ? STREAM_BYTES : IN_BYTES];
+    if (inline_kv) {
+        // from the registers loaded at the top: V scattered into its operand tiles, the channel means, K quantized
+        const int c8 = ic8, r0 = ir0;
+        const bool col = c8 < p.d_src;
+        // V operand: key r, channel ch -> tile (r / 32, ch / 32, (r % 32) / 16), lane (r % 16) / 8 * 32 + ch % 32, element r % 8
+        // (one 1-KiB tile per (32-key block, 32-channel block, 16-key step), see attn_vt_block); padding keys / channels are zeros
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = r0 + i * RPP;
+            if (r < (int)p.knp) {
+                const uint16_t* h = (const uint16_t*)&vraw[i];
+                uint16_t* dst = (uint16_t*)(smem + IN_V) + (r / 32) * (KK * 2 * 512) + ((r & 31) >> 4) * 512 + (((r & 15) >> 3) * 32) * 8 + (r & 7);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ch = c8 + e;
+                    dst[(ch >> 5) * 1024 + (ch & 31) * 8] = h[e];
+                }
+            }
+        }
+        float kv[NR][8];
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            Vec16<V_T>::unpack(kraw[i], kv[i]);  // (zeros where nothing was loaded)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += kv[i][e];
+        }
+        if (p.smooth) {
+            attn_means_reduce(acc, p.kn, D, (float*)(smem + IN_XW), (float*)(smem + IN_MEAN));
+            const float* mean = (const float*)(smem + IN_MEAN) + c8;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                if (col && r0 + i * RPP < p.kn) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kv[i][e] -= mean[e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = r0 + i * RPP;
+            u32 o2[2];
+            const float scale = attn_quant8(kv[i], LPR, o2);
+            if (r < (int)p.knp) {
+                *(uint2*)(smem + attn_kfrag_offset(r, c8, D)) = make_uint2(o2[0], o2[1]);
+                if (c8 == 0) ((float*)(smem + IN_S))[r] = scale;
+            }
+        }
+        __syncthreads();
+        if (!active) return;
+        auto lds_block = [&](int kb, v4i (&kf)[KK], Blk& b) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(smem + (kb * KK + kk) * 1024 + lane * 16);
+#pragma unroll
+            for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) b.v[dd][c] = *(const v4i*)(smem + IN_V + ((kb * KK + dd) * 2 + c) * 1024 + lane * 16);
+            const float* ksl = (const float*)(smem + IN_S) + kb * 32 + 8 * g;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                b.ks[2 * c] = *(const v4f*)(ksl + 16 * c);
+                b.ks[2 * c + 1] = *(const v4f*)(ksl + 16 * c + 4);
+            }
+        };
+#pragma nounroll
+        for (int kb = lo; kb < hi; ++kb) {
+            v4i kf[KK];
+            Blk b;
+            lds_block(kb, kf, b);
+            const v16i sc = qk_mfma(kf);
+            softmax_pv(sc, b, (int64_t)kb * 32, std::false_type{});
+        }
+#pragma nounroll
+        for (int kb = mlo; kb < mhi; ++kb) {
+            v4i kf[KK];
+            Blk b;
+            lds_block(kb, kf, b);
+            const v16i sc = qk_mfma(kf);
+            softmax_pv(sc, b, (int64_t)kb * 32, std::true_type{});
+        }
+        lo = hi; mlo = mhi;  // nothing left for the streaming loops below
+    }
     if (!CAUSAL && !HAS_MASK && p.shared_kv) {
         const int n_st = n_plain / 2;  // full two-block stages; the same for every wave (no causal limit)
         auto dma_stage = [&](int st, int buf) {
@@ -640,7 +911,8 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
                                      int hadamard_group, const int64_t* q_strides, const int64_t* k_strides,
                                      const int64_t* v_strides, void* qq, float* qs, void* kq, float* ks, void* vt, float* kmean,
                                      sdnq_stream_t stream) {
-    if (!q || !k || !v || !qq || !qs || !kq || !ks || !vt || (smooth_k && !kmean)) return SDNQ_ERR_NULL;
+    const bool with_q = qq != nullptr || qs != nullptr;  // both null: Q is quantized by the forward kernel (sdnq_hip_attn_fwd_q16)
+    if (!k || !v || !kq || !ks || !vt || (smooth_k && !kmean) || (with_q && (!q || !qq || !qs))) return SDNQ_ERR_NULL;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
     if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
     if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_UNSUPPORTED;  // PV runs in the value dtype on the matrix cores
@@ -651,7 +923,7 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
         if (hadamard_group < 4 || hadamard_group > head_dim || (hadamard_group & (hadamard_group - 1)) || head_dim % hadamard_group) return SDNQ_ERR_SHAPE;
         while ((1 << log2g) < hadamard_group) ++log2g;
     }
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt) % 16) return SDNQ_ERR_ALIGN;
+    if (((with_q ? (uintptr_t)q | (uintptr_t)qq : 0) | (uintptr_t)k | (uintptr_t)v | (uintptr_t)kq | (uintptr_t)vt) % 16) return SDNQ_ERR_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const int d = (int)head_dim, lpr = d / 8;
     const int64_t kheads = batch * kv_heads;
@@ -665,39 +937,71 @@ extern "C" int sdnq_hip_attn_prepare(const void* q, const void* k, const void* v
         if (st) { out.b = st[0]; out.h = st[1]; out.n = st[2]; } else { out.b = heads * len * head_dim_src; out.h = len * head_dim_src; out.n = head_dim_src; }
         return out.b % 8 == 0 && out.h % 8 == 0 && out.n % 8 == 0;  // 16-byte rows
     };
-    if (!strides_of(q_strides, q_heads, q_len, p.qst) || !strides_of(k_strides, kv_heads, kv_len, p.kst) ||
+    if ((with_q && !strides_of(q_strides, q_heads, q_len, p.qst)) || !strides_of(k_strides, kv_heads, kv_len, p.kst) ||
         !strides_of(v_strides, kv_heads, kv_len, p.vst))
         return SDNQ_ERR_ALIGN;
     p.qheads = batch * q_heads; p.kheads = kheads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32; p.d = d; p.d_src = (int)head_dim_src;
     p.log2g = log2g;
-    p.nqb = (p.qheads * q_len * lpr + 255) / 256;
+    p.nqb = with_q ? (p.qheads * q_len * lpr + 255) / 256 : 0;
     p.nkb = kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
-    const int64_t blocks = p.nqb + p.nkb + kheads * (p.knp / 32);
-    if (dtype == SDNQ_BF16) {
-        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_BF16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d, p.d_src);
-        hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    p.nvb = kheads * (p.knp / 32);
+    p.nmb = 0;
+    p.kpart_out = kmean;
+    auto launch = [&](const PrepParams& pp) {
+        const int64_t blocks = pp.nqb + pp.nkb + pp.nvb + pp.nmb;
+        if (blocks == 0) return;
+        if (dtype == SDNQ_BF16) hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, pp);
+    };
+    if (p.kpart) {
+        PrepParams first = p, second = p;
+        first.nkb = 0; first.nmb = kheads * KMEAN_SPLITS;  // everything that does not need the means, next to the channel sums
+        second.nqb = 0; second.nvb = 0;                     // then the K rows
+        launch(first);
+        launch(second);
     } else {
-        if (p.kpart) hipLaunchKernelGGL((attn_kmean_kernel<SDNQ_F16>), dim3((unsigned)(kheads * KMEAN_SPLITS)), dim3(256), 0, s, k, p.kst, kmean, kv_len, d, p.d_src);
-        hipLaunchKernelGGL((attn_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+        launch(p);
     }
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
 }
 
-extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
-                                 float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
-                                 int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
-                                 const int64_t* out_strides, int64_t batch,
-                                 int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
-                                 sdnq_stream_t stream) {
-    if (!qq || !qs || !kq || !ks || !vt || !out) return SDNQ_ERR_NULL;
+namespace {
+struct RawKV { const void *k, *v; const int64_t *k_strides, *v_strides; int smooth; };  // K / V in the value dtype (at most 128 keys)
+
+// q16 != nullptr: Q in the value dtype with element strides q_strides (null: contiguous [batch][heads][q_len][head_dim]); else qq / qs.
+// raw != nullptr: K / V in the value dtype as well (kq / ks / vt unused), needs q16.
+int attn_fwd_impl(const void* qq, const float* qs, const void* q16, const int64_t* q_strides, const RawKV* raw, const void* kq, const float* ks, const void* vt, int v_dtype,
+                  float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                  int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
+                  const int64_t* out_strides, int64_t batch,
+                  int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                  sdnq_stream_t stream) {
+    if ((!q16 && (!qq || !qs)) || (!raw && (!kq || !ks || !vt)) || (raw && (!raw->k || !raw->v || !q16)) || !out) return SDNQ_ERR_NULL;
     if (mask && mask_dtype != -1 && mask_dtype != SDNQ_F32 && mask_dtype != SDNQ_BF16 && mask_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
     if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
     if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
     const int64_t head_dim_src = head_dim;
     head_dim = head_dim <= 64 ? 64 : 128;  // as in sdnq_hip_attn_prepare: qq / kq / vt hold the padded head dim
-    if (((uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt | (uintptr_t)out) % 8) return SDNQ_ERR_ALIGN;
+    if (((uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt | (uintptr_t)out) % 8 || (uintptr_t)q16 % 16) return SDNQ_ERR_ALIGN;
     AttnParams p{};
+    if (q16) {
+        p.q_src = q16; p.qst.heads = q_heads; p.d_src = (int)head_dim_src;
+        if (q_strides) { p.qst.b = q_strides[0]; p.qst.h = q_strides[1]; p.qst.n = q_strides[2]; }
+        else { p.qst.b = q_heads * q_len * head_dim_src; p.qst.h = q_len * head_dim_src; p.qst.n = head_dim_src; }
+        if (p.qst.b % 8 || p.qst.h % 8 || p.qst.n % 8) return SDNQ_ERR_ALIGN;  // 16-byte rows
+    }
+    if (raw) {
+        if (kv_len > 128) return SDNQ_ERR_UNSUPPORTED;
+        if (((uintptr_t)raw->k | (uintptr_t)raw->v) % 16) return SDNQ_ERR_ALIGN;
+        auto set = [&](const int64_t* st, Strides& o) {
+            o.heads = kv_heads;
+            if (st) { o.b = st[0]; o.h = st[1]; o.n = st[2]; } else { o.b = kv_heads * kv_len * head_dim_src; o.h = kv_len * head_dim_src; o.n = head_dim_src; }
+            return o.b % 8 == 0 && o.h % 8 == 0 && o.n % 8 == 0;
+        };
+        if (!set(raw->k_strides, p.kst) || !set(raw->v_strides, p.vst)) return SDNQ_ERR_ALIGN;
+        p.k_src = raw->k; p.v_src = raw->v; p.smooth = raw->smooth; p.d_src = (int)head_dim_src;
+    }
     p.qq = (const int8_t*)qq; p.qs = qs; p.kq = (const int8_t*)kq; p.ks = ks; p.vt = (const uint16_t*)vt; p.out = out;
     p.qh = q_heads; p.kh = kv_heads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32;
     // few query tiles for the 1024 SIMDs (e.g. SDXL at batch 1: 1280): split every tile's keys over two waves
@@ -715,10 +1019,10 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
         const int64_t kblocks = (kv_len + 31) / 32;
         while (auto_split < 4 && tiles * auto_split < split_target && kblocks >= 4 * (auto_split * 2)) auto_split *= 2;
     }
-    p.split = force_split ? force_split : auto_split;
+    p.split = raw ? 1 : (force_split ? force_split : auto_split);
     if (p.split != 1 && p.split != 2 && p.split != 4) return SDNQ_ERR_SHAPE;
     static const int force_shared = [] { const char* e = getenv("SDNQ_HIP_ATTN_SHARED"); return e ? atoi(e) : -1; }();  // tuning aid
-    p.shared_kv = (p.split == 1 && !is_causal && !mask && kv_len >= 64) ? (force_shared < 0 ? (want_shared ? 1 : 0) : force_shared) : 0;
+    p.shared_kv = (!raw && p.split == 1 && !is_causal && !mask && kv_len >= 64) ? (force_shared < 0 ? (want_shared ? 1 : 0) : force_shared) : 0;
     const int tiles_per_wg = 4 / p.split;
     p.qblocks = (int)((q_len + 32 * tiles_per_wg - 1) / (32 * tiles_per_wg));
     p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
@@ -738,4 +1042,85 @@ extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq
     ATTN_CASE(SDNQ_F16, SDNQ_F32);
 #undef ATTN_CASE
     return SDNQ_ERR_DTYPE;
+}
+}  // namespace
+
+extern "C" int sdnq_hip_attn_fwd(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, int v_dtype,
+                                 float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                                 int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
+                                 const int64_t* out_strides, int64_t batch,
+                                 int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                                 sdnq_stream_t stream) {
+    if (!qq || !qs) return SDNQ_ERR_NULL;
+    return attn_fwd_impl(qq, qs, nullptr, nullptr, nullptr, kq, ks, vt, v_dtype, sm_scale, is_causal, mask, mask_dtype, mask_stride_b, mask_stride_h, mask_stride_q, out,
+                         out_dtype, out_strides, batch, q_heads, kv_heads, q_len, kv_len, head_dim, stream);
+}
+
+extern "C" int sdnq_hip_attn_fwd_q16(const void* q, const int64_t* q_strides, const void* kq, const float* ks, const void* vt, int v_dtype,
+                                     float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                                     int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
+                                     const int64_t* out_strides, int64_t batch,
+                                     int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                                     sdnq_stream_t stream) {
+    if (!q) return SDNQ_ERR_NULL;
+    return attn_fwd_impl(nullptr, nullptr, q, q_strides, nullptr, kq, ks, vt, v_dtype, sm_scale, is_causal, mask, mask_dtype, mask_stride_b, mask_stride_h, mask_stride_q, out,
+                         out_dtype, out_strides, batch, q_heads, kv_heads, q_len, kv_len, head_dim, stream);
+}
+
+// ---- the whole attention as one entry point (sdnq_triton_atten, triton_atten.py:540-618) -------------------------------------------
+namespace {
+constexpr int64_t ATTN_SINGLE_MAX_KEYS = 128;
+inline int64_t up256(int64_t n) { return (n + 255) / 256 * 256; }
+struct AttnWs { int64_t qq, qs, kq, ks, vt, kmean, total; };
+// workspace slices (bytes, 256-byte aligned): quantized Q only when a Hadamard rotation keeps it in the prepare pass
+AttnWs attn_ws(int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, int hadamard_group) {
+    AttnWs w{};
+    const int64_t d = head_dim <= 64 ? 64 : 128, knp = (kv_len + 31) / 32 * 32;
+    const bool with_q = hadamard_group != 0;
+    if (!with_q && kv_len <= ATTN_SINGLE_MAX_KEYS) return w;  // single launch: nothing leaves the kernel
+    int64_t off = 0;
+    w.qq = off; off += with_q ? up256(batch * q_heads * q_len * d) : 0;
+    w.qs = off; off += with_q ? up256(batch * q_heads * q_len * 4) : 0;
+    w.kq = off; off += up256(batch * kv_heads * knp * d);
+    w.ks = off; off += up256(batch * kv_heads * knp * 4);
+    w.vt = off; off += up256(batch * kv_heads * knp * d * 2);
+    w.kmean = off; off += up256(batch * kv_heads * KMEAN_SPLITS * d * 4);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t sdnq_hip_attn_workspace_bytes(int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
+                                                 int hadamard_group) {
+    if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim) || head_dim > 128) return SDNQ_ERR_SHAPE;
+    return attn_ws(batch, q_heads, kv_heads, q_len, kv_len, head_dim, hadamard_group).total;
+}
+
+extern "C" int sdnq_hip_attn(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads, int64_t kv_heads,
+                             int64_t q_len, int64_t kv_len, int64_t head_dim, const int64_t* q_strides, const int64_t* k_strides,
+                             const int64_t* v_strides, int smooth_k, int hadamard_group, float sm_scale, int is_causal, const void* mask,
+                             int mask_dtype, int64_t mask_stride_b, int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype,
+                             const int64_t* out_strides, void* workspace, int64_t workspace_bytes, sdnq_stream_t stream) {
+    if (!q || !k || !v || !out) return SDNQ_ERR_NULL;
+    if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
+    if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
+    if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_UNSUPPORTED;
+    const AttnWs w = attn_ws(batch, q_heads, kv_heads, q_len, kv_len, head_dim, hadamard_group);
+    if (w.total == 0) {  // <= 128 keys, no rotation: Q, K and V are quantized / laid out inside the one forward launch
+        const RawKV raw{k, v, k_strides, v_strides, smooth_k};
+        return attn_fwd_impl(nullptr, nullptr, q, q_strides, &raw, nullptr, nullptr, nullptr, dtype, sm_scale, is_causal, mask, mask_dtype, mask_stride_b,
+                             mask_stride_h, mask_stride_q, out, out_dtype, out_strides, batch, q_heads, kv_heads, q_len, kv_len, head_dim, stream);
+    }
+    if (!workspace) return SDNQ_ERR_NULL;
+    if (workspace_bytes < w.total) return SDNQ_ERR_SHAPE;
+    if ((uintptr_t)workspace % 256) return SDNQ_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    const bool with_q = hadamard_group != 0;
+    const int rc = sdnq_hip_attn_prepare(q, k, v, dtype, batch, q_heads, kv_heads, q_len, kv_len, head_dim, smooth_k, hadamard_group, q_strides, k_strides,
+                                         v_strides, with_q ? ws + w.qq : nullptr, with_q ? (float*)(ws + w.qs) : nullptr, ws + w.kq, (float*)(ws + w.ks),
+                                         ws + w.vt, (float*)(ws + w.kmean), stream);
+    if (rc != SDNQ_OK) return rc;
+    return attn_fwd_impl(with_q ? ws + w.qq : nullptr, with_q ? (const float*)(ws + w.qs) : nullptr, with_q ? nullptr : q, q_strides, nullptr, ws + w.kq,
+                         (const float*)(ws + w.ks), ws + w.vt, dtype, sm_scale, is_causal, mask, mask_dtype, mask_stride_b, mask_stride_h, mask_stride_q, out,
+                         out_dtype, out_strides, batch, q_heads, kv_heads, q_len, kv_len, head_dim, stream);
 }

@@ -130,6 +130,52 @@ def test_hip_attention_masks_vs_oracle(kind, gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_hip_attention_query_quantized_in_the_forward_kernel_is_bit_identical(dtype, gpu_device):
+    """sdnq_hip_attn_fwd_q16 (the forward kernel quantizes its 32 queries per wave) against sdnq_hip_attn_prepare's Q pass followed by
+    sdnq_hip_attn_fwd: same codes and scales, so EQUAL outputs -- on every launch variant (whole / 2 / 4 key parts, shared K / V at
+    head_dim 128, causal, masked), padded head dims, strided query views, all-zero query rows and a ragged last query tile."""
+    import torch
+    from sdnq_amd import attention as A
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtype]
+    g = torch.Generator().manual_seed(5)
+    #        z, qh, kh, qn,   kn,   d,   causal, mask
+    cases = [(1, 3, 3, 77, 77, 64, False, False), (1, 10, 10, 1024, 77, 64, False, False),   # cross-attention: whole
+             (1, 20, 20, 1024, 1024, 64, False, False),                                       # 640 tiles: 4 key parts
+             (1, 18, 18, 2048, 2100, 64, False, True),                                        # 2 parts, masked
+             (1, 4, 2, 2100, 2100, 128, False, False),                                        # shared K / V through LDS, grouped heads
+             (2, 4, 2, 200, 333, 128, True, False), (1, 2, 1, 130, 130, 40, False, False), (1, 5, 5, 1, 500, 72, False, False),
+             # at most 128 keys: sdnq_hip_attn is ONE launch (K / V quantized and laid out in LDS by every workgroup)
+             (2, 4, 2, 200, 100, 128, True, False), (1, 2, 1, 130, 128, 40, False, True), (1, 3, 3, 50, 33, 64, False, False),
+             (1, 6, 3, 300, 1, 64, False, False), (1, 2, 2, 64, 96, 128, False, True), (1, 20, 20, 1024, 77, 64, False, False)]
+    for (z, qh, kh, qn, kn, d, causal, masked) in cases:
+        q = torch.randn(z, qh, qn, d, generator=g).to(tdt)
+        q[:, :, qn // 2] = 0  # a row whose scale is 0 (0 / 0 -> code 0)
+        k = (torch.randn(z, kh, kn, d, generator=g) + torch.randn(1, kh, 1, d, generator=g)).to(tdt)
+        v = torch.randn(z, kh, kn, d, generator=g).to(tdt)
+        mask = (torch.rand(1, 1, qn, kn, generator=g) > 0.3).to(gpu_device) if masked else None
+        q, k, v = q.to(gpu_device), k.to(gpu_device), v.to(gpu_device)
+        views = [q]
+        if d % 8 == 0 and qh > 1:  # the [Z, N, H*D] projection output seen as [Z, H, N, D]
+            views.append(q.transpose(1, 2).contiguous().transpose(1, 2))
+        for qv in views:
+            qq, qs, kq, ks, vt = A.quantize_attn(qv, k, v)
+            m = A.prepare_mask(mask, qn, kn) if masked else None
+            two_pass = A.atten_fwd(qq, qs, kq, ks, vt, kn, d ** -0.5, causal, tdt, m, head_dim=d)
+            q16, none, kq2, ks2, vt2 = A.quantize_attn(qv, k, v, with_query=False)
+            assert none is None and torch.equal(kq2, kq) and torch.equal(ks2, ks) and torch.equal(vt2, vt)
+            fused = A.atten_fwd(q16, None, kq2, ks2, vt2, kn, d ** -0.5, causal, tdt, m, head_dim=d)
+            assert torch.equal(fused, two_pass), (z, qh, kh, qn, kn, d, causal, masked, tuple(qv.stride()))
+            assert torch.equal(A.sdnq_hip_atten(qv, k, v, attn_mask=mask, is_causal=causal).contiguous(), two_pass.contiguous())
+            if kn <= 128:  # and without K smoothing
+                parts = A.quantize_attn(qv, k, v, smooth_k=False)
+                plain = A.atten_fwd(*parts, kn, d ** -0.5, causal, tdt, m, head_dim=d)
+                assert torch.equal(A.sdnq_hip_atten(qv, k, v, attn_mask=mask, is_causal=causal, smooth_k=False).contiguous(), plain.contiguous())
+    with pytest.raises(ValueError, match="Hadamard"):
+        A.quantize_attn(q, k, v, hadamard_group=8, with_query=False)
+
+
+@pytest.mark.gpu
 def test_hip_attention_ragged_shape_sweep(gpu_device):
     """Edge shapes: single query / single key, lengths one below / above the 32-wide blocks, causal with q_len != kv_len, grouped
     heads down to one KV head, f32 output -- every combination against the oracle."""

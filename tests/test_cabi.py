@@ -102,6 +102,28 @@ def test_attention_argument_validation_without_gpu():
     assert fwd(p, p, p, p, p, 1, 0.125, 0, p, 5, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -2          # mask dtype
     assert fwd(p, p, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 0, 64, None) == -3       # kv_len 0
     assert fwd(p, p, p, p, p, 0, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -2       # f32 value operand
+    assert fwd(None, p, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -1    # no quantized Q
+    # K / V only (qq and qs both NULL, q not read) pairs with sdnq_hip_attn_fwd_q16; one of the two alone is an error
+    assert prep(p, p, p, 1, 1, 2, 2, 8, 8, 64, 1, 0, None, None, None, p, None, p, p, p, p, None) == -1
+    assert prep(None, p, None, 1, 1, 2, 2, 8, 8, 64, 1, 0, None, None, None, None, None, p, p, p, p, None) == -1   # NULL value
+    fq = lib.sdnq_hip_attn_fwd_q16
+    assert fq(None, None, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -1  # NULL query
+    assert fq(p + 8, None, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -4  # query rows not 16-byte aligned
+    assert fq(p, bad, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 2, 2, 8, 8, 64, None) == -4       # token stride
+    assert fq(p, None, p, p, p, 1, 0.125, 0, None, 0, 0, 0, 0, p, 1, None, 1, 3, 2, 8, 8, 64, None) == -3      # q_heads % kv_heads
+    # the one-call form: no workspace up to 128 keys without a rotation, else the prepare pass's operands
+    wsb, att = lib.sdnq_hip_attn_workspace_bytes, lib.sdnq_hip_attn
+    assert wsb(1, 2, 2, 4096, 77, 64, 0) == 0 and wsb(1, 2, 2, 4096, 128, 128, 0) == 0
+    assert wsb(1, 2, 2, 4096, 77, 64, 64) > 2 * 4096 * 64            # a rotation keeps the separate pass (with Q)
+    assert wsb(1, 2, 1, 64, 129, 64, 0) == 160 * 64 + 768 + 160 * 64 * 2 + 32 * 64 * 4   # kq + ks (640 -> 768) + vt + channel sums, one kv head
+    assert wsb(1, 3, 2, 64, 129, 64, 0) == -3 and wsb(1, 2, 2, 64, 0, 64, 0) == -3
+    tail = (None, None, None, 1, 0, 0.125, 0, None, 0, 0, 0, 0)      # strides, smooth_k, hadamard_group, sm_scale, causal, mask
+    assert att(p, p, None, 1, 1, 2, 2, 8, 8, 64, *tail, p, 1, None, None, 0, None) == -1       # NULL value
+    assert att(p, p, p, 1, 1, 2, 2, 8, 8, 64, *tail, None, 1, None, None, 0, None) == -1       # NULL out
+    assert att(p, p, p, 0, 1, 2, 2, 8, 8, 64, *tail, p, 1, None, None, 0, None) == -5          # float32 inputs
+    assert att(p, p, p, 1, 1, 2, 2, 8, 200, 64, *tail, p, 1, None, None, 0, None) == -1        # > 128 keys need the workspace
+    assert att(p, p, p, 1, 1, 2, 2, 8, 200, 64, *tail, p, 1, None, p, 100, None) == -3         # ... of the advertised size
+    assert att(p, p + 8, p, 1, 1, 2, 2, 8, 8, 64, *tail, p, 1, None, None, 0, None) == -4      # key rows not 16-byte aligned
 
 
 def test_linear_args_struct_matches_the_header():
