@@ -77,26 +77,6 @@ __device__ __forceinline__ void attn_kmean_block(const void* __restrict__ k, con
     }
 }
 
-typedef float pv2f __attribute__((ext_vector_type(2)));
-// Short launches of these kernels are latency chains of ONE wave per SIMD (~10 cycles per dependent vector instruction: the whole per-token
-// quantization of a 128-query tile costs 2 us at 13 instructions per element), so the per-element work is kept to packed fp32 math:
-//   x / scale, correctly rounded, for two values in three packed instructions (RowDiv::fastdiv, sdnq_dev.h) ...
-__device__ __forceinline__ pv2f fastdiv2(pv2f x, const RowDiv& d) {
-    const pv2f r2 = {d.rcp, d.rcp}, ns = {-d.scale, -d.scale};
-    const pv2f q0 = x * r2;
-    return __builtin_elementwise_fma(__builtin_elementwise_fma(ns, q0, x), r2, q0);
-}
-//   ... and rint + int8 packing without a conversion: |q| <= 128, so q + 1.5 * 2^23 is exact up to the round-to-nearest-even that rint would do
-//   and leaves rint(q) as a two's complement byte in the low mantissa bits; two byte-permutes and one shift-or per four values
-__device__ __forceinline__ u32 pack4_rne_i8(pv2f a, pv2f b) {
-    const pv2f magic = {12582912.0f, 12582912.0f};
-    a += magic;
-    b += magic;
-    const u32 t0 = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x0c0c0400u);
-    const u32 t1 = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x0c0c0400u);
-    return t0 | (t1 << 16);
-}
-
 // ---- channel means of ONE head's K by one 256-thread workgroup (short key sequences: no separate channel-sum section) --------
 // Thread tid owns channels [8 (tid % lpr), + 8) of the rows tid / lpr, + 256 / lpr, ...: `acc` = its sums in row order.  xw: 4 * 128 floats,
 // smean: 128 floats of LDS.  One summation order for every caller (the prepare kernel's inline form and the single-launch attention), so

@@ -68,6 +68,16 @@ __device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[
 template <int MM, int LP_T = SDNQ_F32>
 __device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, int& isum, float zp = 0.0f, bool asym = false) {
     const float scale = d.scale;
+    if constexpr (MM == SDNQ_MM_I8 && LP_T == SDNQ_F32) {
+        if (d.fast && !asym) {  // wave-uniform
+            // the symmetric int8 row of the w8a8 step: packed division, rounding and byte packing in ~3 instructions per element instead of
+            // ~11 (sdnq_dev.h); `fast` excludes scale 0 / inf / nan, and |x| <= amax keeps every quotient inside +-127.5
+            const u32 w0 = pack4_rne_i8(fastdiv2((pv2f){v[0], v[1]}, d), fastdiv2((pv2f){v[2], v[3]}, d));
+            const u32 w1 = pack4_rne_i8(fastdiv2((pv2f){v[4], v[5]}, d), fastdiv2((pv2f){v[6], v[7]}, d));
+            isum = __builtin_amdgcn_sdot4((int)w1, 0x01010101, __builtin_amdgcn_sdot4((int)w0, 0x01010101, isum, false), false);
+            return make_uint2(w0, w1);
+        }
+    }
     float qv[8];
     if (LP_T == SDNQ_F32 && d.fast) {  // wave-uniform
 #pragma unroll
@@ -199,11 +209,16 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
                     for (int e = 0; e < 8; ++e) v[p][e] = FT<T_ID>::round(v[p][e]);
                 }
             }
-            const bool in = k_part + (int64_t)p * 512 + lane * 8 < K;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                amax = fmaxf(amax, fabsf(v[p][e]));
-                if (in) { vmin = fminf(vmin, v[p][e]); vmax = fmaxf(vmax, v[p][e]); }
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[p][e]));
+        }
+        if (asym) {  // (wave-uniform; the symmetric rows of the w8a8 step do not pay for the extrema)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (k_part + (int64_t)p * 512 + lane * 8 < K) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { vmin = fminf(vmin, v[p][e]); vmax = fmaxf(vmax, v[p][e]); }
+                }
             }
         }
         float scale, zpv = 0.0f;

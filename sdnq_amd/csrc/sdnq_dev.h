@@ -179,6 +179,26 @@ struct RowDiv {
     }
 };
 
+typedef float pv2f __attribute__((ext_vector_type(2)));
+// The quantizer launches of a bs = 1 step are latency chains of ONE wave per SIMD (~10 cycles per dependent vector instruction measured: the
+// per-token quantization of a 128-query attention tile cost 2 us at 13 instructions per element), so the per-element work is packed fp32 math:
+//   x / scale, correctly rounded, for two values in three packed instructions (RowDiv::fastdiv, sdnq_dev.h) ...
+__device__ __forceinline__ pv2f fastdiv2(pv2f x, const RowDiv& d) {
+    const pv2f r2 = {d.rcp, d.rcp}, ns = {-d.scale, -d.scale};
+    const pv2f q0 = x * r2;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(ns, q0, x), r2, q0);
+}
+//   ... and rint + int8 packing without a conversion: |q| <= 128, so q + 1.5 * 2^23 is exact up to the round-to-nearest-even that rint would do
+//   and leaves rint(q) as a two's complement byte in the low mantissa bits; two byte-permutes and one shift-or per four values
+__device__ __forceinline__ u32 pack4_rne_i8(pv2f a, pv2f b) {
+    const pv2f magic = {12582912.0f, 12582912.0f};
+    a += magic;
+    b += magic;
+    const u32 t0 = __builtin_amdgcn_perm(__float_as_uint(a[1]), __float_as_uint(a[0]), 0x0c0c0400u);
+    const u32 t1 = __builtin_amdgcn_perm(__float_as_uint(b[1]), __float_as_uint(b[0]), 0x0c0c0400u);
+    return t0 | (t1 << 16);
+}
+
 // ---- fp8 e4m3fn (OCP) -------------------------------------------------------------------------
 // float -> e4m3fn, round-to-nearest-even, input already clamped to [-448, 448] (quant_utils.py:298),
 // so no overflow handling is needed; matches torch's .to(torch.float8_e4m3fn) on that range.
