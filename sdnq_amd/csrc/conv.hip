@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
                 }
 #pragma unroll
                 for (int u = 0; u < CPT; ++u) v[u] = (inb && c0 + u < p.C) ? v[u] : 0.0f;
+                if constexpr (MM == SDNQ_MM_I8) {
+                    if (all_fast) {  // wave-uniform: every scale of the wave is an ordinary number (not 0), |x| <= amax keeps |x / scale| <= 127.5
+                        // rint and the int8 cast without conversions: q + 1.5 * 2^23 rounds to nearest even like rint and leaves the two's
+                        // complement byte in the low mantissa bits, which the byte store takes as is (sdnq_dev.h: pack4_rne_i8)
+#pragma unroll
+                        for (int u = 0; u < CPT; ++u) row[u * P + i * p.KW + j] = (uint8_t)__float_as_uint(rd.fastdiv(v[u]) + 12582912.0f);
+                        continue;
+                    }
+                }
                 if (all_fast) {  // wave-uniform
 #pragma unroll
                     for (int u = 0; u < CPT; ++u) {

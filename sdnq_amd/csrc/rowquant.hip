@@ -78,6 +78,23 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, in
             return make_uint2(w0, w1);
         }
     }
+    if constexpr (MM == SDNQ_MM_FP8 && LP_T == SDNQ_F32) {
+        if (d.fast && !asym) {  // wave-uniform: finite ordinary scale, so no NaN to flush; x = +-amax can still land one ulp above 448
+            float c[8];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const pv2f q = fastdiv2((pv2f){v[2 * h], v[2 * h + 1]}, d);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    // the sign of the numerator ORed onto the quotient: a no-op unless the quotient is the +0 the correction term makes of
+                    // -0.0 / scale, whose fp8 code is 0x80 (round 4, tools/fuzz_ops.py)
+                    const float qs = __uint_as_float(__float_as_uint(q[e]) | (__float_as_uint(v[2 * h + e]) & 0x80000000u));
+                    c[2 * h + e] = __builtin_amdgcn_fmed3f(qs, -448.0f, 448.0f);
+                }
+            }
+            return make_uint2(pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]), pack4_e4m3fn_clamped(c[4], c[5], c[6], c[7]));
+        }
+    }
     float qv[8];
     if (LP_T == SDNQ_F32 && d.fast) {  // wave-uniform
 #pragma unroll
