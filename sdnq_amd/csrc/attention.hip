@@ -28,16 +28,6 @@ namespace {
 
 // element strides of a [batch][heads][tokens][head_dim] tensor whose head_dim is contiguous (e.g. the transposed view of a
 // [batch][tokens][heads * head_dim] projection output); `heads` splits a linear batch*heads index
-// a 64-bit integer division is ~150 instructions on this ISA, a 32-bit one ~30 -- and the quotients of these kernels (head and row indices)
-// fit 32 bits in every call but the > 2^31-element ones; the prepare kernel runs four of them per thread around 60 instructions of work
-__device__ __forceinline__ void divmod(int64_t a, int64_t b, int64_t& q, int64_t& r) {
-    if ((((uint64_t)a | (uint64_t)b) >> 32) == 0) {
-        const uint32_t x = (uint32_t)a, y = (uint32_t)b;
-        q = x / y; r = x % y;
-    } else {
-        q = a / b; r = a % b;
-    }
-}
 struct Strides {
     int64_t b, h, n, heads;
     __device__ __forceinline__ int64_t at(int64_t head_lin, int64_t tok) const {

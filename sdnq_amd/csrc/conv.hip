@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void conv_pixel_amax_kernel(const void* __rest
     const int tid = threadIdx.x, pg = tid & 31, cl = tid >> 5;
     const int64_t q = (int64_t)blockIdx.x * 32 + pg;  // group of 8 consecutive pixels of one image (pixels % 8 == 0)
     const bool ok = q * 8 < total;
-    const int64_t b = ok ? (q * 8) / pixels : 0, px = ok ? (q * 8) - b * pixels : 0;
+    int64_t b = 0, px = 0;
+    if (ok) divmod(q * 8, pixels, b, px);  // (32-bit whenever it fits, sdnq_dev.h)
     const int c_begin = blockIdx.y * cpb, c_end = (c_begin + cpb < channels) ? c_begin + cpb : channels;
     float a[8];
 #pragma unroll
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
     const bool mok = m < p.M;
     const int c_base = blockIdx.y * CT;
     if (mok) {
-        const int wo = (int)(m % p.WO), ho = (int)((m / p.WO) % p.HO), b = (int)(m / ((int64_t)p.WO * p.HO));
+        int64_t t64, wo64, b64, ho64;  // pixel -> (image, row, column): two 32-bit divisions (sdnq_dev.h: divmod), not four 64-bit ones
+        divmod(m, p.WO, t64, wo64);
+        divmod(t64, p.HO, b64, ho64);
+        const int wo = (int)wo64, ho = (int)ho64, b = (int)b64;
         const int64_t img = (int64_t)p.H * p.W;
         float amax = 0.0f;  // window maximum of the channel-amax map = amax of this unfolded row
         for (int i = 0; i < p.KH; ++i) {
@@ -195,7 +199,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const Im2colParams p) {
     const int64_t m0 = (int64_t)blockIdx.x * 64, k0 = (int64_t)blockIdx.y * 64;
     const int64_t m = m0 + lane;
     const bool mok = m < p.M;
-    const int wo = (int)(m % p.WO), ho = (int)((m / p.WO) % p.HO), b = (int)(m / ((int64_t)p.WO * p.HO));
+    int64_t t64, wo64, b64, ho64;
+    divmod(m, p.WO, t64, wo64);
+    divmod(t64, p.HO, b64, ho64);
+    const int wo = (int)wo64, ho = (int)ho64, b = (int)b64;
     const T* xb = (const T*)p.x + (int64_t)b * p.C * p.H * p.W;
     const int P = p.KH * p.KW;
 #pragma unroll 4

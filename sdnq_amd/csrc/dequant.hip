@@ -49,7 +49,9 @@ __device__ __forceinline__ void dequant16(const DeqParams& p, int64_t n, int64_t
             v[j] = zrow ? fmaf(v[j], srow[g], zrow[g]) : v[j] * srow[g];
         }
     } else if ((p.group_size & 15) == 0) {  // one group covers the whole 16-run (wave-uniform branch)
-        const int g = (int)(k0 / p.group_size);
+        int64_t g64, grem;
+        divmod(k0, p.group_size, g64, grem);
+        const int g = (int)g64;
         const float s = srow[g];
         if (zrow) {
             const float z = zrow[g];
@@ -79,7 +81,9 @@ __global__ __launch_bounds__(256) void dequant_kernel(const DeqParams p, void* _
     const int64_t units_per_row = p.K / 16;
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= p.N * units_per_row) return;
-    const int64_t n = u / units_per_row, k0 = (u % units_per_row) * 16;
+    int64_t n, k0;
+    divmod(u, units_per_row, n, k0);  // (32-bit whenever it fits, sdnq_dev.h)
+    k0 *= 16;
     float v[16];
     dequant16(p, n, k0, v);
     if (p.svd_up) {

@@ -179,6 +179,17 @@ struct RowDiv {
     }
 };
 
+// a 64-bit integer division is ~150 instructions on this ISA, a 32-bit one ~30 -- and the index quotients of these kernels (heads, rows,
+// groups) fit 32 bits in every call but the > 2^31-element ones; the attention prepare kernel ran four of them per thread around 60
+// instructions of work, the weight dequantizer three around 16 weights
+__device__ __forceinline__ void divmod(int64_t a, int64_t b, int64_t& q, int64_t& r) {
+    if ((((uint64_t)a | (uint64_t)b) >> 32) == 0) {
+        const uint32_t x = (uint32_t)a, y = (uint32_t)b;
+        q = x / y; r = x % y;
+    } else {
+        q = a / b; r = a % b;
+    }
+}
 typedef float pv2f __attribute__((ext_vector_type(2)));
 // The quantizer launches of a bs = 1 step are latency chains of ONE wave per SIMD (~10 cycles per dependent vector instruction measured: the
 // per-token quantization of a 128-query attention tile cost 2 us at 13 instructions per element), so the per-element work is packed fp32 math:
