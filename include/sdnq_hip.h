@@ -167,6 +167,25 @@ int sdnq_hip_scaled_mm_lp_zp(int mm_dtype, const void* a, const void* b, const f
                              int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, const int32_t* zp_rowsum,
                              const float* zp, void* out, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
+/* The uint8 (asymmetric-activation) matmul on BFLOAT16 scales -- linear_uint8.py:15-23, 57-102 with dequantize_fp32=False; every torch op
+ * of the chain rounds its float32 result to bfloat16 once.
+ * sdnq_hip_rowquant_lp_asym <- quantize_uint_mm_input(input, dtype=scale.dtype) (linear_uint8.py:15-23, quant_utils.py:10-19, 277-286):
+ *     xs = round_T(round_T(max - min) / 255);  xzp = round_T(min + 128 xs);  xq = int8(clamp(rint(round_T(round_T(x - xzp) / xs))))
+ *   x [M][K] of x_dtype = T (bf16 / f16); xs / xzp [M] float32 holding T-representable values; rowsum / xrot / hadamard_group as in
+ *   sdnq_hip_rowquant.
+ * sdnq_hip_scaled_mm_lp_uzp <- get_uint8_matmul_inputs' zero_bias (:61-68) + int_scaled_mm_torch (kernel_wrappers.py:132-144) on bf16 tensors:
+ *     t1 = bf16(bf16(bf16(f32(rowsum[m])) * sa[m]) * zp[n])                  (zp_rowsum / zp: both or neither -- weights with a zero point)
+ *     t2 = bf16(w_colsum_scaled[n] * a_zp[m]),  w_colsum_scaled[n] = bf16(bf16(f32(sum_k b[n][k])) * sb[n]) precomputed by the caller
+ *     zb = bf16(t1 + t2);  zb = bf16(fma(bf16(a_zp[m] * zp[n]), zp_k ? zp_k : K, zb))   (zp_k < 0: the conv order, see sdnq_hip_scaled_mm_zp)
+ *     zb = bf16(zb + bias[n]);   out = bf16(fma(bf16(bf16(acc) * sa[m]), sb[n], zb))
+ *   a / b int8 [M][K] / [N][K]; sa, sb, zp, a_zp, w_colsum_scaled float32 arrays holding bf16-representable values; bias NULL or [N] bf16;
+ *   out [M][N] bf16. */
+int sdnq_hip_rowquant_lp_asym(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int hadamard_group, void* xq, float* xs,
+                              float* xzp, int32_t* rowsum, void* xrot, sdnq_stream_t stream);
+int sdnq_hip_scaled_mm_lp_uzp(const void* a, const void* b, const float* sa, const float* sb, const void* bias, const int32_t* zp_rowsum,
+                              const float* zp, const float* a_zp, const float* w_colsum_scaled, int64_t zp_k, void* out, int64_t m,
+                              int64_t n, int64_t k, sdnq_stream_t stream);
+
 /* the same scaled matmul over the STACKED weights of layers that consume one activation (to_q / to_k / to_v of an attention block),
  * each layer's columns stored in its own contiguous tensor: b [n_outs * seg_n][K], sb / bias [n_outs * seg_n], outs[i] is
  * [M][seg_n] (seg_n % 8 == 0, n_outs <= 4, n == n_outs * seg_n).  One launch and one pass over the quantized activation instead

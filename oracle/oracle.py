@@ -398,8 +398,10 @@ class OracleLinear:
         Returns (wq [N,K] int8 | e4m3 codes uint8, ws [N])."""
         W = self.dequant_f32_nk()
         if self.scale_tag != "f32":  # dequantize_weight(..., dtype=scale.dtype) then quantize_*_mm in that dtype (dequantizer.py:219-239)
-            if self.deq["quantized_matmul_dtype"] == "uint8":
-                raise NotImplementedError("uint8 matmul with 16-bit scales is not restated")
+            if self.deq["quantized_matmul_dtype"] == "uint8":  # re_quantize_uint_mm on the scale-dtype dequantization (dequantizer.py:178-187, 219-239)
+                if self.scale_tag != "bf16":
+                    raise NotImplementedError("uint8 matmul with float16 scales is not restated (the reference's float16 column sums overflow)")
+                return rowquant_asym_lp(round_dtype(W, self.scale_tag), self.scale_tag)
             return rowquant_lp(round_dtype(W, self.scale_tag), self.deq["quantized_matmul_dtype"], self.scale_tag)[:2]
         if self.deq["quantized_matmul_dtype"] == "uint8":
             return rowquant_asym(W)  # re_quantize_uint_mm (dequantizer.py:178-187): (wq int8, ws, zero_point)
@@ -454,6 +456,25 @@ def rowquant_lp(x_t: np.ndarray, matmul_dtype: str, tag: str):
     q = np.clip(np.nan_to_num(q, nan=0.0, posinf=3.4028235e38, neginf=-3.4028235e38), -448.0, 448.0).astype(f)
     codes = np.array([lib().orc_f32_to_e4m3fn(float(v)) for v in q.reshape(-1)], dtype=np.uint8).reshape(q.shape)
     return codes, s.reshape(-1), None
+
+
+def rowquant_asym_lp(x_t: np.ndarray, tag: str):
+    """quantize_uint_mm (quant_utils.py:277-286, get_scale_asymmetric :10-19) on rows held in a 16-bit dtype `tag`
+    (linear_uint8.py:15-18 `input.to(dtype=scale.dtype)`): every torch op rounds its float32 result to the dtype once --
+    scale = round(round(max - min) / 255), zero_point = round(min + 128 scale), q = rint(round(round(x - zero_point) / scale)).
+    Returns (q int8 [M,K], scale [M], zero_point [M]) as float32 values of `tag`."""
+    f = np.float32
+    x = round_dtype(_c(x_t, f), tag)
+    xmin, xmax = x.min(-1, keepdims=True).astype(f), x.max(-1, keepdims=True).astype(f)
+    scale = round_dtype((xmax - xmin).astype(f), tag)          # scale.sub_(zero_point)
+    scale = round_dtype((scale / f(255.0)).astype(f), tag)     # .div_(max - min)
+    zp = round_dtype((xmin + f(128.0) * scale).astype(f), tag)  # zero_point.sub_(scale, alpha=-128): 128 * scale is exact in float32
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = round_dtype((x - zp).astype(f), tag)
+        q = round_dtype((q / scale).astype(f), tag)
+    q = np.clip(np.rint(q), -128, 127)
+    q = np.where(np.isnan(q), 0, q).astype(np.int8)
+    return q, scale.reshape(-1), zp.reshape(-1)
 
 
 def scaled_mm_lp(matmul_dtype: str, a, b_nk, sa, sb, bias, tag: str) -> np.ndarray:
@@ -743,8 +764,13 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: bool 
     K, N = mod.K, mod.N
     M = x2.shape[0]
     f = np.float32
-    if mod.scale_tag != "f32":  # (every weight form: tools/fuzz_oracle_vs_reference.py found the plain-uint8 form slipping through)
-        raise NotImplementedError("uint8 matmul with 16-bit scales is not restated")
+    lp = mod.scale_tag != "f32"
+    if lp and mod.scale_tag != "bf16":
+        # float16 scales: `sum(weight).to(dtype=scale.dtype)` (linear_uint8.py:63) is a float16 column sum of up to 128 K -- inf from
+        # K = 512 on -- and the activation scale is promoted to float32 around it (:20-22); not a mode anybody can use, not restated
+        raise NotImplementedError("uint8 matmul with float16 scales is not restated")
+    if lp:
+        return _forward_uint8_bf16(mod, x2, tag, conv_form)
     if d["re_quantize_for_matmul"]:  # linear_uint8.py:109-111: int8 codes + per-row scale and zero point, no xor
         wq, sc, zp = mod.re_quantize_matmul()
     else:
@@ -783,6 +809,53 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: bool 
     if bias is not None:
         zero_bias = (zero_bias + bias.astype(f)).astype(f)
     return scaled_mm("int8", q, wq, xs, sc, zero_bias, tag)
+
+
+def _forward_uint8_bf16(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: bool = False) -> np.ndarray:
+    """The uint8 matmul of a layer whose scale / zero point are stored in bfloat16 (dequantize_fp32=False): the chain of
+    linear_uint8.py:27-102 on bfloat16 tensors -- every torch op computes in float32 and rounds its result to bfloat16 once."""
+    d = mod.deq
+    K = mod.K
+    f = np.float32
+    r = lambda a: round_dtype(np.asarray(a, dtype=f), "bf16")  # noqa: E731
+    if tag != "bf16":
+        raise NotImplementedError("bfloat16 scales with another activation dtype are not restated")
+    if d["re_quantize_for_matmul"]:
+        wq, sc, zp = mod.re_quantize_matmul()
+    else:
+        assert not d["is_packed"], "packed weights that reach the uint8 matmul without re-quantization are not restated here"
+        vals, sc, zpv, group = mod._nk_values_scale()
+        sc = sc.reshape(-1)
+        if dtype_info(d["weights_dtype"])["kind"] == "uint":  # linear_uint8.py:45-50 on bfloat16 tensors
+            wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
+            zp = r(zpv.reshape(-1) + f(128.0) * sc) if zpv is not None else r(sc * f(128.0))
+        else:
+            wq, zp = vals.astype(np.int8), None
+    if d["use_hadamard"]:
+        x2 = rotate_hadamard(x2, d["hadamard_group_size"], tag)
+    bias = mod.bias
+    if mod.svd_up is not None:
+        up, down = mod.svd_nr_rk()
+        t = linear_float(round_dtype(x2, mod.svd_tag), down, None, mod.svd_tag)
+        bias = lowrank_bias(t, up, None if bias is None else round_dtype(bias, mod.svd_tag), mod.svd_tag)
+    q, xs, xzp = rowquant_asym_lp(x2, "bf16")  # quantize_uint_mm_input(input, dtype=scale.dtype) (linear_uint8.py:15-23)
+    rowsum = q.astype(np.int32).sum(-1)
+    colsum = wq.astype(np.int32).sum(-1)
+    wcs = r(r(colsum.astype(f)) * sc)                   # sum(weight, int32).to(scale.dtype).mul_(scale)
+    t2 = r(wcs[None, :] * xzp[:, None])                 # .mul(input_zero_point)
+    if zp is None:
+        zero_bias = t2
+    else:
+        t1 = r(r(r(rowsum.astype(f)) * xs)[:, None] * zp[None, :])  # sum(input, int32).to(dtype).mul_(input_scale).mul(zero_point)
+        zero_bias = r(t1 + t2)
+        if conv_form:  # conv_uint8.py:66
+            zero_bias = r(zero_bias + r(r(xzp * f(K))[:, None] * zp[None, :]))
+        else:  # zero_bias.add_(mul(input_zero_point, zero_point), alpha=K): float32 fused multiply-add, then the bfloat16 rounding
+            zero_bias = r(_fma_scalar(r(xzp[:, None] * zp[None, :]), f(K), zero_bias))
+    if bias is not None:
+        b2 = _c(bias, f)
+        zero_bias = r(zero_bias + (b2.reshape(1, -1) if b2.ndim == 1 else b2))
+    return round_dtype(scaled_mm_lp("int8", q, wq, xs, sc, zero_bias, "bf16"), tag)
 
 
 # ---- quantized attention forward (SURVEY 8(f) rank 4) ---------------------------------------------------------------

@@ -29,7 +29,7 @@ EXPORTS = [
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
     "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_attn_fwd_q16", "sdnq_hip_attn", "sdnq_hip_attn_workspace_bytes", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
-    "sdnq_hip_rowquant_lp", "sdnq_hip_scaled_mm_lp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
+    "sdnq_hip_rowquant_lp", "sdnq_hip_rowquant_lp_asym", "sdnq_hip_scaled_mm_lp", "sdnq_hip_scaled_mm_lp_uzp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
     "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided",
 ]
@@ -162,6 +162,8 @@ def _declare(lib):
     lib.sdnq_hip_linear_w8a16_grouped.argtypes = [vp, i32, vp, i64, i64, i32, vp, i64, i64, i64, vp]
     lib.sdnq_hip_linear_w8a16.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]
     lib.sdnq_hip_rowquant_lp.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp]
+    lib.sdnq_hip_rowquant_lp_asym.argtypes = [vp, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, vp]
+    lib.sdnq_hip_scaled_mm_lp_uzp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp]
     lib.sdnq_hip_scaled_mm_lp.argtypes = [i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, i32, vp, i64, i64, i64, vp]
     lib.sdnq_hip_scaled_mm_lp_zp.argtypes = [i32, vp, vp, vp, vp, vp, i32, i64, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp]
     lib.sdnq_hip_set_tile_override.argtypes = [i32]

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
     if constexpr (ASYM) {
         vmin = wave_min(vmin);
         vmax = wave_max(vmax);
-        scale = (vmax - vmin) / 255.0f;   // get_scale_asymmetric (quant_utils.py:10-19) with the int8 range
-        zpv = fmaf(128.0f, scale, vmin);  // zero_point.sub_(scale, alpha=-128); 128*scale is exact
+        // get_scale_asymmetric (quant_utils.py:10-19) with the int8 range; zero_point.sub_(scale, alpha=-128): 128 * scale is exact.
+        // A 16-bit scale dtype (dequantize_fp32=False) rounds sub_, div_ and the alpha-sub once each (round_rt is the identity for f32)
+        scale = round_rt(round_rt(vmax - vmin, p.sdt) / 255.0f, p.sdt);
+        zpv = round_rt(fmaf(128.0f, scale, vmin), p.sdt);
         if (lane == 0) wzp[n] = zpv;
     } else {
         amax = wave_max(amax);
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
             for (int j = 0; j < 16; ++j) {
                 u32 byte;
                 if constexpr (MM == SDNQ_MM_I8) {
-                    float q = __builtin_rintf(round_rt((ASYM ? v[j] - zpv : v[j]) / scale, p.sdt));
+                    float q = __builtin_rintf(round_rt((ASYM ? round_rt(v[j] - zpv, p.sdt) : v[j]) / scale, p.sdt));
                     if (q != q) q = 0.0f;  // 0/0 of a constant row: NaN.to(int8) is 0 in the reference
                     q = fminf(fmaxf(q, -128.0f), 127.0f);
                     byte = (u32)(int)q & 0xffu;
@@ -1122,7 +1124,7 @@ extern "C" int sdnq_hip_requant_asym(const SdnqWeight* w, void* wq, float* ws, f
     if (!wq || !ws || !wzp) return SDNQ_ERR_NULL;
     if ((uintptr_t)wq % 16) return SDNQ_ERR_ALIGN;
     p.svd_up = nullptr; p.svd_down = nullptr;  // as sdnq_hip_requant (linear_uint8.py:110)
-    if (p.sdt != SDNQ_F32) return SDNQ_ERR_UNSUPPORTED;  // the uint8 matmul with 16-bit scales is not built
+    // (16-bit scales: get_scale_asymmetric and the quotient round in the scale dtype, see requant_kernel)
     dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
     hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8, true>), grid, block, 0, (hipStream_t)stream, p, (uint8_t*)wq, ws, wzp);
     SDNQ_CHECK_LAUNCH();

@@ -1498,6 +1498,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                             hasz = true;
                         }
                         if (p.a_zp) {  // uint8 matmul: + colsum(w)*ws*xzp  + K * (xzp * wzp)   (linear_uint8.py:61-66)
+                            if constexpr (LP) {  // the same chain on bfloat16 tensors: every torch op rounds once (wcs arrives rounded twice)
+                                const auto rb = [](float x) { return FT<SDNQ_BF16>::round(x); };
+                                const float t2 = rb(s_wcsq[cn] * azp);
+                                zb = hasz ? rb(zb + t2) : t2;
+                                if (p.zp) {
+                                    if (p.zp_k < 0) zb = rb(zb + rb(rb(azp * (float)(-p.zp_k)) * s_zpq[cn]));
+                                    else zb = rb(fmaf(rb(azp * s_zpq[cn]), (float)(p.zp_k ? p.zp_k : hk.K), zb));
+                                }
+                            } else {
                             const float t2 = s_wcsq[cn] * azp;
                             zb = hasz ? zb + t2 : t2;
                             if (p.zp) {
@@ -1505,6 +1514,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                                     zb = __fadd_rn(zb, __fmul_rn(__fmul_rn(azp, (float)(-p.zp_k)), s_zpq[cn]));
                                 else  // linear form (linear_uint8.py:66): add_(mul(xzp, wzp), alpha=K) is ONE fused multiply-add on the CPU
                                     zb = fmaf(azp * s_zpq[cn], (float)(p.zp_k ? p.zp_k : hk.K), zb);
+                            }
                             }
                             hasz = true;
                         }
@@ -1909,6 +1919,20 @@ extern "C" int sdnq_hip_scaled_mm_lp_zp(int mm_dtype, const void* a, const void*
     if (mm_dtype == SDNQ_MM_I8) LPD(SDNQ_MM_I8);
     LPD(SDNQ_MM_FP8);
 #undef LPD
+}
+
+extern "C" int sdnq_hip_scaled_mm_lp_uzp(const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                         const int32_t* zp_rowsum, const float* zp, const float* a_zp, const float* w_colsum_scaled,
+                                         int64_t zp_k, void* out, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+    int st = check_common(SDNQ_MM_I8, a, b, sa, sb, out, SDNQ_BF16, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (!a_zp || !w_colsum_scaled) return SDNQ_ERR_NULL;
+    if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.zp_rowsum = zp_rowsum; p.zp = zp; p.a_zp = a_zp; p.wcs = w_colsum_scaled; p.zp_k = zp_k;
+    p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = SDNQ_BF16;
+    return launch_lp<SDNQ_MM_I8, EPI_LOWRANK>(p, (hipStream_t)stream);
 }
 
 extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,

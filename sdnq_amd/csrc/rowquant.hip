@@ -100,8 +100,9 @@ __device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, in
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[e] = d.fastdiv(asym ? v[e] - zp : v[e]);
     } else {
+        // (16-bit arithmetic: torch.sub(x, zero_point) rounds to the dtype before .div_(scale) does, quant_utils.py:282)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = (asym ? v[e] - zp : v[e]) / scale;
+        for (int e = 0; e < 8; ++e) qv[e] = (asym ? (LP_T == SDNQ_F32 ? v[e] - zp : FT<LP_T>::round(v[e] - zp)) : v[e]) / scale;
     }
     if constexpr (MM == SDNQ_MM_FP8) {  // nan_to_num, clamp (+-inf fall to it), hardware conversion of four values at a time
         float c[8];
@@ -313,8 +314,13 @@ __global__ __launch_bounds__(256) void rowquant_kernel(const void* __restrict__ 
         if (asym) {  // quantize_uint_mm_input, as in the register-resident path above
             vmin = wave_min(vmin);
             vmax = wave_max(vmax);
-            scale = (vmax - vmin) / 255.0f;
-            zpv = fmaf(128.0f, scale, vmin);
+            if constexpr (LP) {  // get_scale_asymmetric on 16-bit tensors (quant_utils.py:10-19): sub_, div_ and the alpha-sub each round once
+                scale = FT<T_ID>::round(FT<T_ID>::round(vmax - vmin) / 255.0f);
+                zpv = FT<T_ID>::round(fmaf(128.0f, scale, vmin));
+            } else {
+                scale = (vmax - vmin) / 255.0f;
+                zpv = fmaf(128.0f, scale, vmin);
+            }
             if (lane == 0) xzp[m] = zpv;
         } else {
             amax = wave_max(amax);
@@ -653,8 +659,8 @@ extern "C" int sdnq_hip_rowquant(const void* x, int x_dtype, int64_t m, int64_t 
     return SDNQ_OK;
 }
 
-extern "C" int sdnq_hip_rowquant_lp(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype, int hadamard_group,
-                                    void* xq, float* xs, int32_t* rowsum, void* xrot, sdnq_stream_t stream) {
+static int rowquant_lp_impl(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype, int hadamard_group,
+                            void* xq, float* xs, float* xzp, int32_t* rowsum, void* xrot, sdnq_stream_t stream) {
     if (!x || !xq || !xs) return SDNQ_ERR_NULL;
     if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
     if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
@@ -673,13 +679,24 @@ extern "C" int sdnq_hip_rowquant_lp(const void* x, int x_dtype, int64_t m, int64
     dim3 grid((unsigned)row_blocks), block(256);
 #define RQLP(T, MMV, H) \
     hipLaunchKernelGGL((rowquant_kernel<T, MMV, H, 0, 1, true>), grid, block, 0, s, x, m, k, ldx, row_blocks, log2g, (uint8_t*)xq, xs, rowsum, xrot, \
-                       (const uint4*)nullptr, (int64_t)0, (float*)nullptr)
+                       (const uint4*)nullptr, (int64_t)0, xzp)
 #define RQLP_H(T, MMV) do { if (log2g) RQLP(T, MMV, true); else RQLP(T, MMV, false); } while (0)
 #define RQLP_MM(T) do { if (mm_dtype == SDNQ_MM_I8) RQLP_H(T, SDNQ_MM_I8); else RQLP_H(T, SDNQ_MM_FP8); } while (0)
     if (x_dtype == SDNQ_BF16) RQLP_MM(SDNQ_BF16);
     else RQLP_MM(SDNQ_F16);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_rowquant_lp(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int mm_dtype, int hadamard_group,
+                                    void* xq, float* xs, int32_t* rowsum, void* xrot, sdnq_stream_t stream) {
+    return rowquant_lp_impl(x, x_dtype, m, k, ldx, mm_dtype, hadamard_group, xq, xs, nullptr, rowsum, xrot, stream);
+}
+
+extern "C" int sdnq_hip_rowquant_lp_asym(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int hadamard_group, void* xq,
+                                         float* xs, float* xzp, int32_t* rowsum, void* xrot, sdnq_stream_t stream) {
+    if (!xzp) return SDNQ_ERR_NULL;
+    return rowquant_lp_impl(x, x_dtype, m, k, ldx, SDNQ_MM_I8, hadamard_group, xq, xs, xzp, rowsum, xrot, stream);
 }
 
 extern "C" int sdnq_hip_hadamard(const void* x, int dtype, int64_t rows, int64_t k, int64_t ldx, int hadamard_group,

@@ -792,7 +792,7 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     if m == 0 or (small_batch_branch and m < 32):
         return _float_forward(self, input, st)
     if st.qw.scale_dtype != torch.float32:
-        raise NotImplementedError("the uint8 matmul with 16-bit scales (dequantize_fp32=False) is not built")
+        return _uint8_lp_matmul_forward(self, input, st)
     wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)
     wcs = st.mm_wcs
     if wcs is None:  # f32(sum_k wq[n][k]) * ws[n]: static per layer (linear_uint8.py:63 computes it every call)
@@ -813,6 +813,32 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
     y = ops.scaled_mm_lowrank(ops.MM_I8, xq, wq, xs, ws, self.bias, t, st.svd_up, rowsum, zp, input.dtype, a_zp=xzp,
                               w_colsum_scaled=wcs)
+    return y.view(*input.shape[:-1], n)
+
+
+def _uint8_lp_matmul_forward(self, input: torch.Tensor, st: _State) -> torch.Tensor:
+    """The uint8 matmul of a layer whose scale / zero point are stored in bfloat16 (dequantize_fp32=False): the chain of
+    linear_uint8.py:15-23, 57-102 on bfloat16 tensors, every step rounded once (sdnq_hip_rowquant_lp_asym, sdnq_hip_scaled_mm_lp_uzp).
+    A compatibility mode like `_lp_matmul_forward`: plain launches, no activation cache.  (sdnq_amd.support keeps float16 scales, SVD
+    factors and conv layers of this mode on the forward they came with.)"""
+    dq = self.sdnq_dequantizer
+    sdt = st.qw.scale_dtype
+    k, n = dq.in_features, dq.out_features
+    if sdt != torch.bfloat16 or input.dtype != sdt or st.svd_up is not None:
+        raise NotImplementedError("the uint8 matmul with 16-bit scales is built for bfloat16 layers without SVD factors "
+                                  f"(scale dtype {sdt}, activations {input.dtype})")
+    wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)  # re-quantization / zero point rounded in the scale dtype
+    wcs = st.mm_wcs
+    if wcs is None:  # sum(weight, int32).to(bf16).mul_(scale): two bfloat16 roundings, static per layer (linear_uint8.py:63)
+        wcs = wq.to(torch.int32).sum(dim=1).to(torch.bfloat16).mul_(ws.reshape(-1).to(torch.bfloat16)).float()
+        if CACHE_WEIGHTS:
+            st.mm_wcs = wcs
+    had = dq.hadamard_group_size if dq.use_hadamard else 0
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+        x2 = x2.contiguous()
+    xq, xs, xzp, rowsum = ops.rowquant_lp_asym(x2, had, want_rowsum=zp is not None)
+    y = ops.scaled_mm_lp_uzp(xq, wq, xs, ws, _attr(self, "bias"), rowsum, zp, xzp, wcs)
     return y.view(*input.shape[:-1], n)
 
 

@@ -49,7 +49,13 @@ def unsupported_reason(module) -> str | None:
         return "16-bit scales with formats wider than 8 bits are not built (the codes are not exact in the scale dtype)"
     uint8_mm = qmm and mm["is_integer"] and mm["is_unsigned"]
     if uint8_mm and lp:
-        return "the uint8 matmul with 16-bit scales (dequantize_fp32=False) is not built"
+        if sdt != torch.bfloat16:
+            return ("the uint8 matmul with float16 scales is not built: the reference's float16 column sums (linear_uint8.py:63) overflow "
+                    "from K = 512 on")
+        if cls not in linear_types:
+            return "the uint8 conv matmul with 16-bit scales (dequantize_fp32=False) is not built"
+        if getattr(module, "svd_up", None) is not None:
+            return "the uint8 matmul with bfloat16 scales and SVD factors is not built"
     if cls in linear_types:
         return None
     # ---- conv layers

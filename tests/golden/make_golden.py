@@ -227,6 +227,14 @@ CASES = [
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="uint8_int8mm_qmm_f16_lpscale_nobias", K=256, N=64, Ms=[40], dtype="f16", bias=False,
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    # the uint8 matmul on bfloat16 scales / zero points (linear_uint8.py:27-102 with every torch op rounding to bfloat16): plain uint8
+    # codes (xor 0x80), signed codes (no weight zero point), and the re-quantized form (re_quantize_uint_mm on the bfloat16 dequantization)
+    dict(name="uint8_uint8mm_qmm_bf16_lpscale", K=256, N=64, Ms=[4, 48], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="int8_uint8mm_qmm_bf16_lpscale_nobias", K=384, N=64, Ms=[64], dtype="bf16", bias=False,
+         cfg=dict(weights_dtype="int8", quantized_matmul_dtype="uint8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="uint4_g32_uint8mm_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint4", quantized_matmul_dtype="uint8", group_size=32, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="uint8_svd32_int8mm_qmm_bf16_lpscale", K=256, N=128, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True,
                   dequantize_fp32=False)),

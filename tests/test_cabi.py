@@ -126,6 +126,27 @@ def test_attention_argument_validation_without_gpu():
     assert att(p, p + 8, p, 1, 1, 2, 2, 8, 8, 64, *tail, p, 1, None, None, 0, None) == -4      # key rows not 16-byte aligned
 
 
+def test_bf16_uint8_matmul_argument_validation_without_gpu():
+    """sdnq_hip_rowquant_lp_asym / sdnq_hip_scaled_mm_lp_uzp (the uint8 matmul on bfloat16 scales) reject bad arguments before any launch."""
+    import ctypes
+    from sdnq_amd import _lib
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(8192)
+    p = ctypes.addressof(buf)
+    p += (-p) % 16
+    rq = lib.sdnq_hip_rowquant_lp_asym
+    assert rq(p, 1, 4, 64, 64, 0, p, p, None, None, None, None) == -1     # no zero-point output
+    assert rq(None, 1, 4, 64, 64, 0, p, p, p, None, None, None) == -1     # NULL input
+    assert rq(p, 0, 4, 64, 64, 0, p, p, p, None, None, None) == -2        # float32 rows: sdnq_hip_rowquant
+    assert rq(p, 1, 4, 60, 64, 0, p, p, p, None, None, None) == -3        # K % 8
+    assert rq(p, 1, 4, 64, 64, 48, p, p, p, None, None, None) == -3       # Hadamard group not a power of two
+    mm = lib.sdnq_hip_scaled_mm_lp_uzp
+    assert mm(p, p, p, p, None, None, None, None, p, 0, p, 4, 16, 64, None) == -1   # no activation zero points
+    assert mm(p, p, p, p, None, p, None, p, p, 0, p, 4, 16, 64, None) == -1         # rowsum without a weight zero point
+    assert mm(p, p, p, p, None, None, None, p, p, 0, None, 4, 16, 64, None) == -1   # NULL out
+    assert mm(p, p, p, p, None, None, None, p, p, 0, p, 4, 16, 60, None) == -3      # K % 16
+
+
 def test_linear_args_struct_matches_the_header():
     """The ctypes mirror of SdnqLinearArgs has the header's field order and the size the library checks (struct_size)."""
     import ctypes

@@ -68,7 +68,8 @@ def test_module_forward_vs_golden_and_oracle(name, gpu_device):
 
 
 @pytest.mark.parametrize("name", ["int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "uint4_qmm_bf16", "int8_svd32_qmm_bf16",
-                                  "int8_rowwise_noqmm_bf16", "fp8_qmm_bf16", "int6_rowwise_packed_qmm_bf16"])
+                                  "int8_rowwise_noqmm_bf16", "fp8_qmm_bf16", "int6_rowwise_packed_qmm_bf16",
+                                  "uint8_uint8mm_qmm_bf16", "uint4_uint8mm_qmm_bf16", "int8_group64_uint8mm_qmm_bf16", "uint8_uint8mm_qmm_bf16_k384"])
 def test_apply_options_dequantize_fp32_false(name, gpu_device):
     """A float32-scale checkpoint switched to model-dtype scales by apply_sdnq_options_to_model(dequantize_fp32=False) (loader.py:
     262-283) computes what the oracle's 16-bit-scale restatement (pinned by the *_lpscale fixtures) gives for the re-typed layer."""
@@ -87,7 +88,7 @@ def test_apply_options_dequantize_fp32_false(name, gpu_device):
         got = to_f32_numpy(model(x))
         orc = O.forward(omod, c.f32(f"x_{M}"), c.tag)
         qmm = d["use_quantized_matmul"] and M >= 32
-        if qmm and d["quantized_matmul_dtype"] == "int8" and not c.has("svd_up"):
+        if qmm and d["quantized_matmul_dtype"] in ("int8", "uint8") and not c.has("svd_up"):
             assert np.array_equal(got, orc), (name, M, int((got != orc).sum()))
         else:
             assert_close_float(got, orc, c.tag, (name, M, "oracle"))
@@ -131,7 +132,7 @@ def test_dequant_and_requant_vs_golden(name, gpu_device):
         assert len(wzp) == int(c.has("requant_zero_point")), name
         if wzp:  # asymmetric re-quantizer of the uint8 matmul (dequantizer.py:178-187)
             assert tuple(wzp[0].shape) == (1, c.N)
-            assert np.array_equal(wzp[0].cpu().numpy().reshape(-1), c.raw("requant_zero_point").reshape(-1)), name
+            assert np.array_equal(wzp[0].float().cpu().numpy().reshape(-1), c.f32("requant_zero_point").reshape(-1)), name  # (values: bf16 bits under 16-bit scales)
 
 
 def test_dequant_every_storage_dtype_bit_exact(gpu_device):
