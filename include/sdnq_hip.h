@@ -465,6 +465,14 @@ int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int channels, 
                              int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
                              void* xq, float* xs, void* amax_ws, sdnq_stream_t stream);
 
+/* sdnq_hip_im2col_rowquant with a SELF-CLEANING workspace: zeroed_ws = 8224 + batch * height * width 32-bit words that are ALL ZERO on entry
+ * (the first 8224: ticket counters) and are all zero again when the call's last kernel has run -- the last workgroup of the quantizing kernel
+ * zeroes the amax map -- so a caller that keeps one such buffer per stream pays the zeroing launch once, not per convolution (4.9 us x 49
+ * convs of an SDXL step).  One call at a time per buffer (stream order); a buffer left dirty by a failed call must be zeroed again. */
+int sdnq_hip_im2col_rowquant_z(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
+                               int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
+                               void* xq, float* xs, void* zeroed_ws, sdnq_stream_t stream);
+
 /* the same few-row linear for 8-bit raw / 4-bit packed integer layers (signed or unsigned, row- or group-wise, group % 4 == 0)
  * WITH SVD factors (w->svd_up [N][R] set): W = round(dequant(q) + svd_up . svd_down) is formed tile by tile with the rank-R product on the matrix cores and never stored (replaces the
  * dequantize incl. addmm_ + F.linear pair of the M < 32 branch, linear_int8.py:102-103 + dequantizer.py:79-83).

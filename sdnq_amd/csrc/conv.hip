@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void conv_pixel_amax_kernel(const void* __rest
 // round-half-even, clamp; 0/0 -> 0).  64 rows x CT channels per workgroup (CT*P % 16 == 0), bytes staged in LDS rows of
 // CT*P (+4 pad) bytes, written out as 16-byte pieces of the [M][K] rows.  Workgroups with blockIdx.y == 0 also write xs.
 template <int T_ID, int MM, int CT>
-__global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, const unsigned int* __restrict__ amap, float qmax,
-                                                         uint8_t* __restrict__ xq, float* __restrict__ xs) {
+__global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, const unsigned int* amap, float qmax,
+                                                         uint8_t* __restrict__ xq, float* __restrict__ xs, unsigned int* ticket, int64_t map_words) {
     SDNQ_KERNARGS_NOW("s"(p.x), "s"(p.out), "s"(p.B), "s"(p.C), "s"(p.H), "s"(p.W), "s"(p.KH), "s"(p.KW), "s"(p.SH), "s"(p.SW), "s"(p.PH), "s"(p.PW), "s"(p.DH),
                       "s"(p.DW), "s"(p.HO), "s"(p.WO), "s"(p.M), "s"(p.K));  // one batch of kernarg loads (sdnq_dev.h)
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
@@ -177,6 +177,36 @@ __global__ __launch_bounds__(256) void conv_quant_kernel(const Im2colParams p, c
         }
     }
     __syncthreads();
+    if (ticket != nullptr) {
+        // self-cleaning amax map (sdnq_hip_im2col_rowquant_z): every workgroup has read its window maxima by now; the LAST one to say so
+        // zeroes the map and the ticket for the next call -- the separate zeroing launch (4.9 us x 49 convs of an SDXL step) goes away
+        // two levels of tickets: thousands of workgroups on ONE counter serialize at ~25 ns per atomic (measured: +65 us per convolution);
+        // the channel tiles of a row strip meet on that strip's counter (one cache line each, 256 of them), the strips on the global one
+        __shared__ unsigned int s_last;
+        // (no fence: an agent-scope release writes the XCD's whole L2 back -- +65 us per convolution when every workgroup did one.  None is
+        //  needed: the map reads below the barrier above have RETURNED -- their values went into the scales this workgroup already used --
+        //  and the device-scope atomics order the tickets; the zero stores leave this XCD's L2 with the end-of-kernel release like any output)
+        if (tid == 0) {
+            unsigned int* rowc = ticket + 32 + (blockIdx.x & 255u) * 32;
+            const unsigned int per_row = gridDim.y * ((gridDim.x - (blockIdx.x & 255u) + 255u) / 256u);  // workgroups that share this strip counter
+            unsigned int last = 0;
+            if (atomicAdd(rowc, 1u) == per_row - 1) {
+                *rowc = 0;
+                const unsigned int strips = gridDim.x < 256u ? gridDim.x : 256u;
+                last = atomicAdd(ticket, 1u) == strips - 1 ? 1u : 0u;
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) {
+            unsigned int* mapw = const_cast<unsigned int*>(amap);
+            for (int64_t i = (int64_t)tid * 4; i < map_words; i += 1024) {
+                if (i + 3 < map_words) *(uint4*)(mapw + i) = make_uint4(0, 0, 0, 0);
+                else for (int64_t j = i; j < map_words; ++j) mapw[j] = 0;
+            }
+            if (tid == 0) *ticket = 0;
+        }
+    }
     const int c_valid = (p.C - c_base) < CT ? (p.C - c_base) : CT;
     const int cpr = c_valid * P / 16;  // 16-byte pieces per row (C*P % 16 == 0 and CT*P % 16 == 0)
     for (int ch = tid; ch < 64 * cpr; ch += 256) {
@@ -248,9 +278,13 @@ int fill_geometry(Im2colParams& p, const void* x, void* out, int batch, int chan
 
 }  // namespace
 
-extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
-                                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
-                                        void* xq, float* xs, void* amax_ws, sdnq_stream_t stream) {
+namespace {
+// self_clean: amax_ws = [header: global ticket, then 256 strip tickets one cache line apart][batch * height * width words], ALL zero on
+// entry, left all zero by the launch
+constexpr int SDNQ_CONV_WS_HEADER_WORDS = 32 + 256 * 32;
+int im2col_rowquant_impl(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
+                         int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
+                         void* xq, float* xs, void* amax_ws, bool self_clean, sdnq_stream_t stream) {
     if (dtype < 0 || dtype > 2) return SDNQ_ERR_DTYPE;
     if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
     if (!xs || !amax_ws) return SDNQ_ERR_NULL;
@@ -266,7 +300,13 @@ extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int
     if ((uintptr_t)x % 16 || (uintptr_t)amax_ws % 16) return SDNQ_ERR_ALIGN;
     // zero the amax map with a plain kernel: hipMemsetAsync goes through the runtime's generic fill kernel (4.6 us per call
     // in the SDXL conv step, profiles/r01_bench_sdxl_conv_kernel_stats.csv)
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, (unsigned int*)amax_ws, total);
+    unsigned int* ticket = nullptr;
+    if (self_clean) {
+        ticket = (unsigned int*)amax_ws;
+        amax_ws = (unsigned int*)amax_ws + SDNQ_CONV_WS_HEADER_WORDS;
+    } else {
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((total + 1023) / 1024)), dim3(256), 0, s, (unsigned int*)amax_ws, total);
+    }
     const float qmax = (mm_dtype == SDNQ_MM_I8) ? 127.0f : 448.0f;
     const unsigned mb = (unsigned)((p.M + 63) / 64);
     const int ct = (P <= 9) ? 32 : 16;
@@ -280,8 +320,8 @@ extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int
     const size_t lds = (size_t)64 * (ct * P + 4);
 #define CQ2(TID, MMV)                                                                                                      \
     do {                                                                                                                   \
-        if (ct == 32) hipLaunchKernelGGL((conv_quant_kernel<TID, MMV, 32>), g2, block, lds, s, p, (const unsigned int*)amax_ws, qmax, (uint8_t*)xq, xs); \
-        else hipLaunchKernelGGL((conv_quant_kernel<TID, MMV, 16>), g2, block, lds, s, p, (const unsigned int*)amax_ws, qmax, (uint8_t*)xq, xs);          \
+        if (ct == 32) hipLaunchKernelGGL((conv_quant_kernel<TID, MMV, 32>), g2, block, lds, s, p, (const unsigned int*)amax_ws, qmax, (uint8_t*)xq, xs, ticket, total); \
+        else hipLaunchKernelGGL((conv_quant_kernel<TID, MMV, 16>), g2, block, lds, s, p, (const unsigned int*)amax_ws, qmax, (uint8_t*)xq, xs, ticket, total); \
     } while (0)
 #define CQ(TID)                                                                                      \
     do {                                                                                             \
@@ -296,6 +336,21 @@ extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int
 #undef CQ2
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
+}
+}  // namespace
+
+extern "C" int sdnq_hip_im2col_rowquant(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
+                                        int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
+                                        void* xq, float* xs, void* amax_ws, sdnq_stream_t stream) {
+    return im2col_rowquant_impl(x, dtype, batch, channels, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, mm_dtype, xq, xs,
+                                amax_ws, false, stream);
+}
+
+extern "C" int sdnq_hip_im2col_rowquant_z(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw,
+                                          int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int mm_dtype,
+                                          void* xq, float* xs, void* zeroed_ws, sdnq_stream_t stream) {
+    return im2col_rowquant_impl(x, dtype, batch, channels, height, width, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, mm_dtype, xq, xs,
+                                zeroed_ws, true, stream);
 }
 
 extern "C" int sdnq_hip_im2col(const void* x, int dtype, int batch, int channels, int height, int width, int kh, int kw, int stride_h,

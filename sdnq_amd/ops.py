@@ -7,6 +7,7 @@ step runs in the hand-written gfx950 kernels of ``libsdnq_hip.so``.  All functio
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 
 import torch
@@ -773,6 +774,30 @@ def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Te
     return out, (b, ho, wo)
 
 
+# per (device, stream): [zeroed int32 buffer (ticket + amax map) of sdnq_hip_im2col_rowquant_z, call-in-flight flag]
+_amax_maps: dict = {}
+_AMAX_HEADER = 32 + 256 * 32  # ticket words in front of the map (csrc/conv.hip: SDNQ_CONV_WS_HEADER_WORDS)
+SELF_CLEANING_AMAX = os.environ.get("SDNQ_HIP_CONV_SELF_CLEAN", "1") != "0"
+
+
+def _zeroed_amax_map(x: torch.Tensor, words: int):
+    """The stream's self-cleaning amax map, at least _AMAX_HEADER + `words` words, or None (then the caller takes the zero-per-call form): a new
+    buffer cannot be made while the stream is capturing (its zero fill would be replayed, its memory would belong to the graph)."""
+    key = (x.device.index, _stream(x))
+    ent = _amax_maps.get(key)
+    need = _AMAX_HEADER + words
+    if ent is None or ent[0].numel() < need or ent[1]:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if ent is not None and ent[0].numel() >= need:  # a call that failed midway may have left marks behind
+            ent[0].zero_()
+            ent[1] = False
+        else:
+            ent = [torch.zeros((max(need, _AMAX_HEADER + 65536),), device=x.device, dtype=torch.int32), False]
+            _amax_maps[key] = ent
+    return ent
+
+
 def im2col_rowquant(x: torch.Tensor, kernel, stride, padding, dilation, mm: int):
     """Fused unfold + row-wise activation quantization for the conv matmul forwards:
     -> (xq [M, K] int8 | fp8, xs [M, 1] f32, (B, H_out, W_out)); equals rowquant(im2col(x))."""
@@ -789,6 +814,13 @@ def im2col_rowquant(x: torch.Tensor, kernel, stride, padding, dilation, mm: int)
     m, k = b * ho * wo, c * kh * kw
     xq = torch.empty((m, k), device=x.device, dtype=_MM_TORCH[mm])
     xs = torch.empty((m, 1), device=x.device, dtype=torch.float32)
+    ent = _zeroed_amax_map(x, b * h * w) if SELF_CLEANING_AMAX else None
+    if ent is not None:  # the stream's persistent map: zero on entry, zeroed again by the quantizing kernel's last workgroup
+        ent[1] = True
+        check(_lib.load().sdnq_hip_im2col_rowquant_z(x.data_ptr(), float_code(x.dtype), b, c, h, w, kh, kw, sh, sw, ph, pw, dh, dw, mm,
+                                                     xq.data_ptr(), xs.data_ptr(), ent[0].data_ptr(), _stream(x)), "im2col_rowquant_z")
+        ent[1] = False
+        return xq, xs, (b, ho, wo)
     ws = torch.empty((b * h * w,), device=x.device, dtype=torch.int32)  # per-pixel channel-amax map (zeroed by the library)
     check(_lib.load().sdnq_hip_im2col_rowquant(x.data_ptr(), float_code(x.dtype), b, c, h, w, kh, kw, sh, sw, ph, pw, dh, dw, mm,
                                                xq.data_ptr(), xs.data_ptr(), ws.data_ptr(), _stream(x)), "im2col_rowquant")

@@ -1612,3 +1612,47 @@ def test_rowquant_fp8_keeps_the_sign_of_zero(dt, gpu_device):
     assert np.array_equal(xs.cpu().numpy().reshape(-1), s.reshape(-1))
     assert np.array_equal(bits_of(xq), q.view(np.uint8))
     assert (bits_of(xq)[0, 5::7] == 0x80).all() and (bits_of(xq)[0, 6::7] == 0x00).all()
+
+
+@pytest.mark.gpu
+def test_conv_quantizer_self_cleaning_amax_map(gpu_device):
+    """sdnq_hip_im2col_rowquant_z: the stream's persistent amax map is zero before and after every call (the quantizing kernel's last
+    workgroup cleans it), so back-to-back convolutions of different sizes, eager and replayed from a hipGraph, give exactly what the
+    zero-per-call form gives."""
+    from sdnq_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1, 32, 24, 24, 3, 1, 1), (2, 48, 16, 8, 3, 2, 1), (1, 320, 64, 64, 3, 1, 1), (1, 64, 40, 8, 1, 1, 0), (1, 32, 24, 24, 3, 1, 1)]
+    xs_in = [(torch.randn(b, c, h, w, generator=g) * (1 + i)).to(torch.bfloat16).to(gpu_device) for i, (b, c, h, w, k, s_, p_) in enumerate(shapes)]
+
+    def run_all():
+        outs = []
+        for x, (b, c, h, w, k, s_, p_) in zip(xs_in, shapes):
+            xq, xs, _ = ops.im2col_rowquant(x, (k, k), (s_, s_), (p_, p_), (1, 1), ops.MM_I8)
+            outs.append((xq.clone(), xs.clone()))
+        return outs
+
+    assert ops.SELF_CLEANING_AMAX
+    ops.SELF_CLEANING_AMAX = False
+    try:
+        want = run_all()
+    finally:
+        ops.SELF_CLEANING_AMAX = True
+    for rep in range(3):
+        got = run_all()
+        for (a, sa), (b_, sb) in zip(got, want):
+            assert torch.equal(a, b_) and torch.equal(sa, sb), rep
+    torch.cuda.synchronize()
+    maps = [e for k_, e in ops._amax_maps.items() if k_[0] == gpu_device.index]
+    assert maps and all(not e[0].any().item() and not e[1] for e in maps)
+    st = torch.cuda.Stream(device=gpu_device)
+    with torch.cuda.stream(st):
+        run_all()  # the stream's map exists before the capture
+        st.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            cap = run_all()
+        for rep in range(3):
+            graph.replay()
+            st.synchronize()
+            for (a, sa), (b_, sb) in zip(cap, want):
+                assert torch.equal(a, b_) and torch.equal(sa, sb), ("replay", rep)
