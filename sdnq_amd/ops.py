@@ -776,6 +776,7 @@ def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Te
 
 # per (device, stream): [zeroed int32 buffer (ticket + amax map) of sdnq_hip_im2col_rowquant_z, call-in-flight flag]
 _amax_maps: dict = {}
+_amax_retired: list = []  # outgrown maps (a few hundred KB each), kept alive for graphs captured while they were current
 _AMAX_HEADER = 32 + 256 * 32  # ticket words in front of the map (csrc/conv.hip: SDNQ_CONV_WS_HEADER_WORDS)
 SELF_CLEANING_AMAX = os.environ.get("SDNQ_HIP_CONV_SELF_CLEAN", "1") != "0"
 
@@ -793,6 +794,8 @@ def _zeroed_amax_map(x: torch.Tensor, words: int):
             ent[0].zero_()
             ent[1] = False
         else:
+            if ent is not None:
+                _amax_retired.append(ent[0])  # a hipGraph captured on this stream may still hold the old address: never freed
             ent = [torch.zeros((max(need, _AMAX_HEADER + 65536),), device=x.device, dtype=torch.int32), False]
             _amax_maps[key] = ent
     return ent
