@@ -61,3 +61,12 @@ def test_fuzz_host_side_reuse_never_serves_stale_results(seed, gpu_device):
     projection groups and the per-module weight state always equal a computation on a fresh clone (tools/fuzz_host_state.py)."""
     import fuzz_host_state
     assert fuzz_host_state.run(seed, 250, verbose=False) == []
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_fuzz_attention_routes_are_bit_identical(seed, gpu_device):
+    """sdnq_hip_attn (one launch up to 128 keys; else K / V prepare + a forward kernel that quantizes its own queries) == the three-call
+    sequence with the separate pass over Q, bit for bit: random grouped heads, lengths around the 32-key blocks and the 128-key limit,
+    padded head dims, causal, bool / additive masks, strided queries, zero rows (tools/fuzz_attention_routes.py)."""
+    import fuzz_attention_routes
+    assert fuzz_attention_routes.run(seed, 40, verbose=False) == []
