@@ -711,7 +711,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         }
         lo = hi; mlo = mhi;  // nothing left for the streaming loops below
     }
-    if (!CAUSAL && !HAS_MASK && p.shared_kv) {
+    // (head_dim 128 only: at 64 sharing never paid -- tools/bench_attention.py, round 2 -- and its two-blocks-at-once register sets kept the
+    //  head_dim 64 kernel at 160 VGPRs)
+    if (D == 128 && !CAUSAL && !HAS_MASK && p.shared_kv) {
         const int n_st = n_plain / 2;  // full two-block stages; the same for every wave (no causal limit)
         auto dma_stage = [&](int st, int buf) {
             uint8_t* dst = smem + buf * STG_BYTES;
@@ -762,6 +764,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
     if (!active) { hi = lo; mhi = mlo; }
     if (p.shared_kv && !active) return;
+    if (D == 64) {
+        // head_dim 64: one block per trip, no software pipeline.  Round 4, judged on the step and per shape: the two-block pipeline below
+        // (162 VGPRs against 132) is no faster at 10 x 4096^2 (70.9 us both) and slower on the short calls (20 x 1024^2: 15.2 -> 13.9 us,
+        // the 77-key shapes -0.3..0.6 us; sdxl_attn_int8 2.904 -> 2.872 ms): its prologue / epilogue blocks are a larger share of 8-block
+        // key parts than of the 144-block rows of FLUX, which keep it
+#pragma nounroll
+        for (int kb = lo; kb < hi; ++kb) {
+            v4i kf[KK];
+            Blk b;
+            load_k(kb, kf);
+            load_vs(kb, b);
+            const v16i sc = qk_mfma(kf);
+            softmax_pv(sc, b, (int64_t)kb * 32, std::false_type{});
+        }
+        lo = hi;
+    }
     if (lo < hi) {
         const int last = hi - 1;
         v4i kfA[KK], kfB[KK];
