@@ -234,6 +234,27 @@ def test_accelerate_never_breaks_a_working_model():
     assert not w
 
 
+def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
+    """The uint8 matmul of dequantize_fp32=False layers: built for bfloat16 Linear layers without SVD factors (round 4), named
+    as unsupported -- with the reason -- for float16 scales, conv layers and SVD layers."""
+    import sdnq_amd
+    from sdnq_amd import support
+
+    def layer(dtype, conv=False, **kw):
+        torch.manual_seed(1)
+        base = torch.nn.Conv2d(32, 32, 3, padding=1) if conv else torch.nn.Linear(64, 64)
+        cfg = dict(weights_dtype="uint8", group_size=-1, dequantize_fp32=False)
+        cfg.update(dict(quant_conv=True, use_quantized_matmul_conv=True) if conv else dict(use_quantized_matmul=True))
+        cfg.update(kw)
+        return sdnq_amd.sdnq_quantize_layer(base.to(dtype), sdnq_amd.SDNQConfig(**cfg))[0]
+
+    assert support.unsupported_reason(layer(torch.bfloat16)) is None
+    assert support.unsupported_reason(layer(torch.bfloat16, weights_dtype="uint4", quantized_matmul_dtype="uint8", group_size=32)) is None
+    assert "float16" in support.unsupported_reason(layer(torch.float16))
+    assert "conv" in support.unsupported_reason(layer(torch.bfloat16, conv=True))
+    assert "SVD" in support.unsupported_reason(layer(torch.bfloat16, use_svd=True, svd_rank=16))
+
+
 def test_peer_arena_ring_steps_over_live_ranges_and_recycles_dead_ones():
     """PeerArena's allocator (the copy-free gather's receive ring), without a GPU: a range is reused only when no tensor made from it
     is alive; live ranges are stepped over; a ring full of live tensors raises."""
