@@ -331,6 +331,19 @@ int sdnq_hip_linear_skinny(const SdnqWeight* w, int hadamard_group, const void* 
 int sdnq_hip_quantize_weight(const void* src, int src_dtype, int64_t ld_src, const SdnqWeight* w, float qmin,
                              float qmax, sdnq_stream_t stream);
 
+/* ---- weight prefetch (round 5) -------------------------------------------------------------------
+ * Pulls [ptr, ptr + bytes) into the memory-side cache (256-MiB Infinity Cache of MI355X): one 4-byte read per 128-byte line, nothing
+ * stored.  Meant for the static weights of the layers that run NEXT, launched on a side stream while the current layer computes -- the
+ * reference has no counterpart (its GEMMs read their weights cold, like any launch-per-layer pipeline); a wrong guess costs bandwidth,
+ * never correctness.  workgroups <= 0: 32. */
+int sdnq_hip_prefetch(const void* ptr, int64_t bytes, int workgroups, sdnq_stream_t stream);
+/* The same work WITHOUT a launch of its own: the next scaled-matmul launch of the calling thread (any sdnq_hip_scaled_mm* / sdnq_hip_linear*
+ * entry point) appends workgroups that pull up to four ranges -- the weights of the launches that run next and after next -- into the
+ * memory-side cache while its tiles compute, when that launch leaves workgroup slots free (a launch whose tiles fill every slot drops
+ * the hint: that is why more than one launch ahead is named).  NULL / 0 for an unused range.  Thread-local; consumed by ONE launch; the
+ * ranges must stay mapped until that launch has run (stream order).  SDNQ_HIP_PREFETCH_WGS caps the workgroups (default 96). */
+int sdnq_hip_prefetch_hint(const void* p0, int64_t b0, const void* p1, int64_t b1, const void* p2, int64_t b2, const void* p3, int64_t b3);
+
 /* ---- 8(e): tensor-parallel glue ------------------------------------------------------------------
  * Re-assembly of a column-sharded Linear's output after the RCCL all-gather (the reference has no inference parallelism, SURVEY 2.1;
  * north_star: "large Linear layers are optionally column-sharded across the 8 GPUs of one node with RCCL all-gather over xGMI").

@@ -31,7 +31,7 @@ EXPORTS = [
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
     "sdnq_hip_rowquant_lp", "sdnq_hip_rowquant_lp_asym", "sdnq_hip_scaled_mm_lp", "sdnq_hip_scaled_mm_lp_uzp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
-    "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided",
+    "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided", "sdnq_hip_prefetch", "sdnq_hip_prefetch_hint",
 ]
 
 
@@ -136,6 +136,8 @@ def _declare(lib):
     lib.sdnq_hip_device_supported.argtypes = [c.c_int]
     lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_prefetch.argtypes = [vp, i64, i32, vp]
+    lib.sdnq_hip_prefetch_hint.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64]
     lib.sdnq_hip_unshard_columns.argtypes = [vp, vp, i32, i64, i64, i64, i64, i32, c.POINTER(c.c_int64), vp]
     lib.sdnq_hip_scaled_mm_lowrank_strided.argtypes = [i32, vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp, i64, i32, i64, i64, i64, vp]
     pvp = c.POINTER(c.c_void_p)
@@ -232,5 +234,10 @@ def _with_typed_binding(lib):
 
 def check(status: int, what: str = ""):
     if status != 0:
-        msg = load().sdnq_hip_strerror(status).decode()
+        lib = load()
+        try:  # a call that failed in front of its GEMM launch leaves its weight-prefetch hint pending: drop it
+            lib.sdnq_hip_prefetch_hint(None, 0, None, 0, None, 0, None, 0)
+        except Exception:  # noqa: BLE001
+            pass
+        msg = lib.sdnq_hip_strerror(status).decode()
         raise SdnqHipError(f"sdnq_hip {what} failed: {msg} (status {status})")

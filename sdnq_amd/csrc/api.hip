@@ -29,6 +29,35 @@ extern "C" int sdnq_hip_device_supported(int ordinal) {
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
+// ---- weight prefetch into the memory-side cache (round 5) -------------------------------------------------------------------------
+// Inside a model step every layer's weights arrive COLD: 2.2 GB of int8 weights per SDXL step stream from HBM once each, at 0.3 TB/s
+// averaged over the step -- 4 % of what the memory delivers -- because each GEMM waits for its own first bytes (tools/trace_in_step.py,
+// 1024 x 1280 x 1280: first stage landed 3 700 cycles after its DMAs were issued, 1 550 when the weights sit in the 256-MiB Infinity
+// Cache; K loop 9 440 vs 7 310 cycles).  The weights are static and the layer order of a step repeats, so the NEXT layers' weights can
+// be pulled into the memory-side cache while the current layer computes: one dword per 128-byte line, nothing kept.
+namespace {
+__global__ __launch_bounds__(256) void prefetch_kernel(const uint8_t* p, int64_t lines) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < lines; i += stride) {
+        int v;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p + i * 128) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+}  // namespace
+
+extern "C" int sdnq_hip_prefetch(const void* ptr, int64_t bytes, int workgroups, sdnq_stream_t stream) {
+    if (!ptr) return SDNQ_ERR_NULL;
+    if (bytes <= 0) return SDNQ_OK;
+    const uintptr_t a = (uintptr_t)ptr & ~(uintptr_t)127;
+    const int64_t lines = (int64_t)(((uintptr_t)ptr + (uintptr_t)bytes + 127 - a) / 128);
+    int wg = workgroups > 0 ? workgroups : 32;
+    if ((int64_t)wg * 256 > lines) wg = (int)((lines + 255) / 256);
+    hipLaunchKernelGGL(prefetch_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)a, lines);
+    return hipGetLastError() == hipSuccess ? SDNQ_OK : SDNQ_ERR_LAUNCH;
+}
+
 // The whole plain w8a8 Linear in one call: row quantization, then the scaled matmul (two launches on `stream`).  Exists for
 // hosts where the per-call binding cost matters (an eager Python model pays the ctypes marshalling once instead of twice).
 extern "C" int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int hadamard_group,

@@ -43,9 +43,12 @@ __device__ unsigned g_trace2[64];
 #endif
 #ifdef SDNQ_TRACE  // development build only: per-workgroup phase timestamps (shader clock), read back by tools/trace_gemm.py
 __device__ unsigned long long g_trace[4096 * 8];
+// launch filter (tools/trace_in_step.py): only launches of this M x N x K are recorded, so that after a replay of a whole step's graph the
+// buffer holds the LAST such launch as it ran INSIDE the step (cold weights, the row quantizer in front of it); 0 = every launch
+__device__ int g_trace_shape[4];
 #define TRACE(slot)                                                                    \
     do {                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+        if (threadIdx.x == 0 && blockIdx.x < 4096 && tr_on) g_trace[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define TRACE(slot) do { } while (0)
@@ -91,6 +94,10 @@ struct GemmParams {
     // weight rows / scales / bias (the layers' own parameters, no stacked copy); BN divides unit_n, so a tile lies inside one unit
     const SdnqGemmUnit* units;  // device table or null
     int64_t unit_n;
+    // weight prefetch (sdnq_hip_prefetch_hint): workgroups past the last tile pull these ranges (128-byte lines) into the memory-side
+    // cache while the tiles compute; see launch_one
+    const uint8_t* pf_ptr[4];
+    int pf_lines[4];
 };
 
 // Where one workgroup's BN output channels live: weight rows, per-channel vectors and the output matrix they belong to.
@@ -405,7 +412,17 @@ template <> struct FragOps<SDNQ_MM_FP8> {
 //              a half-tile is refilled two phases after its last read (the WAR rule of LD_8P) and needed six phases after that; every
 //              phase ends its read/issue section with vmcnt(8): all but the four youngest half-tiles have landed, which covers the
 //              reads of the next phase.  Needs K % 128 == 0 (a partial K tile would read the next row's bytes).
-enum { LD_DMA = 0, LD_PIPE = 2, LD_PP = 3, LD_8P = 4, LD_HT = 5 };
+//   LD_OV  : the LD_DMA ring with every stream of a K stage OVERLAPPED (round 5; the one-round tiles of the bs = 1 steps).  In LD_DMA a
+//            stage is {counted vmcnt, barrier, this wave's DMA pieces, all fragment reads, lgkmcnt, the MFMAs}: the ~85 issue cycles of
+//            every LDS-DMA piece, the LDS reads (64 KB per stage of a 64x128 tile: 256 LDS cycles) and the matrix time of the two waves
+//            of a SIMD ADD UP -- 907 cycles per 24.5-KB stage = 27 B/clk/CU where the fill path alone sustains 45-59
+//            (profiles/r03_dma_shape.txt).  Here the fragments of stage kt + 1 are read (right after the barrier, into the other of two
+//            register sets) while the MFMAs of stage kt run, and the DMA pieces of the stage NS ahead are issued BETWEEN those MFMAs --
+//            one piece per matrix instruction or two, so the wave's issue port is busy with the piece while its MFMA occupies the pipe.
+//            The ring slot of stage kt is free as soon as every wave's reads of it have retired (lgkmcnt(0) in front of the barrier that
+//            opens stage kt), i.e. one stage EARLIER than in LD_DMA: NS slots carry NS stages of DMA in flight.
+//   LD_OG  : LD_OV with the fragments read one K SUB-STEP ahead instead of one stage (wave tiles of several MFMA tiles; see the loop).
+enum { LD_DMA = 0, LD_PIPE = 2, LD_PP = 3, LD_8P = 4, LD_HT = 5, LD_OV = 6, LD_OG = 7 };
 constexpr int HT_BYTES = 16384, HT_SLOTS = 8;
 
 // LP: dequantize_fp32=False with BFLOAT16 scales -- the reference's eager epilogue runs on bf16 tensors (kernel_wrappers.py:132-144:
@@ -488,6 +505,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
                  "s"(p_.bias_dtype), "s"(p_.seg_n), "s"(p_.out_hw), "s"(p_.sa));
 #endif
 #endif
+#ifdef SDNQ_TRACE
+    const bool tr_on = g_trace_shape[0] == 0 || (g_trace_shape[0] == hk_M && g_trace_shape[1] == hk_N && g_trace_shape[2] == hk_K);
+#endif
     TRACE(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -500,6 +520,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     // MALL/HBM for each m-strip: measured 51% of wave cycles parked on vmcnt/barrier at 16384 x 8192 x 4096).
     const int nwg = hk.tiles_m * hk.tiles_n;
     int bid = blockIdx.x;
+    if (bid >= nwg) {
+        // a prefetch workgroup (launch_one appends them when the launch leaves workgroup slots free): one dword of every 128-byte line of
+        // the NEXT layers' weights, nothing kept -- they are in the Infinity Cache when their own GEMM asks for them
+        const int t = (bid - nwg) * (int)blockDim.x + (int)threadIdx.x, stride = ((int)gridDim.x - nwg) * (int)blockDim.x;
+#pragma nounroll
+        for (int r = 0; r < 4; ++r) {
+            const uint8_t* base = p.pf_ptr[r];
+            const int lines = p.pf_lines[r];
+            for (int i = t; i < lines; i += stride) {
+                int v;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(base + (int64_t)i * 128) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SDNQ_TRACE
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_trace[blockIdx.x * 8] = 0;  // (not a tile: tools/trace_*.py count rows with an entry stamp)
+#endif
+        return;
+    }
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
@@ -1131,7 +1170,198 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #endif
 #undef TS
 #undef LUT_EXPAND
-    } else if constexpr (LD == LD_HT + 100) {
+    } else if constexpr (LD == LD_OV) {
+        static_assert(!is_w8a16<MM> && MS == 32, "overlapped ring: the quantized / plain float matmuls on 32x32 MFMA tiles");
+        typedef typename FragOps<MM>::frag_t frag_t;
+        typedef typename FragOps<MM>::fragb_t fragb_t;
+        constexpr int KS = BK / MT::KB, NM = KS * TN * TM;
+        frag_t fa[2][KS][TM];
+        fragb_t fb[2][KS][TN];
+        // A 32x32 wave tile has ONE accumulator: its MFMAs form a dependent chain, and anything issued between two MFMAs on the same
+        // accumulator costs the forwarding path (+43 cycles per gap, MI355X_MICROARCH.md).  Odd K sub-steps accumulate into a second
+        // register set, summed once after the loop (int32: exact, so still bit-identical; fp32: one more addition order).
+        constexpr bool SPLIT_ACC = (TM * TN == 1) && (KS % 2 == 0);
+        typename MT::acc_t acc_odd[SPLIT_ACC ? 1 : 0 + 1];
+        if constexpr (SPLIT_ACC) MT::zero(acc_odd[0]);
+        auto load_stage = [&](int slot, auto setc) {
+            constexpr int st = decltype(setc)::value;
+            const uint8_t* sA = lds + slot * STAGE_BYTES;
+            const uint8_t* sB = sA + BM * BK;
+#ifdef SDNQ_ABL_NOREAD
+            if (slot >= 0) return;
+#endif
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[st][ks][i] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + i * MS + frow, ks, fgrp, hk.swz);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) fa[st][ks][j] = FragOps<MM>::template load<BK>(sA, wm * WM + j * MS + frow, ks, fgrp, hk.swz);
+            }
+        };
+        // one fragment read of a stage, numbered ks-major: r -> (ks, weight sub-tile i | activation sub-tile j)
+        constexpr int NRG = TM + TN, NRT = KS * NRG;
+#ifndef SDNQ_OV_NMR_NUM
+#define SDNQ_OV_NMR_NUM 3
+#endif
+        constexpr int NMR = (NM * SDNQ_OV_NMR_NUM) / 4 > 0 ? (NM * SDNQ_OV_NMR_NUM) / 4 : 1;
+        auto read_one = [&](const uint8_t* sA, const uint8_t* sB, auto setc, auto rc) {
+            constexpr int st = decltype(setc)::value, r = decltype(rc)::value, ks = r / NRG, e = r % NRG;
+#ifdef SDNQ_ABL_NOREAD
+            if (sA != nullptr) return;
+#endif
+            if constexpr (e < TN) fb[st][ks][e] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + e * MS + frow, ks, fgrp, hk.swz);
+            else fa[st][ks][e - TN] = FragOps<MM>::template load<BK>(sA, wm * WM + (e - TN) * MS + frow, ks, fgrp, hk.swz);
+        };
+        // the MFMAs of fragment set `st`; dealt out between them: the fragment reads of the NEXT stage (ring slot `rslot`, into the other
+        // set) and the DMA pieces of logical stage `js` (into ring slot `slot`).  A wave that issued all its reads in one burst after the
+        // barrier sat in the LDS issue queue behind the other seven waves' bursts until nearly all 64-96 KB had been served and only then
+        // reached its first MFMA (reads + MFMAs measured as their SUM, tools/micro/build_abl.sh: nodma 64 us vs mmaonly 43.5)
+        auto mma_issue = [&](auto setc, int js, int slot, int rslot) {
+            constexpr int st = decltype(setc)::value;
+            const uint8_t* sA = lds + rslot * STAGE_BYTES;
+            const uint8_t* sB = sA + BM * BK;
+            static_for_up<NM>([&](auto mc) {
+                constexpr int mi = decltype(mc)::value, ks = mi / (TN * TM), i = (mi / TM) % TN, j = mi % TM;
+#ifndef SDNQ_ABL_NOMMA
+                if constexpr (SPLIT_ACC && (ks & 1)) FragOps<MM>::mma(acc_odd[0], FragOps<MM>::prep(fb[st][ks][i], wrow[i], wflip), fa[st][ks][j]);
+                else FragOps<MM>::mma(acc[i][j], FragOps<MM>::prep(fb[st][ks][i], wrow[i], wflip), fa[st][ks][j]);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                static_for_up<NRT>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    // reads are dealt over the first NMR MFMAs only: the last ones retire under the stage's remaining MFMAs, so the
+                    // lgkmcnt(0) in front of the next barrier does not wait for LDS latency
+                    if constexpr (mi < NMR && r >= (mi * NRT) / NMR && r < ((mi + 1) * NRT) / NMR) read_one(sA, sB, std::integral_constant<int, st ^ 1>{}, rc);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for_up<PPW>([&](auto pc) {
+                    constexpr int pi = decltype(pc)::value;
+                    constexpr int after = ((pi + 1) * NM) / (PPW + 1) - 1 < 0 ? 0 : ((pi + 1) * NM) / (PPW + 1) - 1;
+                    if constexpr (after == mi) {
+#ifndef SDNQ_ABL_NODMA
+                        issue_range(js, slot, std::integral_constant<int, pi>{}, std::integral_constant<int, pi + 1>{});
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            });
+        };
+        // prologue: stages 0 .. NS-2 are in flight (above); stage 0 landed -> the last free slot gets stage NS-1, stage 0 -> set 0
+        wait_ahead();
+        __builtin_amdgcn_s_barrier();
+        if (true) TRACE(2);
+        issue(AHEAD);
+        load_stage(0, std::integral_constant<int, 0>{});
+        auto half = [&](auto setc, int kt) {
+            constexpr int st = decltype(setc)::value;
+            // stage kt + 1 has landed (this wave's pieces; the barrier makes it everybody's), the NS - 2 younger stages stay in flight;
+            // this wave's reads of stage kt have retired, so after the barrier the slot of stage kt belongs to the DMA of stage kt + NS
+#ifndef SDNQ_ABL_NODMA
+            wait_ahead();
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef SDNQ_ABL_NOBAR
+            __builtin_amdgcn_s_barrier();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            const int slot_free = slot_c;
+            slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+            mma_issue(setc, kt + NS, slot_free, slot_c);  // (reads past the end of K: a re-fetched stage nobody multiplies)
+        };
+#pragma nounroll
+        for (int kt = 0; kt < nk; kt += 2) {
+            half(std::integral_constant<int, 0>{}, kt);
+            if (kt + 1 < nk) half(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        if constexpr (SPLIT_ACC) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][0][e] += acc_odd[0][e];
+        }
+    } else if constexpr (LD == LD_OG) {
+        // the overlapped ring for wave tiles of several MFMA tiles: fragments are read ONE K sub-step ahead (two register sets of TM + TN
+        // fragments instead of two whole stages: a 32x160 wave tile would need 192 fragment registers), everything else as LD_OV.  One loop
+        // trip = {counted vmcnt, lgkmcnt(0), barrier} then the LAST sub-step of stage kt (its reads fetch sub-step 0 of stage kt + 1, which
+        // the barrier just published) and sub-steps 0 .. KS-2 of stage kt + 1; the DMA pieces of stage kt + NS (ring slot of stage kt, free
+        // since every wave's reads of it retired in front of the barrier) are dealt out over the trip's MFMAs.
+        static_assert(!is_w8a16<MM> && MS == 32 && (BK / MT::KB) % 2 == 0 && (BK / MT::KB) >= 2, "group-ahead ring: an even number of K sub-steps per stage");
+        typedef typename FragOps<MM>::frag_t frag_t;
+        typedef typename FragOps<MM>::fragb_t fragb_t;
+        constexpr int KS = BK / MT::KB, NMG = TN * TM, NRG = TM + TN, NMT = KS * NMG;
+        frag_t fa[2][TM];
+        fragb_t fb[2][TN];
+        auto read_one = [&](const uint8_t* sA, const uint8_t* sB, auto setc, auto ksc, auto ec) {
+            constexpr int st = decltype(setc)::value, ks = decltype(ksc)::value, e = decltype(ec)::value;
+#ifdef SDNQ_ABL_NOREAD
+            if (sA != nullptr) return;
+#endif
+            if constexpr (e < TN) fb[st][e] = FragOps<MM>::template loadb<BKW>(sB, wn * WN + e * MS + frow, ks, fgrp, hk.swz);
+            else fa[st][e - TN] = FragOps<MM>::template load<BK>(sA, wm * WM + (e - TN) * MS + frow, ks, fgrp, hk.swz);
+        };
+        // MFMA group of set SC; between its MFMAs (FEED): the reads of sub-step KSN (ring slot rslot) into the other set and this group's
+        // share of the DMA pieces; G = position of the group in the trip (0 .. KS-1), which selects the pieces
+        auto group = [&](auto scc, auto ksnc, auto gc, auto feedc, int js, int dslot, int rslot) {
+            constexpr int SC = decltype(scc)::value, KSN = decltype(ksnc)::value, G = decltype(gc)::value;
+            constexpr bool FEED = decltype(feedc)::value;
+            const uint8_t* sA = lds + rslot * STAGE_BYTES;
+            const uint8_t* sB = sA + BM * BK;
+            static_for_up<NMG>([&](auto mc) {
+                constexpr int mi = decltype(mc)::value, i = mi / TM, j = mi % TM, gmi = G * NMG + mi;
+#ifndef SDNQ_ABL_NOMMA
+                FragOps<MM>::mma(acc[i][j], FragOps<MM>::prep(fb[SC][i], wrow[i], wflip), fa[SC][j]);
+#endif
+                if constexpr (FEED) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for_up<NRG>([&](auto ec) {
+                        constexpr int e = decltype(ec)::value;
+                        // a fragment register of the other set is free: its last MFMA was in the previous group
+                        if constexpr (e >= (mi * NRG) / NMG && e < ((mi + 1) * NRG) / NMG) read_one(sA, sB, std::integral_constant<int, SC ^ 1>{}, ksnc, ec);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for_up<PPW>([&](auto pc) {
+                        constexpr int pi = decltype(pc)::value;
+                        constexpr int after = ((pi + 1) * NMT) / (PPW + 1) - 1 < 0 ? 0 : ((pi + 1) * NMT) / (PPW + 1) - 1;
+                        if constexpr (after == gmi) {
+#ifndef SDNQ_ABL_NODMA
+                            issue_range(js, dslot, std::integral_constant<int, pi>{}, std::integral_constant<int, pi + 1>{});
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                }
+            });
+        };
+        // trip kt = -1 has no last sub-step of a stage -1 to multiply: its first group runs on ZERO fragments (adds nothing) instead of
+        // sitting behind a branch per MFMA
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fb[1][i] = fragb_t{};
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fa[1][j] = frag_t{};
+        int slot_d = AHEAD;  // ring slot of stage kt (trip kt = -1: the one slot the prologue left empty)
+        constexpr std::integral_constant<bool, true> feed{};
+#pragma nounroll
+        for (int kt = -1; kt < nk - 1; ++kt) {
+#ifndef SDNQ_ABL_NODMA
+            wait_ahead();  // stage kt + 1 has landed (this wave's pieces); NS - 2 younger stages stay in flight
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of stage kt have retired
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef SDNQ_ABL_NOBAR
+            __builtin_amdgcn_s_barrier();
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt < 0) TRACE(2);
+            const int rslot = slot_c;  // stage kt + 1
+            group(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, feed, kt + NS, slot_d, rslot);
+            static_for_up<KS - 1>([&](auto kc) {
+                constexpr int ks = decltype(kc)::value;
+                group(std::integral_constant<int, ks & 1>{}, std::integral_constant<int, ks + 1>{}, std::integral_constant<int, ks + 1>{}, feed, kt + NS, slot_d, rslot);
+            });
+            slot_d = slot_c;
+            slot_c = (slot_c + 1 == NS) ? 0 : slot_c + 1;
+        }
+        // the last sub-step of the last stage: nothing left to read or fetch
+        group(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<bool, false>{}, 0, 0, 0);
     } else if constexpr (LD == LD_DMA) {
         // K loop: wait only for stage kt with a COUNTED vmcnt (the AHEAD-1 younger stages stay in flight across the
         // single raw barrier), refill the ring slot stage kt-1 occupied (an unconsumed re-fetch past the end of K), run the MFMAs.
@@ -1636,6 +1866,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
     TRACE(6);
 }
 
+// The next GEMM launch of this thread carries these ranges as prefetch work (consumed by that launch whether or not it had room for it)
+struct PrefetchHint { const void* ptr[4]; int64_t bytes[4]; };
+thread_local PrefetchHint g_pf_hint = {};
+inline int cu_count() {
+    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+    return n;
+}
+
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB, bool LP = false>
 int launch_one(GemmParams p, hipStream_t s) {
     static_assert(!LP || (OUT_T == SDNQ_BF16 && !is_float_mm<MM>), "LP: the bf16-scale epilogue of the quantized matmuls");
@@ -1680,7 +1918,40 @@ int launch_one(GemmParams p, hipStream_t s) {
     if (p.M > 0x7fffffffll || p.N > 0x7fffffffll || p.K > 0x7fffffffll || p.lda > 0x7fffffffll || p.ldb > 0x7fffffffll) return SDNQ_ERR_SHAPE;
     const uint32_t hk_flags = (uint32_t)(p.group_m & 0xff) | ((uint32_t)(p.swz & 0xff) << 8) | ((uint32_t)(p.fastmap != 0) << 16) |
                               ((uint32_t)(p.fastunit != 0) << 17) | ((uint32_t)(p.units != nullptr) << 18);
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NW * 64), LDS_BYTES, s, p.a, p.b, (int)p.lda, (int)p.ldb, (int)p.M, (int)p.N, (int)p.K,
+    // prefetch workgroups ride along where the launch leaves workgroup slots free (its last round does not fill the chip): they run
+    // beside the tiles on CUs that would idle, so the hint costs the launch nothing; a launch without room drops the hint
+    int pf_wgs = 0;
+    if (g_pf_hint.ptr[0] || g_pf_hint.ptr[1] || g_pf_hint.ptr[2] || g_pf_hint.ptr[3]) {
+        static std::atomic<int> occ{0};
+        int o = occ.load(std::memory_order_relaxed);
+        if (o == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)kern, NW * 64, LDS_BYTES) != hipSuccess || o <= 0) o = -1;
+            occ.store(o, std::memory_order_relaxed);
+        }
+        const int64_t slots = o > 0 ? (int64_t)o * cu_count() : 0, tiles = (int64_t)p.tiles_m * p.tiles_n;
+        // hosts are the ONE-ROUND launches of the bs = 1 steps: workgroups appended to a multi-round launch start in its last round and
+        // stretch the tail, and beside the power-limited 256x256 tiles of a FLUX-size GEMM they cost more than cold weights do there
+        // (flux_int4_had 34.4 -> 34.8 ms, flux_int8_svd 40.3 -> 40.9 with every launch hosting; profiles/r05_prefetch_across_layers.txt)
+        static const double host_max_mac = [] { const char* e = getenv("SDNQ_HIP_PREFETCH_HOST_MAX_GMAC"); return (e ? atof(e) : 20.0) * 1e9; }();
+        const bool small = (double)p.M * (double)p.N * (double)p.K <= host_max_mac;
+        const int64_t room = slots > 0 && tiles < slots && small ? slots - tiles : 0;
+        int64_t lines = 0;
+        for (int r = 0; r < 4; ++r) {
+            p.pf_ptr[r] = nullptr; p.pf_lines[r] = 0;
+            if (!g_pf_hint.ptr[r] || g_pf_hint.bytes[r] <= 0) continue;
+            const uintptr_t a0 = (uintptr_t)g_pf_hint.ptr[r] & ~(uintptr_t)127;
+            const int64_t n = (int64_t)(((uintptr_t)g_pf_hint.ptr[r] + (uintptr_t)g_pf_hint.bytes[r] + 127 - a0) / 128);
+            if (n > 0x7fffffffll) continue;
+            p.pf_ptr[r] = (const uint8_t*)a0; p.pf_lines[r] = (int)n;
+            lines += n;
+        }
+        static const int pf_max = [] { const char* e = getenv("SDNQ_HIP_PREFETCH_WGS"); return e ? atoi(e) : 96; }();  // tuning aid
+        int64_t want = (lines + NW * 64 * 4 - 1) / (NW * 64 * 4);  // ~4 lines per thread
+        if (want > pf_max) want = pf_max;
+        pf_wgs = (int)(want < room ? want : room);
+        g_pf_hint = PrefetchHint{};
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n + pf_wgs), dim3(NW * 64), LDS_BYTES, s, p.a, p.b, (int)p.lda, (int)p.ldb, (int)p.M, (int)p.N, (int)p.K,
                        p.tiles_m, p.tiles_n, hk_flags, p.mg_per_group, p.mg_group_m, p);
     SDNQ_CHECK_LAUNCH();
     return SDNQ_OK;
@@ -1762,6 +2033,13 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 19) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
         if (force == 20 && (p.K % 128) == 0 && ht_ok(p)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
         if (force == 20) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+        if (force == 21) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_OV, 128>(p, s);
+        if (force == 22) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 4, LD_OV, 128>(p, s);
+        if (force == 23) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_OV, 128>(p, s);
+        if (force == 24) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_OV, 128>(p, s);
+        if (force == 25) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_OG, 128>(p, s);
+        if (force == 26) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_OG, 128>(p, s);
+        if (force == 27) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_OG, 128>(p, s);
         // (round 4 lab, not instantiated: 128x160 tiles -- N = 320 in two exact columns, 256 tiles at M = 16384 -- equal the 64x128 tile on
         //  the conv step, 64x320 tiles are slower; profiles/r04_conv_tiles_in_step.txt)
         // (round 4, profiles/r04_ring_depth_in_step.txt: 5- and 6-deep rings for the 64x128 tile -- the one-workgroup-per-CU problems of the
@@ -1822,8 +2100,10 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
             return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_8P, 128>(p, s);
         //  * wide-N, few-row problems (the GEGLU projection 1024 x 10240 x 1280): 256x160 tiles cut N = 10240 into exactly 256
         //    workgroups of 8 waves (wave tile 32x160), 43 % of the LDS-fill bytes of 64x128 tiles: 27.6 -> 22.4 us
+        //    (round 5: on the group-ahead overlapped ring with 128-byte stage rows -- LD_OG -- 21.3 -> 20.2 us replayed alone and
+        //     -0.08 ms over the 60 launches of the SDXL step once the weights arrive from the Infinity Cache, profiles/r05_*)
         if ((p.N % 160) == 0 && tiles(256, 160) >= 192 && tiles(256, 160) <= 512 && fits(160))
-            return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_PIPE, 64>(p, s);
+            return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_OG, 128>(p, s);
         //  * one round of 128x128 tiles (160..256 of them) with enough K to matter (1024 x 3840 x 1280: 13.4 -> 11.1 us,
         //    4096 x 640 x 2560: 16.2 -> 15.4 us): two thirds of the LDS-fill bytes per CU of 64x128 tiles
         if (tiles(128, 128) >= 160 && tiles(128, 128) <= 256 && p.K >= 1024 && fits(128))
@@ -1837,7 +2117,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
 inline bool force_tile_unfit(const GemmParams& p) {
     const int force = forced_tile_for(p);
     if (force < 0 || p.units == nullptr) return false;
-    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128, 256, 128, 256};
+    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128, 256, 128, 256, 128, 128, 128, 128, 160, 128, 128};
     return force < (int)(sizeof(bn_of) / sizeof(int)) ? (p.unit_n % bn_of[force]) != 0 : false;
 }
 
@@ -1876,12 +2156,27 @@ int check_common(int mm_dtype, const void* a, const void* b, const float* sa, co
 #ifndef SDNQ_LAB  // tools/micro/gemm_lab.hip includes this file for the kernel template only
 extern "C" void sdnq_hip_set_tile_override(int tile_id) { g_forced_tile.store(tile_id < 0 ? -1 : tile_id, std::memory_order_relaxed); }
 
+extern "C" int sdnq_hip_prefetch_hint(const void* p0, int64_t b0, const void* p1, int64_t b1, const void* p2, int64_t b2, const void* p3, int64_t b3) {
+    const void* ps[4] = {p0, p1, p2, p3};
+    const int64_t bs[4] = {b0, b1, b2, b3};
+    for (int r = 0; r < 4; ++r) {
+        if (ps[r] && bs[r] < 0) return SDNQ_ERR_SHAPE;
+        g_pf_hint.ptr[r] = bs[r] > 0 ? ps[r] : nullptr;
+        g_pf_hint.bytes[r] = ps[r] ? bs[r] : 0;
+    }
+    return SDNQ_OK;
+}
+
 #ifdef SDNQ_TRACE
 extern "C" int sdnq_hip_debug_trace(unsigned long long* host, int n_words) {
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n_words) != hipSuccess) return -7;
     void* dptr = nullptr;
     if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_trace)) != hipSuccess) return -7;
     return hipMemset(dptr, 0, sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -7;
+}
+extern "C" int sdnq_hip_debug_trace_shape(int m, int n, int k) {
+    const int h[4] = {m, n, k, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_shape), h, sizeof(h)) == hipSuccess ? 0 : -7;
 }
 #endif
 

@@ -32,6 +32,10 @@ CACHE_WEIGHTS = os.environ.get("SDNQ_HIP_CACHE_WEIGHTS", "1").lower() not in {"0
 # 41.3: the GEMM loses more than the hidden kernel costs): a tested opt-in, off by default
 PIPELINE_WEIGHTS = os.environ.get("SDNQ_HIP_PIPELINE_WEIGHTS", "0").lower() not in {"0", "false", "no"}
 PREFETCH_WEIGHTS = os.environ.get("SDNQ_HIP_PREFETCH_WEIGHTS", "0").lower() not in {"0", "false", "no"}  # measured: no gain
+# Weight prefetch ACROSS layers (round 5): every GEMM launch carries the weights of the launches that ran next and after next in the
+# previous step as prefetch work for the Infinity Cache (sdnq_hip_prefetch_hint, _PrefetchChain below).  SDXL step 7.7 -> 7.0-7.3 ms.
+PREFETCH_NEXT = os.environ.get("SDNQ_HIP_PREFETCH_NEXT", "1").lower() not in {"0", "false", "no"}
+PREFETCH_NEXT_MAX_BYTES = int(os.environ.get("SDNQ_HIP_PREFETCH_NEXT_MAX_MB", "48")) << 20  # per launch unit (the Infinity Cache holds 256 MiB)
 FUSED_SKINNY = os.environ.get("SDNQ_HIP_FUSED_SKINNY", "1").lower() not in {"0", "false", "no"}
 FUSED_DEQUANT_GEMM = os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM", "1").lower() not in {"0", "false", "no"}
 FUSED_DEQUANT_GEMM_MAX_FLOP = float(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_MAX_FLOP", "4e10"))
@@ -198,7 +202,70 @@ def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum
 
 class _State:
     """Per-module cache of kernel-ready tensors, keyed on the identity of the module's parameters."""
-    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "svd_down_t", "wd", "bias")
+    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "svd_down_t", "wd", "bias", "pf")
+
+
+class _LaunchUnit:
+    """One GEMM launch site of a model step (a layer, or a ProjectionGroup) as the weight prefetch sees it: the weight tensors the
+    launch reads (held, so the ranges stay mapped) and a weak link to the unit that launched right after it in the last step."""
+    __slots__ = ("tensors", "ranges", "next", "__weakref__")
+
+    def __init__(self, tensors):
+        self.tensors = tuple(tensors)
+        self.ranges = tuple((t.data_ptr(), t.numel() * t.element_size()) for t in self.tensors)
+        if sum(b for _, b in self.ranges) > PREFETCH_NEXT_MAX_BYTES or len(self.ranges) > 4:
+            self.ranges = ()  # (the model-wide key / value group: 340 MB of weights, more than the cache holds)
+        self.next = None
+
+
+class _PrefetchChain:
+    """Inside a model step every layer's weights arrive cold from HBM: the SDXL step reads 2.2 GB of int8 weights once each, at 4 % of
+    the memory's bandwidth, because every GEMM waits for ITS first bytes (tools/trace_in_step.py: first stage 3 700 cycles after the
+    DMAs were issued, K loop 9 440 cycles; 1 550 / 7 310 with the weights in the 256-MiB Infinity Cache, tools/cold_weights_lab.py).
+    The layer order of a step repeats, so each launch unit remembers which unit launched after it; at its next launch it hands the
+    weights of its successor and of the successor's successor to the C library as a prefetch hint, and the GEMM launch appends
+    workgroups that pull those lines into the memory-side cache beside its tiles (csrc/gemm.hip: launch_one).  A wrong guess (another
+    order this step) costs bandwidth, never correctness; two units ahead because a launch whose tiles fill the chip has no room for
+    the extra workgroups.  Per thread; nothing crosses threads."""
+
+    def __init__(self):
+        import threading
+        self._tls = threading.local()
+
+    def launch(self, unit: _LaunchUnit):
+        tls = self._tls
+        prev = getattr(tls, "prev", None)
+        prev = prev() if prev is not None else None
+        if prev is not None and prev is not unit:
+            nx = prev.next
+            if nx is None or nx() is not unit:
+                import weakref
+                prev.next = weakref.ref(unit)
+        import weakref
+        tls.prev = weakref.ref(unit)
+        n1 = unit.next() if unit.next is not None else None
+        if n1 is None:
+            return
+        n2 = n1.next() if n1.next is not None else None
+        rs = n1.ranges + (n2.ranges if (n2 is not None and n2 is not unit) else ())
+        if not rs:
+            return
+        rs = (rs + ((0, 0),) * 4)[:4]
+        ops._lib.load().sdnq_hip_prefetch_hint(rs[0][0], rs[0][1], rs[1][0], rs[1][1], rs[2][0], rs[2][1], rs[3][0], rs[3][1])
+
+    def reset(self):
+        self._tls.prev = None
+
+
+_prefetch_chain = _PrefetchChain()
+
+
+def _pf_launch(holder, tensors):
+    """Called right in front of a GEMM launch: `holder` (a _State or a ProjectionGroup) owns the launch unit of `tensors`."""
+    unit = holder.pf
+    if unit is None or len(unit.tensors) != len(tensors) or any(a is not b for a, b in zip(unit.tensors, tensors)):
+        unit = holder.pf = _LaunchUnit(tensors)
+    _prefetch_chain.launch(unit)
 
 
 _STATE_FIELDS = ("weight", "scale", "zero_point", "svd_up", "svd_down")
@@ -261,6 +328,7 @@ def _state(mod) -> _State:
     st.svd_up, st.svd_down = st.qw.keep[3], st.qw.keep[4]  # physical [N,R], [R,K]
     st.svd_down_t = None
     st.wd = None
+    st.pf = None
     mod.__dict__["_sdnq_hip_state"] = st
     return st
 
@@ -312,6 +380,8 @@ def _float_forward(mod, input: torch.Tensor, st: _State) -> torch.Tensor:
         if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
             x2 = x2.contiguous()
         w_phys, sc, zp = st.qw.keep[0], st.qw.keep[1], st.qw.keep[2]
+        if PREFETCH_NEXT:
+            _pf_launch(st, (w_phys,))
         return ops.linear_w8a16(x2, w_phys, sc, zp, _attr(mod, "bias")).view(*input.shape[:-1], n)
     wd = st.wd
     if wd is None:
@@ -499,6 +569,8 @@ class ProjectionGroup:
         self.last = None   # (input tensor, its key, stream, outputs, indices not handed out yet)
         self.wasted = 0    # consecutive computes whose outputs were not all claimed
         self.fallback = None  # smaller groups (lists of members) to form when THIS grouping turns out wrong (loader.link_projections)
+        self.pf = None            # _LaunchUnit of the grouped launch (weight prefetch across layers)
+        self.pf_tensors = ()      # the members' weight operands, as the unit table was built from them
         _groups.append(weakref.ref(self))
 
     def dissolve(self):
@@ -561,6 +633,7 @@ class ProjectionGroup:
             self.gemm = ops.GemmGroup(members)
         except ops._lib.SdnqHipError:
             return False
+        self.pf_tensors = tuple(wq for (wq, _, _) in parts)
         return True
 
     def _float_operands(self, input: torch.Tensor) -> bool:
@@ -586,6 +659,7 @@ class ProjectionGroup:
             self.gemm = ops.GemmGroup(members)
         except ops._lib.SdnqHipError:
             return False
+        self.pf_tensors = tuple(w for (w, _, _) in members)
         return True
 
     def _claim(self, idx: int, input: torch.Tensor, key, stream):
@@ -626,6 +700,8 @@ class ProjectionGroup:
         if not self._begin_compute() or not self._operands(mm):
             return None
         x2, xq, xs, _, _ = _rowquant_cached(input, input.shape[-1], mm, 0, False, False, None)
+        if PREFETCH_NEXT:
+            _pf_launch(self, self.pf_tensors)
         outs = ops.scaled_mm_grouped(mm, xq, xs, self.gemm, input.dtype)
         self.last = (input, key, stream, outs, set(range(len(self.mods))))
         return self._claim(idx, input, key, stream)
@@ -651,6 +727,8 @@ class ProjectionGroup:
         if FUSED_DEQUANT_GEMM and self._float_operands(input):
             # signed int8 row-wise members: ONE fused dequantize GEMM over the members' own weights (no dequantize launches, no
             # float copy): 1024 x (3 x 1280) x 1280: 21.9 us vs 3 dequantize launches + a 17.5 us GEMM
+            if PREFETCH_NEXT:
+                _pf_launch(self, self.pf_tensors)
             outs = ops.linear_w8a16_grouped(x2, self.gemm)
             self.last = (input, key, stream, outs, set(range(g)))
             return self._claim(idx, input, key, stream)
@@ -687,6 +765,8 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
     bias = _attr(self, "bias")
+    if PREFETCH_NEXT and st.mm_weight is wq and input.is_cuda:  # (a cached operand: the per-call mode's scratch copies are not prefetched)
+        _pf_launch(st, (wq,))
     if not has_svd and zp is None and (had == 0 or k <= 5120):
         # plain w8a8 layer: on a cache miss the row quantization and the GEMM go through ONE binding call (an eager model is
         # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers

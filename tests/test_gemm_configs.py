@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from sdnq_amd import _lib, ops  # noqa: E402
 
-TILES = list(range(21))
+TILES = list(range(28))
 
 
 @pytest.fixture()
