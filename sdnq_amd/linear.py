@@ -417,7 +417,7 @@ class _WeightPipeline:
     def __init__(self):
         self.order = {}       # id(module) -> weakref of the module that followed it in the last step
         self.prev = None      # weakref of the previous per-call layer of this step
-        self.pending = None   # (id(module), mm, wq, ws, event, slot, stream key)
+        self.pending = None   # (the module's _State, mm, wq, ws, event, slot, stream key): the STATE object, so that rebuilt weights are never served stale
         self.slot = 0         # slot the CURRENT layer uses
         self.scratch = {}     # (device index, slot) -> uint8 buffer
         self.side = {}        # device index -> side stream
@@ -457,7 +457,7 @@ class _WeightPipeline:
         cur = torch.cuda.current_stream(dev)
         nbytes = st.qw.n * st.qw.k
         p = self.pending
-        if p is not None and p[0] == id(mod) and p[1] == mm and p[6] == cur.cuda_stream:
+        if p is not None and p[0] is st and p[1] == mm and p[6] == cur.cuda_stream:
             cur.wait_event(p[4])
             wq, ws, self.slot = p[2], p[3], p[5]
             self.pending = None
@@ -491,7 +491,7 @@ class _WeightPipeline:
                     nwq, nws = ops.requant(nst.qw, mm, nst.mm_scale, out=out)
                     done = torch.cuda.Event()
                     done.record(side)
-                self.pending = (id(nxt), mm, nwq, nws, done, slot, cur.cuda_stream)
+                self.pending = (nst, mm, nwq, nws, done, slot, cur.cuda_stream)
         return wq, ws
 
 
@@ -503,9 +503,11 @@ def join_weight_pipeline():
     _weight_pipeline.join()
 
 
-def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
+def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False, for_group: bool = False):
     """Weight operand of the quantized matmul: (wq [N,K], ws [N], zp [N] | None).  `asymmetric` (the uint8 matmul) only changes
-    the re-quantizer: min / max range and a zero point per output row."""
+    the re-quantizer: min / max range and a zero point per output row.  `for_group`: the caller keeps the operand's POINTER (a unit
+    table of a grouped launch): the per-call pipeline's two shared scratch slots are never handed out for that -- member 3's
+    re-quantization would overwrite member 1's operand before the grouped GEMM ran (advisor, round 4): a fresh buffer instead."""
     dq = mod.sdnq_dequantizer
     key = (mm, asymmetric)
     if st.mm == key and st.mm_weight is not None:
@@ -517,7 +519,7 @@ def _prepare_mm_weights(mod, st: _State, mm: int, asymmetric: bool = False):
         # linear_int8.py:104-107; zero_point folded, none afterwards.  Per-call mode (SDNQ_HIP_CACHE_WEIGHTS=0): the N row scales of
         # the first call are kept (4 bytes per output channel), the [N][K] operand is not
         known = st.mm_scale if (st.mm == key and st.mm_weight is None) else None
-        if not CACHE_WEIGHTS and PIPELINE_WEIGHTS and known is not None and st.qw.keep[0].is_cuda:
+        if not CACHE_WEIGHTS and PIPELINE_WEIGHTS and known is not None and st.qw.keep[0].is_cuda and not for_group:
             # (the first call of a layer derives its row scales inline; from the second on the layer takes part in the pipeline)
             wq, ws = _weight_pipeline.weights(mod, st, mm, known)
         else:
@@ -621,7 +623,7 @@ class ProjectionGroup:
             return False
         try:
             states = [_state(m) for m in self.mods]
-            parts = [_prepare_mm_weights(m, st, mm) for m, st in zip(self.mods, states)]
+            parts = [_prepare_mm_weights(m, st, mm, for_group=True) for m, st in zip(self.mods, states)]
         except ops._lib.SdnqHipError:
             return False
         if any(zp is not None for (_, _, zp) in parts) or len({w.device for (w, _, _) in parts}) != 1:

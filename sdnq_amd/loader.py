@@ -97,7 +97,10 @@ def accelerate(model: torch.nn.Module) -> AccelerateResult:
     for name, module in model.named_modules():
         if getattr(module, "sdnq_dequantizer", None) is None:
             continue
-        why = unsupported_reason(module)
+        try:
+            why = unsupported_reason(module)
+        except Exception as e:  # noqa: BLE001  a foreign record the predicate cannot read is a reason to leave the layer alone, not to fail
+            why = f"{type(e).__name__} while reading the layer's record: {e}"
         if why is None:
             try:
                 dq = adopt_dequantizer(module.sdnq_dequantizer)
@@ -301,6 +304,7 @@ def fuse_projections(model: torch.nn.Module) -> int:
 @torch.no_grad()
 def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
                                 use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):
+    skipped_foreign = []
     for module in model.modules():
         # every SDNQ Linear / conv layer, whether or not the HIP forwards compute its (old or new) configuration: the options only
         # re-type tensors and re-point forward_func; an unbuilt configuration then fails loudly at its forward (support.require)
@@ -310,6 +314,19 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
         conv = cls in ("Conv1d", "Conv2d", "Conv3d", "SDNQConv1d", "SDNQConv2d", "SDNQConv3d")
         if not (conv or cls in ("Linear", "SDNQLinear")):
             continue
+        fwd_now = getattr(module, "forward_func", None)
+        if fwd_now is not None and not str(getattr(fwd_now, "__module__", "")).startswith("sdnq_amd"):
+            # a layer that runs on a FOREIGN forward (accelerate() left it on the reference's, because this package does not build
+            # its configuration): re-pointing it here would turn a working layer into one that raises at its forward.  It stays
+            # what it is -- options for such layers are the business of the package whose forward they run on.
+            from .support import unsupported_reason
+            try:
+                why = unsupported_reason(module)
+            except Exception as e:  # noqa: BLE001
+                why = f"{type(e).__name__}: {e}"
+            if why is not None:
+                skipped_foreign.append(why)
+                continue
         dq = adopt_dequantizer(module.sdnq_dequantizer)
         module.sdnq_dequantizer = dq
         if dtype is not None:
@@ -351,6 +368,10 @@ def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | Non
         module.__dict__.pop("_sdnq_hip_state", None)
         _unlink(module)  # the layer's layout / forward may have changed: its group (if any) dissolves, siblings run alone
         _refresh_compile_plan(module)
+    if skipped_foreign:
+        import warnings
+        warnings.warn(f"sdnq_amd.apply_sdnq_options_to_model: {len(skipped_foreign)} SDNQ layer(s) run on another package's forward in a "
+                      f"configuration the MI355X kernels do not build and were left untouched ({skipped_foreign[0]})", stacklevel=2)
     return model
 
 

@@ -776,7 +776,6 @@ def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Te
 
 # per (device, stream): [zeroed int32 buffer (ticket + amax map) of sdnq_hip_im2col_rowquant_z, call-in-flight flag]
 _amax_maps: dict = {}
-_amax_retired: list = []  # outgrown maps (a few hundred KB each), kept alive for graphs captured while they were current
 _AMAX_HEADER = 32 + 256 * 32  # ticket words in front of the map (csrc/conv.hip: SDNQ_CONV_WS_HEADER_WORDS)
 SELF_CLEANING_AMAX = os.environ.get("SDNQ_HIP_CONV_SELF_CLEAN", "1") != "0"
 
@@ -784,18 +783,19 @@ SELF_CLEANING_AMAX = os.environ.get("SDNQ_HIP_CONV_SELF_CLEAN", "1") != "0"
 def _zeroed_amax_map(x: torch.Tensor, words: int):
     """The stream's self-cleaning amax map, at least _AMAX_HEADER + `words` words, or None (then the caller takes the zero-per-call form): a new
     buffer cannot be made while the stream is capturing (its zero fill would be replayed, its memory would belong to the graph)."""
+    if torch.cuda.is_current_stream_capturing():
+        # never bake the stream's persistent map into a graph: a graph replayed on ANOTHER stream, beside eager convs on the capture stream,
+        # would share one map and one set of tickets with no ordering between them (advisor, round 4).  A captured conv takes the
+        # zero-per-call form on a buffer out of the graph's own pool.
+        return None
     key = (x.device.index, _stream(x))
     ent = _amax_maps.get(key)
     need = _AMAX_HEADER + words
     if ent is None or ent[0].numel() < need or ent[1]:
-        if torch.cuda.is_current_stream_capturing():
-            return None
         if ent is not None and ent[0].numel() >= need:  # a call that failed midway may have left marks behind
             ent[0].zero_()
             ent[1] = False
-        else:
-            if ent is not None:
-                _amax_retired.append(ent[0])  # a hipGraph captured on this stream may still hold the old address: never freed
+        else:  # (an outgrown map is simply dropped: no graph holds its address, and the stream orders its last use before the free)
             ent = [torch.zeros((max(need, _AMAX_HEADER + 65536),), device=x.device, dtype=torch.int32), False]
             _amax_maps[key] = ent
     return ent

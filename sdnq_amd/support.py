@@ -76,7 +76,12 @@ def unsupported_reason(module) -> str | None:
         if dq.use_hadamard:
             return "Hadamard-rotated grouped conv layers are not built for MI355X"
         if qmm:
-            k_total, n = dq.in_features * groups, dq.out_features  # original_shape[1] is C_in / groups
+            # K per group and N from original_shape, NOT from this package's in_features / out_features properties: the predicate runs on
+            # the dequantizer a model CAME with -- the reference's dataclass has no such properties -- before anything is adopted
+            k_group = 1
+            for d in tuple(dq.original_shape)[1:]:  # original_shape[1] is C_in / groups
+                k_group *= int(d)
+            k_total, n = k_group * groups, int(dq.original_shape[0])
             if k_total % groups or n % groups or (k_total // groups) % 16 or (n // groups) % 8:
                 return f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {k_total // groups}, {n // groups})"
             if getattr(module, "svd_up", None) is not None:

@@ -80,6 +80,17 @@ def test_argument_validation_without_gpu():
     assert lfs(p, p, None, 1, p, 40, 32, 32, 16, 32, None) == -3                                   # ldx < K
 
 
+def test_prefetch_argument_validation_without_gpu():
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(buf)
+    assert lib.sdnq_hip_prefetch(None, 128, 0, None) == -1                       # NULL
+    assert lib.sdnq_hip_prefetch(p, 0, 0, None) == 0                             # nothing to fetch: no launch
+    assert lib.sdnq_hip_prefetch_hint(p, -1, None, 0, None, 0, None, 0) == -3    # negative size
+    assert lib.sdnq_hip_prefetch_hint(p, 256, None, 0, p, 128, None, 0) == 0
+    assert lib.sdnq_hip_prefetch_hint(None, 0, None, 0, None, 0, None, 0) == 0   # cleared again (nothing may stay pending for a later launch)
+
+
 def test_attention_argument_validation_without_gpu():
     """The attention entry points validate before launching as well."""
     lib = _lib.load()

@@ -234,6 +234,52 @@ def test_accelerate_never_breaks_a_working_model():
     assert not w
 
 
+def test_accelerate_reads_foreign_records_of_grouped_convs_and_options_leave_foreign_forwards_alone():
+    """Advisor (round 4): the predicate runs on the dequantizer a model CAME with -- a foreign dataclass without this package's
+    in_features / out_features properties -- so the grouped-conv branch must read original_shape; and apply_sdnq_options_to_model
+    must not re-point a layer accelerate() left on a foreign forward because its configuration is not built."""
+    import dataclasses
+    import types
+    import warnings
+    import sdnq_amd
+    from sdnq_amd import support
+
+    def ref_forward(self, x):
+        return x
+
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1, groups=2).to(torch.bfloat16)
+    q = sdnq_amd.sdnq_quantize_layer(conv, sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True))[0]
+    foreign = types.SimpleNamespace(**{f.name: getattr(q.sdnq_dequantizer, f.name) for f in dataclasses.fields(q.sdnq_dequantizer)})
+    assert not hasattr(foreign, "in_features")
+    q.sdnq_dequantizer = foreign
+    q.forward_func = ref_forward
+    assert support.unsupported_reason(q) is None  # (raised AttributeError before)
+    lin = sdnq_amd.sdnq_quantize_layer(torch.nn.Linear(64, 64).to(torch.bfloat16), sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
+    lin.sdnq_dequantizer.quantized_matmul_dtype = "float16"  # the 16-bit float matmul: not built -> stays on its own forward
+    lin.forward_func = ref_forward
+    model = torch.nn.Sequential(q, lin)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        res = sdnq_amd.accelerate(model)
+    assert res.accelerated == 1 and [n for n, _ in res.skipped] == ["1"]
+    assert q.forward_func is not ref_forward and lin.forward_func is ref_forward
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sdnq_amd.apply_sdnq_options_to_model(model, dtype=torch.float16)
+    assert lin.forward_func is ref_forward and lin.sdnq_dequantizer.result_dtype == torch.bfloat16  # untouched
+    assert any("left untouched" in str(x.message) for x in w)
+    assert q.sdnq_dequantizer.result_dtype == torch.float16  # the accelerated layer took the option
+    # a record the predicate cannot read at all is a reason to skip, not an exception out of accelerate()
+    broken = sdnq_amd.sdnq_quantize_layer(torch.nn.Linear(64, 64).to(torch.bfloat16), sdnq_amd.SDNQConfig(weights_dtype="int8"))[0]
+    broken.sdnq_dequantizer = types.SimpleNamespace(layer_class_name="Linear")
+    broken.forward_func = ref_forward
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        res = sdnq_amd.accelerate(torch.nn.Sequential(broken))
+    assert res.accelerated == 0 and len(res.skipped) == 1 and broken.forward_func is ref_forward
+
+
 def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
     """The uint8 matmul of dequantize_fp32=False layers: built for bfloat16 Linear layers without SVD factors (round 4), named
     as unsupported -- with the reason -- for float16 scales, conv layers and SVD layers."""
@@ -281,3 +327,56 @@ def test_peer_arena_ring_steps_over_live_ranges_and_recycles_dead_ones():
             held.append(a._alloc(3000)[1])
     del held, keep
     assert a._alloc(9000)[0] == 256  # everything died: the whole ring is free again
+
+
+def test_prefetch_chain_learns_the_launch_order_and_names_two_units_ahead(monkeypatch):
+    """linear._PrefetchChain (no GPU: the C call is captured): after one pass over units A -> B -> C -> D the second pass hands
+    B + C at A's launch, C + D at B's, ...; a unit whose weights exceed the cap contributes nothing; a changed order is re-learned."""
+    import torch
+    from sdnq_amd import linear as L
+    calls = []
+
+    class FakeLib:
+        def sdnq_hip_prefetch_hint(self, *a):
+            calls.append(a)
+            return 0
+
+    monkeypatch.setattr(L.ops._lib, "load", lambda: FakeLib())
+    chain = L._PrefetchChain()
+    ws = [torch.zeros(64 * (i + 1), dtype=torch.int8) for i in range(4)]
+    units = [L._LaunchUnit((w,)) for w in ws]
+    for u in units:
+        chain.launch(u)
+    assert calls == []  # first step: nothing known yet
+    chain.reset()
+    for u in units:
+        chain.launch(u)
+    rng = lambda i: (ws[i].data_ptr(), ws[i].numel())  # noqa: E731
+    assert calls[0][:4] == (*rng(1), *rng(2)) and calls[0][4:] == (0, 0, 0, 0)
+    assert calls[1][:4] == (*rng(2), *rng(3))
+    assert calls[2][:2] == rng(3) and calls[2][2:] == (0, 0, 0, 0, 0, 0)
+    assert len(calls) == 3  # the last unit has no successor
+    # another order this step: the links follow it
+    calls.clear()
+    chain.reset()
+    for i in (0, 2, 1, 3):
+        chain.launch(units[i])
+    chain.reset()
+    calls.clear()
+    for i in (0, 2, 1, 3):
+        chain.launch(units[i])
+    assert calls[0][:4] == (*rng(2), *rng(1))
+    # a grouped launch of three members names three ranges; over the cap: none
+    g = L._LaunchUnit(tuple(ws[:3]))
+    assert len(g.ranges) == 3
+    monkeypatch.setattr(L, "PREFETCH_NEXT_MAX_BYTES", 100)
+    assert L._LaunchUnit((ws[3],)).ranges == ()
+    # a dead unit (its module was deleted) ends the chain
+    calls.clear()
+    a, b = L._LaunchUnit((ws[0],)), L._LaunchUnit((ws[1],))
+    monkeypatch.setattr(L, "PREFETCH_NEXT_MAX_BYTES", 1 << 30)
+    a, b = L._LaunchUnit((ws[0],)), L._LaunchUnit((ws[1],))
+    chain.reset(); chain.launch(a); chain.launch(b)
+    del b
+    chain.reset(); chain.launch(a)
+    assert calls == []
