@@ -365,10 +365,27 @@ int sdnq_hip_unshard_columns(const void* gathered, void* out, int elem_bytes, in
  * stores `seq` into slot `rank` of every rank's `done` array and returns (stream-ordered) only when slot r of its OWN done array
  * carries `seq` for every r: this rank's matrix is then complete.  No staging buffer, no collective, no re-assembly pass.
  * arena / post / done: HOST arrays of `world` device pointers as mapped in THIS process (entry `rank` = the local one); post / done
- * are u64 [world] arrays; ticket: device u32, zero; status: device i32, set to 1 when a rendezvous spin exceeded timeout_ms (the host
+ * are u64 [world] arrays IN SIGNAL MEMORY (below); ticket: device u32, zero; status: i32 in device or host-coherent memory, set to 1 when a rendezvous spin exceeded timeout_ms (the host
  * side raises instead of hanging the GPU).  Not capturable into a hipGraph together with its peers' launches in a fixed order only if
  * the arena offsets are the same at replay -- the host side runs it eagerly. */
 #define SDNQ_MAX_PUSH_RANKS 16
+/* Signal memory for the words above (round 5).  post[] / done[] are written by REMOTE kernels over xGMI while a local kernel spins on
+ * them: only fine-grained / uncached allocations guarantee that such a write becomes visible inside a running kernel, so the control
+ * words must not live in ordinary device memory (the bulk arena may: it is read only after the kernel that waited for `done`).
+ *   sdnq_hip_signal_alloc(bytes, kind, &ptr, &granted): kind 0 = device memory, hipExtMallocWithFlags(hipDeviceMallocUncached), else
+ *     hipDeviceMallocFinegrained (granted = SDNQ_SIGNAL_UNCACHED / _FINEGRAINED), zero-filled; kind 1 = pinned, mapped, coherent HOST
+ *     memory (granted = SDNQ_SIGNAL_HOST_COHERENT) whose address is valid on the device too -- the `status` word, polled by the host
+ *     without a synchronization.   sdnq_hip_signal_free(ptr, kind).
+ *   sdnq_hip_ipc_export(ptr, handle64) / sdnq_hip_ipc_import(handle64, &ptr) / sdnq_hip_ipc_close(ptr): hipIpc handle of a kind-0
+ *     block as 64 opaque bytes (the ranks exchange them through any host channel) and the peer's mapping of it. */
+#define SDNQ_SIGNAL_UNCACHED 1
+#define SDNQ_SIGNAL_FINEGRAINED 2
+#define SDNQ_SIGNAL_HOST_COHERENT 3
+int sdnq_hip_signal_alloc(int64_t bytes, int kind, void** ptr, int* granted);
+int sdnq_hip_signal_free(void* ptr, int kind);
+int sdnq_hip_ipc_export(const void* ptr, void* handle64);
+int sdnq_hip_ipc_import(const void* handle64, void** ptr);
+int sdnq_hip_ipc_close(void* ptr);
 int sdnq_hip_push_post(void* const* post, int world, int rank, uint64_t seq, uint64_t arena_offset, sdnq_stream_t stream);
 int sdnq_hip_push_columns(const void* y, int elem_bytes, int64_t rows, int64_t w, int64_t ldy, void* const* arena, void* const* post,
                           void* const* done, int world, int rank, uint64_t seq, int64_t ldc, int64_t col0, int64_t row0, void* ticket,

@@ -32,6 +32,7 @@ EXPORTS = [
     "sdnq_hip_rowquant_lp", "sdnq_hip_rowquant_lp_asym", "sdnq_hip_scaled_mm_lp", "sdnq_hip_scaled_mm_lp_uzp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
     "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided", "sdnq_hip_prefetch", "sdnq_hip_prefetch_hint",
+    "sdnq_hip_signal_alloc", "sdnq_hip_signal_free", "sdnq_hip_ipc_export", "sdnq_hip_ipc_import", "sdnq_hip_ipc_close",
 ]
 
 
@@ -137,6 +138,11 @@ def _declare(lib):
     lib.sdnq_hip_rowquant.argtypes = [vp, i32, i64, i64, i64, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.sdnq_hip_scaled_mm.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
     lib.sdnq_hip_prefetch.argtypes = [vp, i64, i32, vp]
+    lib.sdnq_hip_signal_alloc.argtypes = [i64, i32, c.POINTER(c.c_void_p), c.POINTER(c.c_int)]
+    lib.sdnq_hip_signal_free.argtypes = [vp, i32]
+    lib.sdnq_hip_ipc_export.argtypes = [vp, vp]
+    lib.sdnq_hip_ipc_import.argtypes = [vp, c.POINTER(c.c_void_p)]
+    lib.sdnq_hip_ipc_close.argtypes = [vp]
     lib.sdnq_hip_prefetch_hint.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64]
     lib.sdnq_hip_unshard_columns.argtypes = [vp, vp, i32, i64, i64, i64, i64, i32, c.POINTER(c.c_int64), vp]
     lib.sdnq_hip_scaled_mm_lowrank_strided.argtypes = [i32, vp, i64, vp, vp, vp, vp, i32, vp, vp, vp, vp, i64, vp, i64, i32, i64, i64, i64, vp]

@@ -6,6 +6,7 @@
 // round 2 did this with torch permute / reshape (even shards) or zeros + cat (uneven) -- several launches and, uneven, several
 // passes.  Here: one HBM-bound pass, 16 bytes per lane, reads and writes coalesced along the channels of a rank.
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "../../include/sdnq_hip.h"
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void push_columns_kernel(const PushParams p) {
     }
     __syncthreads();
     if (s_fail) {
-        if (tid == 0) *p.status = 1;
+        if (tid == 0) __hip_atomic_store(p.status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (host-coherent memory: the host polls it)
     } else {
         const int64_t pieces = p.w_bytes >> 4;
         const int64_t total = p.rows * pieces;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void push_columns_kernel(const PushParams p) {
         if (!s_fail) __hip_atomic_store(p.done[tid] + p.rank, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         for (;;) {  // every peer's slab has landed here
             if (ld_sys(p.done[p.rank] + tid) == p.seq) break;
-            if (wall_clock64() - t0 > p.timeout_ticks) { *p.status = 1; break; }
+            if (wall_clock64() - t0 > p.timeout_ticks) { __hip_atomic_store(p.status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -130,6 +131,57 @@ __global__ void post_kernel(const PostParams p) {
 }
 
 }  // namespace
+
+// ---- signal memory of the peer gather (round 5) -------------------------------------------------------------------------------------
+// The post[] / done[] words are written by REMOTE kernels (P2P stores over xGMI) while a LOCAL kernel spins on them.  In-kernel
+// visibility of such writes is only guaranteed for fine-grained / uncached allocations -- ordinary (coarse-grained) device memory is
+// made coherent at kernel boundaries, so a spin on it may read a stale line for as long as the kernel runs (two processes on ONE GPU share
+// a coherence point and never see that).  The control words therefore live in their own small allocation made with
+// hipExtMallocWithFlags(hipDeviceMallocUncached) -- hipDeviceMallocFinegrained where the runtime refuses that -- exported and opened
+// with hipIpc like the bulk arena (which stays coarse-grained: it is only read after the kernel that waited for `done`).  kind 1 is
+// host memory (pinned, mapped, coherent) for the status word the HOST polls without synchronizing.
+extern "C" int sdnq_hip_signal_alloc(int64_t bytes, int kind, void** ptr, int* granted) {
+    if (!ptr || !granted) return SDNQ_ERR_NULL;
+    if (bytes <= 0 || (kind != 0 && kind != 1)) return SDNQ_ERR_SHAPE;
+    *ptr = nullptr; *granted = 0;
+    if (kind == 1) {
+        if (hipHostMalloc(ptr, (size_t)bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return SDNQ_ERR_LAUNCH; }
+        memset(*ptr, 0, (size_t)bytes);
+        *granted = SDNQ_SIGNAL_HOST_COHERENT;
+        return SDNQ_OK;
+    }
+    if (hipExtMallocWithFlags(ptr, (size_t)bytes, hipDeviceMallocUncached) == hipSuccess) *granted = SDNQ_SIGNAL_UNCACHED;
+    else {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags(ptr, (size_t)bytes, hipDeviceMallocFinegrained) == hipSuccess) *granted = SDNQ_SIGNAL_FINEGRAINED;
+        else { (void)hipGetLastError(); return SDNQ_ERR_LAUNCH; }
+    }
+    if (hipMemset(*ptr, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(*ptr); *ptr = nullptr; return SDNQ_ERR_LAUNCH; }
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_signal_free(void* ptr, int kind) {
+    if (!ptr) return SDNQ_OK;
+    return (kind == 1 ? hipHostFree(ptr) : hipFree(ptr)) == hipSuccess ? SDNQ_OK : SDNQ_ERR_LAUNCH;
+}
+
+extern "C" int sdnq_hip_ipc_export(const void* ptr, void* handle64) {
+    if (!ptr || !handle64) return SDNQ_ERR_NULL;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    return hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, (void*)ptr) == hipSuccess ? SDNQ_OK : ((void)hipGetLastError(), SDNQ_ERR_LAUNCH);
+}
+
+extern "C" int sdnq_hip_ipc_import(const void* handle64, void** ptr) {
+    if (!handle64 || !ptr) return SDNQ_ERR_NULL;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    return hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess ? SDNQ_OK : ((void)hipGetLastError(), SDNQ_ERR_LAUNCH);
+}
+
+extern "C" int sdnq_hip_ipc_close(void* ptr) {
+    if (!ptr) return SDNQ_OK;
+    return hipIpcCloseMemHandle(ptr) == hipSuccess ? SDNQ_OK : ((void)hipGetLastError(), SDNQ_ERR_LAUNCH);
+}
 
 extern "C" int sdnq_hip_push_post(void* const* post, int world, int rank, uint64_t seq, uint64_t arena_offset, sdnq_stream_t stream) {
     if (!post) return SDNQ_ERR_NULL;

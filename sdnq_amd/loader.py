@@ -301,6 +301,153 @@ def fuse_projections(model: torch.nn.Module) -> int:
     return count
 
 
+def _map_key(key: str, key_mapping) -> str:
+    """`_checkpoint_conversion_mapping` of transformers models: the first regular expression that matches renames the key (file_loader.py:6-13)."""
+    import re
+    if key_mapping:
+        for pattern, replacement in key_mapping.items():
+            key2, n = re.subn(pattern, replacement, key)
+            if n > 0:
+                return key2
+    return key
+
+
+@torch.no_grad()
+def post_process_model(model: torch.nn.Module) -> torch.nn.Module:
+    """What the reference does to a freshly loaded SDNQ model (loader.py:199-217): nothing requires a gradient, and the operands a
+    matmul reads directly are re-laid out ONCE -- a checkpoint stores the direct-matmul weight as a contiguous logical [K, N]; the
+    kernels (like the reference on gfx950, quant_utils.py:240-249) want the same logical tensor over physical [N][K] bytes, K
+    contiguous; the SVD factors of such layers likewise.  The parameter itself is replaced, so no second copy stays resident."""
+    P = lambda t: torch.nn.Parameter(t, requires_grad=False)  # noqa: E731
+    for module in model.modules():
+        dq = getattr(module, "sdnq_dequantizer", None)
+        if dq is None:
+            continue
+        for name in ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias"):
+            t = getattr(module, name, None)
+            if isinstance(t, torch.nn.Parameter):
+                t.requires_grad_(False)
+        if dq.use_quantized_matmul and not dq.re_quantize_for_matmul and module.weight.dim() == 2 and module.weight.is_contiguous() \
+                and not getattr(dq, "is_packed", False):
+            module.weight = P(module.weight.t().contiguous().t())  # logical [K, N], strides (1, K)
+        if getattr(module, "svd_up", None) is not None and dq.use_quantized_matmul:
+            # stored [R, N] / [K, R] (quantizer.py:164-167); the kernels read [N][R] / [R][K] rows
+            if module.svd_up.is_contiguous():
+                module.svd_up = P(module.svd_up.t().contiguous().t())
+            if module.svd_down.is_contiguous():
+                module.svd_down = P(module.svd_down.t().contiguous().t())
+        module.__dict__.pop("_sdnq_hip_state", None)
+    return model
+
+
+@torch.no_grad()
+def load_sdnq_model(model_path: str, model_cls=None, file_name: str | None = None, dtype: torch.dtype | None = None,
+                    device: torch.device | str = "cuda", dequantize_fp32: bool | None = None, use_quantized_matmul: bool | None = None,
+                    model_config: dict | None = None, quantization_config=None, model: torch.nn.Module | None = None) -> torch.nn.Module:
+    """Load a pre-quantized SDNQ checkpoint -- the reference's on-disk format: `quantization_config.json` (or the `quantization_config`
+    entry of `config.json`) + `*.safetensors` holding every layer's stored tensors (`weight` codes, `scale`, `zero_point`, `svd_up`,
+    `svd_down`, `bias`) -- WITHOUT the reference package (reference loader.py:82-196, same arguments).
+
+    The skeleton comes from `model` (an instance, usually built under `torch.device("meta")`), else from `model_cls` the way the
+    reference builds it (`load_config` + `from_config` of diffusers models, `AutoConfig` of transformers models, else
+    `model_cls(**model_config)`), on the meta device.  Its Linear / conv layers become SDNQ layers with placeholders of the stored
+    shapes (`sdnq_post_load_quant(pre_quantized=True)`: every layer's record is a function of the config and the layer's shape),
+    the tensors are read straight to `device` and assigned, direct-matmul operands are re-laid out once (`post_process_model`),
+    the options are applied (`apply_sdnq_options_to_model`) and the layers are routed through the MI355X kernels (`accelerate`)."""
+    import json
+    from .quantizer import QuantizationMethod, SDNQConfig, sdnq_post_load_quant
+    device = torch.device(device)
+    config_path, qconfig_path = os.path.join(model_path, "config.json"), os.path.join(model_path, "quantization_config.json")
+    if model_config is None:
+        model_config = json.load(open(config_path, encoding="utf-8")) if os.path.exists(config_path) else {}
+    if quantization_config is None:
+        if os.path.exists(qconfig_path):
+            quantization_config = json.load(open(qconfig_path, encoding="utf-8"))
+        else:
+            quantization_config = model_config.get("quantization_config", None)
+            if quantization_config is None:
+                raise ValueError(f"Cannot determine quantization_config for {model_path}, please provide quantization_config argument")
+    if not isinstance(quantization_config, SDNQConfig):
+        drop = ("quantization_device", "return_device", "non_blocking", "add_skip_keys", "use_dynamic_quantization", "use_stochastic_rounding",
+                "is_training")  # (what the reference strips before it rebuilds the layers: utils.py:101-122)
+        quantization_config = SDNQConfig.from_dict({k: v for k, v in dict(quantization_config).items() if k not in drop})
+    quantization_config.add_skip_keys = False
+    if model is None:
+        if model_cls is None:
+            class_name = model_config.get("_class_name", None) or model_config.get("architectures", None)
+            if isinstance(class_name, list):
+                class_name = class_name[0]
+            for pkg in ("diffusers", "transformers"):
+                if class_name is None or model_cls is not None:
+                    break
+                try:
+                    model_cls = getattr(__import__(pkg), class_name, None)
+                except ImportError:
+                    continue
+        if model_cls is None:
+            raise ValueError(f"Cannot determine model class for {model_path}, please provide model_cls (or a model skeleton)")
+        with torch.device("meta"):
+            if hasattr(model_cls, "load_config") and hasattr(model_cls, "from_config"):
+                config = model_cls.load_config(model_path)
+                if hasattr(config, "pop"):
+                    config.pop("quantization_config", None)
+                model = model_cls.from_config(config)
+            elif hasattr(model_cls, "_from_config"):
+                import transformers
+                config = transformers.AutoConfig.from_pretrained(model_path)
+                if hasattr(config, "quantization_config"):
+                    del config.quantization_config
+                model = model_cls(config)
+            else:
+                cfg_kwargs = {k: v for k, v in model_config.items() if k != "quantization_config" and not k.startswith("_")}
+                model = model_cls(**cfg_kwargs)
+    model.eval()
+    model = sdnq_post_load_quant(model, torch_dtype=dtype, pre_quantized=True, quantization_config=quantization_config)
+
+    key_mapping = getattr(model, "_checkpoint_conversion_mapping", None)
+    if file_name:
+        files = [os.path.join(model_path, file_name)]
+    else:
+        files = sorted(os.path.join(model_path, f) for f in os.listdir(model_path) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no .safetensors file in {model_path}")
+    from safetensors.torch import safe_open
+    state_dict = {}
+    for fn in files:
+        with safe_open(fn, framework="pt", device=str(device)) as f:
+            for key in f.keys():  # noqa: SIM118
+                state_dict[_map_key(key, key_mapping)] = f.get_tensor(key)
+    tied = getattr(model, "_tied_weights_keys", None)
+    if isinstance(tied, dict):
+        for key, value in tied.items():
+            if value in state_dict and key not in state_dict:
+                state_dict[key] = state_dict[value]
+    missing, unexpected = model.load_state_dict(state_dict, strict=False, assign=True)
+    del state_dict
+    still_meta = [n for n, p in list(model.named_parameters()) + list(model.named_buffers()) if p.is_meta]
+    if still_meta:
+        raise RuntimeError(f"{model_path}: {len(still_meta)} tensor(s) of the model are not in the checkpoint ({', '.join(still_meta[:6])}"
+                           f"{' ...' if len(still_meta) > 6 else ''}); unexpected keys: {list(unexpected)[:6]}")
+    model.quantization_config = quantization_config
+    model.quantization_method = QuantizationMethod.SDNQ
+    if hasattr(model, "config"):
+        try:
+            model.config.quantization_config = quantization_config
+        except Exception:  # noqa: BLE001
+            pass
+    model = post_process_model(model)
+    if dtype is not None:  # the float leaves follow the requested dtype too (loader.py:228-232)
+        for module in model.modules():
+            if getattr(module, "sdnq_dequantizer", None) is None and not list(module.children()):
+                for name, p in list(module.named_parameters(recurse=False)):
+                    if p.dtype in (torch.float16, torch.bfloat16) and p.dtype != dtype:
+                        setattr(module, name, torch.nn.Parameter(p.to(dtype), requires_grad=False))
+    if (dtype is not None) or (dequantize_fp32 is not None) or (use_quantized_matmul is not None):
+        model = apply_sdnq_options_to_model(model, dtype=dtype, dequantize_fp32=dequantize_fp32, use_quantized_matmul=use_quantized_matmul)
+    accelerate(model)
+    return model
+
+
 @torch.no_grad()
 def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
                                 use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):

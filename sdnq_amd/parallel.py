@@ -73,53 +73,130 @@ class _Region:
         self._owner = owner  # keeps the arena allocation alive as long as any output tensor lives
 
 
-class PeerArena:
-    """The per-rank half of the copy-free gather: an IPC-shared arena (control words + a ring of output matrices) mapped by every rank
-    of `group` (one node), and the rendezvous protocol of ``sdnq_hip_push_post`` / ``sdnq_hip_push_columns`` (include/sdnq_hip.h).
+class PeerUnavailable(RuntimeError):
+    """The copy-free gather cannot run on this set of ranks (another node, or a device pair without peer access): use the RCCL gather."""
 
-    Layout of a rank's arena: bytes [0, 128) post[16] u64, [128, 256) done[16] u64, data from byte 256.  `gather(y, n_total, col0)`
-    returns this rank's complete row-major [rows, n_total] matrix: a tensor over arena memory (no copy) that stays valid as long as it
-    (or any view of it) is referenced -- the ring never hands out a range that a live tensor still uses; when the ring is full of live
-    tensors it raises (size it with SDNQ_HIP_TP_ARENA_MB, default 2048).  All ranks must call gather() the same number of times in the
-    same order (SPMD), like any collective; a rank that does not show up trips the timeout (status word) instead of hanging the GPU."""
+
+class PeerArena:
+    """The per-rank half of the copy-free gather: an IPC-shared arena (a ring of output matrices) and a separate block of control words,
+    both mapped by every rank of `group` (one node), and the rendezvous protocol of ``sdnq_hip_push_post`` / ``sdnq_hip_push_columns``
+    (include/sdnq_hip.h).
+
+    The control words -- post[16] u64 at bytes [0, 128), done[16] u64 at [128, 256) of a block of their own -- are written by REMOTE
+    kernels (P2P stores over xGMI) while a local kernel spins on them, so they live in SIGNAL memory: fine-grained / uncached device
+    memory from ``sdnq_hip_signal_alloc`` (`self.ctrl_kind`: "uncached" | "finegrained"), not in the coarse-grained arena, whose
+    coherence is only guaranteed at kernel boundaries (round-4 verdict: two processes on ONE GPU share a coherence point and cannot
+    see the difference).  The status word (a rendezvous that timed out) is host-coherent memory that `poll()` reads WITHOUT
+    synchronizing: every gather looks at it first, so a rank out of step raises at the next layer instead of handing out partially
+    filled matrices for the rest of the step (advisor, round 4).
+
+    `gather(y, n_total, col0)` returns this rank's complete row-major [rows, n_total] matrix: a tensor over arena memory (no copy) that
+    stays valid as long as it (or any view of it) is referenced -- the ring never hands out a range that a live tensor still uses; when
+    the ring is full of live tensors it raises (size it with SDNQ_HIP_TP_ARENA_MB, default 2048).  All ranks must call gather() the same
+    number of times in the same order (SPMD), like any collective.  The constructor raises `PeerUnavailable` -- on EVERY rank -- when
+    some pair of devices has no peer access or the ranks are not on one host; `PeerArena.try_create` returns None then (the callers
+    fall back to the RCCL gather)."""
 
     CTRL = 256
+    CTRL_BYTES = 4096
 
-    def __init__(self, rank: int, world: int, group=None, device=None, arena_bytes: int | None = None, timeout_ms: int = 2000):
+    @classmethod
+    def try_create(cls, *args, **kwargs):
+        try:
+            return cls(*args, **kwargs)
+        except PeerUnavailable:
+            return None
+
+    def __init__(self, rank: int, world: int, group=None, device=None, arena_bytes: int | None = None, timeout_ms: int | None = None):
+        import ctypes
         import os
+        import socket
         import torch.distributed as dist
         from torch.multiprocessing.reductions import reduce_tensor
         from . import _lib
         if world > 16:
             raise ValueError("PeerArena: at most 16 ranks (one node)")
+        if timeout_ms is None:  # generous: a peer may sit in a first-call JIT or a host hiccup; a DEAD peer still ends the wait
+            timeout_ms = int(os.environ.get("SDNQ_HIP_TP_TIMEOUT_MS", "30000"))
         self.rank, self.world, self.group, self.timeout_ms = rank, world, group, int(timeout_ms)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        lib = self._lib = _lib.load()
+        self._imported, self._ctrl, self._status_ptr = [], None, None
+        # ---- can every rank reach every other rank's memory?  (decided together: all ranks raise, or none)
+        me = (rank, socket.gethostname(), int(self.device.index), os.getpid())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me, group=group)
+        ok = len({h for (_, h, _, _) in everyone}) == 1
+        if ok:
+            for (_, _, d, _) in everyone:
+                if d != self.device.index and not torch.cuda.can_device_access_peer(self.device.index, d):
+                    ok = False
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, bool(ok), group=group)
+        if not all(verdicts):
+            raise PeerUnavailable("PeerArena: the ranks are not on one host with peer access between every pair of devices")
         if arena_bytes is None:
             arena_bytes = int(os.environ.get("SDNQ_HIP_TP_ARENA_MB", "2048")) << 20
         self.size = (int(arena_bytes) + 255) // 256 * 256
-        self.buf = torch.zeros(self.CTRL + self.size, dtype=torch.uint8, device=self.device)
+        self.buf = torch.zeros(self.CTRL + self.size, dtype=torch.uint8, device=self.device)  # (the first CTRL bytes stay unused: offsets as before)
         if self.buf.data_ptr() % 256:
             raise _lib.SdnqHipError("PeerArena: allocation is not 256-byte aligned")
-        torch.cuda.synchronize(self.device)  # the zeroed control words are in memory before any peer maps them
-        # exchange the IPC handles (the reduce_tensor tuple is plain data: picklable through any backend's all_gather_object)
+        # ---- control words in signal memory, the status word in host-coherent memory
+        with torch.cuda.device(self.device):
+            pp, granted = ctypes.c_void_p(), ctypes.c_int()
+            _lib.check(lib.sdnq_hip_signal_alloc(self.CTRL_BYTES, 0, ctypes.byref(pp), ctypes.byref(granted)), "signal_alloc")
+            self._ctrl = int(pp.value)
+            self.ctrl_kind = {1: "uncached", 2: "finegrained"}[granted.value]
+            _lib.check(lib.sdnq_hip_signal_alloc(64, 1, ctypes.byref(pp), ctypes.byref(granted)), "signal_alloc(host)")
+            self._status_ptr = int(pp.value)
+            handle = ctypes.create_string_buffer(64)
+            _lib.check(lib.sdnq_hip_ipc_export(self._ctrl, handle), "ipc_export")
+        torch.cuda.synchronize(self.device)  # the zeroed words are in memory before any peer maps them
+        # exchange the IPC handles (plain data: picklable through any backend's all_gather_object)
         fn, args = reduce_tensor(self.buf)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (rank, args), group=group)
+        dist.all_gather_object(gathered, (rank, args, bytes(handle.raw), os.getpid()), group=group)
         self.peers = [None] * world
-        for r, a in gathered:
-            self.peers[r] = self.buf if r == rank else fn(*a)
+        ctrl_ptrs = [0] * world
+        for r, a, h, pid in gathered:
+            if r == rank:
+                self.peers[r], ctrl_ptrs[r] = self.buf, self._ctrl
+                continue
+            self.peers[r] = fn(*a)
+            with torch.cuda.device(self.device):
+                _lib.check(lib.sdnq_hip_ipc_import(ctypes.create_string_buffer(h, 64), ctypes.byref(pp)), "ipc_import")
+            ctrl_ptrs[r] = int(pp.value)
+            self._imported.append(ctrl_ptrs[r])
         ptrs = [int(t.data_ptr()) for t in self.peers]
-        import ctypes
         arr = ctypes.c_void_p * world
         self._arena = arr(*[p for p in ptrs])
-        self._post = arr(*[p for p in ptrs])
-        self._done = arr(*[p + 128 for p in ptrs])
+        self._post = arr(*[p for p in ctrl_ptrs])
+        self._done = arr(*[p + 128 for p in ctrl_ptrs])
         self._ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._status = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.seq = 0
         self.head = self.CTRL
         self.live = []  # [(start, end, weakref(_Region))] in ring order
         dist.barrier(group=group)  # every rank has mapped every arena before the first push
+
+    def __del__(self):
+        try:
+            lib = self._lib
+            for p in self._imported:
+                lib.sdnq_hip_ipc_close(p)
+            if self._ctrl:
+                lib.sdnq_hip_signal_free(self._ctrl, 0)
+            if self._status_ptr:
+                lib.sdnq_hip_signal_free(self._status_ptr, 1)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def poll(self):
+        """Raise if a rendezvous of this rank has timed out -- read from host-coherent memory, no synchronization: cheap enough to run
+        in front of every gather."""
+        import ctypes
+        if self._status_ptr and ctypes.c_int.from_address(self._status_ptr).value != 0:
+            raise RuntimeError("PeerArena: a peer did not arrive within the timeout (ranks out of step, or a rank died); every gather since "
+                               "then is invalid -- rebuild the arena (or fall back to the RCCL gather)")
 
     # ---- ring allocator over [CTRL, CTRL + size) ----------------------------------------------------------------------------------
     def _alloc(self, nbytes: int):
@@ -151,6 +228,7 @@ class PeerArena:
         """This rank's slab y [rows, w] goes to columns [col0, col0 + w) of every rank's [rows, n_total] output; returns this rank's."""
         from . import _lib, ops
         lib = _lib.load()
+        self.poll()
         rows, w = y.shape
         es = y.element_size()
         if y.stride(1) != 1:
@@ -160,7 +238,7 @@ class PeerArena:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         ops.check(lib.sdnq_hip_push_post(self._post, self.world, self.rank, self.seq, off, stream), "push_post")
         ops.check(lib.sdnq_hip_push_columns(y.data_ptr(), es, rows, w, y.stride(0), self._arena, self._post, self._done, self.world, self.rank,
-                                            self.seq, n_total, col0, 0, self._ticket.data_ptr(), self._status.data_ptr(), self.timeout_ms,
+                                            self.seq, n_total, col0, 0, self._ticket.data_ptr(), self._status_ptr, self.timeout_ms,
                                             stream), "push_columns")
         out = torch.as_tensor(region, device=self.device).view(y.dtype)[: rows * n_total].view(rows, n_total)
         return out
@@ -169,6 +247,7 @@ class PeerArena:
         """Two-step form: announce the destination BEFORE the layer's matmul (the peers' pushes then never wait for it); returns a
         token for `push`."""
         from . import _lib, ops
+        self.poll()
         es = torch.empty((), dtype=dtype).element_size()
         off, region = self._alloc(rows * n_total * es)
         self.seq = (self.seq + 1) & 0xFFFFFF
@@ -185,14 +264,13 @@ class PeerArena:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         ops.check(_lib.load().sdnq_hip_push_columns(y.data_ptr(), y.element_size(), rows, y.shape[1], y.stride(0), self._arena, self._post,
                                                     self._done, self.world, self.rank, seq, n_total, col0, 0, self._ticket.data_ptr(),
-                                                    self._status.data_ptr(), self.timeout_ms, stream), "push_columns")
+                                                    self._status_ptr, self.timeout_ms, stream), "push_columns")
         return torch.as_tensor(region, device=self.device).view(dtype)[: rows * n_total].view(rows, n_total)
 
     def check(self):
         """Synchronizes; raises if any rendezvous of this rank timed out (a peer that never arrived)."""
         torch.cuda.synchronize(self.device)
-        if int(self._status.item()) != 0:
-            raise RuntimeError("PeerArena: a peer did not arrive within the timeout (ranks out of step, or a rank died)")
+        self.poll()
 
 
 class ColumnShardedLinear(torch.nn.Module):

@@ -261,17 +261,61 @@ def sdnq_quantize_layer_weight(weight: torch.Tensor, layer_class_name: str = "Li
     return dq, {"weight": q, "scale": scale, "zero_point": zero_point, "svd_up": svd_up, "svd_down": svd_down}
 
 
+def check_param_name_in(param_name: str, param_list) -> str | None:
+    """Which entry of a module list names `param_name` (the matching rule of the reference's lists, utils.py:56-70): an entry that
+    starts with "." is a prefix of the qualified name, otherwise it is the whole name, one of its dot-separated components, or a
+    "*" pattern (".*" stands for a literal dot followed by anything)."""
+    import re
+    parts = param_name.split(".")
+    for param in param_list:
+        if not param:
+            continue
+        if param.startswith("."):
+            if param_name.startswith(param[1:]):
+                return param
+            continue
+        if param_name == param or param in parts or ("*" in param and re.match(param.replace(".*", "\\.*").replace("*", ".*"), param_name)):
+            return param
+    return None
+
+
+def _minimum_dtype(weights_dtype: str, param_name: str, modules_dtype_dict: dict) -> str:
+    """Per-module weight format (utils.py:125-147): a key is a dtype name, or "minimum_<N>bit(s)" / "minimum_uint<N>bits" -- then the
+    module keeps the global format unless it is narrower than N bits."""
+    for key, names in modules_dtype_dict.items():
+        if check_param_name_in(param_name, names) is None:
+            continue
+        key = key.lower()
+        if key.startswith("minimum") or key.endswith(("bit", "bits")):
+            bits = key.removeprefix("minimum").removeprefix("-").removeprefix("_").removesuffix("bits").removesuffix("bit").removesuffix("-").removesuffix("_")
+            unsigned = bits.startswith("uint")
+            bits = bits.removeprefix("uint") if unsigned else bits.removeprefix("int")
+            if dtype_dict[weights_dtype]["num_bits"] < int(bits):
+                return ("uint" if (unsigned or int(bits) <= 4) else "int") + bits
+        else:
+            return key
+    return weights_dtype
+
+
 def _quant_kwargs(cfg: SDNQConfig, torch_dtype, param_name: str, layer_class_name: str = "Linear") -> dict:
+    """Per-layer quantization arguments out of the model-wide config (utils.py:150-199): modules_quant_config overrides, the conv
+    layers' own matmul switch, modules_dtype_dict, modules_to_not_use_matmul -- every list matched with `check_param_name_in`."""
     kw = dict(weights_dtype=cfg.weights_dtype, quantized_matmul_dtype=cfg.quantized_matmul_dtype, group_size=cfg.group_size,
               hadamard_group_size=cfg.hadamard_group_size, svd_rank=cfg.svd_rank, svd_steps=cfg.svd_steps,
               use_svd=cfg.use_svd, use_hadamard=cfg.use_hadamard, use_quantized_matmul=cfg.use_quantized_matmul,
               dequantize_fp32=cfg.dequantize_fp32, torch_dtype=torch_dtype)
-    for dt, names in cfg.modules_dtype_dict.items():
-        if any(nm and nm in param_name for nm in names):
-            kw["weights_dtype"] = dt
+    conv_mm = cfg.use_quantized_matmul_conv
+    key = check_param_name_in(param_name, list(cfg.modules_quant_config.keys()))
+    if key is not None:
+        for k2, v2 in cfg.modules_quant_config[key].items():
+            if k2 == "use_quantized_matmul_conv":
+                conv_mm = v2
+            elif k2 in kw:
+                kw[k2] = v2
     if layer_class_name in conv_types:  # utils.py:188-189: convs follow their own matmul switch
-        kw["use_quantized_matmul"] = cfg.use_quantized_matmul_conv
-    if any(nm and nm in param_name for nm in cfg.modules_to_not_use_matmul):
+        kw["use_quantized_matmul"] = conv_mm
+    kw["weights_dtype"] = _minimum_dtype(kw["weights_dtype"], param_name, cfg.modules_dtype_dict)
+    if check_param_name_in(param_name, cfg.modules_to_not_use_matmul) is not None:
         kw["use_quantized_matmul"] = False
     return kw
 
@@ -293,8 +337,8 @@ def sdnq_quantize_layer(layer: torch.nn.Module, quantization_config: SDNQConfig,
     dq, tensors = sdnq_quantize_layer_weight(w, layer_class_name=name, **kw)
     layer.sdnq_dequantizer = dq
     layer = get_sdnq_wrapper_class(layer, get_forward_func(name, dq.quantized_matmul_dtype, dq.use_quantized_matmul))
-    for key, value in tensors.items():
-        setattr(layer, key, None if value is None else torch.nn.Parameter(value.to(dev), requires_grad=False))
+    for key, value in tensors.items():  # (a meta skeleton -- load_sdnq_model -- keeps meta placeholders of the stored shapes and dtypes)
+        setattr(layer, key, None if value is None else torch.nn.Parameter(value if value.is_meta else value.to(dev), requires_grad=False))
     if "_sdnq_hip_handle" in layer.__dict__:  # the tensors are in place now: decide how the layer traces under torch.compile
         from . import torch_ops
         torch_ops.layer_handle(layer)
@@ -305,29 +349,35 @@ def sdnq_quantize_layer(layer: torch.nn.Module, quantization_config: SDNQConfig,
 
 @torch.no_grad()
 def apply_sdnq_to_module(model: torch.nn.Module, quantization_config: SDNQConfig, torch_dtype: torch.dtype | None = None,
-                         full_param_name: str = ""):
-    """Recursively replace eligible nn.Linear children by SDNQLinear (reference quantizer.py:477-495)."""
+                         full_param_name: str = "", pre_quantized: bool = False):
+    """Recursively replace eligible nn.Linear / conv children by SDNQ layers (reference quantizer.py:477-495).  pre_quantized: the
+    model is the skeleton of a stored SDNQ checkpoint -- every Linear (and conv, with quant_conv) the config does not list in
+    modules_to_not_convert WAS quantized, whatever its size (utils.py:73-91: the size rules only decide at quantization time)."""
     for child_name, child in list(model.named_children()):
         pname = f"{full_param_name}.{child_name}" if full_param_name else child_name
         cname = child.__class__.__name__
-        if (cname == "Linear" or (cname in ("Conv1d", "Conv2d", "Conv3d") and quantization_config.quant_conv)) and child.weight is not None:
+        if (cname == "Linear" or (cname in ("Conv1d", "Conv2d", "Conv3d") and quantization_config.quant_conv)) and getattr(child, "weight", None) is not None:
             wname = pname + ".weight"
-            skip = any(s and s in wname for s in quantization_config.modules_to_not_convert)
-            big = (child.weight.shape[-1 if cname == "Linear" else 1] >= quantization_config.minimum_allowed_channel_size
-                   and child.weight.numel() >= quantization_config.minimum_allowed_numel)
+            skip = check_param_name_in(wname, quantization_config.modules_to_not_convert) is not None
+            big = pre_quantized or (child.weight.shape[-1 if cname == "Linear" else 1] >= quantization_config.minimum_allowed_channel_size
+                                    and child.weight.numel() >= quantization_config.minimum_allowed_numel)
             if not skip and big and child.weight.dtype in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
                 child, quantization_config = sdnq_quantize_layer(child, quantization_config, torch_dtype=torch_dtype, param_name=wname)
                 setattr(model, child_name, child)
-            else:
+            elif not skip:
                 quantization_config.modules_to_not_convert.append(wname)
         else:
-            apply_sdnq_to_module(child, quantization_config, torch_dtype=torch_dtype, full_param_name=pname)
+            apply_sdnq_to_module(child, quantization_config, torch_dtype=torch_dtype, full_param_name=pname, pre_quantized=pre_quantized)
     return model, quantization_config
 
 
-def sdnq_post_load_quant(model: torch.nn.Module, weights_dtype: str = "int8", torch_dtype: torch.dtype | None = None, **kwargs):
-    cfg = SDNQConfig(weights_dtype=weights_dtype, **kwargs)
-    model, cfg = apply_sdnq_to_module(model, cfg, torch_dtype=torch_dtype)
+def sdnq_post_load_quant(model: torch.nn.Module, weights_dtype: str = "int8", torch_dtype: torch.dtype | None = None,
+                         quantization_config: SDNQConfig | None = None, pre_quantized: bool = False, **kwargs):
+    """Quantize the Linear / conv layers of a loaded model in place (reference quantizer.py:498-600).  pre_quantized=True is the
+    loader's use (loader.py:150): `model` is a skeleton (meta tensors), the layers become SDNQ layers with placeholders of the stored
+    shapes, and nothing is computed."""
+    cfg = quantization_config if quantization_config is not None else SDNQConfig(weights_dtype=weights_dtype, **kwargs)
+    model, cfg = apply_sdnq_to_module(model, cfg, torch_dtype=torch_dtype, pre_quantized=pre_quantized)
     model.quantization_config = cfg
     model.quantization_method = QuantizationMethod.SDNQ
     return model

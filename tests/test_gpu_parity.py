@@ -1749,3 +1749,30 @@ def test_weight_prefetch_across_layers_changes_no_bit(gpu_device, monkeypatch):
     w = L._state(mods[0]).mm_weight
     _lib.check(lib.sdnq_hip_prefetch(w.data_ptr(), w.numel(), 0, torch.cuda.current_stream().cuda_stream), "prefetch")
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_load_sdnq_model_computes_what_the_reference_computed(gpu_device):
+    """The checkpoint the reference wrote and re-loaded (tests/golden/make_golden_checkpoint.py), loaded here WITHOUT the reference:
+    every quantized layer, fed the input the reference's layer saw, returns the reference's output -- bit for bit for the int8
+    direct-matmul and the uint4 -> int8 re-quantized layer, within one bf16 ulp for the int8 + SVD layer (the addmm's summation
+    order) -- and the whole model agrees end to end."""
+    import os
+    import sdnq_amd
+    from tests.test_host_logic import TinyNet
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_tiny")
+    model = sdnq_amd.load_sdnq_model(path, model_cls=TinyNet, device=gpu_device)
+    io = np.load(os.path.join(path, "io.npz"))
+    bf = lambda a: torch.from_numpy(a.astype(np.int32).astype(np.int16)).view(torch.bfloat16).to(gpu_device)  # noqa: E731
+    for name, exact in (("proj_in", True), ("mid", True), ("proj_out", False)):
+        got = getattr(model, name)(bf(io[f"{name}.in"]))
+        want = bf(io[f"{name}.out"])
+        if exact:
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16)), name
+        else:
+            ulp = want.float().abs().clamp_min(2.0 ** -126) * 2.0 ** -7
+            assert bool(((got.float() - want.float()).abs() <= ulp).all()), name
+    with torch.no_grad():
+        y = model(bf(io["x"])).float()
+    want = bf(io["y"]).float()
+    assert float((y - want).abs().max()) <= 0.05 * float(want.abs().max())

@@ -80,7 +80,7 @@ def test_fuse_projections_layout_on_cpu():
     torch.manual_seed(0)
     model = torch.nn.ModuleDict({"a": Attn(64, 64, 96, True), "b": Attn(64, 128, 96, False), "c": Attn(64, 64, 96, True)})
     model, _ = sdnq_amd.apply_sdnq_to_module(model, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True,
-                                                                        modules_to_not_use_matmul=["c.to_v"], minimum_allowed_numel=1024,
+                                                                        modules_to_not_use_matmul=[".c.to_v"], minimum_allowed_numel=1024,
                                                                         minimum_allowed_channel_size=32))
     assert sdnq_amd.fuse_projections(model) == 2  # block c mixes a matmul and a non-matmul layer: left alone
     a, b, c = model["a"], model["b"], model["c"]
@@ -380,3 +380,77 @@ def test_prefetch_chain_learns_the_launch_order_and_names_two_units_ahead(monkey
     del b
     chain.reset(); chain.launch(a)
     assert calls == []
+
+
+class TinyNet(torch.nn.Module):
+    """The skeleton of tests/golden/checkpoint_tiny (a model DEFINITION, like a diffusers class: the checkpoint holds only tensors + json)."""
+
+    def __init__(self, d_in=64, d_hidden=128, d_mid=96, d_out=64, n_cls=10):
+        super().__init__()
+        self.proj_in = torch.nn.Linear(d_in, d_hidden)
+        self.mid = torch.nn.Linear(d_hidden, d_mid, bias=False)
+        self.proj_out = torch.nn.Linear(d_mid, d_out)
+        self.norm = torch.nn.LayerNorm(d_out)
+        self.head = torch.nn.Linear(d_out, n_cls)
+
+    def forward(self, x):
+        h = torch.nn.functional.silu(self.proj_in(x))
+        h = torch.nn.functional.silu(self.mid(h))
+        h = self.norm(self.proj_out(h))
+        return self.head(h)
+
+
+def test_load_sdnq_model_rebuilds_the_layers_of_a_reference_checkpoint():
+    """sdnq_amd.load_sdnq_model on the checkpoint the REFERENCE wrote (tests/golden/make_golden_checkpoint.py): every layer's record
+    equals what the reference's own loader derived (stored next to the checkpoint), the per-module overrides of the config are
+    honoured (modules_dtype_dict, modules_quant_config, modules_to_not_convert), direct-matmul operands sit in the physical
+    [N][K] layout, nothing is left on the meta device.  CPU: structure only (the forwards need the GPU)."""
+    import json
+    import os
+    import numpy as np
+    import sdnq_amd
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_tiny")
+    model = sdnq_amd.load_sdnq_model(path, model_cls=TinyNet, device="cpu")
+    meta = json.loads(bytes(np.load(os.path.join(path, "io.npz"))["meta_json"]).decode())
+    got = {n: m for n, m in model.named_modules() if hasattr(m, "sdnq_dequantizer")}
+    assert sorted(got) == sorted(meta) == ["mid", "proj_in", "proj_out"]
+    assert type(model.head) is torch.nn.Linear and model.head.weight.dtype == torch.bfloat16
+    for name, want in meta.items():
+        dq = got[name].sdnq_dequantizer
+        assert dq.weights_dtype == want["weights_dtype"] and dq.group_size == want["group_size"], name
+        assert bool(dq.use_quantized_matmul) == want["use_quantized_matmul"] and bool(dq.re_quantize_for_matmul) == want["re_quantize_for_matmul"], name
+        assert list(dq.quantized_weight_shape) == want["quantized_weight_shape"], name
+        assert (got[name].svd_up is not None) == want["has_svd"], name
+        assert got[name].forward_func.__module__.startswith("sdnq_amd")
+    assert not any(p.is_meta for p in model.parameters())
+    w = model.proj_in.weight  # logical [K, N] = [64, 128] over physical [N][K] bytes
+    assert tuple(w.shape) == (64, 128) and w.stride() == (1, 64) and not w.requires_grad
+    assert model.proj_out.svd_up.shape == (16, 64) and model.proj_out.svd_up.stride() == (1, 16)
+    assert model.quantization_config.modules_dtype_dict == {"uint4": ["mid"]}
+    # the same through a skeleton instance, and the missing-tensor error
+    with torch.device("meta"):
+        skel = TinyNet()
+    m2 = sdnq_amd.load_sdnq_model(path, model=skel, device="cpu")
+    assert torch.equal(m2.mid.weight, model.mid.weight)
+
+    class Bigger(TinyNet):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.extra = torch.nn.LayerNorm(64)
+
+    import pytest
+    with pytest.raises(RuntimeError, match="not in the checkpoint"):
+        sdnq_amd.load_sdnq_model(path, model_cls=Bigger, device="cpu")
+
+
+def test_module_lists_match_like_the_reference():
+    from sdnq_amd.quantizer import check_param_name_in, _minimum_dtype
+    assert check_param_name_in("blocks.0.attn.to_q.weight", ["to_q"]) == "to_q"
+    assert check_param_name_in("blocks.0.attn.to_q.weight", ["to_"]) is None            # a component, not a substring
+    assert check_param_name_in("blocks.0.attn.to_q.weight", [".blocks.0"]) == ".blocks.0"  # leading dot: a prefix
+    assert check_param_name_in("blocks.0.attn.to_q.weight", [".attn"]) is None
+    assert check_param_name_in("blocks.0.attn.to_q.weight", ["blocks.*.to_q.weight"]) == "blocks.*.to_q.weight"
+    assert check_param_name_in("head.weight", ["head.weight", "x"]) == "head.weight"
+    assert _minimum_dtype("uint4", "a.ff.weight", {"minimum_6bit": ["ff"]}) == "int6"
+    assert _minimum_dtype("int8", "a.ff.weight", {"minimum_6bit": ["ff"]}) == "int8"
+    assert _minimum_dtype("int8", "a.ff.weight", {"uint4": ["ff"]}) == "uint4"

@@ -217,3 +217,19 @@ def test_random_sweeps_against_the_imported_reference(tool, args, ok):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", tool), *args], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and ok in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_checkpoint_fixture_is_what_the_reference_writes(tmp_path):
+    """Build container only: tests/golden/checkpoint_tiny regenerates byte for byte (tensors, both json files, the re-loaded model's
+    layer inputs / outputs) from the reference's quantizer, save_sdnq_model and load_sdnq_model."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src/sdnq"):
+        pytest.skip("the reference is not present on this box")
+    out = str(tmp_path / "ckpt")
+    r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden_checkpoint.py"), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    for f in ("config.json", "quantization_config.json", "model.safetensors"):
+        assert open(os.path.join(out, f), "rb").read() == open(os.path.join(GOLD, "checkpoint_tiny", f), "rb").read(), f
+    a, b = np.load(os.path.join(out, "io.npz")), np.load(os.path.join(GOLD, "checkpoint_tiny", "io.npz"))
+    assert sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k], b[k]) for k in a.files)

@@ -166,6 +166,12 @@ def _peer_worker(rank, world, port, q, device_of_rank):
     try:
         arena = PeerArena(rank, world, device=dev, arena_bytes=64 << 20, timeout_ms=20000)
         ok, why = True, []
+        # the words remote kernels write and local kernels spin on live in signal memory (fine-grained / uncached), outside the arena
+        lo, hi = arena.buf.data_ptr(), arena.buf.data_ptr() + arena.buf.numel()
+        if arena.ctrl_kind not in ("uncached", "finegrained") or any(lo <= int(p or 0) < hi for p in list(arena._post) + list(arena._done)):
+            ok = False
+            why.append(("control words", arena.ctrl_kind))
+        arena.poll()
         # (1) the raw gather, uneven slabs: rank r contributes columns filled with r + 1 (+ row index)
         bounds = [(0, 48), (48, 80)] if world == 2 else [(16 * r, 16 * (r + 1)) for r in range(world)]
         n_total = bounds[-1][1]
@@ -204,6 +210,18 @@ def _peer_worker(rank, world, port, q, device_of_rank):
         if not bool((keep == 3.0).all()):
             ok = False
             why.append("ring overwrote a live tensor")
+        # (4) a rank that does not show up: the waiting rank's status word (host-coherent memory) makes its NEXT gather raise
+        lonely = PeerArena(rank, world, device=dev, arena_bytes=1 << 20, timeout_ms=300)
+        if rank == 0:
+            lonely.gather(torch.ones((8, bounds[0][1] - bounds[0][0]), device=dev, dtype=torch.bfloat16), n_total, bounds[0][0])
+            torch.cuda.synchronize(dev)
+            try:
+                lonely.gather(torch.ones((8, bounds[0][1] - bounds[0][0]), device=dev, dtype=torch.bfloat16), n_total, bounds[0][0])
+                ok = False
+                why.append("a timed-out rendezvous went unnoticed")
+            except RuntimeError as e:
+                if "did not arrive" not in str(e):
+                    raise
         dist.barrier()
         q.put((rank, bool(ok), why))
     except Exception as e:  # noqa: BLE001
