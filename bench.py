@@ -67,6 +67,9 @@ def parse():
     p.add_argument("--tp-gather", choices=["rccl", "peer"], default="rccl",
                    help="with --tp: RCCL all-gather + re-assembly pass (default), or the copy-free gather -- every rank pushes its slab into every "
                         "rank's [M, N] output over peer-mapped memory (sdnq_amd.parallel.PeerArena, sdnq_hip_push_columns)")
+    p.add_argument("--tp-report", action="store_true",
+                   help="attach the column-sharded (strong-scaling) numbers of the same workload, RCCL and copy-free gather, to the default line; "
+                        "ON by default when --gpus > 1 without --tp (SDNQ_BENCH_TP_REPORT=0 turns it off)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--launch", choices=["graph", "eager", "compile"], default=None,
                    help="how a step is launched: one captured hipGraph (default), eager Python (= --no-graph), or torch.compile(mode='reduce-overhead') "
@@ -260,6 +263,7 @@ def time_gemm_kernel(layers, mm_name, device):
     from sdnq_amd import ops
     mm = ops.MM_I8 if mm_name == "int8" else ops.MM_FP8
     calls, total_ops, total_bytes, seen_groups = [], 0, 0, set()
+    unit_w = []  # per launch: the weight tensors it reads
     if not L.CACHE_WEIGHTS and L.PIPELINE_WEIGHTS:
         return None  # per-call mode: every layer's operand lives in one of two scratch buffers, they cannot all be held at once
     for (_, mod, x, m, k, n, has_bias) in layers:
@@ -277,6 +281,7 @@ def time_gemm_kernel(layers, mm_name, device):
                 raise RuntimeError("linked group without a unit table")
             xq, xs, _, _ = ops.rowquant(x, mm, 0)
             calls.append((xq, group.gemm, xs, None, None, len(group.mods)))
+            unit_w.append(list(group.pf_tensors))
             for gm in group.mods:
                 gn, gb = gm.sdnq_dequantizer.out_features, gm.bias is not None
                 total_ops += 2 * m * k * gn + (m * gn if gb else 0)
@@ -293,18 +298,29 @@ def time_gemm_kernel(layers, mm_name, device):
         if has_svd or zp is not None:  # the scaled matmul with the low-rank / zero-point epilogue, its t = x . svd_down^T precomputed
             t = ops.lowrank_down(xrot if xrot is not None else x.reshape(-1, k), st.svd_down) if has_svd else None
             calls.append((xq, wq, xs, ws, mod.bias, ("lowrank", t, st.svd_up if has_svd else None, rowsum, zp)))
+            unit_w.append([wq])
             r = int(st.svd_up.shape[1]) if has_svd else 0
             total_ops += 2 * m * n * r
             total_bytes += 2 * r * (m + n)
         else:
             calls.append((xq, wq, xs, ws, mod.bias, 1))
+            unit_w.append([wq])
         total_ops += 2 * m * k * n + (m * n if has_bias else 0)
         total_bytes += m * k + n * k + 2 * m * n + 4 * (m + n) + (2 * n if has_bias else 0)  # xq + Wq + y(bf16) + xs + ws + bias
     if not calls:
         return None
 
+    # the launches carry the weight-prefetch hints they carry in the step (linear._PrefetchChain: the next two launch units' weights)
+    ranges = [L._LaunchUnit(ts).ranges if ts else () for ts in unit_w]
+    lib = ops._lib.load()
+
     def launch_all():
-        for (xq, wq, xs, ws, bias, g) in calls:
+        for i, (xq, wq, xs, ws, bias, g) in enumerate(calls):
+            if L.PREFETCH_NEXT:
+                rs = (ranges[i + 1] if i + 1 < len(calls) else ()) + (ranges[i + 2] if i + 2 < len(calls) else ())
+                if rs:
+                    rs = (tuple(rs) + ((0, 0),) * 4)[:4]
+                    lib.sdnq_hip_prefetch_hint(rs[0][0], rs[0][1], rs[1][0], rs[1][1], rs[2][0], rs[2][1], rs[3][0], rs[3][1])
             if g == 1:
                 ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
             elif isinstance(g, tuple):
@@ -407,6 +423,90 @@ def time_all_gathers(layers, device, reps=3):
     recv_bytes = sum(2 * m * w * (world - 1) for (m, w, world) in msgs)
     return {"gathers_per_step": len(msgs), "seconds_per_step": sec, "bytes_received_per_rank_per_step": recv_bytes,
             "largest_message_bytes": max(2 * m * w for (m, w, _) in msgs)}
+
+
+def time_peer_gathers(layers, peer, device, reps=3):
+    """The copy-free gathers of one step ALONE (PeerArena.gather on slabs of the step's sizes, no matmuls): seconds per step."""
+    import torch.distributed as dist
+    msgs = []
+    for (_, mod, x, m, k, n, b) in layers:
+        if type(mod).__name__ == "ColumnShardedLinear":
+            a, bnd = mod.bounds[mod.rank]
+            msgs.append((m, bnd - a, mod.n_total, a, mod.world))
+    if not msgs:
+        return None
+    slabs = {(m, w): torch.zeros((m, w), device=device, dtype=torch.bfloat16) for (m, w, _, _, _) in msgs}
+
+    def run():
+        for (m, w, n_total, a, _) in msgs:
+            peer.gather(slabs[(m, w)], n_total, a)
+    run()
+    peer.check()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / reps
+    peer.check()
+    return {"gathers_per_step": len(msgs), "seconds_per_step": sec,
+            "bytes_received_per_rank_per_step": sum(2 * m * (n_total - w) for (m, w, n_total, _, _) in msgs),
+            "largest_message_bytes": max(2 * m * w for (m, w, _, _, _) in msgs)}
+
+
+def tp_report(args, device, world, rank, shape_list, cfg_kwargs, ops_per_step):
+    """The SAME workload column-sharded over the ranks (strong scaling), both gathers, a few steps each -- attached to the default
+    (replica) line of a multi-GPU run so that one driver run per N yields the replica number AND the sharded numbers north_star names.
+    Every rank takes part; every mode is guarded (a failing mode reports its error, the replica line is printed regardless)."""
+    import torch.distributed as dist
+    out = {"ranks": world, "scaling": "strong", "workload": args.workload, "xgmi_link_gbps": XGMI_LINK_GBPS, "xgmi_links_used": max(1, world - 1),
+           "note": "ms_per_step: max over ranks of the whole step (row quantization replicated, GEMMs on N / W channels, one gather per layer); "
+                   "gather_*: the step's gathers run alone, bytes RECEIVED per rank against (W - 1) links x 153 GB/s"}
+    steps = max(2, min(args.steps, 5))
+    for mode in ("rccl", "peer"):
+        res = {}
+        try:
+            peer = None
+            if mode == "peer":
+                from sdnq_amd.parallel import PeerArena
+                peer = PeerArena.try_create(rank, world, device=device)
+                if peer is None:
+                    out[mode] = {"unavailable": "no peer access between every pair of ranks' devices (or more than one host): the RCCL gather is the path"}
+                    continue
+                res["control_words"] = peer.ctrl_kind
+            layers = build_layers(shape_list, cfg_kwargs, device, scale=args.layers_scale, tp_rank=rank, tp_world=world, seed=0,
+                                  tp_chunks=args.tp_chunks if mode == "rccl" else 1, tp_peer=peer)
+            for _ in range(2):
+                run_step(layers)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run_step(layers)
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if peer is not None:
+                peer.check()
+            ms = float(t.item()) / steps * 1e3
+            res.update({"ms_per_step": round(ms, 4), "steps": steps, "launch": "eager", "value_gops": round(ops_per_step / (ms / 1e3) / 1e9, 1),
+                        "sharded_layers": sum(1 for l in layers if type(l[1]).__name__ == "ColumnShardedLinear")})
+            g = time_all_gathers(layers, device) if mode == "rccl" else time_peer_gathers(layers, peer, device)
+            if g:
+                gbps = g["bytes_received_per_rank_per_step"] / g["seconds_per_step"] / 1e9 if g["bytes_received_per_rank_per_step"] else 0.0
+                res.update({"gathers_per_step": g["gathers_per_step"], "gather_bytes_received_per_rank_per_step": g["bytes_received_per_rank_per_step"],
+                            "gathers_alone_ms_per_step": round(g["seconds_per_step"] * 1e3, 4), "gather_achieved_gbps_per_rank": round(gbps, 1),
+                            "gather_frac_of_links": round(gbps / (XGMI_LINK_GBPS * max(1, world - 1)), 4)})
+            del layers
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            res["error"] = repr(e)[:400]
+        out[mode] = res
+    return out
 
 
 def cpu_baseline(shape_list, mm_name, budget_s):
@@ -1084,6 +1184,14 @@ def main():
                 "note": "bytes received per rank / time of the step's all-gathers run alone; a fully connected all-gather receives from "
                         "W - 1 peers over W - 1 links at once, each bound by 153 GB/s"})
 
+    want_tp_report = distributed and not tp and not is_conv and (args.tp_report or (world > 1 and os.environ.get("SDNQ_BENCH_TP_REPORT", "1") != "0"))
+    if want_tp_report:
+        # (after the timed replica region; a collective: every rank runs it)
+        try:
+            result["tp"] = tp_report(args, device, world, rank, shape_list, cfg_kwargs, ops_per_step)
+        except Exception as e:  # noqa: BLE001
+            result["tp"] = {"error": repr(e)[:400]}
+
     float_mode = not cfg_kwargs.get("use_quantized_matmul", cfg_kwargs.get("use_quantized_matmul_conv", False))
     if float_mode:
         result["dtype"] = "bf16"
@@ -1095,8 +1203,8 @@ def main():
             gk = time_float_kernel(layers, device) if float_mode else time_gemm_kernel(layers, mm_name, device)
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
-        traffic, traffic_src, traffic_meta = None, None, None
-        pmc_name = "r04_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
+        traffic, traffic_src, traffic_meta, traffic_stale = None, None, None, None
+        pmc_name = "r05_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
         if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
@@ -1106,6 +1214,8 @@ def main():
             traffic = round(pj["_all_gemm_kernel"]["hbm_bytes_per_launch"])
             traffic_src = f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch)"
             traffic_meta = pj.get("_provenance", "collected in an earlier profiling session (see `git log -- profiles/" + pmc_name + "`), not by this run")
+            # the constant describes the library it was collected on: say so when that is not the library this run loaded
+            traffic_stale = not (isinstance(traffic_meta, dict) and traffic_meta.get("library_srchash") == (_lib.source_hash() or "")[:16])
         if gk:
             ach = gk["ops"] / gk["seconds"] / 1e12
             if float_mode:
@@ -1121,6 +1231,7 @@ def main():
                                   "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                                   # the PMC figure is a constant read from a tracked profile (counters cannot be collected inside a timed run)
                                   "traffic_measured_in_run": False if traffic is not None else None, "traffic_provenance": traffic_meta,
+                                  "traffic_stale": traffic_stale if traffic is not None else None,
                                   "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]),
                                   "hbm_achieved_gbps": round(gk["bytes"] / gk["seconds"] / 1e9, 1), "hbm_peak_gbps": HBM_PEAK_GBPS,
                                   "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": kernel,
