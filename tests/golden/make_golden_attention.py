@@ -8,8 +8,14 @@ What this harness has to supply because there is no GPU driver here (nothing of 
     (BLOCK_SIZE_M = BLOCK_SIZE_N = 32, recorded in the fixture's meta; with pv_matmul_dtype=None the result depends on the
     block size only through fp32 rounding order);
   * the interpreter does not convert Python floats to scalars, so `sm_scale` is wrapped as an fp32 scalar handle;
-  * the interpreter has no bfloat16 (numpy), so the fixtures are float16; token counts are multiples of 4 because the
-    interpreter's tensor descriptors want 16-byte aligned bases for the per-token fp32 scale vectors.
+  * the interpreter has no working bfloat16 (numpy has none: Triton 3.6 accepts the tensors and returns garbage), so the f16_* cases are
+    float16; token counts are multiples of 4 because the interpreter's tensor descriptors want 16-byte aligned bases for the per-token
+    fp32 scale vectors;
+  * the bf16_* cases (round 5; the dtype SDXL / FLUX run): the reference's host code `quantize_attn` -- plain torch -- runs on the REAL
+    bfloat16 tensors (its dtype-dependent steps: the Hadamard rotation in the tensor dtype, the values themselves), so q_q / q_scale /
+    k_q / k_scale of the fixture are the reference's bfloat16 path bit for bit; the KERNEL then runs on those quantized operands with V
+    handed over as float32 (the same values: every bfloat16 is a float32), i.e. with P and the output NOT rounded to bfloat16 -- the
+    fixture's `out` is float32 and a bfloat16 implementation is compared with it at bfloat16 tolerance (meta: "out_is").
 Fixtures are DATA only (inputs, the reference's quantized operands, outputs).  Run:  python tests/golden/make_golden_attention.py
 """
 import json
@@ -66,6 +72,11 @@ CASES = [
     dict(name="f16_d80_padded_causal", z=1, qh=2, kh=1, qn=36, kn=36, d=80, kw=dict(is_causal=True)),
     dict(name="f16_d64_hadamard", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(use_hadamard=True)),
     dict(name="f16_d128_hadamard_g32", z=1, qh=2, kh=1, qn=36, kn=40, d=128, kw=dict(use_hadamard=True, hadamard_group_size=32, is_causal=True)),
+    # bfloat16 (round 5): P and the output are rounded to 8 bits of mantissa, V is the bf16 operand of the second matmul
+    dict(name="bf16_d64_tail", dtype="bf16", z=1, qh=2, kh=2, qn=40, kn=52, d=64, kw={}),
+    dict(name="bf16_d128_gqa_causal", dtype="bf16", z=1, qh=4, kh=2, qn=44, kn=44, d=128, kw=dict(is_causal=True)),
+    dict(name="bf16_d64_hadamard", dtype="bf16", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(use_hadamard=True)),
+    dict(name="bf16_d64_boolmask", dtype="bf16", z=2, qh=2, kh=1, qn=40, kn=80, d=64, kw={}, mask=dict(kind="bool", shape=(2, 1, 40, 80), dead_rows=(5,))),
 ]
 
 
@@ -73,6 +84,8 @@ def bits(t):
     t = t.detach().cpu().contiguous()
     if t.dtype == torch.float16:
         return t.view(torch.uint16).numpy().copy(), "f16"
+    if t.dtype == torch.bfloat16:
+        return t.view(torch.uint16).numpy().copy(), "bf16"
     if t.dtype == torch.bool:
         return t.view(torch.uint8).numpy().copy(), "bool"
     return t.numpy().copy(), str(t.dtype).replace("torch.", "")
@@ -85,7 +98,8 @@ def run(case):
     k = torch.randn(z, kh, kn, d, generator=g) + 3.0 * torch.randn(1, kh, 1, d, generator=g)  # channel offsets: what smooth_k removes
     v = torch.randn(z, kh, kn, d, generator=g)
     q[..., 5] *= 6.0
-    q, k, v = q.half(), k.half(), v.half()
+    tdt = torch.bfloat16 if case.get("dtype", "f16") == "bf16" else torch.float16
+    q, k, v = q.to(tdt), k.to(tdt), v.to(tdt)
     mask = None
     if "mask" in case:
         ms = case["mask"]
@@ -98,8 +112,24 @@ def run(case):
             mask = torch.randn(ms["shape"], generator=g) * 2.0
             mask[torch.rand(ms["shape"], generator=g) < 0.2] = float("-inf")
             mask[..., 0] = 0.5  # every query keeps a visible key
-            mask = mask.to(torch.float16 if ms["kind"] == "f16" else torch.float32)
-    out = ta.sdnq_triton_atten(q, k, v, attn_mask=mask, **case["kw"])
+            mask = mask.to(tdt if ms["kind"] == "f16" else torch.float32)
+    bf16 = case.get("dtype", "f16") == "bf16"
+    if bf16:
+        real_quantize, captured = ta.quantize_attn, {}
+
+        def on_bf16(q_, k_, v_, smooth_k=True, hadamard=None, **kw_):
+            r = list(real_quantize(q_.to(torch.bfloat16), k_.to(torch.bfloat16), v_.to(torch.bfloat16), smooth_k=smooth_k,
+                                   hadamard=None if hadamard is None else hadamard.to(torch.bfloat16), **kw_))
+            captured["r"] = tuple(r)
+            r[4] = r[4].float()  # V: the same values as float32, so that the interpreter can run the kernel
+            return tuple(r)
+        ta.quantize_attn = on_bf16
+        try:
+            out = ta.sdnq_triton_atten(q.float(), k.float(), v.float(), attn_mask=mask, **case["kw"])
+        finally:
+            ta.quantize_attn = real_quantize
+    else:
+        out = ta.sdnq_triton_atten(q, k, v, attn_mask=mask, **case["kw"])
     hadamard, hgroup = None, 0
     if case["kw"].get("use_hadamard"):  # the group / matrix choice of sdnq_triton_atten (triton_atten.py:563-569)
         hch = ta.next_power_of_2(d)
@@ -107,9 +137,13 @@ def run(case):
         hadamard = ta.get_hadamard(hgroup, dtype=q.dtype, device=q.device) if ok else None
     q_q, q_s, k_q, k_s, v_q, v_s, used_h, used_g = ta.quantize_attn(q, k, v, smooth_k=case["kw"].get("smooth_k", True), hadamard=hadamard,
                                                                     hadamard_group_size=hgroup or 256)
-    assert v_s is None and v_q.dtype == torch.float16
-    arrays, meta = {}, {"name": case["name"], "dtype": "f16", "shape": dict(z=z, qh=qh, kh=kh, qn=qn, kn=kn, d=d), "kwargs": case["kw"],
-                        "block_m": BLOCK_M, "block_n": BLOCK_N, "hadamard_group": int(used_g) if used_h else 0, "tensors": {}}
+    assert v_s is None and v_q.dtype == tdt
+    if bf16:  # what the kernel really consumed == what the reference's host code gives on the bfloat16 tensors
+        c_ = captured["r"]
+        assert torch.equal(c_[0], q_q) and torch.equal(c_[1], q_s) and torch.equal(c_[2], k_q) and torch.equal(c_[3], k_s) and torch.equal(c_[4], v_q)
+    arrays, meta = {}, {"name": case["name"], "dtype": case.get("dtype", "f16"), "shape": dict(z=z, qh=qh, kh=kh, qn=qn, kn=kn, d=d), "kwargs": case["kw"],
+                        "block_m": BLOCK_M, "block_n": BLOCK_N, "hadamard_group": int(used_g) if used_h else 0, "tensors": {},
+                        **({"out_is": "float32: the reference kernel on the bfloat16 path's quantized operands with V as float32 (P and the output unrounded)"} if bf16 else {})}
     for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s))             + ((("mask", mask),) if mask is not None else ()):
         arrays[key], tag = bits(t)
         meta["tensors"][key] = {"dtype": tag, "shape": list(t.shape)}

@@ -32,10 +32,13 @@ def test_oracle_attention_vs_reference_kernel(name):
     _quant_agreement(inter["k_q"], inter["k_scale"], c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True), hadamard=bool(hg))
     ref = c.f32("out")
     assert out.shape == ref.shape
-    # same arithmetic as the kernel up to exp2 / reduction-order rounding, then one f16 rounding of the output
+    # same arithmetic as the kernel up to exp2 / reduction-order rounding, then one f16 rounding of the output.  bf16_* fixtures hold the
+    # reference kernel's float32 output on the bfloat16 path's quantized operands (P and the output unrounded, make_golden_attention.py):
+    # the bfloat16 restatement rounds both to 8 bits of mantissa
+    lim, lim2 = (1.2e-2, 4e-3) if c.tag == "bf16" else (2e-3, 5e-4)
     err = np.abs(out - ref).max() / np.abs(ref).max()
-    assert err <= 2e-3, (name, err)
-    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= 5e-4, name
+    assert err <= lim, (name, err)
+    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= lim2, name
 
 
 def test_oracle_attention_block_size_only_changes_rounding():
@@ -69,9 +72,10 @@ def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
     for ref, what in ((c.f32("out"), "reference kernel"),
                       (O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
                                    smooth_k=kw.get("smooth_k", True), hadamard_group=hg, mask=c.mask_array()), "oracle")):
+        lim, lim2 = (1.2e-2, 4e-3) if c.tag == "bf16" else (3e-3, 1e-3)  # bf16: P and the output carry 8 bits of mantissa
         err = np.abs(got - ref).max() / np.abs(ref).max()
-        assert err <= 3e-3, (name, what, err)
-        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1e-3, (name, what)
+        assert err <= lim, (name, what, err)
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= lim2, (name, what)
 
 
 @pytest.mark.gpu
