@@ -2040,6 +2040,9 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 25) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_OG, 128>(p, s);
         if (force == 26) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_OG, 128>(p, s);
         if (force == 27) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_OG, 128>(p, s);
+        // (round 5, measured and NOT instantiated: 64x80 tiles on v_mfma_i32_16x16x64_i8 -- four waves of 16x80, 256 workgroups for 1024 x 1280
+        //  outputs, 25 % fewer LDS-fill bytes per CU -- on LD_DMA and on LD_OV, 3 / 4 ring slots: replayed alone 7.67-8.09 us against 7.09 at
+        //  K = 1280, in the step +0.36..+0.53 ms over the 180 launches of 1024 x 1280 x 1280, +0.11..+0.21 at K = 5120; profiles/r05_overlapped_ring_lab.txt)
         // (round 4 lab, not instantiated: 128x160 tiles -- N = 320 in two exact columns, 256 tiles at M = 16384 -- equal the 64x128 tile on
         //  the conv step, 64x320 tiles are slower; profiles/r04_conv_tiles_in_step.txt)
         // (round 4, profiles/r04_ring_depth_in_step.txt: 5- and 6-deep rings for the 64x128 tile -- the one-workgroup-per-CU problems of the
