@@ -1053,6 +1053,7 @@ def main():
         run_step(layers)
     torch.cuda.synchronize()
     graph = None
+    one_launch = None
     if args.launch == "eager":
         args.no_graph = True
     compiled = None
@@ -1099,8 +1100,11 @@ def main():
             run_step(layers)
             side.synchronize()
             graph = torch.cuda.CUDAGraph()
+            from sdnq_amd import ops as _ops
+            _ops.fused_calls[0] = 0
             with torch.cuda.graph(graph, stream=side):
                 run_step(layers)
+            one_launch = _ops.fused_calls[0]
         torch.cuda.synchronize()
 
     def step():
@@ -1156,6 +1160,8 @@ def main():
                    "resident_weight_bytes": resident_weight_bytes(layers),
                    **({"per_call_weight_pipeline": {"enabled": L.PIPELINE_WEIGHTS, **L._weight_pipeline.stats}} if not L.CACHE_WEIGHTS else {}),
                    "linked_projection_groups": linked,
+                   # layers whose row quantization runs INSIDE their GEMM launch (sdnq_hip_linear_w8a8_fused, csrc/gemm_aq.hip); None: not a graph run
+                   "one_launch_linears": one_launch,
                    "ops_per_step": ops_per_step, **{k: v for k, v in cfg_kwargs.items()}},
         **({"tp": {"ranks": world, "rank_devices": [f"cuda:{r}" for r in range(world)], "rccl_version": list(torch.cuda.nccl.version()),
                    "sharded_layers": sum(1 for l in layers if type(l[1]).__name__ == "ColumnShardedLinear"),

@@ -408,6 +408,17 @@ int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, in
                          void* xq, float* xs, const void* b, const float* sb, const void* bias, int bias_dtype, void* out,
                          int out_dtype, int64_t n, sdnq_stream_t stream);
 
+/* The plain w8a8 Linear (int8_matmul / fp8_matmul: linear_int8.py:15-22, 64, 75-97 -> kernels/triton_scaled_mm.py:194-232; linear_fp8.py
+ * the same) as ONE launch: every GEMM workgroup row-quantizes its own 64 activation rows into LDS (amax, scale = amax / qmax, codes with the
+ * arithmetic of sdnq_hip_rowquant) and streams only the weight operand -- no quantized copy of the activation exists in HBM.  Results are
+ * bit-identical to sdnq_hip_linear_w8a8 (csrc/gemm_aq.hip).  x [M][K] bf16 / f16 with row stride ldx, b [N][K] codes, sb [N], bias NULL or
+ * [N] of bias_dtype, out [M][N] of x's dtype.  Built for K % 128 == 0, K <= 1280 (the rows stay resident in LDS); other shapes return
+ * SDNQ_ERR_UNSUPPORTED -- callers ask sdnq_hip_linear_w8a8_fused_supported first: 1 where this route is built AND expected to win (one
+ * round of workgroups, few column tiles per row block: the projections of a bs = 1 step; SDNQ_HIP_FUSED_ROWQUANT=0 turns it off). */
+int sdnq_hip_linear_w8a8_fused(int mm_dtype, const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, const void* b, const float* sb,
+                               const void* bias, int bias_dtype, void* out, int out_dtype, int64_t n, sdnq_stream_t stream);
+int sdnq_hip_linear_w8a8_fused_supported(int mm_dtype, int x_dtype, int out_dtype, int64_t m, int64_t n, int64_t k);
+
 /* ---- the whole quantized-matmul forward of one layer behind ONE call -------------------------------------------------
  * int8_matmul / fp8_matmul / uint8_matmul (layers/linear/linear_int8.py:75-97, linear_fp8.py:58-78, linear_uint8.py:80-102) for every
  * layer form: row quantization of the activation (Hadamard-rotated when the layer is, asymmetric for the uint8 matmul), the low-rank

@@ -33,6 +33,7 @@ EXPORTS = [
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
     "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided", "sdnq_hip_prefetch", "sdnq_hip_prefetch_hint",
     "sdnq_hip_signal_alloc", "sdnq_hip_signal_free", "sdnq_hip_ipc_export", "sdnq_hip_ipc_import", "sdnq_hip_ipc_close",
+    "sdnq_hip_linear_w8a8_fused", "sdnq_hip_linear_w8a8_fused_supported",
 ]
 
 
@@ -75,7 +76,7 @@ _lock = threading.Lock()
 _lib = None
 
 
-_SRCS = ("api", "rowquant", "gemm", "dequant", "quantize", "conv", "attention", "parallel")
+_SRCS = ("api", "rowquant", "gemm", "gemm_aq", "dequant", "quantize", "conv", "attention", "parallel")
 _FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-command-line-argument"
 
 
@@ -97,7 +98,7 @@ def source_hash() -> str:
             extra = "-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
         if f == "gemm" and os.environ.get("SDNQ_PRELOAD_GEMM", "1") != "0":
             extra = "-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
-        if f in ("dequant", "conv"):
+        if f in ("dequant", "conv", "gemm_aq"):
             extra = "-mllvm -amdgpu-kernarg-preload-count=14"
         g = hashlib.sha256((f"{hdr_hash} {flags} {extra}\n").encode())
         g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())
@@ -166,6 +167,8 @@ def _declare(lib):
     lib.sdnq_hip_quantize_weight.argtypes = [vp, i32, i64, c.POINTER(SdnqWeight), c.c_float, c.c_float, vp]
     lib.sdnq_hip_linear_skinny_svd.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, i32, vp, i64, i64, vp]
     lib.sdnq_hip_linear_w8a8.argtypes = [i32, vp, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
+    lib.sdnq_hip_linear_w8a8_fused.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, vp, i32, i64, vp]
+    lib.sdnq_hip_linear_w8a8_fused_supported.argtypes = [i32, i32, i32, i64, i64, i64]
     lib.sdnq_hip_scaled_mm_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i64, i64, i64, vp]
     lib.sdnq_hip_linear_w8a16_grouped.argtypes = [vp, i32, vp, i64, i64, i32, vp, i64, i64, i64, vp]
     lib.sdnq_hip_linear_w8a16.argtypes = [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp]

@@ -40,6 +40,7 @@ static __typeof__(&sdnq_hip_linear_w8a16) f_linear_w8a16;
 static __typeof__(&sdnq_hip_linear_w8a16_grouped) f_linear_w8a16_grouped;
 static __typeof__(&sdnq_hip_linear_float) f_linear_float;
 static __typeof__(&sdnq_hip_prefetch_hint) f_prefetch_hint;
+static __typeof__(&sdnq_hip_linear_w8a8_fused) f_linear_w8a8_fused;
 
 #define NOT_READY(f) if (!(f)) { PyErr_SetString(PyExc_RuntimeError, "sdnq_amd._binding.init(path) has not been called"); return NULL; }
 
@@ -90,6 +91,12 @@ static PyObject* w_linear_float(PyObject* s, PyObject* const* args, Py_ssize_t n
     return PyLong_FromLong(f_linear_float(P(0), P(1), P(2), I(3), P(4), L(5), L(6), L(7), L(8), P(9)));
 }
 
+static PyObject* w_linear_w8a8_fused(PyObject* s, PyObject* const* args, Py_ssize_t n) {
+    i64 a[14]; (void)s; NOT_READY(f_linear_w8a8_fused);
+    if (ints(args, n, 14, a, "sdnq_hip_linear_w8a8_fused")) return NULL;
+    return PyLong_FromLong(f_linear_w8a8_fused(I(0), P(1), I(2), L(3), L(4), L(5), P(6), (const float*)P(7), P(8), I(9), P(10), I(11), L(12), P(13)));
+}
+
 static PyObject* w_prefetch_hint(PyObject* s, PyObject* const* args, Py_ssize_t n) {
     i64 a[8]; (void)s; NOT_READY(f_prefetch_hint);
     if (ints(args, n, 8, a, "sdnq_hip_prefetch_hint")) return NULL;
@@ -106,14 +113,14 @@ static PyObject* w_init(PyObject* s, PyObject* arg) {
     if (!h) { PyErr_Format(PyExc_OSError, "dlopen(%s): %s", path, dlerror()); return NULL; }
 #define R(name) do { *(void**)(&f_##name) = dlsym(h, "sdnq_hip_" #name); if (!f_##name) { PyErr_SetString(PyExc_OSError, "missing symbol sdnq_hip_" #name); return NULL; } } while (0)
     R(rowquant); R(scaled_mm); R(linear_w8a8); R(scaled_mm_grouped); R(scaled_mm_lowrank); R(lowrank_down); R(linear_w8a16);
-    R(linear_w8a16_grouped); R(linear_float); R(prefetch_hint);
+    R(linear_w8a16_grouped); R(linear_float); R(prefetch_hint); R(linear_w8a8_fused);
 #undef R
     Py_RETURN_NONE;
 }
 
 #define M(name) {"sdnq_hip_" #name, (PyCFunction)(void (*)(void))w_##name, METH_FASTCALL, "see include/sdnq_hip.h"}
 static PyMethodDef methods[] = {M(rowquant), M(scaled_mm), M(linear_w8a8), M(scaled_mm_grouped), M(scaled_mm_lowrank), M(lowrank_down),
-                                M(linear_w8a16), M(linear_w8a16_grouped), M(linear_float), M(prefetch_hint),
+                                M(linear_w8a16), M(linear_w8a16_grouped), M(linear_float), M(prefetch_hint), M(linear_w8a8_fused),
                                 {"init", (PyCFunction)w_init, METH_O, "init(path of libsdnq_hip.so)"},
                                 {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_binding", "typed binding of libsdnq_hip.so's hot entry points", -1, methods,

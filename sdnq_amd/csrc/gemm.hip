@@ -2157,6 +2157,29 @@ int check_common(int mm_dtype, const void* a, const void* b, const float* sa, co
 }  // namespace
 
 #ifndef SDNQ_LAB  // tools/micro/gemm_lab.hip includes this file for the kernel template only
+// The pending weight-prefetch hint handed to ANOTHER translation unit's launcher (gemm_aq.hip: the activation-quantizing GEMM hosts
+// prefetch workgroups exactly as launch_one does): line ranges of the hint + how many workgroups of `threads` threads to append, given the
+// launch's free workgroup slots.  Consumes the hint.  Internal to the library (not part of the C ABI).
+int sdnq_internal_take_prefetch(int64_t room, int threads, const uint8_t* pf_ptr[4], int pf_lines[4]) {
+    for (int r = 0; r < 4; ++r) { pf_ptr[r] = nullptr; pf_lines[r] = 0; }
+    if (!(g_pf_hint.ptr[0] || g_pf_hint.ptr[1] || g_pf_hint.ptr[2] || g_pf_hint.ptr[3])) return 0;
+    int64_t lines = 0;
+    for (int r = 0; r < 4; ++r) {
+        if (!g_pf_hint.ptr[r] || g_pf_hint.bytes[r] <= 0) continue;
+        const uintptr_t a0 = (uintptr_t)g_pf_hint.ptr[r] & ~(uintptr_t)127;
+        const int64_t n = (int64_t)(((uintptr_t)g_pf_hint.ptr[r] + (uintptr_t)g_pf_hint.bytes[r] + 127 - a0) / 128);
+        if (n > 0x7fffffffll) continue;
+        pf_ptr[r] = (const uint8_t*)a0; pf_lines[r] = (int)n;
+        lines += n;
+    }
+    static const int pf_max = [] { const char* e = getenv("SDNQ_HIP_PREFETCH_WGS"); return e ? atoi(e) : 96; }();
+    int64_t want = (lines + (int64_t)threads * 4 - 1) / ((int64_t)threads * 4);
+    if (want > pf_max) want = pf_max;
+    g_pf_hint = PrefetchHint{};
+    if (room < 0) room = 0;
+    return (int)(want < room ? want : room);
+}
+
 extern "C" void sdnq_hip_set_tile_override(int tile_id) { g_forced_tile.store(tile_id < 0 ? -1 : tile_id, std::memory_order_relaxed); }
 
 extern "C" int sdnq_hip_prefetch_hint(const void* p0, int64_t b0, const void* p1, int64_t b1, const void* p2, int64_t b2, const void* p3, int64_t b3) {

@@ -16,6 +16,7 @@
 #include <cstdlib>
 
 #include "hadamard_dev.h"
+#include "quant8_dev.h"
 #include "sdnq_dev.h"
 
 namespace {
@@ -61,91 +62,6 @@ __device__ __forceinline__ void store8(void* row, int64_t idx, const float (&v)[
     } else {
         *(uint4*)((uint16_t*)row + idx) = Vec16<T_ID>::pack(v);
     }
-}
-
-// LP_T: SDNQ_F32 = the reference's default float32 arithmetic; SDNQ_BF16 / SDNQ_F16 = the quotient is rounded to that dtype
-// before round-half-even / the fp8 cast (torch.div on 16-bit tensors, dequantize_fp32=False: linear_int8.py:15-22)
-template <int MM, int LP_T = SDNQ_F32>
-__device__ __forceinline__ uint2 quant8(const float (&v)[8], const RowDiv& d, int& isum, float zp = 0.0f, bool asym = false) {
-    const float scale = d.scale;
-    if constexpr (MM == SDNQ_MM_I8 && LP_T == SDNQ_F32) {
-        if (d.fast && !asym) {  // wave-uniform
-            // the symmetric int8 row of the w8a8 step: packed division, rounding and byte packing in ~3 instructions per element instead of
-            // ~11 (sdnq_dev.h); `fast` excludes scale 0 / inf / nan, and |x| <= amax keeps every quotient inside +-127.5
-            const u32 w0 = pack4_rne_i8(fastdiv2((pv2f){v[0], v[1]}, d), fastdiv2((pv2f){v[2], v[3]}, d));
-            const u32 w1 = pack4_rne_i8(fastdiv2((pv2f){v[4], v[5]}, d), fastdiv2((pv2f){v[6], v[7]}, d));
-            isum = __builtin_amdgcn_sdot4((int)w1, 0x01010101, __builtin_amdgcn_sdot4((int)w0, 0x01010101, isum, false), false);
-            return make_uint2(w0, w1);
-        }
-    }
-    if constexpr (MM == SDNQ_MM_FP8 && LP_T == SDNQ_F32) {
-        if (d.fast && !asym) {  // wave-uniform: finite ordinary scale, so no NaN to flush; x = +-amax can still land one ulp above 448
-            float c[8];
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                const pv2f q = fastdiv2((pv2f){v[2 * h], v[2 * h + 1]}, d);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    // the sign of the numerator ORed onto the quotient: a no-op unless the quotient is the +0 the correction term makes of
-                    // -0.0 / scale, whose fp8 code is 0x80 (round 4, tools/fuzz_ops.py)
-                    const float qs = __uint_as_float(__float_as_uint(q[e]) | (__float_as_uint(v[2 * h + e]) & 0x80000000u));
-                    c[2 * h + e] = __builtin_amdgcn_fmed3f(qs, -448.0f, 448.0f);
-                }
-            }
-            return make_uint2(pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]), pack4_e4m3fn_clamped(c[4], c[5], c[6], c[7]));
-        }
-    }
-    float qv[8];
-    if (LP_T == SDNQ_F32 && d.fast) {  // wave-uniform
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = d.fastdiv(asym ? v[e] - zp : v[e]);
-    } else {
-        // (16-bit arithmetic: torch.sub(x, zero_point) rounds to the dtype before .div_(scale) does, quant_utils.py:282)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[e] = (asym ? (LP_T == SDNQ_F32 ? v[e] - zp : FT<LP_T>::round(v[e] - zp)) : v[e]) / scale;
-    }
-    if constexpr (MM == SDNQ_MM_FP8) {  // nan_to_num, clamp (+-inf fall to it), hardware conversion of four values at a time
-        float c[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            // -0.0 / scale is -0.0 and its fp8 code 0x80: the three-instruction division returns +0 there (its correction term
-            // x - scale * q0 is +0, and -0 + +0 = +0), so a zero numerator passes through (round 4, tools/fuzz_ops.py: f16 activations
-            // that underflow to -0.0; the int8 codes have no signed zero)
-            if (LP_T == SDNQ_F32 && d.fast && v[e] == 0.0f) qv[e] = v[e];
-            float q = FT<LP_T>::round(qv[e]);
-            if (q != q) q = 0.0f;
-            c[e] = fminf(fmaxf(q, -448.0f), 448.0f);
-        }
-        return make_uint2(pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]), pack4_e4m3fn_clamped(c[4], c[5], c[6], c[7]));
-    }
-    u32 w0 = 0, w1 = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        u32 byte;
-        if constexpr (MM == SDNQ_MM_I8) {
-            // x/0 -> NaN -> int8 cast gives 0 in the reference; define it explicitly
-            // asymmetric (quantize_uint_mm, quant_utils.py:277-286): (x - zero_point) / scale
-            float q;
-            if constexpr (LP_T == SDNQ_F32) {
-                q = (scale == 0.0f) ? 0.0f : __builtin_rintf(qv[e]);
-            } else {  // a 16-bit scale can underflow to 0 under a nonzero row: x / 0 = +-inf -> the clamp, 0 / 0 = NaN -> 0
-                q = __builtin_rintf(FT<LP_T>::round(qv[e]));
-                if (q != q) q = 0.0f;
-            }
-            q = fminf(fmaxf(q, -128.0f), 127.0f);
-            const int qi = (int)q;
-            isum += qi;
-            byte = (u32)qi & 0xffu;
-        } else {
-            float q = FT<LP_T>::round(qv[e]);
-            if (q != q) q = 0.0f;  // nan_to_num; +-inf fall to the clamp
-            q = fminf(fmaxf(q, -448.0f), 448.0f);
-            byte = f32_to_e4m3fn(q);
-        }
-        if (e < 4) w0 |= byte << (8 * e);
-        else w1 |= byte << (8 * (e - 4));
-    }
-    return make_uint2(w0, w1);
 }
 
 // T_ID: activation dtype; MM: SdnqMM; HAD: rotate first; NP: 512-element passes of the row held in registers

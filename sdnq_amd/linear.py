@@ -43,6 +43,9 @@ FUSED_DEQUANT_GEMM_MAX_FLOP = float(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_
 # fused 43.0 us vs 29.0 + ~8 us for dequantize + bf16 GEMM), but inside the step -- cold weights, the 13 MB float copy written and read
 # back -- a K limit of 2560 made the SDXL default-mode step SLOWER (13.63 vs 13.37 ms, same box): no limit by default
 FUSED_DEQUANT_GEMM_MAX_K = int(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_MAX_K", str(1 << 30)))
+# Round 5: the plain w8a8 Linear as ONE launch where it is built and wins (sdnq_hip_linear_w8a8_fused, csrc/gemm_aq.hip); the library's
+# own switch (SDNQ_HIP_FUSED_ROWQUANT=0) makes `..._supported` answer no, this one skips the question
+FUSED_ROWQUANT = os.environ.get("SDNQ_HIP_FUSED_ROWQUANT", "1").lower() not in {"0", "false", "no"}
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
 
 
@@ -773,6 +776,17 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
         # plain w8a8 layer: on a cache miss the row quantization and the GEMM go through ONE binding call (an eager model is
         # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers
         use_cache = cache_input and CACHE_ACTIVATIONS > 0
+        if (FUSED_ROWQUANT and had == 0 and input.is_cuda
+                and (not use_cache or (UNSHARED_FAST_PATH and self.__dict__.get("_sdnq_unshared", 0) >= UNSHARED_AFTER))):
+            # nobody else consumes this layer's quantized activation (its input is its own: to_out, to_q of the cross attention, proj_in /
+            # proj_out, ...): where the one-launch route is built and expected to win, the GEMM row-quantizes its own activation rows in
+            # LDS -- no row-quantization launch, no quantized copy in HBM, one allocation, safe under graph capture (no scratch buffer)
+            x2 = input if input.dim() == 2 else input.reshape(-1, k)
+            if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+                x2 = x2.contiguous()
+            if ops.linear_w8a8_fused_supported(mm, x2, n, input.dtype):
+                y = ops.linear_w8a8_fused(mm, x2, wq, ws, bias, input.dtype)
+                return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         if (use_cache and UNSHARED_FAST_PATH and self.__dict__.get("_sdnq_unshared", 0) >= UNSHARED_AFTER and input.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             # nobody ever used the quantized copy this layer parked (see _ActivationCache._retire): no key, no look-up, the quantized

@@ -432,6 +432,38 @@ def linear_w8a8_ws(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.T
     return out
 
 
+def linear_w8a8_fused_supported(mm: int, x2d: torch.Tensor, n: int, out_dtype: torch.dtype) -> bool:
+    """True where the ONE-launch w8a8 Linear (sdnq_hip_linear_w8a8_fused: the GEMM row-quantizes its own activation rows in LDS) is
+    built and expected to win; the answer per (dtype, M, N, K) is memoized."""
+    if x2d.dtype not in (torch.bfloat16, torch.float16) or out_dtype != x2d.dtype or not x2d.is_cuda:
+        return False
+    key = (mm, x2d.dtype, x2d.shape[0], n, x2d.shape[1])
+    r = _fused_ok.get(key)
+    if r is None:
+        r = bool(_lib.load().sdnq_hip_linear_w8a8_fused_supported(mm, float_code(x2d.dtype), float_code(out_dtype), x2d.shape[0], n, x2d.shape[1]))
+        _fused_ok[key] = r
+    return r
+
+
+_fused_ok = {}
+fused_calls = [0]  # how many Linear calls took the one-launch route (bench.py reports it per step)
+
+
+def linear_w8a8_fused(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype) -> torch.Tensor:
+    """The plain w8a8 Linear as one launch (no quantized copy of the activation is produced); bit-identical to linear_w8a8."""
+    _require_cuda(x2d, b_phys, sb, bias)
+    m, k = x2d.shape
+    n = b_phys.shape[0]
+    out = torch.empty((m, n), device=x2d.device, dtype=out_dtype)
+    if bias is not None:
+        bias = bias.contiguous()
+    fused_calls[0] += 1
+    check(_lib.load().sdnq_hip_linear_w8a8_fused(mm, x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), b_phys.data_ptr(), sb.data_ptr(),
+                                                 _ptr(bias), 0 if bias is None else float_code(bias.dtype), out.data_ptr(), float_code(out_dtype),
+                                                 n, _stream(x2d)), "linear_w8a8_fused")
+    return out
+
+
 def scaled_mm_nchw(mm: int, a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype,
                    batch: int, pixels: int) -> torch.Tensor:
     """Conv flavour of scaled_mm: rows m = (b, pixel); returns the channel-major image [batch, N, pixels] (the reference's

@@ -1,6 +1,14 @@
 mkdir -p gpurun_out/r5
-timeout 900 python -m pytest tests/test_gemm_configs.py -x -q -k "tile_configuration and (28 or 29 or 30 or 31)" 2>&1 | tail -5 > gpurun_out/r5/t28_pytest.txt
-timeout 600 python tools/tile_ab.py "1024,1280,1280;1024,1280,5120;4096,640,640;4096,640,2560" "-1,28,29,30,31" > gpurun_out/r5/t28_ab.txt 2>&1
-TUNE_SHAPES="1024x1280x1280,1024x1280x5120,4096x640x640,4096x640x2560" TUNE_CANDS="28,29,30,31" timeout 1500 python tools/tune_tiles_in_step.py sdxl_int8 20 > gpurun_out/r5/t28_tune.txt 2>&1
-timeout 900 python -m pytest tests/test_attention.py -x -q -m gpu 2>&1 | tail -3 >> gpurun_out/r5/t28_pytest.txt
-cat gpurun_out/r5/t28_*.txt
+timeout 2400 python -m pytest tests -x -q -m gpu -n 4 2>&1 | tail -8 > gpurun_out/r5/aq5_pytest_all.txt
+cat gpurun_out/r5/aq5_pytest_all.txt
+for w in sdxl_int8 sdxl_fp8; do for on in 0 1; do
+SDNQ_HIP_FUSED_ROWQUANT=$on timeout 600 python bench.py --workload $w --steps 20 --warmup 3 > gpurun_out/r5/aq5_${w}_$on.json 2> gpurun_out/r5/aq5_${w}_$on.err
+done; done
+for on in 0 1; do SDNQ_HIP_FUSED_ROWQUANT=$on timeout 600 python bench.py --launch eager --steps 20 --warmup 3 > gpurun_out/r5/aq5_eager_$on.json 2> gpurun_out/r5/aq5_eager_$on.err; done
+for f in sdxl_int8_0 sdxl_int8_1 sdxl_fp8_0 sdxl_fp8_1 eager_0 eager_1; do python - <<PY
+import json
+try:
+    d=json.loads(open("gpurun_out/r5/aq5_$f.json").read().strip().splitlines()[-1]); print("$f", d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"])
+except Exception as e: print("$f", "ERR", e)
+PY
+done
