@@ -185,6 +185,13 @@ int sdnq_hip_rowquant_lp_asym(const void* x, int x_dtype, int64_t m, int64_t k, 
 int sdnq_hip_scaled_mm_lp_uzp(const void* a, const void* b, const float* sa, const float* sb, const void* bias, const int32_t* zp_rowsum,
                               const float* zp, const float* a_zp, const float* w_colsum_scaled, int64_t zp_k, void* out, int64_t m,
                               int64_t n, int64_t k, sdnq_stream_t stream);
+/* ... of a layer with SVD factors (linear_uint8.py:57-62 on bfloat16 tensors): t [M][R] = bf16(x . svd_down) (sdnq_hip_lowrank_down) and
+ * svd_up [N][R], both bfloat16; the last bias step becomes zb = bf16(zb + bf16(f32(bias[n]) + sum_r t[m][r] svd_up[n][r])) -- the
+ * addmm of :60, one rounding -- everything else as sdnq_hip_scaled_mm_lp_uzp. */
+int sdnq_hip_scaled_mm_lp_uzp_svd(const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                  const int32_t* zp_rowsum, const float* zp, const float* a_zp, const float* w_colsum_scaled, int64_t zp_k,
+                                  const void* t, const void* svd_up, int rank, void* out, int64_t m, int64_t n, int64_t k,
+                                  sdnq_stream_t stream);
 
 /* the same scaled matmul over the STACKED weights of layers that consume one activation (to_q / to_k / to_v of an attention block),
  * each layer's columns stored in its own contiguous tensor: b [n_outs * seg_n][K], sb / bias [n_outs * seg_n], outs[i] is

@@ -572,9 +572,29 @@ def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str
             outs.append(linear_float(_c(x2d[:, g * Kg:(g + 1) * Kg], np.float32), _c(W[g * Ng:(g + 1) * Ng], np.float32), b, tag))
         return np.concatenate(outs, axis=1)
     mmd = d["quantized_matmul_dtype"]
-    assert mmd in ("int8", "uint8", "float8_e4m3fn", "fp8") and mod.svd_up is None and mod.scale_tag == "f32"
+    assert mmd in ("int8", "uint8", "float8_e4m3fn", "fp8") and mod.svd_up is None
     f = np.float32
     K_row = groups * Kg  # input.shape[-1] of the reference: the WHOLE unfolded row
+    if mod.scale_tag != "f32":
+        # 16-bit scales (dequantize_fp32=False) on the plain grouped matmul (conv_int8.py:64, 73-79): the row is quantized in the scale
+        # dtype; `cat(int_mm per group).to(dtype=input_scale.dtype).mul_(input_scale)` then addcmul(bias, ., scale) / .mul(scale) --
+        # on bfloat16 tensors every step rounds (= scaled_mm_lp per group).  float16 scales are not restated: the activation scale is
+        # promoted to float32 (linear_int8.py:20-21) but dequantize_symmetric / _asymmetric cast `acc * input_scale` to float16 before the
+        # weight scale is applied (dequantizer.py:27, 63) -- an epilogue of its own, and one that overflows
+        assert mmd != "uint8", "the grouped uint8 matmul on 16-bit scales is not restated"
+        assert mod.scale_tag == "bf16", "grouped conv matmul on float16 scales is not restated"
+        mm = "int8" if mmd == "int8" else "fp8"
+        wq, ws, zp = _mm_weights(mod, mm)
+        assert zp is None, "grouped conv with a weight zero point on 16-bit scales is not restated"
+        xq, xs, _rs = rowquant_lp(x2d, mm, mod.scale_tag)
+        wq = wq.reshape(N, Kg)
+        ws = _c(ws, f).reshape(-1)
+        for g in range(groups):
+            sl = slice(g * Ng, (g + 1) * Ng)
+            b = None if mod.bias is None else mod.bias[sl]
+            a_g, w_g = np.ascontiguousarray(xq[:, g * Kg:(g + 1) * Kg]), np.ascontiguousarray(wq[sl])
+            outs.append(round_dtype(scaled_mm_lp(mm, a_g, w_g, xs, np.ascontiguousarray(ws[sl]), b, "bf16"), tag))
+        return np.concatenate(outs, axis=1)
     if mmd == "uint8":
         # conv_uint8.py:58-79: asymmetric activations over the whole row; zero_bias from whole-row statistics, colsum over the group's own K
         if d["re_quantize_for_matmul"]:

@@ -166,10 +166,12 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
 def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) -> torch.Tensor:
     """conv_int8.py:73-79 / conv_fp8.py:56-60: the whole unfolded row is quantized with ONE scale, every group multiplies its column
     slice of the codes with its own weight rows, and the epilogue fma(acc * xs, ws, bias) is the ungrouped one."""
-    if st.svd_up is not None or st.qw.scale_dtype != torch.float32:
-        raise NotImplementedError("grouped conv with SVD or 16-bit scales: the reference's per-group matmul has no "
-                                  "valid form for them (its SVD product does not match the grouped weight)")
+    if st.svd_up is not None:
+        raise NotImplementedError("grouped conv with SVD: the reference's per-group matmul has no valid form for it (its SVD product does not "
+                                  "match the grouped weight)")
     x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
+    if st.qw.scale_dtype != torch.float32:
+        return _grouped_lp_matmul_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, mm, st, wq, ws, zp)
     if zp is not None:
         return _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, wq, ws, zp, asymmetric=False)
     if FUSED_CONV_QUANT and kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
@@ -194,6 +196,28 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
             return out.view(imgs, n, depth_out, ho, wo)
         return out.view(b, n, wo) if nd == 1 else out.view(b, n, ho, wo)
     return _folder(self, nd, b, ho, wo, depth_out)(out)
+
+
+def _grouped_lp_matmul_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, mm: int, st, wq, ws, zp) -> torch.Tensor:
+    """Grouped conv of a layer whose scale is stored in bfloat16 (dequantize_fp32=False; round 5): the whole unfolded row is quantized
+    in bfloat16 (`quantize_int_mm_input(input, dtype=scale.dtype)`, conv_int8.py:64), `cat(int_mm per group).to(bf16).mul_(input_scale)`
+    and addcmul(bias, ., scale) / .mul(scale) round once each (conv_int8.py:73-79, dequantizer.py:27, 63) -- per group exactly the
+    bfloat16 epilogue of the ungrouped scaled matmul (sdnq_hip_scaled_mm_lp).  A compatibility mode: one launch per group on contiguous
+    copies of the group's columns.  (float16 scales / zero-point terms: sdnq_amd.support names them unsupported.)"""
+    if st.qw.scale_dtype != torch.bfloat16 or zp is not None or x4.dtype != torch.bfloat16:
+        raise NotImplementedError("grouped conv matmul with 16-bit scales is built for bfloat16 layers without a weight zero point")
+    x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
+    xq, xs, _rowsum, _xrot = ops.rowquant_lp(x2d, mm, 0)
+    kg, ng = _group_slices(self, xq.shape[1])
+    if kg % 16 or ng % 8:
+        raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
+    n = self.sdnq_dequantizer.out_features
+    wq2, ws1 = wq.reshape(n, kg), ws.reshape(-1)
+    outs = []
+    for g in range(int(self.groups)):
+        sl = slice(g * ng, (g + 1) * ng)
+        outs.append(ops.scaled_mm_lp(mm, xq[:, g * kg:(g + 1) * kg].contiguous(), wq2[sl], xs, ws1[sl], None if self.bias is None else self.bias[sl]))
+    return _folder(self, nd, b, ho, wo, depth_out)(torch.cat(outs, dim=1))
 
 
 def _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, wq, ws, zp, asymmetric: bool, wcs=None):

@@ -2256,6 +2256,24 @@ extern "C" int sdnq_hip_scaled_mm_lp_uzp(const void* a, const void* b, const flo
     return launch_lp<SDNQ_MM_I8, EPI_LOWRANK>(p, (hipStream_t)stream);
 }
 
+extern "C" int sdnq_hip_scaled_mm_lp_uzp_svd(const void* a, const void* b, const float* sa, const float* sb, const void* bias,
+                                             const int32_t* zp_rowsum, const float* zp, const float* a_zp, const float* w_colsum_scaled,
+                                             int64_t zp_k, const void* t, const void* svd_up, int rank, void* out, int64_t m, int64_t n,
+                                             int64_t k, sdnq_stream_t stream) {
+    int st = check_common(SDNQ_MM_I8, a, b, sa, sb, out, SDNQ_BF16, m, n, k);
+    if (st != SDNQ_OK) return st;
+    if (!a_zp || !w_colsum_scaled || !t || !svd_up) return SDNQ_ERR_NULL;
+    if ((zp_rowsum == nullptr) != (zp == nullptr)) return SDNQ_ERR_NULL;
+    if (rank <= 0) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)t % 16) || ((uintptr_t)svd_up % 16)) return SDNQ_ERR_ALIGN;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.lr_t = t; p.lr_up = svd_up; p.rank = rank;
+    p.zp_rowsum = zp_rowsum; p.zp = zp; p.a_zp = a_zp; p.wcs = w_colsum_scaled; p.zp_k = zp_k;
+    p.M = m; p.N = n; p.K = k; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = SDNQ_BF16;
+    return launch_lp<SDNQ_MM_I8, EPI_LOWRANK>(p, (hipStream_t)stream);
+}
+
 extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,
                                      int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
                                      int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {

@@ -398,6 +398,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NG >= 16 |
                 *(uint2*)((uint16_t*)xrot + m * K + eoff + (int64_t)(g0 + g) * 256) = make_uint2(pk[g][0], pk[g][1]);
         }
     }
+#ifndef SDNQ_HAD256_NO_LEAN  // (A/B builds)
+    if (MM == SDNQ_MM_I8 && rd.fast) {  // wave-uniform
+        // the lean codes of the plain row quantizer (quant8_fast: packed correctly rounded division, rint + int8 cast as one packed add,
+        // byte permutes, v_dot4 row sums -- ~4 instructions per element where the general loop below spends ~10; bit-identical by
+        // construction).  Round 4 built this as a second path INSIDE the general loop and spilled; as its own loop nothing does.
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g0 + g < ngroups && row_ok) {
+                // (opaque copies: left visible, the unpacking of all NG groups is hoisted above the branch as common to both loops --
+                //  64 more live registers; the 16-group instantiation then spilled 28)
+                u32 p0 = pk[g][0], p1 = pk[g][1];
+                asm volatile("" : "+v"(p0), "+v"(p1));
+                const pv2f a = {unpk<T_ID>(p0, 0), unpk<T_ID>(p0, 1)}, b = {unpk<T_ID>(p1, 0), unpk<T_ID>(p1, 1)};
+                const u32 w = pack4_rne_i8(fastdiv2(a, rd), fastdiv2(b, rd));
+                isum = __builtin_amdgcn_sdot4((int)w, 0x01010101, isum, false);
+                store_codes4(qrow + (int64_t)(g0 + g) * 256, w);
+            }
+        }
+    } else
+#endif
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g0 + g < ngroups && row_ok) {

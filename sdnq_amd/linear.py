@@ -915,14 +915,16 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
 def _uint8_lp_matmul_forward(self, input: torch.Tensor, st: _State) -> torch.Tensor:
     """The uint8 matmul of a layer whose scale / zero point are stored in bfloat16 (dequantize_fp32=False): the chain of
     linear_uint8.py:15-23, 57-102 on bfloat16 tensors, every step rounded once (sdnq_hip_rowquant_lp_asym, sdnq_hip_scaled_mm_lp_uzp).
-    A compatibility mode like `_lp_matmul_forward`: plain launches, no activation cache.  (sdnq_amd.support keeps float16 scales, SVD
-    factors and conv layers of this mode on the forward they came with.)"""
+    A compatibility mode like `_lp_matmul_forward`: plain launches, no activation cache.  (sdnq_amd.support keeps float16 scales and
+    conv layers of this mode on the forward they came with.)"""
     dq = self.sdnq_dequantizer
     sdt = st.qw.scale_dtype
     k, n = dq.in_features, dq.out_features
-    if sdt != torch.bfloat16 or input.dtype != sdt or st.svd_up is not None:
-        raise NotImplementedError("the uint8 matmul with 16-bit scales is built for bfloat16 layers without SVD factors "
-                                  f"(scale dtype {sdt}, activations {input.dtype})")
+    if sdt != torch.bfloat16 or input.dtype != sdt:
+        raise NotImplementedError(f"the uint8 matmul with 16-bit scales is built for bfloat16 layers (scale dtype {sdt}, activations {input.dtype})")
+    has_svd = st.svd_up is not None
+    if has_svd and st.svd_up.dtype != sdt:
+        raise NotImplementedError(f"the uint8 matmul with bfloat16 scales needs bfloat16 SVD factors (got {st.svd_up.dtype})")
     wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)  # re-quantization / zero point rounded in the scale dtype
     wcs = st.mm_wcs
     if wcs is None:  # sum(weight, int32).to(bf16).mul_(scale): two bfloat16 roundings, static per layer (linear_uint8.py:63)
@@ -933,8 +935,11 @@ def _uint8_lp_matmul_forward(self, input: torch.Tensor, st: _State) -> torch.Ten
     x2 = input.reshape(-1, k)
     if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
         x2 = x2.contiguous()
-    xq, xs, xzp, rowsum = ops.rowquant_lp_asym(x2, had, want_rowsum=zp is not None)
-    y = ops.scaled_mm_lp_uzp(xq, wq, xs, ws, _attr(self, "bias"), rowsum, zp, xzp, wcs)
+    xq, xs, xzp, rowsum, xrot = ops.rowquant_lp_asym(x2, had, want_rowsum=zp is not None, want_xrot=has_svd)
+    # SVD layers (round 5; linear_uint8.py:57-62 on bfloat16 tensors): t = bf16(x . svd_down) on the ROTATED activation of a Hadamard layer,
+    # the addmm with svd_up inside the epilogue, where it is the 2-D bias the zero_bias chain ends with
+    t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
+    y = ops.scaled_mm_lp_uzp(xq, wq, xs, ws, _attr(self, "bias"), rowsum, zp, xzp, wcs, t=t, svd_up=st.svd_up if has_svd else None)
     return y.view(*input.shape[:-1], n)
 
 

@@ -215,9 +215,10 @@ def rowquant_lp(x2d: torch.Tensor, mm: int, hadamard_group: int = 0, want_rowsum
     return xq, xs, rowsum, xrot
 
 
-def rowquant_lp_asym(x2d: torch.Tensor, hadamard_group: int = 0, want_rowsum: bool = False):
+def rowquant_lp_asym(x2d: torch.Tensor, hadamard_group: int = 0, want_rowsum: bool = False, want_xrot: bool = False):
     """sdnq_hip_rowquant_lp_asym: quantize_uint_mm_input in x2d's own 16-bit dtype (the uint8 matmul of dequantize_fp32=False layers).
-    Returns (xq int8, xs [M,1] f32, xzp [M] f32 -- both holding dtype-representable values --, rowsum | None)."""
+    Returns (xq int8, xs [M,1] f32, xzp [M] f32 -- both holding dtype-representable values --, rowsum | None, xrot | None: the rotated
+    activation of a Hadamard layer, for its SVD product)."""
     _require_cuda(x2d)
     assert x2d.ndim == 2 and x2d.stride(1) == 1 and x2d.dtype in (torch.bfloat16, torch.float16)
     m, k = x2d.shape
@@ -225,15 +226,17 @@ def rowquant_lp_asym(x2d: torch.Tensor, hadamard_group: int = 0, want_rowsum: bo
     xs = torch.empty((m, 1), device=x2d.device, dtype=torch.float32)
     xzp = torch.empty((m,), device=x2d.device, dtype=torch.float32)
     rowsum = torch.empty((m,), device=x2d.device, dtype=torch.int32) if want_rowsum else None
+    xrot = torch.empty((m, k), device=x2d.device, dtype=x2d.dtype) if (want_xrot and hadamard_group) else None
     check(_lib.load().sdnq_hip_rowquant_lp_asym(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), hadamard_group, xq.data_ptr(),
-                                                xs.data_ptr(), xzp.data_ptr(), _ptr(rowsum), None, _stream(x2d)), "rowquant_lp_asym")
-    return xq, xs, xzp, rowsum
+                                                xs.data_ptr(), xzp.data_ptr(), _ptr(rowsum), _ptr(xrot), _stream(x2d)), "rowquant_lp_asym")
+    return xq, xs, xzp, rowsum, xrot
 
 
 def scaled_mm_lp_uzp(a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, rowsum, zp, a_zp: torch.Tensor,
-                     w_colsum_scaled: torch.Tensor, zp_k: int = 0) -> torch.Tensor:
-    """sdnq_hip_scaled_mm_lp_uzp: the uint8 matmul's epilogue on bfloat16 tensors (see the header).  Returns [M,N] bf16."""
-    _require_cuda(a, b_phys, sa, sb, bias, rowsum, zp, a_zp, w_colsum_scaled)
+                     w_colsum_scaled: torch.Tensor, zp_k: int = 0, t=None, svd_up=None) -> torch.Tensor:
+    """sdnq_hip_scaled_mm_lp_uzp[_svd]: the uint8 matmul's epilogue on bfloat16 tensors (see the header); t [M,R] / svd_up [N,R] bf16 add the
+    low-rank product to the bias (layers with SVD factors).  Returns [M,N] bf16."""
+    _require_cuda(a, b_phys, sa, sb, bias, rowsum, zp, a_zp, w_colsum_scaled, t, svd_up)
     m, k = a.shape
     n = b_phys.shape[0]
     if bias is not None and bias.dtype != torch.bfloat16:
@@ -241,6 +244,14 @@ def scaled_mm_lp_uzp(a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb
     out = torch.empty((m, n), device=a.device, dtype=torch.bfloat16)
     f32 = lambda t: None if t is None else t.reshape(-1).to(torch.float32).contiguous()  # noqa: E731
     sa_, sb_, zp_, azp_, wcs_ = f32(sa), f32(sb), f32(zp), f32(a_zp), f32(w_colsum_scaled)
+    if t is not None:
+        if t.dtype != torch.bfloat16 or svd_up.dtype != torch.bfloat16:
+            raise _lib.SdnqHipError("scaled_mm_lp_uzp: low-rank factors must be bfloat16")
+        t, svd_up = t.contiguous(), svd_up.contiguous()
+        check(_lib.load().sdnq_hip_scaled_mm_lp_uzp_svd(a.data_ptr(), b_phys.data_ptr(), sa_.data_ptr(), sb_.data_ptr(), _ptr(None if bias is None else bias.contiguous()),
+                                                        _ptr(rowsum), _ptr(zp_), azp_.data_ptr(), wcs_.data_ptr(), zp_k, t.data_ptr(), svd_up.data_ptr(),
+                                                        t.shape[1], out.data_ptr(), m, n, k, _stream(a)), "scaled_mm_lp_uzp_svd")
+        return out
     check(_lib.load().sdnq_hip_scaled_mm_lp_uzp(a.data_ptr(), b_phys.data_ptr(), sa_.data_ptr(), sb_.data_ptr(), _ptr(None if bias is None else bias.contiguous()),
                                                 _ptr(rowsum), _ptr(zp_), azp_.data_ptr(), wcs_.data_ptr(), zp_k, out.data_ptr(), m, n, k, _stream(a)),
           "scaled_mm_lp_uzp")

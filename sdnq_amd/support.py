@@ -54,8 +54,6 @@ def unsupported_reason(module) -> str | None:
                     "from K = 512 on")
         if cls not in linear_types:
             return "the uint8 conv matmul with 16-bit scales (dequantize_fp32=False) is not built"
-        if getattr(module, "svd_up", None) is not None:
-            return "the uint8 matmul with bfloat16 scales and SVD factors is not built"
     if cls in linear_types:
         return None
     # ---- conv layers
@@ -86,8 +84,10 @@ def unsupported_reason(module) -> str | None:
                 return f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {k_total // groups}, {n // groups})"
             if getattr(module, "svd_up", None) is not None:
                 return "grouped conv with SVD: the reference's per-group matmul has no valid form for it (its SVD product does not match the grouped weight)"
-            if lp:
-                return "grouped conv matmul with 16-bit scales is not built"
+            if lp and (sdt != torch.bfloat16 or uint8_mm
+                       or (getattr(module, "zero_point", None) is not None and not dq.re_quantize_for_matmul)):
+                return ("grouped conv matmul with 16-bit scales is built for bfloat16 scales on the int8 / fp8 matmul without a weight zero point (float16: the reference "
+                        "casts acc * input_scale to float16 before the weight scale, dequantizer.py:27, 63 -- an epilogue of its own)")
     return None
 
 

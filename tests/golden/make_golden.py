@@ -238,6 +238,10 @@ CASES = [
     dict(name="uint8_svd32_int8mm_qmm_bf16_lpscale", K=256, N=128, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True,
                   dequantize_fp32=False)),
+    # round 5: the uint8 matmul on bfloat16 scales WITH SVD factors (linear_uint8.py:57-62: the low-rank product lands in the 2-D bias the
+    # bfloat16 zero_bias chain ends with)
+    dict(name="uint8_svd32_uint8mm_qmm_bf16_lpscale", K=256, N=128, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="fp8_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
 ]
@@ -369,6 +373,11 @@ CONV_CASES = [
     dict(name="conv1d_g4_uint4_noqmm_f32", nd=1, cin=64, cout=32, k=3, conv=dict(padding=1, groups=4), xs=[(2, 20)], dtype="f32",
          cfg=dict(weights_dtype="uint4")),
     # grouped convs whose epilogue carries zero-point terms (round 4): unsigned weights through the int8 matmul (conv_int8.py:45-50, 65-79)
+    # round 5: grouped conv on 16-bit scales (conv_int8.py:73-79 with `.to(dtype=input_scale.dtype).mul_(input_scale)` and the addcmul of
+    # dequantize_asymmetric / the mul of dequantize_symmetric on bfloat16 tensors.  float16 scales are NOT built: dequantize_symmetric / _asymmetric
+    # cast the float32 `acc * input_scale` to float16 first, dequantizer.py:27, 63 -- a different epilogue from every other path)
+    dict(name="conv2d_g2_int8_qmm_bf16_lpscale", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True, dequantize_fp32=False)),
     # and the uint8 matmul (conv_uint8.py:58-79) -- whole-row statistics, per-group matmuls
     dict(name="conv2d_g2_uint8_int8mm_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),

@@ -281,8 +281,8 @@ def test_accelerate_reads_foreign_records_of_grouped_convs_and_options_leave_for
 
 
 def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
-    """The uint8 matmul of dequantize_fp32=False layers: built for bfloat16 Linear layers without SVD factors (round 4), named
-    as unsupported -- with the reason -- for float16 scales, conv layers and SVD layers."""
+    """The uint8 matmul of dequantize_fp32=False layers: built for bfloat16 Linear layers (round 4; with SVD factors since round 5),
+    named as unsupported -- with the reason -- for float16 scales and conv layers."""
     import sdnq_amd
     from sdnq_amd import support
 
@@ -298,7 +298,24 @@ def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
     assert support.unsupported_reason(layer(torch.bfloat16, weights_dtype="uint4", quantized_matmul_dtype="uint8", group_size=32)) is None
     assert "float16" in support.unsupported_reason(layer(torch.float16))
     assert "conv" in support.unsupported_reason(layer(torch.bfloat16, conv=True))
-    assert "SVD" in support.unsupported_reason(layer(torch.bfloat16, use_svd=True, svd_rank=16))
+    assert support.unsupported_reason(layer(torch.bfloat16, use_svd=True, svd_rank=16)) is None
+
+
+def test_support_predicate_on_grouped_convs_with_16_bit_scales():
+    """Grouped conv matmul of dequantize_fp32=False layers (round 5): built for bfloat16 scales without a weight zero point; float16
+    scales (the reference rounds acc * input_scale to float16 first) and unsigned weights keep their reason."""
+    import sdnq_amd
+    from sdnq_amd import support
+
+    def layer(dtype, **kw):
+        torch.manual_seed(2)
+        cfg = dict(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True, dequantize_fp32=False)
+        cfg.update(kw)
+        return sdnq_amd.sdnq_quantize_layer(torch.nn.Conv2d(64, 64, 3, padding=1, groups=2).to(dtype), sdnq_amd.SDNQConfig(**cfg))[0]
+
+    assert support.unsupported_reason(layer(torch.bfloat16)) is None
+    assert "float16" in support.unsupported_reason(layer(torch.float16))
+    assert "zero point" in support.unsupported_reason(layer(torch.bfloat16, weights_dtype="uint8", quantized_matmul_dtype="int8"))
 
 
 def test_peer_arena_ring_steps_over_live_ranges_and_recycles_dead_ones():
