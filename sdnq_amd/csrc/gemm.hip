@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 #undef TS
 #undef LUT_EXPAND
     } else if constexpr (LD == LD_OV) {
-        static_assert(!is_w8a16<MM> && MS == 32, "overlapped ring: the quantized / plain float matmuls on 32x32 MFMA tiles");
+        static_assert(MS == 32, "overlapped ring: 32x32 MFMA tiles");
         typedef typename FragOps<MM>::frag_t frag_t;
         typedef typename FragOps<MM>::fragb_t fragb_t;
         constexpr int KS = BK / MT::KB, NM = KS * TN * TM;
@@ -2312,6 +2312,9 @@ int launch_tiles_w8(const GemmParams& p, hipStream_t s) {
     const bool fit128 = p.units == nullptr || (p.unit_n % 128) == 0;
     if (force == 0 && fit128) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 128>(p, s);
     if (force == 2 && fit128) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+    // (round 5: the overlapped ring LD_OV on this kernel's 64x128 tile -- DMA issue and the next stage's fragment reads dealt out between
+    //  the MFMAs and conversions, 3 / 4 ring slots -- compiled, bit-identical, and judged on the step: -0.09 ... +0.11 ms per problem, all
+    //  problems together +0.03 / +0.11 ms of 12.67 (profiles/r05_fused_rowquant_gemm.txt item 9); not instantiated)
     if (force == 3 || (force < 0 && p.M <= 64) || !fit128) return launch_one<MM, OUT_T, EPI, 64, 64, 64, 32, 4, LD_DMA, 128>(p, s);
     // (round 3 re-sweep on the buffer-load loaders, profiles/r03_w8a16_sweep.txt: 160-240 tiles of 128x128 lose to 64x128 -- 4096 x 640 x 640
     //  12.7 vs 11.4 us, 1024 x 3840 x 1280 20.2 vs 19.2 -- from 480 tiles up they win: 4096 x 1920 x 640 17.2 vs 21.0)

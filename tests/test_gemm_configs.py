@@ -148,7 +148,7 @@ def test_fused_dequant_gemm_equals_dequant_then_linear(wdt, dt, gpu_device, tile
             tile_override(-1)
             want = mod(x)
             L.FUSED_DEQUANT_GEMM = True
-            for tile in (-1, 0, 1, 2, 3):
+            for tile in (-1, 0, 1, 2, 3, 4):
                 tile_override(tile)
                 got = mod(x)
                 assert got.shape == want.shape
