@@ -12,7 +12,7 @@ from .kernel_wrappers import fp8_scaled_mm_func, int_scaled_mm_func
 from .layers import SDNQLayer, SDNQLinear, get_sdnq_wrapper_class
 from .linear import invalidate
 from . import torch_ops  # registers the sdnq_hip::* operators with torch.library
-from .loader import accelerate, apply_sdnq_options_to_model, fuse_projections, link_layers, link_projections, load_sdnq_model, post_process_model
+from .loader import accelerate, apply_sdnq_options_to_model, fuse_projections, link_layers, link_projections, load_sdnq_model, post_process_model, save_sdnq_model
 from .quantizer import (QuantizationMethod, SDNQConfig, apply_sdnq_to_module, sdnq_post_load_quant, sdnq_quantize_layer,
                         sdnq_quantize_layer_weight)
 
@@ -20,7 +20,7 @@ __version__ = sdnq_version
 
 __all__ = [
     "QuantizationMethod", "SDNQConfig", "SDNQDequantizer", "SDNQLayer", "SDNQLinear", "accelerate", "fuse_projections", "link_layers", "link_projections",
-    "apply_sdnq_options_to_model", "apply_sdnq_to_module", "load_sdnq_model", "post_process_model", "dtype_dict", "fp8_scaled_mm_func", "get_forward_func",
+    "apply_sdnq_options_to_model", "apply_sdnq_to_module", "load_sdnq_model", "save_sdnq_model", "post_process_model", "dtype_dict", "fp8_scaled_mm_func", "get_forward_func",
     "get_sdnq_wrapper_class", "int_scaled_mm_func", "invalidate", "sdnq_post_load_quant", "sdnq_quantize_layer",
     "sdnq_quantize_layer_weight",
 ]

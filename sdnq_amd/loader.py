@@ -449,6 +449,66 @@ def load_sdnq_model(model_path: str, model_cls=None, file_name: str | None = Non
 
 
 @torch.no_grad()
+def save_sdnq_model(model: torch.nn.Module, model_path: str, max_shard_size: str = "5GB", is_pipeline: bool = False, sdnq_config=None) -> None:
+    """Write `model` in the reference's on-disk format (reference loader.py:46-79, same arguments): the tensors as safetensors --
+    through the model's own `save_pretrained` when it has one (diffusers / transformers models), else `model.safetensors` + the model's
+    `config` (a mapping) as `config.json` -- and `quantization_config.json` (the given `sdnq_config`, else the model's own; for a pipeline
+    one per quantized sub-module).  What is stored is the LOGICAL tensor of every layer as a contiguous array -- the direct-matmul weight
+    as [K, N], SVD factors as [R, N] / [K, R]: the layout `save_pretrained` leaves behind in the reference and `post_process_model`
+    (here and there) re-lays out at load time -- so the checkpoint loads in the reference and here alike.  The model is not modified."""
+    import json
+    from .quantizer import SDNQConfig
+    os.makedirs(model_path, exist_ok=True)
+
+    def write_config(cfg, path):  # diffusers' QuantizationConfigMixin.to_json_file: json.dumps(to_dict(), indent=2, sort_keys=True) + "\n"
+        with open(path, "w", encoding="utf-8") as f:
+            f.write(json.dumps(cfg.to_dict(), indent=2, sort_keys=True) + "\n")
+
+    def config_of(module):
+        q = getattr(module, "quantization_config", None)
+        if isinstance(q, SDNQConfig):
+            return q
+        q = getattr(getattr(module, "config", None), "quantization_config", None)
+        return q if isinstance(q, SDNQConfig) else None
+
+    if hasattr(model, "save_pretrained"):
+        # safetensors refuses strided tensors: the layers' parameters are presented contiguous for the duration of the save
+        swapped = []
+        try:
+            for module in model.modules() if isinstance(model, torch.nn.Module) else []:
+                if getattr(module, "sdnq_dequantizer", None) is None:
+                    continue
+                for name in ("weight", "svd_up", "svd_down"):
+                    t = getattr(module, name, None)
+                    if isinstance(t, torch.nn.Parameter) and not t.is_contiguous():
+                        swapped.append((module, name, t))
+                        setattr(module, name, torch.nn.Parameter(t.contiguous(), requires_grad=False))
+            model.save_pretrained(model_path, max_shard_size=max_shard_size)
+        finally:
+            for module, name, t in swapped:
+                setattr(module, name, t)
+    else:
+        from safetensors.torch import save_file
+        save_file({k: v.detach().contiguous() for k, v in model.state_dict().items()}, os.path.join(model_path, "model.safetensors"))
+        cfg = getattr(model, "config", None)
+        if isinstance(cfg, dict) or hasattr(cfg, "items"):
+            with open(os.path.join(model_path, "config.json"), "w", encoding="utf-8") as f:
+                json.dump({k: v for k, v in dict(cfg).items() if k != "quantization_config"}, f, indent=1)
+    qpath = os.path.join(model_path, "quantization_config.json")
+    if sdnq_config is not None:
+        write_config(sdnq_config, qpath)
+    if is_pipeline:
+        names = [n for n in getattr(model, "_internal_dict", {}).keys() if not n.startswith("_")] if hasattr(model, "_internal_dict") else \
+            [n for n, _ in model.named_children()]
+        for n in sorted(set(names)):
+            sub = getattr(model, n, None)
+            if isinstance(sub, torch.nn.Module) and config_of(sub) is not None and os.path.isdir(os.path.join(model_path, n)):
+                write_config(config_of(sub), os.path.join(model_path, n, "quantization_config.json"))
+    elif sdnq_config is None and config_of(model) is not None:
+        write_config(config_of(model), qpath)
+
+
+@torch.no_grad()
 def apply_sdnq_options_to_model(model: torch.nn.Module, dtype: torch.dtype | None = None, dequantize_fp32: bool | None = None,
                                 use_quantized_matmul: bool | None = None, quantized_matmul_dtype: str | None = None):
     skipped_foreign = []

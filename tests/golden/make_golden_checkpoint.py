@@ -21,7 +21,7 @@ import make_golden as G  # noqa: E402  (environment switches of the reference + 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "checkpoint_tiny")
+OUT = sys.argv[1] if (len(sys.argv) > 1 and not sys.argv[1].startswith("--")) else os.path.join(HERE, "checkpoint_tiny")
 
 
 class TinyNet(torch.nn.Module):
@@ -92,5 +92,23 @@ def main():
     print("wrote", OUT, sorted(os.listdir(OUT)), {k: v for k, v in meta.items()})
 
 
+def verify_foreign(path):
+    """`--verify <dir>`: a checkpoint written by ANOTHER writer (sdnq_amd.save_sdnq_model) loads in the reference's load_sdnq_model and
+    the loaded model reproduces the stored layer outputs of the fixture (io.npz of checkpoint_tiny) bit for bit."""
+    import sdnq  # noqa: F401  (imported by make_golden above)
+    from sdnq.loader import load_sdnq_model
+    loaded = load_sdnq_model(path, model_cls=TinyNet, device="cpu")
+    io = np.load(os.path.join(HERE, "checkpoint_tiny", "io.npz"))
+    x = torch.from_numpy(io["x"].copy()).view(torch.bfloat16)
+    with torch.no_grad():
+        y = loaded(x)
+    got = y.detach().contiguous().view(torch.uint16).numpy()
+    assert np.array_equal(got, io["y"]), int((got != io["y"]).sum())
+    print("reference loaded", path, "and reproduced the fixture's outputs")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[1] == "--verify":
+        verify_foreign(sys.argv[2])
+    else:
+        main()

@@ -417,6 +417,49 @@ class TinyNet(torch.nn.Module):
         return self.head(h)
 
 
+def test_save_sdnq_model_writes_what_the_reference_wrote(tmp_path):
+    """sdnq_amd.save_sdnq_model (reference loader.py:46-79): the reference-written checkpoint, loaded here and saved again, is the same
+    checkpoint -- every tensor bit for bit under the same key (the direct-matmul weight back in its contiguous logical [K, N] form), the
+    same quantization_config.json content -- through both writers: the built-in one and a model's own `save_pretrained`."""
+    import json
+    import os
+    from safetensors.torch import load_file, save_file
+    import sdnq_amd
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoint_tiny")
+    model = sdnq_amd.load_sdnq_model(src, model_cls=TinyNet, device="cpu")
+    before = {k: (v.stride(), v.data_ptr()) for k, v in model.state_dict().items()}
+    want = load_file(os.path.join(src, "model.safetensors"))
+    want_cfg = json.load(open(os.path.join(src, "quantization_config.json")))
+
+    def check(path):
+        got = load_file(os.path.join(path, "model.safetensors"))
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, k
+            assert torch.equal(got[k].view(torch.uint8), want[k].view(torch.uint8)), k
+        cfg = json.load(open(os.path.join(path, "quantization_config.json")))
+        for k, v in want_cfg.items():
+            if k not in ("quantization_device", "return_device", "non_blocking", "add_skip_keys", "modules_to_not_convert"):
+                assert cfg[k] == v, (k, cfg[k], v)
+        assert set(want_cfg["modules_to_not_convert"]) <= set(cfg["modules_to_not_convert"])
+
+    sdnq_amd.save_sdnq_model(model, str(tmp_path / "a"))
+    check(str(tmp_path / "a"))
+    # a model with its own save_pretrained (what diffusers' ModelMixin does: the state_dict as it is -- safetensors refuses strided tensors)
+    def save_pretrained(path, max_shard_size=None):
+        os.makedirs(path, exist_ok=True)
+        save_file(dict(model.state_dict()), os.path.join(path, "model.safetensors"))
+    model.save_pretrained = save_pretrained
+    sdnq_amd.save_sdnq_model(model, str(tmp_path / "b"))
+    check(str(tmp_path / "b"))
+    # the model itself is untouched: same storage, same strides (the matmul operand stays in its physical [N][K] layout)
+    assert {k: (v.stride(), v.data_ptr()) for k, v in model.state_dict().items()} == before
+    # ... and what was written loads again
+    again = sdnq_amd.load_sdnq_model(str(tmp_path / "a"), model_cls=TinyNet, device="cpu")
+    for (k, a), (_, b) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert a.stride() == b.stride() and a.dtype == b.dtype and torch.equal(a, b), k
+
+
 def test_load_sdnq_model_rebuilds_the_layers_of_a_reference_checkpoint():
     """sdnq_amd.load_sdnq_model on the checkpoint the REFERENCE wrote (tests/golden/make_golden_checkpoint.py): every layer's record
     equals what the reference's own loader derived (stored next to the checkpoint), the per-module overrides of the config are

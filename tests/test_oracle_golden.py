@@ -233,3 +233,22 @@ def test_checkpoint_fixture_is_what_the_reference_writes(tmp_path):
         assert open(os.path.join(out, f), "rb").read() == open(os.path.join(GOLD, "checkpoint_tiny", f), "rb").read(), f
     a, b = np.load(os.path.join(out, "io.npz")), np.load(os.path.join(GOLD, "checkpoint_tiny", "io.npz"))
     assert sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k], b[k]) for k in a.files)
+
+
+def test_reference_loads_what_save_sdnq_model_wrote(tmp_path):
+    """Build container only: a checkpoint written by sdnq_amd.save_sdnq_model (from the model sdnq_amd.load_sdnq_model built out of the
+    fixture) is read by the REFERENCE's load_sdnq_model, and the reference's forward on it reproduces the fixture's outputs bit for bit."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src/sdnq"):
+        pytest.skip("the reference is not present on this box")
+    import json
+    import sdnq_amd
+    from tests.test_host_logic import TinyNet
+    src = os.path.join(GOLD, "checkpoint_tiny")
+    model = sdnq_amd.load_sdnq_model(src, model_cls=TinyNet, device="cpu")
+    model.config = json.load(open(os.path.join(src, "config.json")))  # (the constructor arguments, as diffusers' save_pretrained writes them)
+    out = str(tmp_path / "ours")
+    sdnq_amd.save_sdnq_model(model, out)
+    r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden_checkpoint.py"), "--verify", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "reproduced" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
