@@ -888,7 +888,7 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     if m == 0 or (small_batch_branch and m < 32):
         return _float_forward(self, input, st)
     if st.qw.scale_dtype != torch.float32:
-        return _uint8_lp_matmul_forward(self, input, st)
+        return _uint8_lp_matmul_forward(self, input, st, conv_form=conv_form)
     wq, ws, zp = _prepare_mm_weights(self, st, ops.MM_I8, asymmetric=True)
     wcs = st.mm_wcs
     if wcs is None:  # f32(sum_k wq[n][k]) * ws[n]: static per layer (linear_uint8.py:63 computes it every call)
@@ -912,11 +912,13 @@ def _uint8_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = 
     return y.view(*input.shape[:-1], n)
 
 
-def _uint8_lp_matmul_forward(self, input: torch.Tensor, st: _State) -> torch.Tensor:
+def _uint8_lp_matmul_forward(self, input: torch.Tensor, st: _State, conv_form: bool = False) -> torch.Tensor:
     """The uint8 matmul of a layer whose scale / zero point are stored in bfloat16 (dequantize_fp32=False): the chain of
     linear_uint8.py:15-23, 57-102 on bfloat16 tensors, every step rounded once (sdnq_hip_rowquant_lp_asym, sdnq_hip_scaled_mm_lp_uzp).
-    A compatibility mode like `_lp_matmul_forward`: plain launches, no activation cache.  (sdnq_amd.support keeps float16 scales and
-    conv layers of this mode on the forward they came with.)"""
+    A compatibility mode like `_lp_matmul_forward`: plain launches, no activation cache.  conv_form: the conv forwards build the
+    K * xzp * wzp term as bf16(bf16(xzp * K) * wzp) plus a plain add (conv_uint8.py:66: `input_zero_point.mul_(K)` in place) where the
+    Linear forward has one fused multiply-add (linear_uint8.py:66).  (sdnq_amd.support keeps float16 scales, grouped convs and conv
+    layers with SVD factors of this mode on the forward they came with.)"""
     dq = self.sdnq_dequantizer
     sdt = st.qw.scale_dtype
     k, n = dq.in_features, dq.out_features
@@ -939,7 +941,8 @@ def _uint8_lp_matmul_forward(self, input: torch.Tensor, st: _State) -> torch.Ten
     # SVD layers (round 5; linear_uint8.py:57-62 on bfloat16 tensors): t = bf16(x . svd_down) on the ROTATED activation of a Hadamard layer,
     # the addmm with svd_up inside the epilogue, where it is the 2-D bias the zero_bias chain ends with
     t = ops.lowrank_down(xrot if xrot is not None else x2, st.svd_down) if has_svd else None
-    y = ops.scaled_mm_lp_uzp(xq, wq, xs, ws, _attr(self, "bias"), rowsum, zp, xzp, wcs, t=t, svd_up=st.svd_up if has_svd else None)
+    y = ops.scaled_mm_lp_uzp(xq, wq, xs, ws, _attr(self, "bias"), rowsum, zp, xzp, wcs, zp_k=-k if conv_form else 0, t=t,
+                             svd_up=st.svd_up if has_svd else None)
     return y.view(*input.shape[:-1], n)
 
 

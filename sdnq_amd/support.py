@@ -52,8 +52,8 @@ def unsupported_reason(module) -> str | None:
         if sdt != torch.bfloat16:
             return ("the uint8 matmul with float16 scales is not built: the reference's float16 column sums (linear_uint8.py:63) overflow "
                     "from K = 512 on")
-        if cls not in linear_types:
-            return "the uint8 conv matmul with 16-bit scales (dequantize_fp32=False) is not built"
+        if cls not in linear_types and int(getattr(module, "groups", 1)) != 1:
+            return "the grouped uint8 conv matmul with 16-bit scales (dequantize_fp32=False) is not built"
     if cls in linear_types:
         return None
     # ---- conv layers

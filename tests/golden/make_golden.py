@@ -359,6 +359,9 @@ CONV_CASES = [
     # dequantize_fp32=False on conv layers: scales in the model dtype (quantizer.py:147-156)
     dict(name="conv2d_int8_qmm_bf16_lpscale", nd=2, cin=32, cout=64, k=3, conv=dict(padding=1), xs=[(2, 8, 8)], dtype="bf16",
          cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True, dequantize_fp32=False)),
+    # round 5: the uint8 conv matmul on bfloat16 scales (conv_uint8.py:58-68 on bfloat16 tensors; its K * xzp * wzp term in the conv order)
+    dict(name="conv2d_uint8_uint8mm_qmm_bf16_lpscale", nd=2, cin=32, cout=48, k=3, conv=dict(padding=1), xs=[(2, 8, 8)], dtype="bf16",
+         cfg=dict(weights_dtype="uint8", use_quantized_matmul_conv=True, dequantize_fp32=False)),
     dict(name="conv2d_uint4_noqmm_f16_lpscale", nd=2, cin=32, cout=32, k=3, conv=dict(padding=1), xs=[(1, 6, 6)], dtype="f16",
          cfg=dict(weights_dtype="uint4", dequantize_fp32=False)),
     # grouped convs (conv_int8.py:73-79, conv_fp8.py:56-60; the float forward is F.conv2d(..., groups))

@@ -282,7 +282,7 @@ def test_accelerate_reads_foreign_records_of_grouped_convs_and_options_leave_for
 
 def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
     """The uint8 matmul of dequantize_fp32=False layers: built for bfloat16 Linear layers (round 4; with SVD factors since round 5),
-    named as unsupported -- with the reason -- for float16 scales and conv layers."""
+    conv layers too), named as unsupported -- with the reason -- for float16 scales."""
     import sdnq_amd
     from sdnq_amd import support
 
@@ -297,7 +297,7 @@ def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
     assert support.unsupported_reason(layer(torch.bfloat16)) is None
     assert support.unsupported_reason(layer(torch.bfloat16, weights_dtype="uint4", quantized_matmul_dtype="uint8", group_size=32)) is None
     assert "float16" in support.unsupported_reason(layer(torch.float16))
-    assert "conv" in support.unsupported_reason(layer(torch.bfloat16, conv=True))
+    assert support.unsupported_reason(layer(torch.bfloat16, conv=True)) is None  # (built in round 5; grouped convs keep a reason)
     assert support.unsupported_reason(layer(torch.bfloat16, use_svd=True, svd_rank=16)) is None
 
 
