@@ -30,6 +30,14 @@ def test_fuzz_fused_dequantize_gemm_bit_exact(seed, gpu_device):
     assert fuzz_w8a16.run(seed, 30, verbose=False) == []
 
 
+@pytest.mark.parametrize("seed", [707, 808])
+def test_fuzz_one_launch_linear_equals_the_two_launch_route(seed, gpu_device):
+    """Random shapes / dtypes / strides / degenerate rows through sdnq_hip_linear_w8a8_fused (the GEMM that row-quantizes its own
+    activation rows in LDS), eager and replayed from a hipGraph, bit for bit against sdnq_hip_linear_w8a8 (tools/fuzz_fused.py)."""
+    import fuzz_fused
+    assert fuzz_fused.run(seed, 40, verbose=False) == []
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_fuzz_configuration_space_vs_oracle(seed, gpu_device):
     """Storage dtype x group size x matmul dtype x Hadamard x SVD x scale dtype x odd shapes (tools/fuzz_modes.py).  Round 4: this
