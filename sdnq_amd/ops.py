@@ -446,8 +446,8 @@ def linear_w8a8_ws(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.T
 def linear_w8a8_fused_supported(mm: int, x2d: torch.Tensor, n: int, out_dtype: torch.dtype) -> bool:
     """True where the ONE-launch w8a8 Linear (sdnq_hip_linear_w8a8_fused: the GEMM row-quantizes its own activation rows in LDS) is
     built and expected to win; the answer per (dtype, M, N, K) is memoized."""
-    if x2d.dtype not in (torch.bfloat16, torch.float16) or out_dtype != x2d.dtype or not x2d.is_cuda:
-        return False
+    if x2d.dtype not in (torch.bfloat16, torch.float16) or out_dtype != x2d.dtype or not x2d.is_cuda or x2d.stride(0) * 128 >= (1 << 31):
+        return False  # (a tile's 64 rows are addressed with 32-bit byte offsets)
     key = (mm, x2d.dtype, x2d.shape[0], n, x2d.shape[1])
     r = _fused_ok.get(key)
     if r is None:

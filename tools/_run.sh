@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r5
-timeout 1200 python tools/fuzz_fused.py 1 300 2>&1 | tail -4 > gpurun_out/r5/g1_fuzz_fused.txt
-cat gpurun_out/r5/g1_fuzz_fused.txt
-timeout 900 python -m pytest tests/test_fuzz_gpu.py -x -q -k one_launch 2>&1 | tail -3
+timeout 600 python tools/host_cost.py > gpurun_out/r5/h1_host_cost.txt 2>&1; cat gpurun_out/r5/h1_host_cost.txt
+timeout 600 python tools/eager_call_cost.py 2>&1 | head -45 > gpurun_out/r5/h1_eager_call.txt; cat gpurun_out/r5/h1_eager_call.txt
