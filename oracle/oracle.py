@@ -557,20 +557,23 @@ def _grouped_conv_rows(mod: OracleLinear, x2d: np.ndarray, groups: int, tag: str
     (layers/conv/forward.py:80-81); the int8 / fp8 matmuls quantize the WHOLE row with one scale and multiply per group
     (conv_int8.py:64, 73-79; conv_fp8.py:56-60: int_mm per column slice, cat, .mul_(input_scale), addcmul(bias, ., scale))."""
     d = mod.deq
-    if d["use_hadamard"]:
-        # the reference rotates a grouped conv's rows too; that form is not restated (and sdnq_amd.support names it unsupported)
-        raise NotImplementedError("Hadamard-rotated grouped conv layers are not restated")
     Kg, N = mod.K, mod.N
     Ng = N // groups
     assert x2d.shape[1] == groups * Kg and N % groups == 0
     x2d = _c(x2d, np.float32)
     outs = []
     if not d["use_quantized_matmul"] or small:
-        W = mod.dequantize(mod.result_tag)
+        W = mod.dequantize(mod.result_tag)  # (a rotated weight is un-rotated here, as for every float forward)
         for g in range(groups):
             b = None if mod.bias is None else mod.bias[g * Ng:(g + 1) * Ng]
             outs.append(linear_float(_c(x2d[:, g * Kg:(g + 1) * Kg], np.float32), _c(W[g * Ng:(g + 1) * Ng], np.float32), b, tag))
         return np.concatenate(outs, axis=1)
+    if d["use_hadamard"]:
+        # conv_int8.py:52-53: the WHOLE unfolded row is rotated in blocks of the rotation group; the group divides C_in / groups
+        # (quant_utils.py:222-236), hence K', so no block straddles two conv groups and every group's columns meet the rotation its
+        # weight rows got at quantization
+        assert Kg % d["hadamard_group_size"] == 0
+        x2d = _c(rotate_hadamard(x2d, d["hadamard_group_size"], tag), np.float32)
     mmd = d["quantized_matmul_dtype"]
     assert mmd in ("int8", "uint8", "float8_e4m3fn", "fp8") and mod.svd_up is None
     f = np.float32

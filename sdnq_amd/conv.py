@@ -45,8 +45,6 @@ def _geometry(self, input: torch.Tensor):
     (C_in, kd, kh, kw)) becomes a 2-D problem by gathering the kd depth taps of every output depth into the channel axis:
     Z[(b, do), (c, kd)] = x[b, c, do * sd + kd * dd] -- one strided copy (kd times the input, what the reference's own unfold
     materialises kd * kh * kw times) -- whose 2-D unfold has exactly the reference's row order; depth_out = D_out there, None otherwise."""
-    if self.sdnq_dequantizer.use_hadamard and self.groups != 1:
-        raise NotImplementedError("Hadamard-rotated grouped conv layers are not built for MI355X")
     if isinstance(self.padding, str):
         raise NotImplementedError("string padding modes ('same' / 'valid') are not supported by the reference's conv matmul either")
     nd = input.ndim - 2
@@ -112,7 +110,7 @@ def _grouped_float_forward(self, x2d: torch.Tensor, fold):
     if x2d.dtype != dq.result_dtype:
         raise RuntimeError(f"expected input dtype {dq.result_dtype} (the layer's result_dtype) but got {x2d.dtype}")
     kg, ng = _group_slices(self, x2d.shape[1])
-    wd = ops.dequant(st.qw, dq.result_dtype, 0)  # [N, K']
+    wd = ops.dequant(st.qw, dq.result_dtype, dq.hadamard_group_size if dq.use_hadamard else 0)  # [N, K'], un-rotated
     out = torch.empty((x2d.shape[0], dq.out_features), device=x2d.device, dtype=x2d.dtype)
     aligned = (kg * x2d.element_size()) % 16 == 0
     for g in range(int(self.groups)):
@@ -174,12 +172,17 @@ def _grouped_matmul_forward(self, input: torch.Tensor, mm: int, st, wq, ws, zp) 
         return _grouped_lp_matmul_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, mm, st, wq, ws, zp)
     if zp is not None:
         return _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd, depth_out, wq, ws, zp, asymmetric=False)
-    if FUSED_CONV_QUANT and kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
+    # Hadamard-rotated weights (round 5; conv_int8.py:52-53): the WHOLE unfolded row is rotated in blocks of the rotation group -- it
+    # divides C_in / groups (quant_utils.py:222-236), hence K', so no block straddles two conv groups
+    had = self.sdnq_dequantizer.hadamard_group_size if self.sdnq_dequantizer.use_hadamard else 0
+    if FUSED_CONV_QUANT and not had and kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
         xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
     else:
         x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
-        xq, xs = ops.rowquant(x2d, mm, 0)[:2]
+        xq, xs = ops.rowquant(x2d, mm, had)[:2]
     kg, ng = _group_slices(self, xq.shape[1])
+    if had and kg % had:
+        raise NotImplementedError(f"rotation group {had} does not divide the {kg} columns of a conv group")
     if kg % 16 or ng % 8:
         raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
     n = self.sdnq_dequantizer.out_features
@@ -207,7 +210,7 @@ def _grouped_lp_matmul_forward(self, x4, kernel, stride, padding, dilation, nd, 
     if st.qw.scale_dtype != torch.bfloat16 or zp is not None or x4.dtype != torch.bfloat16:
         raise NotImplementedError("grouped conv matmul with 16-bit scales is built for bfloat16 layers without a weight zero point")
     x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
-    xq, xs, _rowsum, _xrot = ops.rowquant_lp(x2d, mm, 0)
+    xq, xs, _rowsum, _xrot = ops.rowquant_lp(x2d, mm, self.sdnq_dequantizer.hadamard_group_size if self.sdnq_dequantizer.use_hadamard else 0)
     kg, ng = _group_slices(self, xq.shape[1])
     if kg % 16 or ng % 8:
         raise NotImplementedError(f"grouped conv matmul needs 16 | K per group and 8 | channels per group (got {kg}, {ng})")
@@ -227,7 +230,8 @@ def _grouped_zero_point_forward(self, x4, kernel, stride, padding, dilation, nd,
     -- and every group multiplies its column slice of the codes with its own weight rows; result = addcmul(zero_bias, acc * xs, ws)
     (conv_int8.py:73-79 / conv_uint8.py:70-79).  One launch per group on views, the general GEMM epilogue does the terms."""
     x2d, (b, ho, wo) = ops.im2col(x4, kernel, stride, padding, dilation)
-    res = ops.rowquant(x2d, ops.MM_I8, 0, want_rowsum=True, asymmetric=asymmetric)
+    had = self.sdnq_dequantizer.hadamard_group_size if self.sdnq_dequantizer.use_hadamard else 0
+    res = ops.rowquant(x2d, ops.MM_I8, had, want_rowsum=True, asymmetric=asymmetric)
     xq, xs, rowsum = res[0], res[1], res[2]
     xzp = res[4] if asymmetric else None
     kg, ng = _group_slices(self, xq.shape[1])

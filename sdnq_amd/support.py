@@ -71,8 +71,6 @@ def unsupported_reason(module) -> str | None:
     if uint8_mm and getattr(module, "svd_up", None) is not None:
         return "the uint8 conv matmul with SVD factors is not built (its K * xzp * wzp term is rounded in the conv forwards' own order)"
     if groups != 1:
-        if dq.use_hadamard:
-            return "Hadamard-rotated grouped conv layers are not built for MI355X"
         if qmm:
             # K per group and N from original_shape, NOT from this package's in_features / out_features properties: the predicate runs on
             # the dequantizer a model CAME with -- the reference's dataclass has no such properties -- before anything is adopted

@@ -381,6 +381,11 @@ CONV_CASES = [
     # cast the float32 `acc * input_scale` to float16 first, dequantizer.py:27, 63 -- a different epilogue from every other path)
     dict(name="conv2d_g2_int8_qmm_bf16_lpscale", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
          cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True, dequantize_fp32=False)),
+    # round 5: Hadamard-rotated grouped convs (the rotation group divides C_in / groups; the whole unfolded row is rotated, conv_int8.py:52-53)
+    dict(name="conv2d_g2_int8_had_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
+         cfg=dict(weights_dtype="int8", use_quantized_matmul_conv=True, use_hadamard=True)),
+    dict(name="conv2d_g2_uint4_had_noqmm_f16", nd=2, cin=64, cout=32, k=3, conv=dict(padding=1, groups=2), xs=[(1, 6, 6)], dtype="f16",
+         cfg=dict(weights_dtype="uint4", group_size=16, use_hadamard=True)),
     # and the uint8 matmul (conv_uint8.py:58-79) -- whole-row statistics, per-group matmuls
     dict(name="conv2d_g2_uint8_int8mm_qmm_bf16", nd=2, cin=64, cout=64, k=3, conv=dict(padding=1, groups=2), xs=[(2, 8, 8), (1, 5, 7)], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True)),

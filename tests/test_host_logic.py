@@ -206,13 +206,13 @@ def test_accelerate_never_breaks_a_working_model():
     model[0] = sdnq_amd.sdnq_quantize_layer(model[0], sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
     model[1] = sdnq_amd.sdnq_quantize_layer(model[1], sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
     model[2] = sdnq_amd.sdnq_quantize_layer(model[2], sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True,
-                                                                          use_hadamard=True))[0]
-    # layer 1: the reference's 16-bit float matmul (linear_fp16.py) -- not built here; layer 2: Hadamard on a grouped conv -- not built
+                                                                          use_svd=True, svd_rank=8))[0]
+    # layer 1: the reference's 16-bit float matmul (linear_fp16.py) -- not built here; layer 2: a grouped conv with SVD factors -- not built
     model[1].sdnq_dequantizer.quantized_matmul_dtype = "float16"
     for i in (0, 1, 2):
         model[i].forward_func = ref_forward
     assert support.unsupported_reason(model[0]) is None
-    assert "float16" in support.unsupported_reason(model[1]) and "Hadamard" in support.unsupported_reason(model[2])
+    assert "float16" in support.unsupported_reason(model[1]) and "SVD" in support.unsupported_reason(model[2])
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         res = sdnq_amd.accelerate(model)

@@ -170,6 +170,8 @@ def test_conv_case_dequant_and_forward(name):
             assert np.abs(W - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
         elif d["use_hadamard"] and c.tag == "f32":  # the un-rotation is an fp32 matmul: summation order is the library's
             assert np.abs(W - ref).max() <= 1e-6 * np.abs(ref).max(), (name, "dequant")
+        elif d["use_hadamard"]:  # ... and in a 16-bit dtype that order flips the last bit of a few elements (the Linear cases' bound)
+            assert np.all(np.abs(W - ref) <= 2 * ulp_bf16(ref) + 1e-6) and np.mean(W != ref) < 1e-3, (name, "dequant")
         else:
             assert np.array_equal(W, ref), (name, "dequant")
     if c.has("requant_weight"):
