@@ -2081,7 +2081,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
             }
         }
     } else if constexpr (EPI != EPI_BIAS2D) {
-        if (tiles(256, 256) >= 160 && p.K >= 2048 && fits(256)) {
+        if (p.M > 128 && tiles(256, 256) >= 160 && p.K >= 2048 && fits(256)) {  // (few rows against many channels: the 128-row stream below)
             // round 3: the half-tile ring (LD_HT: 128-byte rows, buffer-load DMAs with no vector-ALU address work, fine ping-pong) is
             // 15-22 % faster than the 64-byte-stage software pipeline on every FLUX / large shape (profiles/r03_gemm_ht.txt)
             if (ht_ok(p)) return launch_one<MM, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
@@ -2113,6 +2113,14 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
             return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
     }
     if (p.M > 128 && fits(128)) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
+    if constexpr (PP_OK<MM, OUT_T, EPI>) {
+        //  * 65..128 rows against MANY weight rows (all cross-attention k / v projections of a UNet in one grouped launch: 77 text tokens x
+        //    2048 -> 120 x 1280 channels, 315 MB of weights read once): a pure weight stream -- one 128-row tile reads every weight row once
+        //    where two 64-row tiles read it twice through LDS, and half as many workgroups pay a prologue: 104 -> 88 us (3.0 -> 3.6 TB/s,
+        //    tools/kv_group_lab.py; the 20 x 640 group, 100 such tiles, stays: 19.8 vs 22 us)
+        if (p.M > 64 && tiles(128, 128) >= 512 && p.K >= 1024 && fits(128))
+            return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
+    }
     return launch_one<MM, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
 }
 
