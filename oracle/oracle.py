@@ -797,9 +797,12 @@ def _forward_uint8(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: bool 
     if d["re_quantize_for_matmul"]:  # linear_uint8.py:109-111: int8 codes + per-row scale and zero point, no xor
         wq, sc, zp = mod.re_quantize_matmul()
     else:
-        assert not d["is_packed"], "packed weights that reach the uint8 matmul without re-quantization are not restated here"
         vals, sc, zpv, group = mod._nk_values_scale()
-        if dtype_info(d["weights_dtype"])["kind"] == "uint":  # linear_uint8.py:45-50: w ^ 0x80, zero_point + 128 * scale
+        if d["is_packed"]:
+            # linear_uint8.py:38-44: packed row-wise codes are unpacked straight to int8 -- the codes AS THEY ARE (7 bits at most: they
+            # fit), no xor, the zero point as stored (None for signed formats)
+            wq, zp = vals.astype(np.int8), (None if zpv is None else zpv.astype(f))
+        elif dtype_info(d["weights_dtype"])["kind"] == "uint":  # linear_uint8.py:45-50: w ^ 0x80, zero_point + 128 * scale
             wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
             zp = (zpv + f(128.0) * sc).astype(f) if zpv is not None else (sc * f(128.0)).astype(f)
         else:  # signed row-wise int8 through the uint8 matmul: no weight zero point, only the activation's (linear_uint8.py:67-68)
@@ -846,10 +849,11 @@ def _forward_uint8_bf16(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: 
     if d["re_quantize_for_matmul"]:
         wq, sc, zp = mod.re_quantize_matmul()
     else:
-        assert not d["is_packed"], "packed weights that reach the uint8 matmul without re-quantization are not restated here"
         vals, sc, zpv, group = mod._nk_values_scale()
         sc = sc.reshape(-1)
-        if dtype_info(d["weights_dtype"])["kind"] == "uint":  # linear_uint8.py:45-50 on bfloat16 tensors
+        if d["is_packed"]:  # linear_uint8.py:38-44: the unpacked codes as they are, the stored zero point (no arithmetic, so no rounding)
+            wq, zp = vals.astype(np.int8), (None if zpv is None else _c(zpv, f).reshape(-1))
+        elif dtype_info(d["weights_dtype"])["kind"] == "uint":  # linear_uint8.py:45-50 on bfloat16 tensors
             wq = (vals.astype(np.int32).astype(np.uint8) ^ 0x80).view(np.int8)
             zp = r(zpv.reshape(-1) + f(128.0) * sc) if zpv is not None else r(sc * f(128.0))
         else:

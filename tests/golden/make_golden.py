@@ -177,6 +177,12 @@ CASES = [
          cfg=dict(weights_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=False)),
     dict(name="int6_rowwise_packed_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
          cfg=dict(weights_dtype="int6", use_quantized_matmul=True)),
+    # round 5: packed row-wise codes that reach the UINT8 matmul un-re-quantized (linear_uint8.py:38-44: unpack_int(..., dtype=int8), the
+    # codes as they are -- no xor, the stored zero point -- found uncovered by tools/fuzz_modes.py: signed and unsigned)
+    dict(name="uint7_rowwise_packed_uint8mm_qmm_bf16", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint7", quantized_matmul_dtype="uint8", group_size=-1, use_quantized_matmul=True)),
+    dict(name="int5_rowwise_packed_uint8mm_qmm_f16_nobias", K=384, N=64, Ms=[40], dtype="f16", bias=False,
+         cfg=dict(weights_dtype="int5", quantized_matmul_dtype="uint8", group_size=-1, use_quantized_matmul=True)),
     dict(name="uint7_rowwise_packed_qmm_bf16", K=256, N=64, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="uint7", use_quantized_matmul=True)),
     dict(name="uint8_int8mm_qmm_bf16", K=256, N=64, Ms=[4, 48], dtype="bf16",
@@ -235,6 +241,8 @@ CASES = [
          cfg=dict(weights_dtype="int8", quantized_matmul_dtype="uint8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="uint4_g32_uint8mm_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="uint4", quantized_matmul_dtype="uint8", group_size=32, use_quantized_matmul=True, dequantize_fp32=False)),
+    dict(name="uint7_rowwise_packed_uint8mm_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
+         cfg=dict(weights_dtype="uint7", quantized_matmul_dtype="uint8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="uint8_svd32_int8mm_qmm_bf16_lpscale", K=256, N=128, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="uint8", quantized_matmul_dtype="int8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True,
                   dequantize_fp32=False)),

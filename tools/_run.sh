@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r5
-timeout 600 python tools/kv_group_lab.py 2>&1 | grep -v amdgpu > gpurun_out/r5/k2_kv_lab.txt; cut -c1-200 gpurun_out/r5/k2_kv_lab.txt
-timeout 900 python -m pytest tests/test_gemm_configs.py -x -q -k "grouped" 2>&1 | tail -2
-for i in 1 2 3; do timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; done
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "packed_uint8mm" 2>&1 | tail -15 > gpurun_out/r5/m1_pytest.txt; cat gpurun_out/r5/m1_pytest.txt
+for seed in 7 8; do timeout 900 python tools/fuzz_modes.py $seed 250 2>&1 | grep -v amdgpu | tail -3; done 2>&1 | cut -c1-220

@@ -46,13 +46,18 @@ def run(seed: int = 0, iters: int = 40, verbose: bool = True, variety: bool = Fa
             continue
         # configuration: mostly the int8 matmul on int8 weights (bit-exact), sometimes unsigned weights (zero-point terms), the uint8
         # (asymmetric-activation) matmul, fp8, re-quantized 4-bit weights or the float mode
-        cfgname = rng.choice(["int8", "int8", "int8", "uint8w", "uint8mm", "fp8", "int4g16", "float"]) if variety else "int8"
+        # (round 5: Hadamard-rotated weights -- grouped convs included --, 16-bit scales on the int8 / uint8 matmuls)
+        cfgname = rng.choice(["int8", "int8", "int8", "uint8w", "uint8mm", "fp8", "int4g16", "float", "int8had", "floathad", "int8lp", "uint8mmlp"]) if variety else "int8"
         cfg = {"int8": dict(weights_dtype="int8", use_quantized_matmul_conv=True),
                "uint8w": dict(weights_dtype="uint8", quantized_matmul_dtype="int8", use_quantized_matmul_conv=True),
                "uint8mm": dict(weights_dtype="uint8", use_quantized_matmul_conv=True),
                "fp8": dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", use_quantized_matmul_conv=True),
                "int4g16": dict(weights_dtype="int4", group_size=16, use_quantized_matmul_conv=True),
-               "float": dict(weights_dtype="uint4")}[cfgname]
+               "float": dict(weights_dtype="uint4"),
+               "int8had": dict(weights_dtype="int8", use_quantized_matmul_conv=True, use_hadamard=True),
+               "floathad": dict(weights_dtype="uint4", group_size=16, use_hadamard=True),
+               "int8lp": dict(weights_dtype="int8", use_quantized_matmul_conv=True, dequantize_fp32=False),
+               "uint8mmlp": dict(weights_dtype="uint8", use_quantized_matmul_conv=True, dequantize_fp32=False)}[cfgname]
         try:
             mod, _ = sdnq_amd.sdnq_quantize_layer(conv.to(dt).to(dev), sdnq_amd.SDNQConfig(quant_conv=True, **cfg))
         except (NotImplementedError, ValueError):
@@ -64,10 +69,13 @@ def run(seed: int = 0, iters: int = 40, verbose: bool = True, variety: bool = Fa
         y = mod(x.to(dev)).float().cpu().numpy()
         meta = {"nd": nd, "kernel_size": list(mod.kernel_size), "stride": list(mod.stride), "padding": list(mod.padding), "dilation": list(mod.dilation),
                 "padding_mode": mod.padding_mode, "groups": groups}
-        ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
+        try:
+            ref = O.conv_forward(oracle_from_module(mod), x.float().numpy(), meta, tag)
+        except (NotImplementedError, AssertionError):  # a form the oracle does not restate
+            continue
         done += 1
         d = mod.sdnq_dequantizer
-        exact = d.use_quantized_matmul and str(d.quantized_matmul_dtype) in ("int8", "uint8") and x.numel() / x.shape[2] >= 32
+        exact = d.use_quantized_matmul and str(d.quantized_matmul_dtype) in ("int8", "uint8") and x.numel() / x.shape[2] >= 32 and not d.use_hadamard
         if not exact and y.shape == ref.shape:  # float / fp8 matmuls: the float tolerance of the parity tests
             scale = float(np.abs(ref).max()) or 1.0
             if float(np.abs(y - ref).max()) / scale <= {"bf16": 2 * 2.0 ** -8, "f16": 2 * 2.0 ** -11}[tag]:
