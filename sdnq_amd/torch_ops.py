@@ -153,6 +153,8 @@ def layer_matmul(xq: torch.Tensor, xs: torch.Tensor, handle: int, out_dtype: tor
     wq, ws, zp = L._prepare_mm_weights(mod, st, mm)
     if zp is not None or st.svd_up is not None:
         raise _lib.SdnqHipError("sdnq_hip::layer_matmul: the layer changed to a form with zero-point / low-rank terms after tracing")
+    if L.PREFETCH_NEXT and st.mm_weight is wq:  # the weight prefetch across layers (linear._PrefetchChain), as on the eager / graph path
+        L._pf_launch(st, (wq,))
     return ops.scaled_mm(mm, xq, wq, xs, ws, L._attr(mod, "bias"), out_dtype)
 
 
@@ -193,6 +195,8 @@ def layer_matmul_group(xq: torch.Tensor, xs: torch.Tensor, handles: List[int], o
     mm = ops.MM_I8 if xq.dtype == torch.int8 else ops.MM_FP8
     pg = _matmul_group(handles, mm)
     if pg is not None:
+        if L.PREFETCH_NEXT and getattr(pg, "pf_tensors", None):
+            L._pf_launch(pg, pg.pf_tensors)
         outs = ops.scaled_mm_grouped(mm, xq, xs, pg.gemm, out_dtype)
         return outs[0]._base if outs[0]._base is not None else torch.cat([o.reshape(-1) for o in outs])
     # the members stopped being groupable after tracing (a parameter moved / changed form): one launch each, same layout

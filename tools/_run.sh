@@ -1,1 +1,2 @@
-for seed in 7 8 9; do timeout 900 python tools/fuzz_modes.py $seed 250 2>&1 | grep -i "cover\|skip\|not built\|unsupported" | cut -c1-330 | sort | uniq -c | sort -rn | head -12; done
+timeout 900 python -m pytest tests/test_torch_ops.py -x -q 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_torch_ops.py -x -q -m gpu 2>&1 | tail -2
