@@ -34,6 +34,9 @@ from . import linear, ops
 FUSED_CONV_QUANT = os.environ.get("SDNQ_HIP_FUSED_CONV_QUANT", "1").lower() not in {"0", "false", "no"}
 
 
+CONV_PREFETCH = os.environ.get("SDNQ_HIP_CONV_PREFETCH", "1").lower() not in {"0", "false", "no"}
+
+
 def _pair(v, n):
     return (int(v),) * n if isinstance(v, int) else tuple(int(e) for e in v)
 
@@ -146,6 +149,8 @@ def _conv_matmul_forward(self, input: torch.Tensor, mm: int) -> torch.Tensor:
         x4, kernel, stride, padding, dilation, nd, depth_out = _geometry(self, input)
         if kernel[0] * kernel[1] <= 25 and (x4.shape[2] * x4.shape[3]) % 8 == 0:
             xq, xs, (b, ho, wo) = ops.im2col_rowquant(x4, kernel, stride, padding, dilation, mm)
+            if linear.PREFETCH_NEXT and st.mm_weight is wq and CONV_PREFETCH:  # the weight prefetch across layers (linear._PrefetchChain)
+                linear._pf_launch(st, (wq,))
             # channel-major store fused into the GEMM epilogue; Conv3d: the rows of one image are its D_out * H_out * W_out positions
             imgs, px = (b, ho * wo) if nd != 3 else (b // depth_out, depth_out * ho * wo)
             if px % 8 == 0 and input.dtype != torch.float32:
