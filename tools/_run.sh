@@ -1,7 +1,22 @@
-for i in 1 2 3; do
-SDNQ_HIP_CONV_PREFETCH=0 timeout 900 python bench.py --workload sdxl_conv_int8 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('conv off', d['ms_per_step'])"
-timeout 900 python bench.py --workload sdxl_conv_int8 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('conv on', d['ms_per_step'])"
+mkdir -p gpurun_out/r5/final2
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > gpurun_out/r5/final2/pytest_gpu_serial.txt
+cat gpurun_out/r5/final2/pytest_gpu_serial.txt
+SDNQ_HIP_FUSED_ROWQUANT=0 bash tools/pmc_step.sh r5/final2_pmc > gpurun_out/r5/final2/pmc.log 2>&1
+cp gpurun_out/r5/final2_pmc/pmc_gemm_traffic.json gpurun_out/r5/final2/r05_pmc_gemm_traffic_linked.json
+cp gpurun_out/r5/final2_pmc/pmc_rowquant_traffic.json gpurun_out/r5/final2/r05_pmc_rowquant_traffic_linked.json
+cp gpurun_out/r5/final2/r05_pmc_gemm_traffic_linked.json profiles/r05_pmc_gemm_traffic_linked.json
+bash tools/prof_bench.sh r5/final2_prof --steps 20 --warmup 3 > gpurun_out/r5/final2/prof.log 2>&1
+timeout 900 python bench.py > gpurun_out/r5/final2/bench_sdxl_int8.json 2> gpurun_out/r5/final2/bench.err
+for w in sdxl_fp8 sdxl_int8_dequant flux_int4_had flux_int8_svd sdxl_conv_int8 sdxl_attn_int8 linear_int8 sdxl_unet_all; do
+timeout 900 python bench.py --workload $w --no-cpu-baseline > gpurun_out/r5/final2/bench_$w.json 2>> gpurun_out/r5/final2/bench.err
 done
-SDNQ_HIP_CONV_PREFETCH=0 timeout 900 python bench.py --workload sdxl_unet_all --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('all off', d['ms_per_step'])"
-timeout 900 python bench.py --workload sdxl_unet_all --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('all on', d['ms_per_step'])"
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -n 4 -k conv 2>&1 | tail -2
+timeout 1200 python bench.py --launch compile --no-cpu-baseline > gpurun_out/r5/final2/bench_sdxl_int8_compile.json 2>> gpurun_out/r5/final2/bench.err
+timeout 600 python bench.py --launch eager --no-cpu-baseline > gpurun_out/r5/final2/bench_sdxl_int8_eager.json 2>> gpurun_out/r5/final2/bench.err
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r5/final2/bench_*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d.get("roofline",{})
+        print(f.split("/")[-1], d["ms_per_step"], r.get("frac"), r.get("avg_launch_us"), r.get("traffic"), r.get("traffic_stale"))
+    except Exception as e: print(f, "ERR", e)
+PY
