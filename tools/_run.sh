@@ -1,22 +1,11 @@
-mkdir -p gpurun_out/r5/final2
-timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > gpurun_out/r5/final2/pytest_gpu_serial.txt
-cat gpurun_out/r5/final2/pytest_gpu_serial.txt
-SDNQ_HIP_FUSED_ROWQUANT=0 bash tools/pmc_step.sh r5/final2_pmc > gpurun_out/r5/final2/pmc.log 2>&1
-cp gpurun_out/r5/final2_pmc/pmc_gemm_traffic.json gpurun_out/r5/final2/r05_pmc_gemm_traffic_linked.json
-cp gpurun_out/r5/final2_pmc/pmc_rowquant_traffic.json gpurun_out/r5/final2/r05_pmc_rowquant_traffic_linked.json
-cp gpurun_out/r5/final2/r05_pmc_gemm_traffic_linked.json profiles/r05_pmc_gemm_traffic_linked.json
-bash tools/prof_bench.sh r5/final2_prof --steps 20 --warmup 3 > gpurun_out/r5/final2/prof.log 2>&1
-timeout 900 python bench.py > gpurun_out/r5/final2/bench_sdxl_int8.json 2> gpurun_out/r5/final2/bench.err
-for w in sdxl_fp8 sdxl_int8_dequant flux_int4_had flux_int8_svd sdxl_conv_int8 sdxl_attn_int8 linear_int8 sdxl_unet_all; do
-timeout 900 python bench.py --workload $w --no-cpu-baseline > gpurun_out/r5/final2/bench_$w.json 2>> gpurun_out/r5/final2/bench.err
-done
-timeout 1200 python bench.py --launch compile --no-cpu-baseline > gpurun_out/r5/final2/bench_sdxl_int8_compile.json 2>> gpurun_out/r5/final2/bench.err
-timeout 600 python bench.py --launch eager --no-cpu-baseline > gpurun_out/r5/final2/bench_sdxl_int8_eager.json 2>> gpurun_out/r5/final2/bench.err
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/r5/final2/bench_*.json")):
-    try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d.get("roofline",{})
-        print(f.split("/")[-1], d["ms_per_step"], r.get("frac"), r.get("avg_launch_us"), r.get("traffic"), r.get("traffic_stale"))
-    except Exception as e: print(f, "ERR", e)
-PY
+mkdir -p gpurun_out/r5
+(
+for s in 51 52; do timeout 900 python tools/fuzz_linear.py $s 150 2>&1 | tail -1; done
+for s in 53 54; do timeout 900 python tools/fuzz_ops.py $s 150 2>&1 | tail -1; done
+timeout 1200 python tools/fuzz_tiles.py 55 40 2>&1 | tail -1
+for s in 56 57; do timeout 900 python tools/fuzz_host_state.py $s 600 2>&1 | tail -1; done
+timeout 900 python tools/fuzz_attention_routes.py 58 60 2>&1 | tail -1
+for s in 59 60; do timeout 900 python tools/fuzz_w8a16.py $s 100 2>&1 | tail -1; done
+for s in 61 62; do timeout 900 python tools/fuzz_fused.py $s 300 2>&1 | tail -1; done
+) 2>&1 | grep -v amdgpu | cut -c1-200 > gpurun_out/r5/n1_fuzz_all.txt
+cat gpurun_out/r5/n1_fuzz_all.txt
