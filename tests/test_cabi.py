@@ -177,3 +177,31 @@ def test_linear_args_struct_matches_the_header():
         del parts
     assert names == [f[0] for f in _lib.SdnqLinearArgs._fields_], names
     assert ctypes.sizeof(_lib.SdnqLinearArgs) == 10 * 4 + 4 * 8 + 16 * 8
+
+
+def test_one_launch_linear_predicate_and_argument_validation_without_gpu():
+    """sdnq_hip_linear_w8a8_fused_supported is host logic (no launch): where the one-launch w8a8 Linear is built AND offered -- 16-bit
+    activations, K % 128 == 0, K <= 1280, one round of 64 x 128 tiles, at most 12 column tiles per row block, int8 (fp8 behind its
+    switch) -- and the entry point's argument checks return before anything is launched."""
+    from sdnq_amd import _lib
+    lib = _lib.load()
+    sup = lib.sdnq_hip_linear_w8a8_fused_supported
+    I8, FP8, F32, BF16, F16 = 0, 1, 0, 1, 2
+    assert sup(I8, BF16, BF16, 1024, 1280, 1280) == 1 and sup(I8, F16, F16, 1024, 1280, 640) == 1
+    assert sup(I8, BF16, BF16, 1024, 1280, 5120) == 0      # the rows do not fit LDS
+    assert sup(I8, BF16, BF16, 1024, 1280, 1200) == 0      # K % 128
+    assert sup(I8, BF16, BF16, 1024, 10240, 1280) == 0     # 80 column tiles per row block
+    assert sup(I8, BF16, BF16, 2048, 1280, 1280) == 0      # 320 tiles: two rounds
+    assert sup(I8, BF16, BF16, 16, 1280, 1280) == 0        # the M < 32 branch is not a matmul at all
+    assert sup(I8, F32, F32, 1024, 1280, 1280) == 0 and sup(I8, BF16, F16, 1024, 1280, 1280) == 0
+    assert sup(FP8, BF16, BF16, 1024, 1280, 1280) == 0     # built and bit-identical, off by default (SDNQ_HIP_FUSED_ROWQUANT_FP8)
+    f = lib.sdnq_hip_linear_w8a8_fused
+    p = 4096  # any non-null, 16-byte aligned address: every call below returns before a launch
+    assert f(I8, None, BF16, 64, 128, 128, p, p, None, 0, p, BF16, 128, None) == -1      # NULL activation
+    assert f(2, p, BF16, 64, 128, 128, p, p, None, 0, p, BF16, 128, None) == -2          # unknown matmul dtype
+    assert f(I8, p, BF16, 64, 128, 64, p, p, None, 0, p, BF16, 128, None) == -3          # ldx < K
+    assert f(I8, p, BF16, 64, 128, 128, p, p, None, 0, p, BF16, 132, None) == -3         # N % 8
+    assert f(I8, p, BF16, 64, 192, 192, p, p, None, 0, p, BF16, 128, None) == -5         # K % 128: valid in the reference, not built here
+    assert f(I8, p, BF16, 64, 2560, 2560, p, p, None, 0, p, BF16, 128, None) == -5       # K > 1280
+    assert f(I8, p, F32, 64, 128, 128, p, p, None, 0, p, F32, 128, None) == -5           # float32 activations
+    assert f(I8, p + 8, BF16, 64, 128, 128, p, p, None, 0, p, BF16, 128, None) == -4     # alignment
