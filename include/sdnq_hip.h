@@ -415,6 +415,10 @@ int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, in
                          void* xq, float* xs, const void* b, const float* sb, const void* bias, int bias_dtype, void* out,
                          int out_dtype, int64_t n, sdnq_stream_t stream);
 
+/* *id = the id of the stream capture `stream` is part of, 0 when it is not capturing (nothing in the reference: its Triton launches keep no
+ * per-stream device state).  Used by hosts that keep such state: a captured launch must address a buffer of ITS capture. */
+int sdnq_hip_stream_capture_id(sdnq_stream_t stream, unsigned long long* id);
+
 /* The plain w8a8 Linear (int8_matmul / fp8_matmul: linear_int8.py:15-22, 64, 75-97 -> kernels/triton_scaled_mm.py:194-232; linear_fp8.py
  * the same) as ONE launch: every GEMM workgroup row-quantizes its own 64 activation rows into LDS (amax, scale = amax / qmax, codes with the
  * arithmetic of sdnq_hip_rowquant) and streams only the weight operand -- no quantized copy of the activation exists in HBM.  Results are

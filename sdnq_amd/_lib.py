@@ -33,7 +33,7 @@ EXPORTS = [
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
     "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided", "sdnq_hip_prefetch", "sdnq_hip_prefetch_hint",
     "sdnq_hip_signal_alloc", "sdnq_hip_signal_free", "sdnq_hip_ipc_export", "sdnq_hip_ipc_import", "sdnq_hip_ipc_close",
-    "sdnq_hip_linear_w8a8_fused", "sdnq_hip_linear_w8a8_fused_supported", "sdnq_hip_scaled_mm_lp_uzp_svd",
+    "sdnq_hip_linear_w8a8_fused", "sdnq_hip_linear_w8a8_fused_supported", "sdnq_hip_scaled_mm_lp_uzp_svd", "sdnq_hip_stream_capture_id",
 ]
 
 
@@ -167,6 +167,7 @@ def _declare(lib):
     lib.sdnq_hip_quantize_weight.argtypes = [vp, i32, i64, c.POINTER(SdnqWeight), c.c_float, c.c_float, vp]
     lib.sdnq_hip_linear_skinny_svd.argtypes = [c.POINTER(SdnqWeight), vp, vp, vp, i32, vp, i64, i64, vp]
     lib.sdnq_hip_linear_w8a8.argtypes = [i32, vp, i32, i64, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, vp]
+    lib.sdnq_hip_stream_capture_id.argtypes = [vp, c.POINTER(c.c_uint64)]
     lib.sdnq_hip_linear_w8a8_fused.argtypes = [i32, vp, i32, i64, i64, i64, vp, vp, vp, i32, vp, i32, i64, vp]
     lib.sdnq_hip_linear_w8a8_fused_supported.argtypes = [i32, i32, i32, i64, i64, i64]
     lib.sdnq_hip_scaled_mm_multi.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i32, i64, i32, i64, i64, i64, vp]

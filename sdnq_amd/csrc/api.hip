@@ -58,6 +58,19 @@ extern "C" int sdnq_hip_prefetch(const void* ptr, int64_t bytes, int workgroups,
     return hipGetLastError() == hipSuccess ? SDNQ_OK : SDNQ_ERR_LAUNCH;
 }
 
+// The id of the stream capture `stream` is part of (0: not capturing).  Host code that keeps per-stream device state (the conv
+// quantizer's self-cleaning amax map) keys the state a CAPTURED launch may address by this id: one buffer per capture, never the
+// stream's persistent one.
+extern "C" int sdnq_hip_stream_capture_id(sdnq_stream_t stream, unsigned long long* id) {
+    if (!id) return SDNQ_ERR_NULL;
+    *id = 0;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long cid = 0;
+    if (hipStreamGetCaptureInfo((hipStream_t)stream, &st, &cid) != hipSuccess) return SDNQ_ERR_LAUNCH;
+    if (st == hipStreamCaptureStatusActive) *id = cid ? cid : 1;
+    return SDNQ_OK;
+}
+
 // The whole plain w8a8 Linear in one call: row quantization, then the scaled matmul (two launches on `stream`).  Exists for
 // hosts where the per-call binding cost matters (an eager Python model pays the ctypes marshalling once instead of twice).
 extern "C" int sdnq_hip_linear_w8a8(int mm_dtype, const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, int hadamard_group,

@@ -819,6 +819,7 @@ def im2col(x: torch.Tensor, kernel, stride, padding, dilation) -> tuple[torch.Te
 
 # per (device, stream): [zeroed int32 buffer (ticket + amax map) of sdnq_hip_im2col_rowquant_z, call-in-flight flag]
 _amax_maps: dict = {}
+_capture_amax_maps: dict = {}  # per (device, stream): (capture id, the map the convs of that capture address)
 _AMAX_HEADER = 32 + 256 * 32  # ticket words in front of the map (csrc/conv.hip: SDNQ_CONV_WS_HEADER_WORDS)
 SELF_CLEANING_AMAX = os.environ.get("SDNQ_HIP_CONV_SELF_CLEAN", "1") != "0"
 
@@ -828,9 +829,21 @@ def _zeroed_amax_map(x: torch.Tensor, words: int):
     buffer cannot be made while the stream is capturing (its zero fill would be replayed, its memory would belong to the graph)."""
     if torch.cuda.is_current_stream_capturing():
         # never bake the stream's persistent map into a graph: a graph replayed on ANOTHER stream, beside eager convs on the capture stream,
-        # would share one map and one set of tickets with no ordering between them (advisor, round 4).  A captured conv takes the
-        # zero-per-call form on a buffer out of the graph's own pool.
-        return None
+        # would share one map and one set of tickets with no ordering between them (advisor, round 4).  A captured conv addresses a map of
+        # ITS capture: made by the capture's first conv out of the graph's own pool -- its zero fill is part of the graph, ONE zeroing launch
+        # per replay -- and kept all-zero between the graph's convs by the self-cleaning kernel (round 5: the zero-per-call form cost a
+        # captured SDXL conv step 48 launches of 5 us, 8 % of it).
+        cid = ctypes.c_uint64(0)
+        check(_lib.load().sdnq_hip_stream_capture_id(_stream(x), ctypes.byref(cid)), "stream_capture_id")
+        if cid.value == 0:
+            return None
+        key = (x.device.index, _stream(x))
+        cap = _capture_amax_maps.get(key)
+        need = _AMAX_HEADER + words
+        if cap is None or cap[0] != cid.value or cap[1].numel() < need:
+            cap = (cid.value, torch.zeros((max(need, _AMAX_HEADER + 65536),), device=x.device, dtype=torch.int32))
+            _capture_amax_maps[key] = cap  # (the previous capture's map goes back to ITS graph's pool; that graph keeps addressing it)
+        return [cap[1], False]
     key = (x.device.index, _stream(x))
     ent = _amax_maps.get(key)
     need = _AMAX_HEADER + words
