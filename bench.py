@@ -1191,12 +1191,6 @@ def main():
                         "W - 1 peers over W - 1 links at once, each bound by 153 GB/s"})
 
     want_tp_report = distributed and not tp and not is_conv and (args.tp_report or (world > 1 and os.environ.get("SDNQ_BENCH_TP_REPORT", "1") != "0"))
-    if want_tp_report:
-        # (after the timed replica region; a collective: every rank runs it)
-        try:
-            result["tp"] = tp_report(args, device, world, rank, shape_list, cfg_kwargs, ops_per_step)
-        except Exception as e:  # noqa: BLE001
-            result["tp"] = {"error": repr(e)[:400]}
 
     float_mode = not cfg_kwargs.get("use_quantized_matmul", cfg_kwargs.get("use_quantized_matmul_conv", False))
     if float_mode:
@@ -1264,10 +1258,35 @@ def main():
                     result["cpu_baseline"]["torch_version"] = torch.__version__
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline_error"] = repr(e)
-        print(json.dumps(result))
+    import threading as _threading
+    done, printed = _threading.Event(), [False]
+    if want_tp_report:
+        # LAST, after everything the replica line is made of (a collective: every rank runs it; the other ranks wait for rank 0 at its first
+        # barrier), and under a watchdog: the sharded modes have never met real xGMI links, and a rank stuck in a collective cannot be
+        # interrupted from Python -- after SDNQ_BENCH_TP_TIMEOUT seconds (default 240) every rank's watchdog prints (rank 0) the replica
+        # line with the timeout named in `tp` and leaves the process, so the driver always gets its line and the launcher a clean exit
+        import threading
+
+        def _watchdog():
+            if done.wait(float(os.environ.get("SDNQ_BENCH_TP_TIMEOUT", "240"))):
+                return
+            if rank == 0 and not printed[0]:
+                result["tp"] = {"error": "the sharded report did not finish in time (watchdog); the replica numbers above are complete"}
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=_watchdog, daemon=True).start()
+        try:
+            result["tp"] = tp_report(args, device, world, rank, shape_list, cfg_kwargs, ops_per_step)
+        except Exception as e:  # noqa: BLE001
+            result["tp"] = {"error": repr(e)[:400]}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+        printed[0] = True
     if distributed:
-        dist.barrier()
+        dist.barrier()  # (still under the watchdog: a rank that left the sharded report early waits here for one that is stuck in it)
         dist.destroy_process_group()
+    done.set()
 
 
 if __name__ == "__main__":
