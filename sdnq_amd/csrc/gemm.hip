@@ -1886,11 +1886,16 @@ int launch_one(GemmParams p, hipStream_t s) {
     constexpr int LDS_BYTES = (MAIN > EPIB ? MAIN : EPIB) + ((is_lr<EPI> || is_w8a16<MM>) ? 4 : 2) * BN * 4;  // ring | staging, then the per-channel vectors
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = gemm_kernel<MM, OUT_T, EPI, BM, BN, WM, WN, NS, LD, BK, LP>;
-    static std::atomic<bool> attr_set{false};
-    if (LDS_BYTES > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return SDNQ_ERR_LAUNCH;
-        attr_set.store(true, std::memory_order_release);
+    // (the attribute belongs to the function ON ONE DEVICE: a process that drives several GPUs sets it once per device, not once)
+    static std::atomic<uint64_t> attr_devices{0};
+    if (LDS_BYTES > 64 * 1024) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return SDNQ_ERR_LAUNCH;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return SDNQ_ERR_LAUNCH;
+            attr_devices.fetch_or(bit, std::memory_order_release);
+        }
     }
     if (p.lda == 0) p.lda = p.K;
     if (p.ldb == 0) p.ldb = is_w8a16<MM> ? p.K / 2 : p.K;

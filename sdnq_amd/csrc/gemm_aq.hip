@@ -365,10 +365,16 @@ int launch_aq(const void* x, const void* w, int64_t ldx, int64_t m, int64_t n, i
     constexpr int LDS_BYTES = NJ * A_STAGE + NSB * B_STAGE + (2 * BN + BM) * 4;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     auto kern = linear_aq_kernel<X_T, MM, HAS_BIAS, NJ, NSB>;
-    static std::atomic<bool> attr_set{false};
-    if (LDS_BYTES > 64 * 1024 && !attr_set.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return SDNQ_ERR_LAUNCH;
-        attr_set.store(true, std::memory_order_release);
+    // (the attribute belongs to the function ON ONE DEVICE: a process that drives several GPUs sets it once per device, not once)
+    static std::atomic<uint64_t> attr_devices{0};
+    if (LDS_BYTES > 64 * 1024) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return SDNQ_ERR_LAUNCH;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(attr_devices.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return SDNQ_ERR_LAUNCH;
+            attr_devices.fetch_or(bit, std::memory_order_release);
+        }
     }
     const int tiles_m = (int)((m + BM - 1) / BM), tiles_n = (int)((n + BN - 1) / BN);
     const int64_t tiles = (int64_t)tiles_m * tiles_n;
