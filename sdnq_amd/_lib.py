@@ -76,7 +76,7 @@ _lock = threading.Lock()
 _lib = None
 
 
-_SRCS = ("api", "rowquant", "gemm", "gemm_aq", "dequant", "quantize", "conv", "attention", "parallel")
+_SRCS = ("api", "rowquant", "gemm", "gemm_aq", "gemm_ks", "dequant", "quantize", "conv", "attention", "parallel")
 _FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-command-line-argument"
 
 
@@ -98,7 +98,7 @@ def source_hash() -> str:
             extra = "-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
         if f == "gemm" and os.environ.get("SDNQ_PRELOAD_GEMM", "1") != "0":
             extra = "-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
-        if f in ("dequant", "conv", "gemm_aq"):
+        if f in ("dequant", "conv", "gemm_aq", "gemm_ks"):
             extra = "-mllvm -amdgpu-kernarg-preload-count=14"
         g = hashlib.sha256((f"{hdr_hash} {flags} {extra}\n").encode())
         g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())

@@ -32,6 +32,12 @@
 
 #include "sdnq_dev.h"
 
+// gemm_ks.hip: the 64 x 80 tile with an in-workgroup K split (8 waves, partial sums reduced through LDS) -- tile id 28
+bool sdnq_internal_ks_eligible(int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb);
+bool sdnq_internal_ks_preferred(int64_t m, int64_t n, int64_t k);
+int sdnq_internal_scaled_mm_ks(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, void* out,
+                               int out_dtype, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldc, hipStream_t s);
+
 namespace {
 
 constexpr int BKB = 128;  // default bytes of K per LDS stage row (a full 128-byte line per row)
@@ -2006,6 +2012,12 @@ inline bool ht_ok(const GemmParams& p) {
     return (p.K % 128) == 0 && 256 * lda + p.K < (int64_t)1 << 31 && 256 * ldb + p.K < (int64_t)1 << 31;
 }
 
+// what the K-split tile (gemm_ks.hip) takes: one plain [M][N] output, no unit table
+inline bool ks_ok(const GemmParams& p) {
+    return p.units == nullptr && p.seg_n == 0 && p.out_hw == 0 && (p.bias == nullptr || p.bias_ndim <= 1) &&
+           sdnq_internal_ks_eligible(p.M, p.N, p.K, p.lda ? p.lda : p.K, p.ldb ? p.ldb : p.K);
+}
+
 // the ping-pong configurations exist for the quantized matmuls with the plain epilogues and 16-bit outputs (the model paths)
 template <int MM, int OUT_T, int EPI> constexpr bool PP_OK = !is_float_mm<MM> && EPI <= EPI_BIAS1D && OUT_T != SDNQ_F32;
 
@@ -2045,6 +2057,12 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (force == 25) return launch_one<MM, OUT_T, EPI, 256, 160, 32, 160, 3, LD_OG, 128>(p, s);
         if (force == 26) return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_OG, 128>(p, s);
         if (force == 27) return launch_one<MM, OUT_T, EPI, 256, 128, 64, 64, 3, LD_OG, 128>(p, s);
+        // 28: 64x80 tiles, eight waves in two K groups that share one 8-deep ring, int32 partial sums reduced through LDS (gemm_ks.hip, round 6);
+        //     problems it does not take (fp8, grouped / linked / conv outputs, K tails) fall through to the heuristics
+        if constexpr (MM == SDNQ_MM_I8) {
+            if (force == 28 && ks_ok(p))
+                return sdnq_internal_scaled_mm_ks(p.a, p.b, p.sa, p.sb, EPI == EPI_BIAS1D ? p.bias : nullptr, p.bias_dtype, p.out, OUT_T, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, s);
+        }
         // (round 5, measured and NOT instantiated: 64x80 tiles on v_mfma_i32_16x16x64_i8 -- four waves of 16x80, 256 workgroups for 1024 x 1280
         //  outputs, 25 % fewer LDS-fill bytes per CU -- on LD_DMA and on LD_OV, 3 / 4 ring slots: replayed alone 7.67-8.09 us against 7.09 at
         //  K = 1280, in the step +0.36..+0.53 ms over the 180 launches of 1024 x 1280 x 1280, +0.11..+0.21 at K = 5120; profiles/r05_overlapped_ring_lab.txt)
@@ -2052,9 +2070,9 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         //  the conv step, 64x320 tiles are slower; profiles/r04_conv_tiles_in_step.txt)
         // (round 4, profiles/r04_ring_depth_in_step.txt: 5- and 6-deep rings for the 64x128 tile -- the one-workgroup-per-CU problems of the
         //  SDXL step, 160 tiles on 256 CUs -- judged on the step: 1024 x 1280 x 1280 +0.11 / +0.13 ms, 4096 x 640 x 640 +0.15 / +0.16 ms,
-        //  1024 x 1280 x 5120 +-0.00: more bytes in flight do not raise the per-CU fill rate, so the 27 B/clk is not latency x bytes-in-flight
-        //  (Little's law would have predicted a gain) but the rate at which a CU's LDS-DMA requests are served; the deeper prologue only
-        //  delays the first MFMA.  Not instantiated in the library.)
+        //  1024 x 1280 x 5120 +-0.00: more bytes in flight did not shorten that loop -- its 720 cycles per stage are the SUM of DMA issue,
+        //  fragment reads and MFMAs of a lock-step stage (round 5, DESIGN.md section 6: the fill path alone sustains 47 B/clk/CU), not a service
+        //  rate -- and the deeper prologue only delays the first MFMA.  Not instantiated in the library.)
         // (64x80 tiles on v_mfma_i32_16x16x64_i8 -- MM_I8_16, instantiated by tools/micro/gemm_lab.hip only -- cut 1024 x 1280 outputs
         //  into exactly 256 workgroups with 25 % fewer LDS-fill bytes per CU, and measured SLOWER than 160 tiles of 64x128: 9.5 vs 7.9 us
         //  at K = 1280, 23.5 vs 19.0 us at K = 5120: four waves of 16x80 read six fragments per five 16-cycle MFMAs)
@@ -2117,6 +2135,12 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         if (tiles(128, 128) >= 160 && tiles(128, 128) <= 256 && p.K >= 1024 && fits(128))
             return launch_one<MM, OUT_T, EPI, 128, 128, 64, 32, 3, LD_PIPE, 128>(p, s);
     }
+    if constexpr (PP_OK<MM, OUT_T, EPI> && MM == SDNQ_MM_I8) {
+        //  * one round of 64x80 tiles where 64x128 tiles leave CUs idle (1024 x 1280 outputs: 256 workgroups instead of 160, 25 % fewer
+        //    LDS-fill bytes per CU): the K-split tile of gemm_ks.hip (round 6; profiles/r06_ksplit_*)
+        if (force < 0 && ks_ok(p) && sdnq_internal_ks_preferred(p.M, p.N, p.K))
+            return sdnq_internal_scaled_mm_ks(p.a, p.b, p.sa, p.sb, EPI == EPI_BIAS1D ? p.bias : nullptr, p.bias_dtype, p.out, OUT_T, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, s);
+    }
     if (p.M > 128 && fits(128)) return launch_one<MM, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
     if constexpr (PP_OK<MM, OUT_T, EPI>) {
         //  * 65..128 rows against MANY weight rows (all cross-attention k / v projections of a UNet in one grouped launch: 77 text tokens x
@@ -2133,7 +2157,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
 inline bool force_tile_unfit(const GemmParams& p) {
     const int force = forced_tile_for(p);
     if (force < 0 || p.units == nullptr) return false;
-    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128, 256, 128, 256, 128, 128, 128, 128, 160, 128, 128};
+    static const int bn_of[] = {256, 128, 64, 128, 256, 128, 256, 128, 128, 128, 128, 256, 160, 160, 320, 160, 320, 128, 256, 128, 256, 128, 128, 128, 128, 160, 128, 128, 128};  // (28 falls back to the heuristics on grouped launches)
     return force < (int)(sizeof(bn_of) / sizeof(int)) ? (p.unit_n % bn_of[force]) != 0 : false;
 }
 

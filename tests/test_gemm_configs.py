@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from sdnq_amd import _lib, ops  # noqa: E402
 
-TILES = list(range(28))
+TILES = list(range(29))
 
 
 @pytest.fixture()
