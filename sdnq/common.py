@@ -1,0 +1,5 @@
+"""sdnq.common of the import-name drop-in: the names of sdnq_amd.common (see sdnq/__init__.py)."""
+from sdnq_amd.common import *  # noqa: F401,F403
+from sdnq_amd import common as _m
+
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

@@ -1,0 +1,5 @@
+"""sdnq.layers of the import-name drop-in: the names of sdnq_amd.layers (see sdnq/__init__.py)."""
+from sdnq_amd.layers import *  # noqa: F401,F403
+from sdnq_amd import layers as _m
+
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

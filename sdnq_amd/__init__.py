@@ -18,6 +18,15 @@ from .quantizer import (QuantizationMethod, SDNQConfig, apply_sdnq_to_module, sd
 
 __version__ = sdnq_version
 
+
+def __getattr__(name):  # the transformers / diffusers plugin imports `transformers` (1-2 s): loaded on first use
+    if name in ("SDNQQuantizer", "hf_quantizer"):
+        import importlib
+        hf_quantizer = importlib.import_module(__name__ + ".hf_quantizer")
+        return hf_quantizer if name == "hf_quantizer" else hf_quantizer.SDNQQuantizer
+    raise AttributeError(f"module 'sdnq_amd' has no attribute {name!r}")
+
+
 __all__ = [
     "QuantizationMethod", "SDNQConfig", "SDNQDequantizer", "SDNQLayer", "SDNQLinear", "accelerate", "fuse_projections", "link_layers", "link_projections",
     "apply_sdnq_options_to_model", "apply_sdnq_to_module", "load_sdnq_model", "save_sdnq_model", "post_process_model", "dtype_dict", "fp8_scaled_mm_func", "get_forward_func",

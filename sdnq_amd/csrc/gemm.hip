@@ -1186,8 +1186,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
         // A 32x32 wave tile has ONE accumulator: its MFMAs form a dependent chain, and anything issued between two MFMAs on the same
         // accumulator costs the forwarding path (+43 cycles per gap, MI355X_MICROARCH.md).  Odd K sub-steps accumulate into a second
         // register set, summed once after the loop (int32: exact, so still bit-identical; fp32: one more addition order).
-        constexpr bool SPLIT_ACC = (TM * TN == 1) && (KS % 2 == 0);
-        typename MT::acc_t acc_odd[SPLIT_ACC ? 1 : 0 + 1];
+        constexpr bool SPLIT_ACC = (TM * TN == 1) && (KS % 2 == 0) && (MM == SDNQ_MM_I8);  // (integer sums only: a second fp32 accumulator would make the result depend on the tile)
+        typename MT::acc_t acc_odd[1];
         if constexpr (SPLIT_ACC) MT::zero(acc_odd[0]);
         auto load_stage = [&](int slot, auto setc) {
             constexpr int st = decltype(setc)::value;
@@ -1873,11 +1873,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_kernel(const 
 }
 
 // The next GEMM launch of this thread carries these ranges as prefetch work (consumed by that launch whether or not it had room for it)
-struct PrefetchHint { const void* ptr[4]; int64_t bytes[4]; };
+// (`device`: the device that was current when the hint was given -- the one its pointers live on; a launch on another device drops it)
+struct PrefetchHint { const void* ptr[4]; int64_t bytes[4]; int device; };
 thread_local PrefetchHint g_pf_hint = {};
-inline int cu_count() {
-    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
-    return n;
+inline int current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : -1; }
+// the pending hint, if it belongs to the device this thread is launching on; a hint of another device is discarded
+inline bool pf_hint_pending() {
+    if (!(g_pf_hint.ptr[0] || g_pf_hint.ptr[1] || g_pf_hint.ptr[2] || g_pf_hint.ptr[3])) return false;
+    if (g_pf_hint.device != current_device()) { g_pf_hint = PrefetchHint{}; return false; }
+    return true;
+}
+inline int cu_count() {  // of the CURRENT device (a process may drive different parts / partitions)
+    static std::atomic<int> cus[64];
+    const int dev = current_device();
+    if (dev < 0 || dev >= 64) return 256;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB, bool LP = false>
@@ -1932,7 +1947,7 @@ int launch_one(GemmParams p, hipStream_t s) {
     // prefetch workgroups ride along where the launch leaves workgroup slots free (its last round does not fill the chip): they run
     // beside the tiles on CUs that would idle, so the hint costs the launch nothing; a launch without room drops the hint
     int pf_wgs = 0;
-    if (g_pf_hint.ptr[0] || g_pf_hint.ptr[1] || g_pf_hint.ptr[2] || g_pf_hint.ptr[3]) {
+    if (pf_hint_pending()) {
         static std::atomic<int> occ{0};
         int o = occ.load(std::memory_order_relaxed);
         if (o == 0) {
@@ -2199,7 +2214,7 @@ int check_common(int mm_dtype, const void* a, const void* b, const float* sa, co
 // launch's free workgroup slots.  Consumes the hint.  Internal to the library (not part of the C ABI).
 int sdnq_internal_take_prefetch(int64_t room, int threads, const uint8_t* pf_ptr[4], int pf_lines[4]) {
     for (int r = 0; r < 4; ++r) { pf_ptr[r] = nullptr; pf_lines[r] = 0; }
-    if (!(g_pf_hint.ptr[0] || g_pf_hint.ptr[1] || g_pf_hint.ptr[2] || g_pf_hint.ptr[3])) return 0;
+    if (!pf_hint_pending()) return 0;
     int64_t lines = 0;
     for (int r = 0; r < 4; ++r) {
         if (!g_pf_hint.ptr[r] || g_pf_hint.bytes[r] <= 0) continue;
@@ -2227,6 +2242,7 @@ extern "C" int sdnq_hip_prefetch_hint(const void* p0, int64_t b0, const void* p1
         g_pf_hint.ptr[r] = bs[r] > 0 ? ps[r] : nullptr;
         g_pf_hint.bytes[r] = ps[r] ? bs[r] : 0;
     }
+    g_pf_hint.device = current_device();
     return SDNQ_OK;
 }
 

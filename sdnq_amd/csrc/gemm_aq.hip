@@ -353,9 +353,16 @@ inline int64_t aq_env(const char* name, int64_t dflt) {
     return e ? atoll(e) : dflt;
 }
 
-inline int aq_cu_count() {
-    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
-    return n;
+inline int aq_cu_count() {  // of the CURRENT device (a process may drive different parts / partitions)
+    static std::atomic<int> cus[64];
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 std::atomic<unsigned long long*> g_aq_trace{nullptr};
@@ -434,8 +441,6 @@ extern "C" int sdnq_hip_linear_w8a8_fused(int mm_dtype, const void* x, int x_dty
 #undef AQ_NJ
 }
 
-// lab: phase stamps of the one-launch Linear (device buffer of 1024 x 8 uint64, or null to stop)
-extern "C" int sdnq_hip_debug_aq_trace(unsigned long long* device_buf) {
-    g_aq_trace.store(device_buf, std::memory_order_relaxed);
-    return SDNQ_OK;
-}
+// lab: phase stamps of the one-launch Linear (device buffer of 1024 x 8 uint64, or null to stop).  A C++ symbol internal to the library
+// (tools/aq_lab.py binds its mangled name), not part of the C ABI of include/sdnq_hip.h
+void sdnq_internal_aq_trace(unsigned long long* device_buf) { g_aq_trace.store(device_buf, std::memory_order_relaxed); }

@@ -211,11 +211,16 @@ class _State:
 class _LaunchUnit:
     """One GEMM launch site of a model step (a layer, or a ProjectionGroup) as the weight prefetch sees it: the weight tensors the
     launch reads (held, so the ranges stay mapped) and a weak link to the unit that launched right after it in the last step."""
-    __slots__ = ("tensors", "ranges", "next", "__weakref__")
+    __slots__ = ("tensors", "ranges", "next", "device", "__weakref__")
 
     def __init__(self, tensors):
         self.tensors = tuple(tensors)
-        self.ranges = tuple((t.data_ptr(), t.numel() * t.element_size()) for t in self.tensors)
+        # (round 5 advice: a bare pointer range says nothing about the GPU it lives on; a thread that drives several devices must never
+        #  hand cuda:1 pointers to a launch on cuda:0)
+        self.device = self.tensors[0].device if self.tensors else None
+        if any(t.device != self.device for t in self.tensors):
+            self.device = None
+        self.ranges = tuple((t.data_ptr(), t.numel() * t.element_size()) for t in self.tensors) if self.device is not None else ()
         if sum(b for _, b in self.ranges) > PREFETCH_NEXT_MAX_BYTES or len(self.ranges) > 4:
             self.ranges = ()  # (the model-wide key / value group: 340 MB of weights, more than the cache holds)
         self.next = None
@@ -249,8 +254,10 @@ class _PrefetchChain:
         n1 = unit.next() if unit.next is not None else None
         if n1 is None:
             return
+        if n1.device != unit.device:  # the successor lives on another GPU (a model split across devices): nothing to prefetch from here
+            return
         n2 = n1.next() if n1.next is not None else None
-        rs = n1.ranges + (n2.ranges if (n2 is not None and n2 is not unit) else ())
+        rs = n1.ranges + (n2.ranges if (n2 is not None and n2 is not unit and n2.device == unit.device) else ())
         if not rs:
             return
         rs = (rs + ((0, 0),) * 4)[:4]

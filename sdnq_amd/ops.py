@@ -448,10 +448,11 @@ def linear_w8a8_fused_supported(mm: int, x2d: torch.Tensor, n: int, out_dtype: t
     built and expected to win; the answer per (dtype, M, N, K) is memoized."""
     if x2d.dtype not in (torch.bfloat16, torch.float16) or out_dtype != x2d.dtype or not x2d.is_cuda or x2d.stride(0) * 128 >= (1 << 31):
         return False  # (a tile's 64 rows are addressed with 32-bit byte offsets)
-    key = (mm, x2d.dtype, x2d.shape[0], n, x2d.shape[1])
+    key = (mm, x2d.dtype, x2d.shape[0], n, x2d.shape[1], x2d.device.index)  # (per device: the answer depends on its CU count)
     r = _fused_ok.get(key)
     if r is None:
-        r = bool(_lib.load().sdnq_hip_linear_w8a8_fused_supported(mm, float_code(x2d.dtype), float_code(out_dtype), x2d.shape[0], n, x2d.shape[1]))
+        with torch.cuda.device(x2d.device):
+            r = bool(_lib.load().sdnq_hip_linear_w8a8_fused_supported(mm, float_code(x2d.dtype), float_code(out_dtype), x2d.shape[0], n, x2d.shape[1]))
         _fused_ok[key] = r
     return r
 

@@ -254,3 +254,24 @@ def test_reference_loads_what_save_sdnq_model_wrote(tmp_path):
     sdnq_amd.save_sdnq_model(model, out)
     r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden_checkpoint.py"), "--verify", out], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "reproduced" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_hf_checkpoint_fixture_is_what_the_reference_plugin_writes(tmp_path):
+    """Build container only: tests/golden/checkpoint_hf_tiny regenerates from the reference's transformers plugin -- tensors and stored
+    logits byte for byte, the config up to the order of `modules_to_not_convert` (the reference builds it from a set)."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src/sdnq"):
+        pytest.skip("the reference is not present on this box")
+    out = str(tmp_path / "ckpt")
+    r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden_hf.py"), out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    src = os.path.join(GOLD, "checkpoint_hf_tiny")
+    assert open(os.path.join(out, "model.safetensors"), "rb").read() == open(os.path.join(src, "model.safetensors"), "rb").read()
+    a, b = np.load(os.path.join(out, "io.npz")), np.load(os.path.join(src, "io.npz"))
+    assert sorted(a.files) == sorted(b.files) and all(np.array_equal(a[k], b[k]) for k in a.files)
+    ca, cb = json.load(open(os.path.join(out, "config.json"))), json.load(open(os.path.join(src, "config.json")))
+    for c in (ca, cb):
+        c["quantization_config"]["modules_to_not_convert"] = sorted(c["quantization_config"]["modules_to_not_convert"])
+    assert ca == cb

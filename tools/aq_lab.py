@@ -57,15 +57,17 @@ for (m, n, k) in shapes:
     # phase stamps (shader clock, 100 MHz memtime ticks -> reported in ticks): entry, loads+ring issued, quantized, K loop done, synced, staged, stored
     try:
         buf = torch.zeros(1024 * 8, dtype=torch.int64, device=dev)
-        lib.sdnq_hip_debug_aq_trace.argtypes = [ctypes.c_void_p]
-        lib.sdnq_hip_debug_aq_trace(buf.data_ptr())
+        aq_trace = getattr(ctypes.CDLL(_lib.LIB_PATH), "_Z22sdnq_internal_aq_tracePy")
+        aq_trace.argtypes = [ctypes.c_void_p]
+        aq_trace.restype = None
+        aq_trace(buf.data_ptr())
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         b = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=dev)
         for _ in range(3):
             buf.zero_()
             ops.linear_w8a8_fused(ops.MM_I8, x, b, sb, bias, torch.bfloat16)
             torch.cuda.synchronize()
-        lib.sdnq_hip_debug_aq_trace(None)
+        aq_trace(None)
         t = buf.view(1024, 8).cpu()
         t = t[t[:, 0] > 0]
         d = (t[:, 1:7] - t[:, 0:6]).double()
