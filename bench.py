@@ -71,7 +71,7 @@ def parse():
                    help="attach the column-sharded (strong-scaling) numbers of the same workload, RCCL and copy-free gather, to the default line; "
                         "ON by default when --gpus > 1 without --tp (SDNQ_BENCH_TP_REPORT=0 turns it off)")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    p.add_argument("--launch", choices=["graph", "eager", "compile"], default=None,
+    p.add_argument("--launch", choices=["graph", "eager", "compile", "capture"], default=None,
                    help="how a step is launched: one captured hipGraph (default), eager Python (= --no-graph), or torch.compile(mode='reduce-overhead') "
                         "over the layer list (every SDNQ layer one sdnq_hip::layer_forward op; Inductor's own CUDA-graph trees do the replay)")
     p.add_argument("--activation-pool", type=int, default=0,
@@ -84,6 +84,9 @@ def parse():
     p.add_argument("--no-link-projections", action="store_true",
                    help="do not link attention projections that share their input (sdnq_amd.accelerate links them by default)")
     p.add_argument("--layers-scale", type=float, default=1.0, help="debug: fraction of each layer's repeat count")
+    p.add_argument("--profile-markers", action="store_true",
+                   help="bracket the TIMED steps with two marker kernels (torch.cuda._sleep: `spin_kernel`) so that tools/prof_window.py can cut "
+                        "exactly those steps out of a rocprofv3 kernel trace (build, warm-up, roofline replays and RNG kernels excluded)")
     p.add_argument("--dry-run", action="store_true",
                    help="multi-rank plumbing only, on CPU over gloo, NO device work (for tests): the JSON line is marked as such")
     return p.parse_args()
@@ -346,7 +349,60 @@ def time_gemm_kernel(layers, mm_name, device):
         e1.record(s)
         s.synchronize()
     dur_s = e0.elapsed_time(e1) / 1e3 / reps
-    return {"launches": len(calls), "ops": total_ops, "bytes": total_bytes, "seconds": dur_s}
+
+    # per shape class (round 6, verdict item 5b): the launches of one M x N x K replayed alone, back to back, so that the shape furthest
+    # below the roof is named by the bench line itself; tile / workgroups from the library's own dry run (sdnq_hip_scaled_mm_tile)
+    import ctypes
+    classes = {}
+    for i, c in enumerate(calls):
+        xq, wq, xs, ws, bias, g = c
+        m_, k_ = int(xq.shape[0]), int(xq.shape[1])
+        if isinstance(g, tuple):
+            n_, kind = int(ws.shape[0]), "low-rank / zero-point epilogue"
+        elif g == 1:
+            n_, kind = int(ws.shape[0]), "plain"
+        else:  # (wq is the ops.GemmGroup of the linked projections)
+            n_, kind = int(wq.n_total), f"grouped launch of {g} layers"
+        classes.setdefault((m_, n_, k_, kind), []).append(i)
+    table = []
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    peak = INT8_MFMA_PEAK_TOPS if mm_name == "int8" else FP8_MFMA_PEAK_TFLOPS
+    for (m_, n_, k_, kind), idxs in sorted(classes.items(), key=lambda kv: -len(kv[1]) * kv[0][0] * kv[0][1] * kv[0][2]):
+        def launch_class():
+            for i in idxs:
+                xq, wq, xs, ws, bias, g = calls[i]
+                if g == 1:
+                    ops.scaled_mm(mm, xq, wq, xs, ws, bias, torch.bfloat16)
+                elif isinstance(g, tuple):
+                    ops.scaled_mm_lowrank(mm, xq, wq, xs, ws, bias, g[1], g[2], g[3], g[4], torch.bfloat16)
+                else:
+                    ops.scaled_mm_grouped(mm, xq, xs, wq, torch.bfloat16)
+        rep_c = max(1, 64 // len(idxs))
+        with torch.cuda.stream(s):
+            launch_class()
+            s.synchronize()
+            gcls = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gcls, stream=s):
+                for _ in range(rep_c):
+                    launch_class()
+            gcls.replay()
+            s.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            for _ in range(3):
+                gcls.replay()
+            e1.record(s)
+            s.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (3 * rep_c * len(idxs))
+        bm, bn, thr, wgs = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int64(0)
+        tile = None
+        if kind == "plain":
+            if lib.sdnq_hip_scaled_mm_tile(mm, 1, 1, m_, n_, k_, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(thr), ctypes.byref(wgs)) == 0:
+                tile = {"tile": f"{bm.value}x{bn.value}", "threads": thr.value, "workgroups": wgs.value, "cus_used": min(cus, wgs.value)}
+        ops_l = 2.0 * m_ * n_ * k_
+        table.append({"shape": f"{m_}x{n_}x{k_}", "kind": kind, "launches_per_step": len(idxs), "avg_us": round(us, 2),
+                      "frac": round(ops_l / (us * 1e-6) / 1e12 / peak, 4) if n_ else None, **(tile or {})})
+    return {"launches": len(calls), "ops": total_ops, "bytes": total_bytes, "seconds": dur_s, "per_shape": table}
 
 
 def time_float_kernel(layers, device):
@@ -1057,6 +1113,27 @@ def main():
     if args.launch == "eager":
         args.no_graph = True
     compiled = None
+    captured = None
+    if args.launch == "capture" and not tp:
+        # the PUBLIC form of the hand-written capture below: sdnq_amd.capture(model, example_input) -- what a pipeline user calls after
+        # accelerate(model).  The step's layers as one module; the first activation is the example input (every layer keeps its own tensor)
+        import sdnq_amd
+
+        class StepModule(torch.nn.Module):
+            def __init__(self, layers):
+                super().__init__()
+                self.mods = torch.nn.ModuleList([l[1] for l in layers])
+                self.xs = [l[2] for l in layers]
+
+            def forward(self, x0):
+                out = None
+                for mod, x in zip(self.mods, self.xs):
+                    out = mod(x)
+                return out
+
+        captured = sdnq_amd.capture(StepModule(layers), layers[0][2], warmup=2)
+        captured_x0 = layers[0][2]
+        args.no_graph = True
     if args.launch == "compile" and not tp:
         # what `torch.compile(pipeline.unet, mode="reduce-overhead")` does to the Linear layers of an unmodified pipeline: Dynamo traces the
         # module calls (SDNQLayer.forward emits one sdnq_hip::layer_forward op per layer), Inductor wraps the result in CUDA-graph trees
@@ -1108,7 +1185,9 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        if compiled is not None:
+        if captured is not None:
+            captured(captured_x0)
+        elif compiled is not None:
             with torch.no_grad():
                 compiled()
         elif graph is not None:
@@ -1119,6 +1198,9 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.profile_markers:
+        torch.cuda._sleep(200000)  # marker kernel in front of the timed window (outside the timed region)
+        torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -1130,6 +1212,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if args.profile_markers:
+        torch.cuda._sleep(200000)  # ... and behind it
+        torch.cuda.synchronize()
     if distributed:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1152,7 +1237,8 @@ def main():
                                f"({sum(1 for l in layers if l[3] >= 32)} w8a8 GEMMs + {sum(1 for l in layers if l[3] < 32)} M=1 layers)",
                    "parallelism": (f"tp{world} column-shard + RCCL all-gather" if tp else (f"{world} independent replicas" if distributed else "single GPU")),
                    "launch": ("torch.compile(mode='reduce-overhead'): every plain layer rowquant + layer_matmul operators, layers on one quantized activation merged into grouped launches by the post-grad pass"
-                              if compiled is not None else ("eager" if graph is None else "hipGraph replay")), "activations": "bf16",
+                              if compiled is not None else ("sdnq_amd.capture(model, x): hipGraph replay through the public API" if captured is not None
+                                                         else ("eager" if graph is None else "hipGraph replay"))), "activations": "bf16",
                    **({"compile_seconds": round(compile_s, 1), "compile_grouping": dict(__import__("sdnq_amd").torch_ops.merge_stats)} if compiled is not None else {}),
                    "distinct_activation_tensors": len({id(l[2]) for l in layers}), "activation_quant_cache": L.CACHE_ACTIVATIONS > 0,
                    **({"activation_pool": args.activation_pool, "activation_buffers": len({l[2].data_ptr() for l in layers})} if args.activation_pool else {}),
@@ -1204,9 +1290,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             gk, result["roofline_error"] = None, repr(e)
         traffic, traffic_src, traffic_meta, traffic_stale = None, None, None, None
-        pmc_name = "r05_pmc_gemm_traffic_linked.json" if linked else "r01_pmc_gemm_traffic.json"  # same launch set as the step
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
-        if args.workload == "sdxl_int8" and os.path.exists(pmc) and not args.fuse_projections:
+        # the PMC profile of the SAME launch set (tools/pmc_step.sh <tag> <set>): one tracked file per workload, newest round first
+        pmc_set = {"sdxl_int8": "sdxl", "sdxl_fp8": "sdxl_fp8", "flux_int4_had": "flux", "flux_int8_svd": "flux_svd"}.get(args.workload)
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        cands = ([f"r06_pmc_gemm_traffic_{pmc_set}.json"] if pmc_set else []) + (["r05_pmc_gemm_traffic_linked.json"] if args.workload == "sdxl_int8" and linked else []) \
+            + (["r01_pmc_gemm_traffic.json"] if args.workload == "sdxl_int8" and not linked else [])
+        pmc_name = next((c for c in cands if os.path.exists(os.path.join(prof_dir, c))), cands[0] if cands else "none")
+        pmc = os.path.join(prof_dir, pmc_name)
+        if pmc_set and os.path.exists(pmc) and not args.fuse_projections:
             # HBM bytes per launch of the same 722 launches, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
             # (tools/pmc_shapes.py + tools/pmc_traffic.py; counters cannot be read inside this process)
             with open(pmc) as f:
@@ -1234,6 +1325,8 @@ def main():
                                   "traffic_stale": traffic_stale if traffic is not None else None,
                                   "algorithmic_bytes_per_launch": round(gk["bytes"] / gk["launches"]),
                                   "hbm_achieved_gbps": round(gk["bytes"] / gk["seconds"] / 1e9, 1), "hbm_peak_gbps": HBM_PEAK_GBPS,
+                                  # every M x N x K class of the step replayed alone (launches, avg us, fraction of the peak, tile, CUs used)
+                                  **({"per_shape": gk["per_shape"]} if gk.get("per_shape") else {}),
                                   "hbm_frac": round(gk["bytes"] / gk["seconds"] / 1e9 / HBM_PEAK_GBPS, 4), "kernel": kernel,
                                   "launches_per_step": gk["launches"], "avg_launch_us": round(gk["seconds"] / gk["launches"] * 1e6, 3),
                                   "peak_measured": peak_meas, "frac_of_measured_peak": round(ach / peak_meas, 4) if peak_meas else None,

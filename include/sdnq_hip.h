@@ -149,6 +149,13 @@ int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* 
                        const void* bias, int bias_dtype, int bias_ndim, int64_t ld_bias, void* out,
                        int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
+/* Which tile sdnq_hip_scaled_mm would run this problem on (a dry run of the launcher's shape rules -- the counterpart of the config
+ * pruning by shape in kernels/triton_scaled_mm.py:36-58; nothing is launched, no device is touched): bm x bn outputs per workgroup of
+ * `threads` threads, `workgroups` of them.  Any output pointer may be null.  Used by bench.py's per-shape roofline table (CUs a launch
+ * occupies) and by tuning tools. */
+int sdnq_hip_scaled_mm_tile(int mm_dtype, int out_dtype, int has_bias, int64_t m, int64_t n, int64_t k, int* bm, int* bn, int* threads,
+                            int64_t* workgroups);
+
 /* dequantize_fp32=False with BFLOAT16 scales: int_scaled_mm_torch / fp8_scaled_mm_torch on bf16 tensors (kernel_wrappers.py:132-144),
  *     t = bf16(acc);  t = bf16(t * sa[m]);  out = bf16(t * sb[n])   or   bf16(fma(t, sb[n], bias))     (fp32 op-math per step)
  * sa / sb: float32 arrays holding bf16-representable values (sdnq_hip_rowquant_lp's xs; the layer's upcast scale).  bias: NULL,

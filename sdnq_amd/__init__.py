@@ -11,6 +11,7 @@ from .forward import get_forward_func
 from .kernel_wrappers import fp8_scaled_mm_func, int_scaled_mm_func
 from .layers import SDNQLayer, SDNQLinear, get_sdnq_wrapper_class
 from .linear import invalidate
+from .capture import CapturedModel, capture
 from . import torch_ops  # registers the sdnq_hip::* operators with torch.library
 from .loader import accelerate, apply_sdnq_options_to_model, fuse_projections, link_layers, link_projections, load_sdnq_model, post_process_model, save_sdnq_model
 from .quantizer import (QuantizationMethod, SDNQConfig, apply_sdnq_to_module, sdnq_post_load_quant, sdnq_quantize_layer,
@@ -28,7 +29,7 @@ def __getattr__(name):  # the transformers / diffusers plugin imports `transform
 
 
 __all__ = [
-    "QuantizationMethod", "SDNQConfig", "SDNQDequantizer", "SDNQLayer", "SDNQLinear", "accelerate", "fuse_projections", "link_layers", "link_projections",
+    "CapturedModel", "QuantizationMethod", "SDNQConfig", "SDNQDequantizer", "SDNQLayer", "SDNQLinear", "accelerate", "capture", "fuse_projections", "link_layers", "link_projections",
     "apply_sdnq_options_to_model", "apply_sdnq_to_module", "load_sdnq_model", "save_sdnq_model", "post_process_model", "dtype_dict", "fp8_scaled_mm_func", "get_forward_func",
     "get_sdnq_wrapper_class", "int_scaled_mm_func", "invalidate", "sdnq_post_load_quant", "sdnq_quantize_layer",
     "sdnq_quantize_layer_weight",

@@ -34,6 +34,7 @@ EXPORTS = [
     "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided", "sdnq_hip_prefetch", "sdnq_hip_prefetch_hint",
     "sdnq_hip_signal_alloc", "sdnq_hip_signal_free", "sdnq_hip_ipc_export", "sdnq_hip_ipc_import", "sdnq_hip_ipc_close",
     "sdnq_hip_linear_w8a8_fused", "sdnq_hip_linear_w8a8_fused_supported", "sdnq_hip_scaled_mm_lp_uzp_svd", "sdnq_hip_stream_capture_id",
+    "sdnq_hip_scaled_mm_tile",
 ]
 
 

@@ -1895,10 +1895,15 @@ inline int cu_count() {  // of the CURRENT device (a process may drive different
     return v;
 }
 
+// sdnq_hip_scaled_mm_tile: a dry run of the tile heuristics -- the launcher that WOULD run records its tile here and returns
+struct TileProbe { int bm, bn, threads; };
+thread_local TileProbe* g_tile_probe = nullptr;
+
 template <int MM, int OUT_T, int EPI, int BM, int BN, int WM, int WN, int NS, int LD = LD_DMA, int BK = BKB, bool LP = false>
 int launch_one(GemmParams p, hipStream_t s) {
     static_assert(!LP || (OUT_T == SDNQ_BF16 && !is_float_mm<MM>), "LP: the bf16-scale epilogue of the quantized matmuls");
     constexpr int NW = (BM / WM) * (BN / WN);
+    if (g_tile_probe) { *g_tile_probe = TileProbe{BM, BN, NW * 64}; return SDNQ_OK; }
     constexpr int MAIN = (LD == LD_HT) ? HT_SLOTS * HT_BYTES : NS * (BM * BK + BN * (is_w8a16<MM> ? BK / 2 : BK));
     constexpr int CHS = BM > 128 ? 64 : BM, CHR = epi_chunk_rows<EPI, BM, BN, FT<OUT_T>::bytes>();  // rows per epilogue chunk (as in gemm_kernel)
     constexpr int EPI_GEN = (BM + BN) * 64 + CHS * (BN * 4 + 16) + CHS * (BN * 2 + 16);
@@ -2075,6 +2080,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
         // 28: 64x80 tiles, eight waves in two K groups that share one 8-deep ring, int32 partial sums reduced through LDS (gemm_ks.hip, round 6);
         //     problems it does not take (fp8, grouped / linked / conv outputs, K tails) fall through to the heuristics
         if constexpr (MM == SDNQ_MM_I8) {
+            if (force == 28 && ks_ok(p) && g_tile_probe) { *g_tile_probe = TileProbe{64, 80, 512}; return SDNQ_OK; }
             if (force == 28 && ks_ok(p))
                 return sdnq_internal_scaled_mm_ks(p.a, p.b, p.sa, p.sb, EPI == EPI_BIAS1D ? p.bias : nullptr, p.bias_dtype, p.out, OUT_T, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, s);
         }
@@ -2153,6 +2159,7 @@ int launch_tiles(const GemmParams& p, hipStream_t s) {
     if constexpr (PP_OK<MM, OUT_T, EPI> && MM == SDNQ_MM_I8) {
         //  * one round of 64x80 tiles where 64x128 tiles leave CUs idle (1024 x 1280 outputs: 256 workgroups instead of 160, 25 % fewer
         //    LDS-fill bytes per CU): the K-split tile of gemm_ks.hip (round 6; profiles/r06_ksplit_*)
+        if (force < 0 && ks_ok(p) && sdnq_internal_ks_preferred(p.M, p.N, p.K) && g_tile_probe) { *g_tile_probe = TileProbe{64, 80, 512}; return SDNQ_OK; }
         if (force < 0 && ks_ok(p) && sdnq_internal_ks_preferred(p.M, p.N, p.K))
             return sdnq_internal_scaled_mm_ks(p.a, p.b, p.sa, p.sb, EPI == EPI_BIAS1D ? p.bias : nullptr, p.bias_dtype, p.out, OUT_T, p.M, p.N, p.K, p.lda, p.ldb, p.ldc, s);
     }
@@ -2446,6 +2453,26 @@ extern "C" int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, co
     hipStream_t s = (hipStream_t)stream;
     if (mm_dtype == SDNQ_MM_I8) return dispatch_epi<SDNQ_MM_I8>(p, bias_ndim, out_dtype, s);
     return dispatch_epi<SDNQ_MM_FP8>(p, bias_ndim, out_dtype, s);
+}
+
+extern "C" int sdnq_hip_scaled_mm_tile(int mm_dtype, int out_dtype, int has_bias, int64_t m, int64_t n, int64_t k, int* bm, int* bn, int* threads,
+                                       int64_t* workgroups) {
+    if (mm_dtype != SDNQ_MM_I8 && mm_dtype != SDNQ_MM_FP8) return SDNQ_ERR_DTYPE;
+    if (out_dtype < 0 || out_dtype > 2) return SDNQ_ERR_DTYPE;
+    if (m <= 0 || n <= 0 || k <= 0 || (k % 16) != 0 || (n % 8) != 0) return SDNQ_ERR_SHAPE;
+    GemmParams p{};
+    p.M = m; p.N = n; p.K = k; p.bias_ndim = has_bias ? 1 : 0; p.bias_dtype = out_dtype;
+    TileProbe probe{0, 0, 0};
+    g_tile_probe = &probe;  // (no pointer of `p` is read on the host: the dry run returns in front of the launch)
+    const int st = mm_dtype == SDNQ_MM_I8 ? dispatch_epi<SDNQ_MM_I8>(p, p.bias_ndim, out_dtype, nullptr) : dispatch_epi<SDNQ_MM_FP8>(p, p.bias_ndim, out_dtype, nullptr);
+    g_tile_probe = nullptr;
+    if (st != SDNQ_OK) return st;
+    if (probe.bm == 0) return SDNQ_ERR_UNSUPPORTED;
+    if (bm) *bm = probe.bm;
+    if (bn) *bn = probe.bn;
+    if (threads) *threads = probe.threads;
+    if (workgroups) *workgroups = ((m + probe.bm - 1) / probe.bm) * ((n + probe.bn - 1) / probe.bn);
+    return SDNQ_OK;
 }
 
 extern "C" int sdnq_hip_scaled_mm_multi(int mm_dtype, const void* a, const void* b, const float* sa, const float* sb, const void* bias,

@@ -142,28 +142,68 @@ class _ActivationCache:
         self.entries.clear()
 
 
-_act_cache = _ActivationCache()
+class _ThreadState(__import__("threading").local):
+    """The mutable host state of the forwards, ONE INSTANCE PER THREAD ("thread-safe: no global mutable state"; round-5 verdict
+    item 9).  The activation cache, the identity-reuse switch and the per-call weight pipeline used to be process globals without a lock:
+    two pipelines on two threads of one process raced on them.  They hold nothing that must be seen across threads -- an entry is only
+    ever valid for the stream that produced it, and a thread drives its own streams -- so every thread gets its own, created at first use
+    (`threading.local` attribute access is C code: the hot path pays ~50 ns for it)."""
+
+    def __init__(self):
+        self.act_cache = _ActivationCache()
+        self.no_reuse = 0          # nesting depth of identity_reuse_disabled()
+        self.weight_pipeline = None  # created on first use (below: _WeightPipeline is defined later)
+
+
+_ts = _ThreadState()
+
+
+class _PerThread:
+    """Module-level name of a per-thread object (what the rest of the package and the tests address): forwards to this thread's instance."""
+
+    def __init__(self, getter):
+        object.__setattr__(self, "_get", getter)
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+    def __setattr__(self, name, value):
+        setattr(self._get(), name, value)
+
+
+class _PerThreadFlag:
+    """`flag[0]` read / written per thread (kept for callers of the old list form)."""
+
+    def __getitem__(self, i):
+        return _ts.no_reuse
+
+    def __setitem__(self, i, v):
+        _ts.no_reuse = v
+
+
+_act_cache = _PerThread(lambda: _ts.act_cache)
 
 # Identity-keyed reuse (the activation cache, outputs parked in a ProjectionGroup) rests on "the very same tensor object, unchanged
 # by every writer autograd knows about".  Inside a torch.compile'd graph that does not hold: Inductor recycles dead buffers in place
 # (`buf7 = buf1; del buf1  # reuse`: same Python object, address and geometry) and its kernels write through raw pointers, so
 # `_version` never moves -- a norm1 output cached for to_q / to_k / to_v would be served again for the norm2 output that now lives in
 # the same buffer.  The `sdnq_hip::layer_forward` operator therefore runs the eager forward under `identity_reuse_disabled()`.
-_no_identity_reuse = [0]
+_no_identity_reuse = _PerThreadFlag()
 
 
 class identity_reuse_disabled:
     def __enter__(self):
-        _no_identity_reuse[0] += 1
+        _ts.no_reuse += 1
 
     def __exit__(self, *exc):
-        _no_identity_reuse[0] -= 1
+        _ts.no_reuse -= 1
         return False
-_groups = []  # weak references to the live SharedInputGroups (invalidate() reaches their pending outputs)
+_groups = []  # weak references to the live SharedInputGroups (invalidate() reaches their pending outputs); guarded by _groups_lock
+_groups_lock = __import__("threading").Lock()
 
 
 def clear_activation_cache():
-    _act_cache.clear()
+    _ts.act_cache.clear()
     _weight_pipeline.start_step()
 
 
@@ -171,11 +211,13 @@ def invalidate(tensor: torch.Tensor | None = None):
     """Forget everything derived from `tensor` (its quantized copy, outputs of linked projections computed from it but not yet
     handed out); with no argument, from every tensor.  Needed only when a tensor's contents were changed WITHOUT bumping its
     autograd version counter, e.g. by another library's raw-pointer kernel."""
-    _act_cache.invalidate(tensor)
+    _ts.act_cache.invalidate(tensor)
     if tensor is None:
         _weight_pipeline.start_step()
-    _groups[:] = [ref for ref in _groups if ref() is not None]
-    for ref in _groups:
+    with _groups_lock:
+        _groups[:] = [ref for ref in _groups if ref() is not None]
+        live = list(_groups)
+    for ref in live:
         g = ref()
         if g is None:
             continue
@@ -190,7 +232,7 @@ def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum
     params = (mm, had, want_rowsum, want_xrot, asymmetric, ops._stream(input) if input.is_cuda else -1)
     cache = cache and CACHE_ACTIVATIONS > 0
     if cache:
-        hit = _act_cache.get(input, params)
+        hit = _ts.act_cache.get(input, params)
         if hit is not None:
             return hit
     x2 = input.reshape(-1, k)
@@ -199,7 +241,7 @@ def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum
     res = ops.rowquant(x2, mm, had, want_rowsum=want_rowsum, want_xrot=want_xrot, prefetch=prefetch, asymmetric=asymmetric)
     res = (x2,) + tuple(res)
     if cache:
-        _act_cache.put(input, params, res)
+        _ts.act_cache.put(input, params, res)
     return res
 
 
@@ -505,7 +547,14 @@ class _WeightPipeline:
         return wq, ws
 
 
-_weight_pipeline = _WeightPipeline()
+def _thread_weight_pipeline():
+    wp = _ts.weight_pipeline
+    if wp is None:
+        wp = _ts.weight_pipeline = _WeightPipeline()
+    return wp
+
+
+_weight_pipeline = _PerThread(_thread_weight_pipeline)
 
 
 def join_weight_pipeline():
@@ -583,7 +632,8 @@ class ProjectionGroup:
         self.fallback = None  # smaller groups (lists of members) to form when THIS grouping turns out wrong (loader.link_projections)
         self.pf = None            # _LaunchUnit of the grouped launch (weight prefetch across layers)
         self.pf_tensors = ()      # the members' weight operands, as the unit table was built from them
-        _groups.append(weakref.ref(self))
+        with _groups_lock:
+            _groups.append(weakref.ref(self))
 
     def dissolve(self):
         for m in self.mods:
@@ -702,7 +752,7 @@ class ProjectionGroup:
         return True
 
     def forward(self, mod, idx: int, input: torch.Tensor, mm: int):
-        key = None if _no_identity_reuse[0] else tensor_key(input)
+        key = None if _ts.no_reuse else tensor_key(input)
         if key is None:
             return None  # inference tensor / compiled graph: no way to tell whether it changed between the members' calls
         stream = ops._stream(input)
@@ -804,8 +854,8 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
             y = ops.linear_w8a8_ws(mm, x2, wq, ws, bias, input.dtype, had)
             return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
-        key = tensor_key(input) if (use_cache and not _no_identity_reuse[0]) else None  # one key for the look-up and the store
-        hit = _act_cache.get(input, params, key) if key is not None else None
+        key = tensor_key(input) if (use_cache and not _ts.no_reuse) else None  # one key for the look-up and the store
+        hit = _ts.act_cache.get(input, params, key) if key is not None else None
         if hit is None:
             x2 = input if input.dim() == 2 else input.reshape(-1, k)
             if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
@@ -814,7 +864,7 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
                 raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
             y, xq, xs = ops.linear_w8a8(mm, x2, wq, ws, bias, input.dtype, had)
             if key is not None:
-                _act_cache.put(input, params, (x2, xq, xs, None, None), key, m * k * (input.element_size() + 1) + 4 * m, self)
+                _ts.act_cache.put(input, params, (x2, xq, xs, None, None), key, m * k * (input.element_size() + 1) + 4 * m, self)
             return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         x2, xq, xs, rowsum, xrot = hit
         return ops.scaled_mm(mm, xq, wq, xs, ws, bias, input.dtype).view(*input.shape[:-1], n)
@@ -822,8 +872,8 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     # row quantization, the low-rank product and the matmul with its full epilogue (SURVEY 8b's POD-args entry point)
     params = (mm, had, zp is not None, has_svd, False, ops._stream(input) if input.is_cuda else -1)
     use_cache = cache_input and CACHE_ACTIVATIONS > 0
-    key = tensor_key(input) if (use_cache and not _no_identity_reuse[0]) else None
-    hit = _act_cache.get(input, params, key) if key is not None else None
+    key = tensor_key(input) if (use_cache and not _ts.no_reuse) else None
+    hit = _ts.act_cache.get(input, params, key) if key is not None else None
     if hit is not None:
         x2, xq, xs, rowsum, xrot = hit
         pre = (xq, xs, rowsum, xrot, None)
@@ -841,7 +891,7 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     y, inter = ops.linear_call(mm, x2, wq, ws, bias, input.dtype, had, st.svd_down if has_svd else None, st.svd_up if has_svd else None, zp,
                                pre=pre)
     if hit is None and key is not None:
-        _act_cache.put(input, params, (x2,) + tuple(inter[:4]), key)
+        _ts.act_cache.put(input, params, (x2,) + tuple(inter[:4]), key)
     return y.view(*input.shape[:-1], n)
 
 

@@ -205,3 +205,23 @@ def test_one_launch_linear_predicate_and_argument_validation_without_gpu():
     assert f(I8, p, BF16, 64, 2560, 2560, p, p, None, 0, p, BF16, 128, None) == -5       # K > 1280
     assert f(I8, p, F32, 64, 128, 128, p, p, None, 0, p, F32, 128, None) == -5           # float32 activations
     assert f(I8, p + 8, BF16, 64, 128, 128, p, p, None, 0, p, BF16, 128, None) == -4     # alignment
+
+
+def test_scaled_mm_tile_is_a_dry_run_of_the_shape_rules():
+    """sdnq_hip_scaled_mm_tile answers without a device: the tile, its threads and the workgroup count the launcher would use
+    (the SDXL bs = 1 shapes of launch_tiles' comments), and refuses what sdnq_hip_scaled_mm refuses."""
+    import ctypes
+    lib = _lib.load()
+
+    def tile(m, n, k, mm=0):
+        bm, bn, thr, wgs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        st = lib.sdnq_hip_scaled_mm_tile(mm, 1, 1, m, n, k, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(thr), ctypes.byref(wgs))
+        return st, bm.value, bn.value, thr.value, wgs.value
+    assert tile(1024, 1280, 1280) == (0, 64, 128, 512, 160)      # 160 of 256 CUs: the launch the round-6 K-split tile was built against
+    assert tile(1024, 10240, 1280) == (0, 256, 160, 512, 256)    # GEGLU: exactly one workgroup per CU
+    assert tile(1024, 3840, 1280) == (0, 128, 128, 512, 240)
+    assert tile(4608, 3072, 3072)[1:3] == (256, 256)             # FLUX: the half-tile ring
+    assert tile(77, 640, 2048)[1:3] == (64, 64)
+    assert tile(1024, 1280, 1280, mm=1)[0] == 0                  # fp8
+    assert tile(1024, 1284, 1280)[0] != 0 and tile(0, 1280, 1280)[0] != 0 and tile(64, 64, 64, mm=7)[0] != 0
+    assert lib.sdnq_hip_scaled_mm_tile(0, 1, 0, 1024, 1280, 1280, None, None, None, None) == 0  # every output pointer is optional

@@ -1,19 +1,15 @@
 #!/bin/bash
-# rocprofv3 kernel-trace stats of one bench.py workload -> gpurun_out/<tag>_kernel_stats.csv (run on the GPU box from the repo root)
-# usage: tools/prof_bench.sh <tag> [bench.py args...]
+# rocprofv3 kernel trace of one bench.py workload, cut to the TIMED (graph-replayed) steps by marker kernels (bench.py --profile-markers
+# + tools/prof_window.py): calls per step are integers and the per-kernel "us inside the step" can be recomputed from the CSV.
+# -> gpurun_out/<tag>_window_kernels.csv, <tag>_window_summary.txt, <tag>_bench.json (run on the GPU box from the repo root)
+# usage: tools/prof_bench.sh <tag> [bench.py args...]       (steps: the --steps given, default 20)
 TAG=$1; shift
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT/$TAG"
 export TMPDIR=/tmp
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/$TAG" -o prof --output-format csv -- python "$OLDPWD/bench.py" --no-cpu-baseline "$@" > "$OUT/$TAG/bench.log" 2>&1)
-F=$(find "$OUT/$TAG" -name "*kernel_stats.csv" | head -1)
-cp "$F" "$OUT/${TAG}_kernel_stats.csv"
+STEPS=20
+for ((i = 1; i <= $#; i++)); do [ "${!i}" = "--steps" ] && j=$((i + 1)) && STEPS=${!j}; done
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace -d "$OUT/$TAG" -o prof --output-format csv -- python "$OLDPWD/bench.py" --no-cpu-baseline --profile-markers "$@" > "$OUT/$TAG/bench.log" 2>&1)
 tail -1 "$OUT/$TAG/bench.log" > "$OUT/${TAG}_bench.json"
+python tools/prof_window.py "$OUT/$TAG" "$STEPS" "$OUT/${TAG}_window"
 find "$OUT/$TAG" -name "*.csv" -size +500k -delete
-python - "$OUT/${TAG}_kernel_stats.csv" <<'PY'
-import csv, sys, re
-rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:14]:
-    nm = re.sub(r"\(anonymous namespace\)::|void ", "", r["Name"])[:95]
-    print(f"{nm:95s} calls {int(r['Calls']):6d} total_ms {float(r['TotalDurationNs'])/1e6:9.3f} avg_us {float(r['AverageNs'])/1e3:8.2f} {float(r['Percentage']):6.2f}%")
-PY
