@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant",
+    p.add_argument("--workload", default="sdxl_int8", choices=["sdxl_int8", "sdxl_fp8", "sdxl_int4", "flux_int4_had", "flux_int8_svd", "linear_int8", "sdxl_conv_int8", "sdxl_int8_dequant",
                             "sdxl_attn_int8", "flux_attn_int8", "sdxl_unet_all"])
     p.add_argument("--tp", action="store_true", help="column-shard every Linear across ranks + RCCL all-gather")
     p.add_argument("--tp-chunks", type=int, default=2, help="with --tp: M chunks per layer (gather of chunk i on a side stream under the matmul of chunk i + 1; 1 = plain)")
@@ -99,6 +99,8 @@ def workload_config(name: str):
     if name == "sdxl_fp8":
         return shapes.sdxl_unet_layer_sequence(), dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1,
                                                 use_quantized_matmul=True), "fp8", 16384
+    if name == "sdxl_int4":  # N1's question at SDXL sizes: 4-bit group-wise weights on the int8 matmul (re_quantize_for_matmul: dequantizer.py:166-239)
+        return shapes.sdxl_unet_layer_sequence(), dict(weights_dtype="uint4", use_quantized_matmul=True), "int8", 16384
     if name == "flux_int4_had":
         return shapes.flux_dev_layer_sequence(), dict(weights_dtype="int4", use_hadamard=True, hadamard_group_size=256,
                                                use_quantized_matmul=True), "int8", 4608

@@ -42,3 +42,23 @@ def test_mismatched_world_size_is_an_error():
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_gpus_8_dry_run_through_the_drivers_launcher():
+    """The driver's own command for the 8-GPU line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` -- on CPU (`--dry-run`, gloo): eight ranks rendezvous, ONE line from rank 0 with n_gpus = 8
+    and the MAX over ranks (round-5 verdict item 7: the N = 8 path had never executed in any form)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["dry_run"] is True and j["scaling"] == "weak"
+    assert j["ms_per_step"] >= 8.0  # rank r sleeps (r + 1) ms per step: rank 7's 8 ms is the step, not rank 0's 1 ms

@@ -186,3 +186,54 @@ def test_column_shard_module_world2_gloo(cfg):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+# ---- world 8: the slab geometry of BASELINE configs[4] (FLUX int8 + SVD r = 32, TP = 8) ---------------------------------------
+def _worker_flux_geometry(rank, world, port, q):
+    import sdnq_amd
+    from sdnq_amd.parallel import column_shard_module, shard_bounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for n in (3072, 9216, 12288):  # attention out / joint qkv / feed-forward widths of FLUX.1-dev; K reduced (slicing does not depend on it)
+            torch.manual_seed(n)  # (torch.svd_lowrank draws from the global generator: every rank must hold the SAME layer)
+            lin = torch.nn.Linear(256, n, bias=True).to(torch.bfloat16)
+            mod, _ = sdnq_amd.sdnq_quantize_layer(lin, sdnq_amd.SDNQConfig(weights_dtype="int8", group_size=-1, use_quantized_matmul=True, use_svd=True,
+                                                                          svd_rank=32))
+            a, b = shard_bounds(n, rank, world)
+            sharded = column_shard_module(mod, rank, world)
+            slab = sharded.local
+            ok &= (b - a) == n // world and slab.sdnq_dequantizer.out_features == n // world
+            ok &= tuple(slab.svd_up.shape) == (32, n // world) and slab.svd_down.data_ptr() == mod.svd_down.data_ptr()  # up sliced, down shared
+            sharded.local = _OracleForward(slab)
+            x = torch.randn(8, 256).to(torch.bfloat16)
+            y = sharded(x)
+            if rank == 0:  # (one full-width oracle forward per width is enough: every rank received the same gathered matrix)
+                ok &= torch.equal(y, _OracleForward(mod)(x))
+            ys = [torch.empty_like(y) for _ in range(world)]
+            dist.all_gather(ys, y)
+            ok &= all(torch.equal(ys[0], t) for t in ys) and tuple(y.shape) == (8, n)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_shard_module_world8_flux_cfg5_geometry():
+    """Eight gloo ranks (round-5 verdict item 7: no code path had ever run with more than two): the three FLUX widths cut into 8 slabs
+    of 384 / 1152 / 1536 channels, `svd_up[:, a:b]` sliced and `svd_down` shared, each slab computed (oracle standing in for the HIP
+    forward), gathered -- every rank ends with the bits of the unsharded layer."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_flux_geometry, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    results = dict(q.get(timeout=10) for _ in range(8))
+    assert results == {r: True for r in range(8)}
