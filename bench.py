@@ -258,6 +258,8 @@ def resident_weight_bytes(layers):
         if st is not None:
             for name in ("mm_weight", "mm_scale", "mm_zp", "mm_wcs", "wd", "svd_down_t"):
                 cached += add(getattr(st, name, None))
+            if isinstance(getattr(st, "lut", None), tuple):  # the fused 4-bit route's tables + row scales (per-call mode)
+                cached += add(st.lut[0]) + add(st.lut[1])
     return {"stored_parameters": stored, "cached_matmul_operands": cached, "per_call_scratch": L._weight_pipeline.scratch_bytes(),
             "total": stored + cached + L._weight_pipeline.scratch_bytes()}
 

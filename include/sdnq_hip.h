@@ -156,6 +156,25 @@ int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* 
 int sdnq_hip_scaled_mm_tile(int mm_dtype, int out_dtype, int has_bias, int64_t m, int64_t n, int64_t k, int* bm, int* bn, int* threads,
                             int64_t* workgroups);
 
+/* ---- N1: the re-quantization of 4-bit weights fused into the matmul (round 6) -----------------------------------------------
+ * replaces, as ONE launch per call, what sdnq_hip_requant + sdnq_hip_scaled_mm compute for 4-bit packed weights
+ * (dequantizer.py:166-239 re_quantize_matmul + layers/linear/linear_int8.py:104-107): the stored codes are the weight operand, the
+ * re-quantized int8 value of a code comes from a 16-entry table per (row, 64 columns).
+ *
+ * sdnq_hip_lut4_build: the tables of a weight -- lut[n][K / 64][16] bytes (entry c = the int8 byte sdnq_hip_requant writes for code c
+ * in that block of that row; 16-byte aligned) -- and the row scales ws[N] (ws_known != 0: read from ws instead of derived).  Built
+ * once per layer (they depend only on static parameters).  4-bit packed storage, positions == 1, group_size % 64 == 0, K % 64 == 0,
+ * K <= 16384; anything else: SDNQ_ERR_UNSUPPORTED.  mm_dtype: SDNQ_MM_I8 or SDNQ_MM_FP8 (the tables then hold e4m3 bytes).
+ *
+ * sdnq_hip_scaled_mm_w4: out[m][n] = cast(fma(f32(sum_k a[m][k] * table(codes[n][k])) * sa[m], sb[n], bias[n])) -- bit for bit
+ * sdnq_hip_scaled_mm on the operand sdnq_hip_requant would have written.  a: [M][K] int8 (row stride lda bytes, 0: K); codes: the
+ * stored packed tensor [N][K / 2]; int8 matmul, 16-bit outputs, 1-D bias or none, K % 128 == 0.  ..._supported: 1 where this route is
+ * built AND expected to win (few-row problems: every row block of 64 rows repeats the expansion). */
+int sdnq_hip_lut4_build(const SdnqWeight* w, int mm_dtype, float* ws, int ws_known, void* lut, sdnq_stream_t stream);
+int sdnq_hip_scaled_mm_w4(const void* a, const void* codes, const void* lut, const float* sa, const float* sb, const void* bias, int bias_dtype,
+                          void* out, int out_dtype, int64_t m, int64_t n, int64_t k, int64_t lda, sdnq_stream_t stream);
+int sdnq_hip_scaled_mm_w4_supported(int mm_dtype, int out_dtype, int64_t m, int64_t n, int64_t k);
+
 /* dequantize_fp32=False with BFLOAT16 scales: int_scaled_mm_torch / fp8_scaled_mm_torch on bf16 tensors (kernel_wrappers.py:132-144),
  *     t = bf16(acc);  t = bf16(t * sa[m]);  out = bf16(t * sb[n])   or   bf16(fma(t, sb[n], bias))     (fp32 op-math per step)
  * sa / sb: float32 arrays holding bf16-representable values (sdnq_hip_rowquant_lp's xs; the layer's upcast scale).  bias: NULL,

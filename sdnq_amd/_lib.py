@@ -34,7 +34,7 @@ EXPORTS = [
     "sdnq_hip_push_post", "sdnq_hip_push_columns", "sdnq_hip_scaled_mm_lowrank_strided", "sdnq_hip_prefetch", "sdnq_hip_prefetch_hint",
     "sdnq_hip_signal_alloc", "sdnq_hip_signal_free", "sdnq_hip_ipc_export", "sdnq_hip_ipc_import", "sdnq_hip_ipc_close",
     "sdnq_hip_linear_w8a8_fused", "sdnq_hip_linear_w8a8_fused_supported", "sdnq_hip_scaled_mm_lp_uzp_svd", "sdnq_hip_stream_capture_id",
-    "sdnq_hip_scaled_mm_tile",
+    "sdnq_hip_scaled_mm_tile", "sdnq_hip_lut4_build", "sdnq_hip_scaled_mm_w4", "sdnq_hip_scaled_mm_w4_supported",
 ]
 
 
@@ -77,7 +77,7 @@ _lock = threading.Lock()
 _lib = None
 
 
-_SRCS = ("api", "rowquant", "gemm", "gemm_aq", "gemm_ks", "dequant", "quantize", "conv", "attention", "parallel")
+_SRCS = ("api", "rowquant", "gemm", "gemm_aq", "gemm_ks", "gemm_w4", "dequant", "quantize", "conv", "attention", "parallel")
 _FLAGS = " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-command-line-argument"
 
 
@@ -99,7 +99,7 @@ def source_hash() -> str:
             extra = "-DSDNQ_PRELOAD_ROWQUANT -mllvm -amdgpu-kernarg-preload-count=14"
         if f == "gemm" and os.environ.get("SDNQ_PRELOAD_GEMM", "1") != "0":
             extra = "-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
-        if f in ("dequant", "conv", "gemm_aq", "gemm_ks"):
+        if f in ("dequant", "conv", "gemm_aq", "gemm_ks", "gemm_w4"):
             extra = "-mllvm -amdgpu-kernarg-preload-count=14"
         g = hashlib.sha256((f"{hdr_hash} {flags} {extra}\n").encode())
         g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())
@@ -193,6 +193,10 @@ def _declare(lib):
     lib.sdnq_hip_attn_fwd_q16.argtypes = [vp, vp, vp, vp, vp, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp] + [i64] * 6 + [vp]
     lib.sdnq_hip_attn.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [vp, vp, vp, i32, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp, vp, i64, vp]
     lib.sdnq_hip_attn_workspace_bytes.argtypes = [i64] * 6 + [i32]
+    lib.sdnq_hip_scaled_mm_tile.argtypes = [i32, i32, i32, i64, i64, i64, c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int), c.POINTER(c.c_int64)]
+    lib.sdnq_hip_lut4_build.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp, vp]
+    lib.sdnq_hip_scaled_mm_w4.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
+    lib.sdnq_hip_scaled_mm_w4_supported.argtypes = [i32, i32, i64, i64, i64]
     for name in EXPORTS:
         if name not in ("sdnq_hip_strerror", "sdnq_hip_set_tile_override"):
             getattr(lib, name).restype = c.c_int

@@ -12,7 +12,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="${SDNQ_EXTRA_FLAGS:-} --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=${SDNQ_FP_CONTRACT:-off} -Wno-unused-command-line-argument"
 OBJ="${SDNQ_OBJ_DIR:-$HERE/../../build/obj}"  # (a second object directory lets an A/B build with other flags coexist)
 mkdir -p "$OBJ"
-SRCS="api rowquant gemm gemm_aq gemm_ks dequant quantize conv attention parallel"
+SRCS="api rowquant gemm gemm_aq gemm_ks gemm_w4 dequant quantize conv attention parallel"
 HDR_HASH=$(cat "$HERE"/*.h "$HERE/../../include/sdnq_hip.h" | sha256sum | cut -d' ' -f1)
 pids=()
 ALL=""
@@ -27,7 +27,7 @@ for f in $SRCS; do
   # gemm.hip: the same for the GEMM kernel's 14 leading scalar arguments (tile mapping, operand descriptors, prologue DMAs)
   [ "$f" = gemm ] && [ "${SDNQ_PRELOAD_GEMM:-1}" != 0 ] && EXTRA="-DSDNQ_PRELOAD_GEMM -mllvm -amdgpu-kernarg-preload-count=14"
   # dequant.hip / conv.hip: kernels with scalar arguments (lowrank_down, linear_float, conv_pixel_amax) get theirs preloaded as well
-  { [ "$f" = dequant ] || [ "$f" = conv ] || [ "$f" = gemm_aq ] || [ "$f" = gemm_ks ]; } && EXTRA="-mllvm -amdgpu-kernarg-preload-count=14"
+  { [ "$f" = dequant ] || [ "$f" = conv ] || [ "$f" = gemm_aq ] || [ "$f" = gemm_ks ] || [ "$f" = gemm_w4 ]; } && EXTRA="-mllvm -amdgpu-kernarg-preload-count=14"
   H=$( (echo "$HDR_HASH $FLAGS $EXTRA"; cat "$HERE/$f.hip") | sha256sum | cut -d' ' -f1)
   ALL="$ALL $f:$H"
   if [ "${FORCE:-0}" != 1 ] && [ -f "$OBJ/$f.o" ] && [ "$(cat "$OBJ/$f.hash" 2>/dev/null)" = "$H" ]; then continue; fi

@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256) void requant_kernel(const DeqParams p, uint8_t
 // (they depend only on the static weights) and are read from `ws` instead of being derived in a first pass over the row: the
 // per-call path of SDNQ_HIP_CACHE_WEIGHTS=0 then reads the codes once.  Needs packed 4-bit storage, group_size % 64 == 0, P == 1.
 template <int MM, int NP>
-__global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws, int ws_known) {
+__global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, uint8_t* __restrict__ wq, float* __restrict__ ws, int ws_known, u32* __restrict__ lut) {
     SDNQ_DEQ_ARGS_NOW(p);
-    SDNQ_KERNARGS_NOW("s"(wq), "s"(ws), "s"(ws_known));
+    SDNQ_KERNARGS_NOW("s"(wq), "s"(ws), "s"(ws_known), "s"(lut));
     // NP = passes of 1024 elements per row (K <= 1024 NP), compile time: every load of the row -- codes and group scales of all
     // passes -- is issued before the first use (unconditionally, from clamped addresses: a load under a condition gets its own
     // vmcnt(0)), so a row costs one memory round trip instead of one per pass
@@ -271,6 +271,12 @@ __global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, ui
                 byte = f32_to_e4m3fn_clamped(q);
             }
             mine |= byte << (8 * e);
+        }
+        // sdnq_hip_lut4_build (round 6: the GEMM that expands the codes itself, gemm_w4.hip): the tables ARE the result -- lane l's four
+        // entries are dword (l & 3) of the table of (row n, columns 64 (l >> 2) ..), i.e. lut[n][K / 64][16 bytes] written lane-linearly
+        if (lut != nullptr) {
+            if (k0 < p.K) lut[(n * p.K + k0) >> 4] = mine;
+            continue;
         }
         // the quad's four dwords = the 16-entry table (entry c in byte c & 3 of dword c >> 2)
         const u32 t0 = (u32)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
@@ -1063,16 +1069,17 @@ extern "C" int sdnq_hip_dequant(const SdnqWeight* w, int hadamard_group, void* o
 
 // 4-bit packed weights in groups of a multiple of 64 go through the table kernel (bit-identical, ~2-3x fewer vector instructions);
 // `ws_known` (row scales already in ws) is honoured by it and ignored -- the scales are simply recomputed -- by the general kernel
-static int launch_requant(const DeqParams& p, int mm_dtype, void* wq, float* ws, int ws_known, hipStream_t s) {
+static int launch_requant(const DeqParams& p, int mm_dtype, void* wq, float* ws, int ws_known, hipStream_t s, void* lut = nullptr) {
     dim3 grid((unsigned)((p.N + 3) / 4)), block(256);
     // test / tuning aid, read per call (a re-quantization is a whole-weight pass: a getenv is nothing beside it) so that one
     // process can A/B the table kernel against the general one (tests/test_gpu_parity.py)
     const char* lut_env = getenv("SDNQ_HIP_REQUANT_LUT");
     const bool no_lut = lut_env && atoi(lut_env) == 0;
-    const bool lut = !no_lut && p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && p.P == 1 && (p.group_size % 64) == 0 && (p.K % 64) == 0 &&
-                     !p.fmt.native_float;
+    const bool lut_ok = p.fmt.storage == SDNQ_ST_PACKED_U8 && p.fmt.bits == 4 && p.P == 1 && (p.group_size % 64) == 0 && (p.K % 64) == 0 && !p.fmt.native_float;
+    const bool use_lut = lut_ok && (!no_lut || lut != nullptr);
     const int np = (int)((p.K + 1023) / 1024);
-#define LUT_NP(MMV, NPV) hipLaunchKernelGGL((requant_lut4_kernel<MMV, NPV>), grid, block, 0, s, p, (uint8_t*)wq, ws, ws_known)
+    if (lut != nullptr && !(lut_ok && np <= 16)) return SDNQ_ERR_UNSUPPORTED;  // tables exist for what the table kernel handles
+#define LUT_NP(MMV, NPV) hipLaunchKernelGGL((requant_lut4_kernel<MMV, NPV>), grid, block, 0, s, p, (uint8_t*)wq, ws, ws_known, (u32*)lut)
 #define LUT_CASES(MMV)                                                                                   \
     switch (np) {                                                                                        \
         case 1: LUT_NP(MMV, 1); break;   case 2: LUT_NP(MMV, 2); break;   case 3: LUT_NP(MMV, 3); break;   \
@@ -1082,10 +1089,10 @@ static int launch_requant(const DeqParams& p, int mm_dtype, void* wq, float* ws,
         default: LUT_NP(MMV, 16); break;                                                                 \
     }
     if (mm_dtype == SDNQ_MM_I8) {
-        if (lut && np <= 16) { LUT_CASES(SDNQ_MM_I8) }
+        if (use_lut && np <= 16) { LUT_CASES(SDNQ_MM_I8) }
         else hipLaunchKernelGGL((requant_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq, ws, (float*)nullptr);
     } else if (mm_dtype == SDNQ_MM_FP8) {
-        if (lut && np <= 16) { LUT_CASES(SDNQ_MM_FP8) }
+        if (use_lut && np <= 16) { LUT_CASES(SDNQ_MM_FP8) }
         else hipLaunchKernelGGL((requant_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq, ws, (float*)nullptr);
     } else {
         return SDNQ_ERR_DTYPE;
@@ -1115,6 +1122,16 @@ extern "C" int sdnq_hip_requant_ws(const SdnqWeight* w, int mm_dtype, void* wq, 
     if ((uintptr_t)wq % 16) return SDNQ_ERR_ALIGN;
     p.svd_up = nullptr; p.svd_down = nullptr;
     return launch_requant(p, mm_dtype, wq, ws, ws_known, (hipStream_t)stream);
+}
+
+extern "C" int sdnq_hip_lut4_build(const SdnqWeight* w, int mm_dtype, float* ws, int ws_known, void* lut, sdnq_stream_t stream) {
+    DeqParams p{};
+    int st = fill_params(w, p);
+    if (st != SDNQ_OK) return st;
+    if (!ws || !lut) return SDNQ_ERR_NULL;
+    if ((uintptr_t)lut % 16) return SDNQ_ERR_ALIGN;
+    p.svd_up = nullptr; p.svd_down = nullptr;  // as sdnq_hip_requant
+    return launch_requant(p, mm_dtype, nullptr, ws, ws_known, (hipStream_t)stream, lut);
 }
 
 extern "C" int sdnq_hip_requant_asym(const SdnqWeight* w, void* wq, float* ws, float* wzp, sdnq_stream_t stream) {

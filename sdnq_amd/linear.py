@@ -46,6 +46,10 @@ FUSED_DEQUANT_GEMM_MAX_K = int(os.environ.get("SDNQ_HIP_FUSED_DEQUANT_GEMM_MAX_K
 # Round 5: the plain w8a8 Linear as ONE launch where it is built and wins (sdnq_hip_linear_w8a8_fused, csrc/gemm_aq.hip); the library's
 # own switch (SDNQ_HIP_FUSED_ROWQUANT=0) makes `..._supported` answer no, this one skips the question
 FUSED_ROWQUANT = os.environ.get("SDNQ_HIP_FUSED_ROWQUANT", "1").lower() not in {"0", "false", "no"}
+# Round 6 (north_star N1): in the memory-lean mode (SDNQ_HIP_CACHE_WEIGHTS=0) the few-row layers on 4-bit weights do not re-quantize their
+# weight per call any more: the GEMM reads the STORED codes and expands them through per-(row, 64 columns) tables built once
+# (sdnq_hip_scaled_mm_w4, csrc/gemm_w4.hip; 0.25 B per weight resident instead of the cached mode's 1.0).  Bit-identical.
+FUSED_LUT4 = os.environ.get("SDNQ_HIP_FUSED_LUT4", "1").lower() not in {"0", "false", "no"}
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
 
 
@@ -247,7 +251,7 @@ def _rowquant_cached(input: torch.Tensor, k: int, mm: int, had: int, want_rowsum
 
 class _State:
     """Per-module cache of kernel-ready tensors, keyed on the identity of the module's parameters."""
-    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "svd_down_t", "wd", "bias", "pf")
+    __slots__ = ("key", "qw", "mm", "mm_weight", "mm_scale", "mm_zp", "mm_wcs", "svd_up", "svd_down", "svd_down_t", "wd", "bias", "pf", "lut")
 
 
 class _LaunchUnit:
@@ -381,6 +385,7 @@ def _state(mod) -> _State:
     st.svd_down_t = None
     st.wd = None
     st.pf = None
+    st.lut = None  # (tables, row scales) of the fused 4-bit route, False: not built for this layer
     mod.__dict__["_sdnq_hip_state"] = st
     return st
 
@@ -823,6 +828,10 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
         y = group[0].forward(self, group[1], input, mm)
         if y is not None:
             return y
+    if FUSED_LUT4 and not CACHE_WEIGHTS and dq.re_quantize_for_matmul and mm == ops.MM_I8 and st.lut is not False and st.svd_up is None and input.is_cuda:
+        y = _lut4_forward(self, input, st, mm, cache_input)
+        if y is not None:
+            return y
     wq, ws, zp = _prepare_mm_weights(self, st, mm)
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
@@ -892,6 +901,35 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
                                pre=pre)
     if hit is None and key is not None:
         _ts.act_cache.put(input, params, (x2,) + tuple(inter[:4]), key)
+    return y.view(*input.shape[:-1], n)
+
+
+def _lut4_forward(self, input: torch.Tensor, st: _State, mm: int, cache_input: bool):
+    """The quantized matmul of a 4-bit layer on its STORED codes (per-call mode, few rows): row quantization, then ONE GEMM that expands
+    the codes through the layer's re-quantization tables.  None: this layer / this problem takes the general route."""
+    dq = self.sdnq_dequantizer
+    k, n = dq.in_features, dq.out_features
+    m = input.numel() // input.shape[-1]
+    if not ops.scaled_mm_w4_supported(mm, m, n, k, input.dtype):
+        return None
+    if st.lut is None:
+        ent = dtype_dict[dq.weights_dtype]
+        ok = (ent["num_bits"] == 4 and ent["is_packed"] and st.qw.scale_dtype == torch.float32 and dq.kernel_positions == 1 and k % 128 == 0
+              and st.qw.group_size % 64 == 0)
+        if ok:
+            try:
+                st.lut = ops.lut4_build(st.qw, mm)  # (tables [N, K / 64, 16], row scales [N]): built once, they depend on static parameters only
+            except ops._lib.SdnqHipError:
+                ok = False
+        if not ok:
+            st.lut = False
+            return None
+    lut, ws = st.lut
+    had = dq.hadamard_group_size if dq.use_hadamard else 0
+    x2, xq, xs, _, _ = _rowquant_cached(input, k, mm, had, False, False, None, cache=cache_input)
+    if PREFETCH_NEXT:
+        _pf_launch(st, (st.qw.keep[0], lut))
+    y = ops.scaled_mm_w4(xq, st.qw.keep[0], lut, xs, ws, _attr(self, "bias"), input.dtype)
     return y.view(*input.shape[:-1], n)
 
 

@@ -602,6 +602,38 @@ def requant(qw: QuantWeight, mm: int, ws: torch.Tensor | None = None, out: torch
     return wq, ws
 
 
+def lut4_build(qw: QuantWeight, mm: int, ws: torch.Tensor | None = None):
+    """The re-quantization tables of a 4-bit weight (sdnq_hip_lut4_build): (lut uint8 [N, K / 64, 16], ws [N] f32) -- entry c of a table is
+    the byte `requant` writes for code c in that 64-column block of that row.  Built once per layer; the operand of scaled_mm_w4."""
+    dev = qw.keep[0].device
+    lut = torch.empty((qw.n, qw.k // 64, 16), device=dev, dtype=torch.uint8)
+    known = ws is not None
+    if not known:
+        ws = torch.empty((qw.n,), device=dev, dtype=torch.float32)
+    check(_lib.load().sdnq_hip_lut4_build(ctypes.byref(qw.desc), mm, ws.data_ptr(), 1 if known else 0, lut.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "lut4_build")
+    return lut, ws
+
+
+def scaled_mm_w4_supported(mm: int, m: int, n: int, k: int, out_dtype: torch.dtype) -> bool:
+    return out_dtype in (torch.bfloat16, torch.float16) and bool(_lib.load().sdnq_hip_scaled_mm_w4_supported(mm, float_code(out_dtype), m, n, k))
+
+
+def scaled_mm_w4(a: torch.Tensor, codes: torch.Tensor, lut: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype):
+    """The quantized matmul on the STORED 4-bit codes (sdnq_hip_scaled_mm_w4): bit for bit scaled_mm(a, requant(weight), ...).
+    a [M, K] int8 (row stride >= K), codes: the packed weight tensor (N * K / 2 bytes), lut: lut4_build's tables."""
+    _require_cuda(a, codes, lut, sa, sb, bias)
+    m, k = a.shape
+    n = lut.shape[0]
+    if a.stride(-1) != 1 or codes.numel() * codes.element_size() != n * k // 2 or not codes.is_contiguous() or tuple(lut.shape) != (n, k // 64, 16):
+        raise _lib.SdnqHipError("scaled_mm_w4: a [M, K] int8 (unit inner stride), contiguous packed codes of N * K / 2 bytes, lut [N, K / 64, 16]")
+    out = torch.empty((m, n), device=a.device, dtype=out_dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_w4(a.data_ptr(), codes.data_ptr(), lut.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias),
+                                            0 if bias is None else float_code(bias.dtype), out.data_ptr(), float_code(out_dtype), m, n, k,
+                                            a.stride(0), _stream(a)), "scaled_mm_w4")
+    return out
+
+
 def requant_asym(qw: QuantWeight):
     """re_quantize_uint_mm (dequantizer.py:178-187): (wq int8 [N,K], ws [N], zero_point [N])."""
     dev = qw.keep[0].device

@@ -225,3 +225,12 @@ def test_scaled_mm_tile_is_a_dry_run_of_the_shape_rules():
     assert tile(1024, 1280, 1280, mm=1)[0] == 0                  # fp8
     assert tile(1024, 1284, 1280)[0] != 0 and tile(0, 1280, 1280)[0] != 0 and tile(64, 64, 64, mm=7)[0] != 0
     assert lib.sdnq_hip_scaled_mm_tile(0, 1, 0, 1024, 1280, 1280, None, None, None, None) == 0  # every output pointer is optional
+
+
+def test_every_export_has_declared_argument_types():
+    """ctypes converts an undeclared Python int to a 32-bit C int: a device pointer or an int64 size would be truncated silently (round 6:
+    a new entry point without argtypes sent truncated pointers to the GPU).  Every export must carry argtypes."""
+    lib = _lib.load()
+    raw = getattr(lib, "_ctypes", lib)
+    missing = [name for name in _lib.EXPORTS if name not in ("sdnq_hip_version",) and getattr(raw, name).argtypes is None]
+    assert missing == [], missing

@@ -1,20 +1,10 @@
 mkdir -p gpurun_out/r6
-bash tools/prof_bench.sh r6/prof_sdxl_int8 --steps 20 --warmup 3 > gpurun_out/r6/prof_sdxl_int8.log 2>&1
-tail -25 gpurun_out/r6/prof_sdxl_int8.log
-timeout 900 python bench.py --no-cpu-baseline > gpurun_out/r6/bench_b.json 2> gpurun_out/r6/bench_b.err
-python - <<'PY'
+timeout 1500 python -m pytest tests/test_gemm_w4.py tests/test_cabi.py -x -q 2>&1 | grep -v "^  File\|Extension modules" | tail -5 | tee gpurun_out/r6/pytest_w4.txt
+for i in 1 2; do for cfg in "1 1" "0 1" "0 0"; do set -- $cfg
+SDNQ_HIP_CACHE_WEIGHTS=$1 SDNQ_HIP_FUSED_LUT4=$2 timeout 900 python bench.py --workload sdxl_int4 --no-cpu-baseline > gpurun_out/r6/bench_sdxl_int4_c$1_l$2.json 2> gpurun_out/r6/bench_sdxl_int4_c$1_l$2.err
+python - <<PY
 import json
-d=json.loads(open("gpurun_out/r6/bench_b.json").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["roofline"]["frac"])
-for r in d["roofline"].get("per_shape", []): print(r)
+d=json.loads(open("gpurun_out/r6/bench_sdxl_int4_c$1_l$2.json").read().strip().splitlines()[-1])
+print("sdxl_int4 CACHE_WEIGHTS=$1 FUSED_LUT4=$2", d["ms_per_step"], d["config"]["resident_weight_bytes"]["total"])
 PY
-for set in sdxl sdxl_fp8 flux flux_svd; do
-bash tools/pmc_step.sh r6/pmc_$set $set > gpurun_out/r6/pmc_$set.log 2>&1
-cp gpurun_out/r6/pmc_$set/pmc_gemm_traffic.json gpurun_out/r6/r06_pmc_gemm_traffic_$set.json
-tail -6 gpurun_out/r6/pmc_$set.log
-done
-O=gpurun_out/r6/launch_modes_2.txt; : > $O
-for i in 1 2; do for mode in graph capture eager; do
-ms=$(python bench.py --steps 20 --warmup 3 --no-cpu-baseline --launch $mode 2>/dev/null | tail -1 | python -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"])')
-echo "launch=$mode: $ms" | tee -a $O
-done; done
+done; done 2>&1 | tee gpurun_out/r6/sdxl_int4_modes.txt
