@@ -9,7 +9,8 @@ mkdir -p "$OUT/$TAG"
 export TMPDIR=/tmp
 STEPS=20
 for ((i = 1; i <= $#; i++)); do [ "${!i}" = "--steps" ] && j=$((i + 1)) && STEPS=${!j}; done
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace -d "$OUT/$TAG" -o prof --output-format csv -- python "$OLDPWD/bench.py" --no-cpu-baseline --profile-markers "$@" > "$OUT/$TAG/bench.log" 2>&1)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/$TAG" -o prof --output-format csv -- python "$OLDPWD/bench.py" --no-cpu-baseline --profile-markers "$@" > "$OUT/$TAG/bench.log" 2>&1)
 tail -1 "$OUT/$TAG/bench.log" > "$OUT/${TAG}_bench.json"
 python tools/prof_window.py "$OUT/$TAG" "$STEPS" "$OUT/${TAG}_window"
+F=$(find "$OUT/$TAG" -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" "$OUT/${TAG}_kernel_stats.csv"  # (whole process: build, warm-up, roofline replays included)
 find "$OUT/$TAG" -name "*.csv" -size +500k -delete
