@@ -1522,6 +1522,7 @@ def test_per_call_weight_pipeline_is_bit_identical(gpu_device, monkeypatch):
     want = [m(x).clone() for m, x in zip(mods, xs)]  # cached mode
     monkeypatch.setattr(L, "CACHE_WEIGHTS", False)
     monkeypatch.setattr(L, "PIPELINE_WEIGHTS", True)
+    monkeypatch.setattr(L, "FUSED_LUT4", False)  # (round 6: few-row 4-bit layers would multiply on their stored codes instead -- tests/test_gemm_w4.py)
     pipe = L._WeightPipeline()
     monkeypatch.setattr(L, "_weight_pipeline", pipe)
     for m in mods:
