@@ -53,7 +53,7 @@ typedef enum SdnqStatus {
 typedef enum SdnqFloat { SDNQ_F32 = 0, SDNQ_BF16 = 1, SDNQ_F16 = 2 } SdnqFloat;
 
 /* matmul operand types (dtype_dict rows "int8", "float8_e4m3fn"; common.py:20,65) */
-typedef enum SdnqMM { SDNQ_MM_I8 = 0, SDNQ_MM_FP8 = 1 } SdnqMM;
+typedef enum SdnqMM { SDNQ_MM_I8 = 0, SDNQ_MM_FP8 = 1, SDNQ_MM_F16 = 2 /* float16 operands: sdnq_hip_unpack_mm, sdnq_hip_rowquant_f16, sdnq_hip_scaled_mm_f16 only */ } SdnqMM;
 
 /* how the quantized weight elements are held in HBM */
 typedef enum SdnqStorage {
@@ -155,6 +155,17 @@ int sdnq_hip_scaled_mm(int mm_dtype, const void* a, const void* b, const float* 
  * occupies) and by tuning tools. */
 int sdnq_hip_scaled_mm_tile(int mm_dtype, int out_dtype, int has_bias, int64_t m, int64_t n, int64_t k, int* bm, int* bn, int* threads,
                             int64_t* workgroups);
+
+/* ---- the float16 quantized matmul (quantized_matmul_dtype = "float16"; round 6) ------------------------------------------------
+ * replaces quantize_fp_mm_input(..., matmul_dtype="float16") (layers/linear/linear_fp8.py:15-22 -> quant_utils.py:290-299, called
+ * from linear_fp16.py:46) and fp_scaled_mm_func (kernel_wrappers.py:207-211; Triton kernels/triton_scaled_mm.py with float16 operands):
+ * sdnq_hip_rowquant_f16: per row, in float32, xs[m] = amax|x| / 65504, xq[m][k] = float16(clamp(nan_to_num(x / xs[m]), +-65504)).
+ * sdnq_hip_scaled_mm_f16: out[m][n] = cast(fma(f32(sum_k a[m][k] * b[n][k]) * sa[m], sb[n], bias[n])), a [M][K], b [N][K] float16,
+ * fp32 accumulation on the f16 matrix cores (the reference's CPU route instead pre-scales both operands by 1 / sqrt(65536 K) and rounds
+ * them to float16 again, kernel_wrappers.py:115-129: results agree to the float16 rounding of the operands).  K % 8 == 0, N % 8 == 0. */
+int sdnq_hip_rowquant_f16(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, void* xq, float* xs, sdnq_stream_t stream);
+int sdnq_hip_scaled_mm_f16(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, void* out,
+                           int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
 /* ---- N1: the re-quantization of 4-bit weights fused into the matmul (round 6) -----------------------------------------------
  * replaces, as ONE launch per call, what sdnq_hip_requant + sdnq_hip_scaled_mm compute for 4-bit packed weights
@@ -309,6 +320,7 @@ int sdnq_hip_requant_asym(const SdnqWeight* w, void* wq, float* ws, float* wzp, 
  *   int8 mm: packed signed -> value; packed unsigned -> raw code (caller keeps zero_point);
  *            raw uint8 -> code ^ 0x80 (caller adds 128*scale to the zero point); raw int8 -> copy
  *   fp8  mm: packed custom float -> e4m3fn(decoded value); native float8_e4m3fn -> copy
+ *   f16  mm (round 6; linear_fp16.py:27-31): any float format of <= 16 bits -> the decoded value rounded to float16, wq [N][K] x 2 bytes
  * wq: physical [N][K] bytes. Scales are untouched (row-wise, already [N]). */
 int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, sdnq_stream_t stream);
 

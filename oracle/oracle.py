@@ -733,6 +733,9 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
     if mmd == "uint8":
         y = _forward_uint8(mod, x2, tag, conv_form=conv_form)
         return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
+    if mmd == "float16":
+        y = _forward_fp16(mod, x2, tag, inter)
+        return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
     mm = "int8" if mmd == "int8" else "fp8"
 
     wq, ws, zp = _mm_weights(mod, mm)
@@ -773,6 +776,43 @@ def forward(mod: OracleLinear, x: np.ndarray, tag: str, want_intermediates: bool
         bias = zero_bias
     y = scaled_mm(mm, xq, wq, xs, ws, bias, tag)
     return (y.reshape(*lead, N), inter) if want_intermediates else y.reshape(*lead, N)
+
+
+def _forward_fp16(mod: OracleLinear, x2: np.ndarray, tag: str, inter: dict) -> np.ndarray:
+    """quantized_linear_forward_fp16_matmul (layers/linear/linear_fp16.py:16-110) as the reference's CPU route computes it
+    (fp_scaled_mm_torch -> fp_mm_torch, kernel_wrappers.py:115-129, 153-157), row-wise float weights without SVD / Hadamard:
+      weight = decoded codes .to(float16)  (linear_fp16.py:27-31);  input, input_scale = quantize_fp_mm_input(x, f32, "float16")
+      fp_mm_torch: both operands x 1 / sqrt(65536 K) in float32, rounded to float16 AGAIN; torch.mm in float16 (the accumulated dot
+      product is rounded to float16); x 65536 K in float32
+      out = addcmul(bias, mm * input_scale, scale)  |  mm * input_scale * scale
+    The float16 GEMM's summation order is the library's: the float32-accumulated dot product rounded once to float16 stands in for it."""
+    d = mod.deq
+    K, N = mod.K, mod.N
+    assert not d["re_quantize_for_matmul"] and mod.svd_up is None and not d["use_hadamard"], "fp16 matmul oracle: row-wise float weights only"
+    vals, sc, zpv, group = mod._nk_values_scale()
+    assert group == K and zpv is None
+    w16 = _c(vals, np.float32).astype(np.float16)
+    x = _c(x2, np.float32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        amax = np.abs(x).max(axis=1, keepdims=True).astype(np.float32)
+        xs = (amax / np.float32(65504.0)).astype(np.float32)
+        q = (x / xs).astype(np.float32)
+        q = np.nan_to_num(q, nan=0.0, posinf=np.finfo(np.float32).max, neginf=np.finfo(np.float32).min)
+        xq = np.clip(q, np.float32(-65504.0), np.float32(65504.0)).astype(np.float16)
+    inter["xq"], inter["xs"], inter["wq"], inter["ws"] = xq, xs.reshape(-1), w16, sc
+    fp16_scale = np.float32(65536.0 * K)  # (b is float16 here, never float8: kernel_wrappers.py:116-119)
+    in_scale = np.float32(1.0 / float(fp16_scale) ** 0.5)
+    a = (xq.astype(np.float32) * in_scale).astype(np.float16)
+    b = (w16.astype(np.float32) * in_scale).astype(np.float16)
+    mm = (a.astype(np.float32) @ b.astype(np.float32).T).astype(np.float16)  # torch.mm on float16 tensors returns float16
+    acc = (mm.astype(np.float32) * fp16_scale).astype(np.float32)
+    vv = (acc * xs).astype(np.float32)
+    sb = _c(sc, np.float32).reshape(1, -1)
+    if mod.bias is not None:  # addcmul: the product and the sum round once (float64 holds the float32 product exactly)
+        y = (vv.astype(np.float64) * sb.astype(np.float64) + _c(mod.bias, np.float32).astype(np.float64).reshape(1, -1)).astype(np.float32)
+    else:
+        y = (vv * sb).astype(np.float32)
+    return round_dtype(y, tag)
 
 
 def _fma_scalar(a: np.ndarray, k, c: np.ndarray) -> np.ndarray:

@@ -17,7 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 
 # enums of include/sdnq_hip.h
 F32, BF16, F16 = 0, 1, 2
-MM_I8, MM_FP8 = 0, 1
+MM_I8, MM_FP8, MM_F16 = 0, 1, 2
 ST_PACKED_U8, ST_PACKED_I16, ST_RAW8, ST_RAW16 = 0, 1, 2, 3
 KIND_INT, KIND_UINT, KIND_FLOAT, KIND_UFLOAT = 0, 1, 2, 3
 
@@ -35,6 +35,7 @@ EXPORTS = [
     "sdnq_hip_signal_alloc", "sdnq_hip_signal_free", "sdnq_hip_ipc_export", "sdnq_hip_ipc_import", "sdnq_hip_ipc_close",
     "sdnq_hip_linear_w8a8_fused", "sdnq_hip_linear_w8a8_fused_supported", "sdnq_hip_scaled_mm_lp_uzp_svd", "sdnq_hip_stream_capture_id",
     "sdnq_hip_scaled_mm_tile", "sdnq_hip_lut4_build", "sdnq_hip_scaled_mm_w4", "sdnq_hip_scaled_mm_w4_supported",
+    "sdnq_hip_rowquant_f16", "sdnq_hip_scaled_mm_f16",
 ]
 
 
@@ -197,6 +198,8 @@ def _declare(lib):
     lib.sdnq_hip_lut4_build.argtypes = [c.POINTER(SdnqWeight), i32, vp, i32, vp, vp]
     lib.sdnq_hip_scaled_mm_w4.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
     lib.sdnq_hip_scaled_mm_w4_supported.argtypes = [i32, i32, i64, i64, i64]
+    lib.sdnq_hip_rowquant_f16.argtypes = [vp, i32, i64, i64, i64, vp, vp, vp]
+    lib.sdnq_hip_scaled_mm_f16.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, vp]
     for name in EXPORTS:
         if name not in ("sdnq_hip_strerror", "sdnq_hip_set_tile_override"):
             getattr(lib, name).restype = c.c_int

@@ -298,6 +298,18 @@ __global__ __launch_bounds__(256) void requant_lut4_kernel(const DeqParams p, ui
     }
 }
 
+// float16 matmul operand straight from stored FLOAT codes (round 6, linear_fp16.py:27-31: `unpack_float(...).to(float16)` for packed
+// formats, `weight.to(float16)` for native fp8): the decoded value rounded to float16 (exact for every format of <= 11 significand bits)
+__global__ __launch_bounds__(256) void unpack_mm_f16_kernel(const DeqParams p, uint16_t* __restrict__ wq) {
+    const int64_t units = p.N * p.K / 16;
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    float v[16];
+    load16_values(p.w, u * 16, p.fmt, v);
+    *(uint4*)(wq + u * 16) = Vec16<SDNQ_F16>::pack(v);
+    *(uint4*)(wq + u * 16 + 8) = Vec16<SDNQ_F16>::pack(v + 8);
+}
+
 // matmul operand straight from the stored codes (no scaling): see sdnq_hip_unpack_mm in the header
 template <int MM>
 __global__ __launch_bounds__(256) void unpack_mm_kernel(const DeqParams p, uint8_t* __restrict__ wq) {
@@ -1158,12 +1170,19 @@ extern "C" int sdnq_hip_unpack_mm(const SdnqWeight* w, int mm_dtype, void* wq, s
         if ((p.fmt.kind != SDNQ_KIND_INT && p.fmt.kind != SDNQ_KIND_UINT) || p.fmt.bits > 8) return SDNQ_ERR_DTYPE;
     } else if (mm_dtype == SDNQ_MM_FP8) {
         if (p.fmt.kind != SDNQ_KIND_FLOAT || p.fmt.bits > 8) return SDNQ_ERR_DTYPE;
+    } else if (mm_dtype == SDNQ_MM_F16) {
+        if (p.fmt.kind != SDNQ_KIND_FLOAT || p.fmt.bits > 16) return SDNQ_ERR_DTYPE;
     } else {
         return SDNQ_ERR_DTYPE;
     }
     hipStream_t s = (hipStream_t)stream;
     const int64_t units = p.N * p.K / 16;
     dim3 grid((unsigned)((units + 255) / 256)), block(256);
+    if (mm_dtype == SDNQ_MM_F16) {
+        hipLaunchKernelGGL(unpack_mm_f16_kernel, grid, block, 0, s, p, (uint16_t*)wq);
+        SDNQ_CHECK_LAUNCH();
+        return SDNQ_OK;
+    }
     if (mm_dtype == SDNQ_MM_I8) hipLaunchKernelGGL((unpack_mm_kernel<SDNQ_MM_I8>), grid, block, 0, s, p, (uint8_t*)wq);
     else hipLaunchKernelGGL((unpack_mm_kernel<SDNQ_MM_FP8>), grid, block, 0, s, p, (uint8_t*)wq);
     SDNQ_CHECK_LAUNCH();

@@ -184,6 +184,12 @@ template <int MM> struct FloatMma {
 template <> struct MmaTraits<MM_BF16> : FloatMma<MM_BF16> {};
 template <> struct MmaTraits<MM_F16> : FloatMma<MM_F16> {};
 template <> struct MmaTraits<MM_F32> : FloatMma<MM_F32> {};
+// The float16 quantized matmul (quantized_matmul_dtype="float16": layers/linear/linear_fp16.py:16-74, fp_scaled_mm_func
+// kernel_wrappers.py:207-211): float16 operands -- activations row-quantized to float16 with a row scale, weights as float16 codes --
+// on v_mfma_f32_32x32x16_f16 with the SCALED epilogue of the int8 / fp8 matmuls (out = cast(fma(acc * sa, sb, bias))).  K counted in
+// bytes like the float GEMMs.  Round 6.
+enum { MM_F16S = 10 };
+template <> struct MmaTraits<MM_F16S> : FloatMma<MM_F16S> {};
 // Fused dequantize + float GEMM (the reference's DEFAULT mode, use_quantized_matmul=False: dequantize_symmetric / _asymmetric
 // then F.linear, dequantizer.py:52-84 + layers/linear/forward.py:25-26) for row-wise 8-bit weights: the B operand stays int8 /
 // uint8 in HBM and in LDS (HALF the bytes of a dequantized bf16 copy, and no dequantize launch, no [N][K] float matrix in HBM);
@@ -330,7 +336,7 @@ template <int MM> struct FragOps {
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(w, x, c, 0, 0, 0);
         } else if constexpr (MM == MM_BF16) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, w), __builtin_bit_cast(v8bf, x), c, 0, 0, 0);
-        } else if constexpr (MM == MM_F16) {
+        } else if constexpr (MM == MM_F16 || MM == MM_F16S) {
             c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, w), __builtin_bit_cast(v8h, x), c, 0, 0, 0);
         } else {
             const v4f wf = __builtin_bit_cast(v4f, w), xf = __builtin_bit_cast(v4f, x);
@@ -2338,6 +2344,36 @@ extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b,
                                      int bias_ndim, int64_t ld_bias, const void* t, const void* svd_up, int rank, void* out,
                                      int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
     return sdnq_hip_scaled_mm_lp_zp(mm_dtype, a, b, sa, sb, bias, bias_ndim, ld_bias, t, svd_up, rank, nullptr, nullptr, out, m, n, k, stream);
+}
+
+// tile choice of the float16 scaled matmul (the reference's compatibility mode for GPUs without int8 / fp8 matrix cores, linear_fp16.py):
+// the four tile shapes the float GEMMs of launch_tiles use, by the same rules (K of the rules in BYTES)
+template <int OUT_T, int EPI>
+int launch_f16s(const GemmParams& p, hipStream_t s) {
+    auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if (p.M > 128 && tiles(256, 256) >= 160 && p.K >= 2048) {
+        if (ht_ok(p)) return launch_one<MM_F16S, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
+        return launch_one<MM_F16S, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
+    }
+    if (p.M >= 2048 && tiles(256, 128) >= 230) return launch_one<MM_F16S, OUT_T, EPI, 256, 128, 64, 64, 3, LD_PIPE, 64>(p, s);
+    if (p.M > 128) return launch_one<MM_F16S, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
+    return launch_one<MM_F16S, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
+}
+
+extern "C" int sdnq_hip_scaled_mm_f16(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, void* out,
+                                      int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+    if (!a || !b || !sa || !sb || !out) return SDNQ_ERR_NULL;
+    if (out_dtype < 0 || out_dtype > 2) return SDNQ_ERR_DTYPE;
+    if (bias && (bias_dtype < 0 || bias_dtype > 2)) return SDNQ_ERR_DTYPE;
+    if (m <= 0 || n <= 0 || k <= 0 || (k % 8) != 0 || (n % 8) != 0) return SDNQ_ERR_SHAPE;
+    if (((uintptr_t)a % 16) || ((uintptr_t)b % 16) || ((uintptr_t)out % 16)) return SDNQ_ERR_ALIGN;
+    GemmParams p{};
+    p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
+    p.M = m; p.N = n; p.K = k * 2; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias ? bias_dtype : out_dtype;
+    hipStream_t s = (hipStream_t)stream;
+    if (out_dtype == SDNQ_BF16) return bias ? launch_f16s<SDNQ_BF16, EPI_BIAS1D>(p, s) : launch_f16s<SDNQ_BF16, EPI_NONE>(p, s);
+    if (out_dtype == SDNQ_F16) return bias ? launch_f16s<SDNQ_F16, EPI_BIAS1D>(p, s) : launch_f16s<SDNQ_F16, EPI_NONE>(p, s);
+    return bias ? launch_f16s<SDNQ_F32, EPI_BIAS1D>(p, s) : launch_f16s<SDNQ_F32, EPI_NONE>(p, s);
 }
 
 // internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`

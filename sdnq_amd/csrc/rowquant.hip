@@ -635,6 +635,62 @@ extern "C" int sdnq_hip_rowquant_lp_asym(const void* x, int x_dtype, int64_t m, 
     return rowquant_lp_impl(x, x_dtype, m, k, ldx, SDNQ_MM_I8, hadamard_group, xq, xs, xzp, rowsum, xrot, stream);
 }
 
+// Activation row quantization of the float16 matmul (round 6): quantize_fp_mm_input(input, dtype=scale.dtype, matmul_dtype="float16")
+// (layers/linear/linear_fp8.py:15-22 -> quantize_fp_mm, quant_utils.py:290-299, called from linear_fp16.py:46): in float32,
+// scale = amax(|x|) / 65504, q = clamp(nan_to_num(x / scale), +-65504) rounded to float16.  One wave per row, two passes over the row
+// (the second is L2-hot): a compatibility path, not a tuned one.
+template <int T_ID>
+__global__ __launch_bounds__(256) void rowquant_f16_kernel(const void* __restrict__ x, int64_t M, int64_t K, int64_t ldx, uint16_t* __restrict__ xq,
+                                                           float* __restrict__ xs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const void* row = (const char*)x + m * ldx * FT<T_ID>::bytes;
+    float amax = 0.0f;
+    bool has_nan = false;
+    for (int64_t k0 = (int64_t)lane * 8; k0 < K; k0 += 512) {
+        float v[8];
+        load8<T_ID>(row, k0, true, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            amax = fmaxf(amax, fabsf(v[e]));  // (fmaxf drops a NaN operand: torch.amax propagates it)
+            has_nan |= v[e] != v[e];
+        }
+    }
+    amax = wave_max(amax);
+    if (__builtin_amdgcn_ballot_w64(has_nan) != 0) amax = __uint_as_float(0x7fc00000u);
+    const float scale = amax / 65504.0f;
+    if (lane == 0) xs[m] = scale;
+    for (int64_t k0 = (int64_t)lane * 8; k0 < K; k0 += 512) {
+        float v[8], q[8];
+        load8<T_ID>(row, k0, true, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = v[e] / scale;
+            if (t != t) t = 0.0f;  // nan_to_num (0 / 0 of an all-zero row, a NaN row); +-inf fall to the clamp
+            q[e] = fminf(fmaxf(t, -65504.0f), 65504.0f);
+        }
+        *(uint4*)(xq + m * K + k0) = Vec16<SDNQ_F16>::pack(q);
+    }
+}
+
+extern "C" int sdnq_hip_rowquant_f16(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, void* xq, float* xs, sdnq_stream_t stream) {
+    if (!x || !xq || !xs) return SDNQ_ERR_NULL;
+    if (x_dtype < 0 || x_dtype > 2) return SDNQ_ERR_DTYPE;
+    if (m <= 0 || k <= 0 || (k % 8) != 0 || ldx < k) return SDNQ_ERR_SHAPE;
+    const int eb = (x_dtype == SDNQ_F32) ? 4 : 2;
+    if (((uintptr_t)x % 16) || ((uintptr_t)xq % 16) || ((ldx * eb) % 16)) return SDNQ_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    switch (x_dtype) {
+        case SDNQ_F32: hipLaunchKernelGGL((rowquant_f16_kernel<SDNQ_F32>), grid, block, 0, s, x, m, k, ldx, (uint16_t*)xq, xs); break;
+        case SDNQ_BF16: hipLaunchKernelGGL((rowquant_f16_kernel<SDNQ_BF16>), grid, block, 0, s, x, m, k, ldx, (uint16_t*)xq, xs); break;
+        default: hipLaunchKernelGGL((rowquant_f16_kernel<SDNQ_F16>), grid, block, 0, s, x, m, k, ldx, (uint16_t*)xq, xs); break;
+    }
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
 extern "C" int sdnq_hip_hadamard(const void* x, int dtype, int64_t rows, int64_t k, int64_t ldx, int hadamard_group,
                                  void* y, int64_t ldy, sdnq_stream_t stream) {
     if (!x || !y) return SDNQ_ERR_NULL;

@@ -1048,4 +1048,22 @@ def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Te
 
 @_no_grad
 def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Tensor:
-    raise NotImplementedError("quantized_matmul_dtype='float16' is outside the MI355X hot path (SURVEY 8a note)")
+    """quantized_matmul_dtype = "float16" (layers/linear/linear_fp16.py:16-110; round 6): float16 operands on the f16 matrix cores with
+    the scaled epilogue.  Built for row-wise float weights whose codes ARE the operand (native fp8, packed eXmY floats: linear_fp16.py:27-31),
+    no SVD, no Hadamard; `support.unsupported_reason` names the rest.  A compatibility mode: plain launches, the operand cached per module."""
+    dq = self.sdnq_dequantizer
+    st = _state(self)
+    k, n = dq.in_features, dq.out_features
+    m = input.numel() // input.shape[-1]
+    if m < 32:  # linear_fp16.py:79-80
+        return _float_forward(self, input, st)
+    if not input.is_cuda:
+        raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
+    key = ("f16", False)
+    if st.mm != key or st.mm_weight is None:
+        st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, ops.unpack_mm_f16(st.qw), st.qw.keep[1], None, None
+    x2 = input.reshape(-1, k)
+    if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
+        x2 = x2.contiguous()
+    xq, xs = ops.rowquant_f16(x2)
+    return ops.scaled_mm_f16(xq, st.mm_weight, xs, st.mm_scale, _attr(self, "bias"), input.dtype).view(*input.shape[:-1], n)

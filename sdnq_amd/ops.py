@@ -634,6 +634,39 @@ def scaled_mm_w4(a: torch.Tensor, codes: torch.Tensor, lut: torch.Tensor, sa: to
     return out
 
 
+def rowquant_f16(x2d: torch.Tensor):
+    """quantize_fp_mm_input(..., matmul_dtype="float16") (linear_fp8.py:15-22, quant_utils.py:290-299): (xq float16 [M, K], xs f32 [M])."""
+    _require_cuda(x2d)
+    m, k = x2d.shape
+    if x2d.stride(-1) != 1:
+        raise _lib.SdnqHipError("rowquant_f16: unit inner stride")
+    xq = torch.empty((m, k), device=x2d.device, dtype=torch.float16)
+    xs = torch.empty((m,), device=x2d.device, dtype=torch.float32)
+    check(_lib.load().sdnq_hip_rowquant_f16(x2d.data_ptr(), float_code(x2d.dtype), m, k, x2d.stride(0), xq.data_ptr(), xs.data_ptr(), _stream(x2d)), "rowquant_f16")
+    return xq, xs
+
+
+def unpack_mm_f16(qw: QuantWeight) -> torch.Tensor:
+    """Stored float codes -> float16 matmul operand [N, K] (linear_fp16.py:27-31)."""
+    dev = qw.keep[0].device
+    wq = torch.empty((qw.n, qw.k), device=dev, dtype=torch.float16)
+    check(_lib.load().sdnq_hip_unpack_mm(ctypes.byref(qw.desc), _lib.MM_F16, wq.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "unpack_mm_f16")
+    return wq
+
+
+def scaled_mm_f16(a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype) -> torch.Tensor:
+    """fp_scaled_mm_func on float16 operands (kernel_wrappers.py:207-211): a [M, K] f16, b_phys [N, K] f16 -> [M, N]."""
+    _require_cuda(a, b_phys, sa, sb, bias)
+    m, k = a.shape
+    n = b_phys.shape[0]
+    if a.dtype != torch.float16 or b_phys.dtype != torch.float16 or not a.is_contiguous() or not b_phys.is_contiguous() or b_phys.shape[1] != k:
+        raise _lib.SdnqHipError("scaled_mm_f16: contiguous float16 operands a [M, K], b [N, K]")
+    out = torch.empty((m, n), device=a.device, dtype=out_dtype)
+    check(_lib.load().sdnq_hip_scaled_mm_f16(a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), 0 if bias is None else float_code(bias.dtype),
+                                             out.data_ptr(), float_code(out_dtype), m, n, k, _stream(a)), "scaled_mm_f16")
+    return out
+
+
 def requant_asym(qw: QuantWeight):
     """re_quantize_uint_mm (dequantizer.py:178-187): (wq int8 [N,K], ws [N], zero_point [N])."""
     dev = qw.keep[0].device

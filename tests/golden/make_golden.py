@@ -252,6 +252,11 @@ CASES = [
          cfg=dict(weights_dtype="uint8", group_size=-1, use_svd=True, svd_rank=32, use_quantized_matmul=True, dequantize_fp32=False)),
     dict(name="fp8_qmm_bf16_lpscale", K=256, N=64, Ms=[48], dtype="bf16",
          cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="fp8", group_size=-1, use_quantized_matmul=True, dequantize_fp32=False)),
+    # round 6: the float16 matmul forward (layers/linear/linear_fp16.py): native fp8 codes and a packed eXmY format as float16 operands
+    dict(name="fp8_f16mm_bf16", K=512, N=256, Ms=[4, 48, 200], dtype="bf16",
+         cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="float16", group_size=-1, use_quantized_matmul=True)),
+    dict(name="float6_e3m2_f16mm_f16_nobias", K=256, N=80, Ms=[40, 136], dtype="f16", bias=False,
+         cfg=dict(weights_dtype="float6_e3m2fn", quantized_matmul_dtype="float16", group_size=-1, use_quantized_matmul=True)),
 ]
 
 # Every packed storage dtype gets a dequant-only golden (small).

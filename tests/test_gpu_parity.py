@@ -34,13 +34,16 @@ def bits_of(t: torch.Tensor) -> np.ndarray:
     return t.numpy()
 
 
-def assert_close_float(got: np.ndarray, ref: np.ndarray, tag: str, what, hadamard=False, f32_lim=2e-6):
+def assert_close_float(got: np.ndarray, ref: np.ndarray, tag: str, what, hadamard=False, f32_lim=2e-6, f16mm=False):
+    """f16mm: the float16 matmul forward.  The reference's CPU route (the fixtures, the oracle) rounds BOTH operands to float16 a second
+    time after its 1 / sqrt(65536 K) pre-scaling and rounds the accumulated dot product to float16 (kernel_wrappers.py:115-129); the
+    matrix cores accumulate the once-rounded operands in float32 (what the reference's Triton route does): three 2^-11 roundings apart."""
     scale = float(np.abs(ref).max()) or 1.0
     err = float(np.abs(got - ref).max()) / scale
-    lim = {"bf16": 2 * 2.0 ** -8, "f16": 2 * 2.0 ** -11, "f32": f32_lim}[tag] * (2.0 if hadamard else 1.0)
+    lim = {"bf16": 2 * 2.0 ** -8, "f16": (8 if f16mm else 2) * 2.0 ** -11, "f32": f32_lim}[tag] * (2.0 if hadamard else 1.0)
     assert err <= lim, (what, "max err / scale", err, lim)
     l2 = float(np.linalg.norm(got - ref) / (np.linalg.norm(ref) or 1.0))
-    assert l2 <= {"bf16": 2e-3, "f16": 5e-4, "f32": max(1e-5, f32_lim)}[tag], (what, "rel l2", l2)
+    assert l2 <= {"bf16": 2e-3, "f16": (2e-3 if f16mm else 5e-4), "f32": max(1e-5, f32_lim)}[tag], (what, "rel l2", l2)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -63,8 +66,69 @@ def test_module_forward_vs_golden_and_oracle(name, gpu_device):
             assert np.array_equal(got, ref), (name, M, "vs golden", int((got != ref).sum()))
             assert np.array_equal(got, orc), (name, M, "vs oracle")
         else:
-            assert_close_float(got, ref, c.tag, (name, M, "golden"), hadamard=d["use_hadamard"])
-            assert_close_float(got, orc, c.tag, (name, M, "oracle"), hadamard=d["use_hadamard"])
+            f16mm = qmm and d["quantized_matmul_dtype"] == "float16"
+            assert_close_float(got, ref, c.tag, (name, M, "golden"), hadamard=d["use_hadamard"], f16mm=f16mm)
+            assert_close_float(got, orc, c.tag, (name, M, "oracle"), hadamard=d["use_hadamard"], f16mm=f16mm)
+
+
+@pytest.mark.parametrize("name", ["fp8_f16mm_bf16", "float6_e3m2_f16mm_f16_nobias"])
+def test_float16_matmul_operators_vs_oracle(name, gpu_device):
+    """The three pieces of the float16 matmul forward (round 6; linear_fp16.py): the activation quantizer and the weight operand are
+    elementwise and must equal the oracle (= the reference's) bit for bit; the scaled matmul is checked against a float64 evaluation of
+    fma(acc * sa, sb, bias) on the SAME float16 operands: float32 accumulation error only (2 sqrt(K) 2^-24 of the row's magnitude)."""
+    from sdnq_amd import linear as L, ops
+    c = Case(name)
+    mod = module_from_case(c, gpu_device)
+    omod = c.oracle_module()
+    st = L._state(mod)
+    w16 = ops.unpack_mm_f16(st.qw)
+    for M in [m for m in c.ms() if m >= 32]:
+        x = c.torch_tensor(f"x_{M}", device=gpu_device)
+        x2 = x.reshape(-1, c.K)
+        _, inter = O.forward(omod, c.f32(f"x_{M}"), c.tag, want_intermediates=True)
+        xq, xs = ops.rowquant_f16(x2)
+        assert np.array_equal(xq.cpu().numpy().view(np.uint16), inter["xq"].view(np.uint16)), (name, M, "float16 codes")
+        assert np.array_equal(xs.cpu().numpy(), inter["xs"]), (name, M, "row scales")
+        assert np.array_equal(w16.cpu().numpy().view(np.uint16), inter["wq"].view(np.uint16)), (name, "weight operand")
+        for out_dtype, tag in ((torch.float32, "f32"), (x.dtype, c.tag)):
+            y = ops.scaled_mm_f16(xq, w16, xs, st.qw.keep[1], mod.bias, out_dtype)
+            acc = inter["xq"].astype(np.float64) @ inter["wq"].astype(np.float64).T
+            want = acc * inter["xs"].astype(np.float64)[:, None] * inter["ws"].astype(np.float64).reshape(1, -1)
+            if mod.bias is not None:
+                want = want + mod.bias.detach().float().cpu().numpy().astype(np.float64).reshape(1, -1)
+            got = to_f32_numpy(y).astype(np.float64)
+            mag = (np.abs(inter["xq"].astype(np.float64)) @ np.abs(inter["wq"].astype(np.float64)).T) * inter["xs"].astype(np.float64)[:, None] \
+                * np.abs(inter["ws"].astype(np.float64)).reshape(1, -1) + 1e-30
+            lim = 2 * np.sqrt(c.K) * 2.0 ** -24 * mag + {"f32": 0.0, "bf16": 2.0 ** -8, "f16": 2.0 ** -11}[tag] * np.abs(want) + 1e-30
+            assert np.all(np.abs(got - want) <= lim), (name, M, tag, float((np.abs(got - want) / lim).max()))
+    # a NaN / all-zero row: nan_to_num and the clamp
+    xz = torch.zeros(40, c.K, device=gpu_device, dtype=torch.bfloat16)
+    xz[3, 5] = float("nan")
+    xz[7, :] = 3.0
+    q, s = ops.rowquant_f16(xz)
+    assert torch.all(q[0] == 0) and s[0].item() == 0.0 and torch.isnan(s[3]) and torch.all(q[3] == 0) and torch.all(q[7] == 65504.0)
+
+
+@pytest.mark.parametrize("m,n,k", [(4096, 2560, 1024), (4096, 5120, 320), (300, 264, 200), (64, 128, 4104)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_float16_scaled_mm_all_tiles(m, n, k, out_dtype, gpu_device):
+    """Every tile shape of sdnq_hip_scaled_mm_f16 (256x256 half-tile ring, 256x128, 64x128, 64x64; ragged M / N / K) against float64 on the
+    same operands: float32 accumulation error (2 sqrt(K) 2^-24 of sum|a||b|) plus the output rounding."""
+    from sdnq_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(m + n + k)
+    a = (torch.randn(m, k, generator=g) * 3000).to(torch.float16).to(gpu_device)
+    b = (torch.randn(n, k, generator=g) * 20).to(torch.float16).to(gpu_device)
+    sa = (torch.rand(m, generator=g) * 1e-4 + 1e-5).to(gpu_device)
+    sb = (torch.rand(n, generator=g) * 1e-2 + 1e-3).to(gpu_device)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16).to(gpu_device)
+    for bs in (bias, None):
+        y = ops.scaled_mm_f16(a, b, sa, sb, bs, out_dtype).double()
+        want = (a.double() @ b.double().t()) * sa.double()[:, None] * sb.double()[None, :]
+        mag = (a.double().abs() @ b.double().abs().t()) * sa.double()[:, None] * sb.double()[None, :]
+        if bs is not None:
+            want = want + bs.double()[None, :]
+        lim = 2 * (k ** 0.5) * 2.0 ** -24 * mag + (2.0 ** -8 if out_dtype == torch.bfloat16 else 2.0 ** -23) * want.abs() + 1e-30
+        assert bool(((y - want).abs() <= lim).all()), (m, n, k, out_dtype, float(((y - want).abs() / lim).max()))
 
 
 @pytest.mark.parametrize("name", ["int8_rowwise_qmm_bf16", "int8_rowwise_qmm_f16_nobias", "uint4_qmm_bf16", "int8_svd32_qmm_bf16",

@@ -301,6 +301,33 @@ def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
     assert support.unsupported_reason(layer(torch.bfloat16, use_svd=True, svd_rank=16)) is None
 
 
+def test_float16_matmul_support_rules():
+    """The float16 matmul forward (linear_fp16.py; round 6): built for Linear layers with row-wise float weights, float32 scales, no SVD /
+    Hadamard; integer weights (re-quantized to float16 by the reference), conv layers and 16-bit scales keep a reason."""
+    import sdnq_amd
+    from sdnq_amd import support
+    import pytest
+    from sdnq_amd.linear import quantized_linear_forward_fp16_matmul
+
+    def layer(conv=False, **kw):
+        torch.manual_seed(2)
+        base = torch.nn.Conv2d(32, 32, 3, padding=1) if conv else torch.nn.Linear(64, 64)
+        cfg = dict(weights_dtype="fp8", quantized_matmul_dtype="float16", group_size=-1)
+        cfg.update(dict(quant_conv=True, use_quantized_matmul_conv=True) if conv else dict(use_quantized_matmul=True))
+        cfg.update(kw)
+        return sdnq_amd.sdnq_quantize_layer(base.to(torch.bfloat16), sdnq_amd.SDNQConfig(**cfg))[0]
+
+    q = layer()
+    assert support.unsupported_reason(q) is None and q.forward_func is quantized_linear_forward_fp16_matmul
+    assert support.unsupported_reason(layer(weights_dtype="float6_e3m2fn")) is None
+    assert "row-wise float" in support.unsupported_reason(layer(weights_dtype="int8"))
+    assert "row-wise float" in support.unsupported_reason(layer(weights_dtype="int4", group_size=32))
+    with pytest.raises(NotImplementedError, match="float16"):  # the conv forwards in float16 are not built: loud at quantize time
+        layer(conv=True)
+    assert "16-bit scales" in support.unsupported_reason(layer(dequantize_fp32=False))
+    assert "SVD" in support.unsupported_reason(layer(use_svd=True, svd_rank=8))
+
+
 def test_support_predicate_on_grouped_convs_with_16_bit_scales():
     """Grouped conv matmul of dequantize_fp32=False layers (round 5): built for bfloat16 scales without a weight zero point; float16
     scales (the reference rounds acc * input_scale to float16 first) and unsigned weights keep their reason."""

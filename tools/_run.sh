@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/r6/final
-timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -6 > gpurun_out/r6/final/pytest_gpu_serial.txt
-cat gpurun_out/r6/final/pytest_gpu_serial.txt
+mkdir -p gpurun_out/r6
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "f16mm or float16" 2>&1 | grep -v "^  File\|Extension modules" | tail -25 | tee gpurun_out/r6/pytest_f16.txt
+timeout 600 python tools/f16_lab.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6/f16_lab.txt
