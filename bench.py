@@ -224,8 +224,10 @@ def link_shared_input_layers(layers):
     return sum(1 for mods in by_input.values() if len(mods) > 1 and sdnq_amd.link_layers(mods))
 
 
+@torch.no_grad()
 def run_step(layers):
-    """One pass over every layer.  The activation-quantization cache is emptied first: within a step a tensor consumed by
+    """One pass over every layer (under no_grad, the state every inference pipeline runs its model in -- the reference decorates each forward
+    with its inference context).  The activation-quantization cache is emptied first: within a step a tensor consumed by
     several layers is quantized once (sdnq_amd/linear.py:_ActivationCache), but nothing is carried across steps."""
     from sdnq_amd import linear as L
     L.clear_activation_cache()
@@ -1182,10 +1184,10 @@ def main():
             side.synchronize()
             graph = torch.cuda.CUDAGraph()
             from sdnq_amd import ops as _ops
-            _ops.fused_calls[0] = 0
+            _ops.reset_fused_calls()
             with torch.cuda.graph(graph, stream=side):
                 run_step(layers)
-            one_launch = _ops.fused_calls[0]
+            one_launch = _ops.fused_call_count()
         torch.cuda.synchronize()
 
     def step():

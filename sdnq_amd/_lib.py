@@ -106,12 +106,15 @@ def source_hash() -> str:
         g.update(open(os.path.join(_CSRC, f + ".hip"), "rb").read())
         parts += f" {f}:{g.hexdigest()}"
     parts += " binding:" + hashlib.sha256(open(os.path.join(_CSRC, "binding.c"), "rb").read()).hexdigest()
+    parts += " fastpath:" + hashlib.sha256(open(os.path.join(_CSRC, "fastpath.cpp"), "rb").read()
+                                           + open(os.path.join(_HERE, "..", "include", "sdnq_hip.h"), "rb").read()).hexdigest()
     return hashlib.sha256((parts + "\n").encode()).hexdigest()
 
 
 def lib_is_current() -> bool:
     try:
-        return os.path.exists(LIB_PATH) and open(LIB_PATH + ".srchash").read().strip() == source_hash()
+        host = [os.path.join(os.path.dirname(LIB_PATH), f) for f in ("_binding.so", "_fastpath.so")]  # built by the same script
+        return os.path.exists(LIB_PATH) and all(os.path.exists(f) for f in host) and open(LIB_PATH + ".srchash").read().strip() == source_hash()
     except OSError:
         return False
 
@@ -249,6 +252,32 @@ def _with_typed_binding(lib):
         return lib  # binding only: every call still lands in libsdnq_hip.so, through ctypes
     _binding.init(LIB_PATH)
     return _BoundLib(lib, _binding)
+
+
+USE_FAST_PLANS = os.environ.get("SDNQ_HIP_FAST_PLANS", "1").lower() not in {"0", "false", "no"}
+_fastpath = None  # None: not looked for yet; False: unavailable / switched off
+
+
+def fastpath():
+    """The C++ fast path of the eager Linear forward (csrc/fastpath.cpp -> sdnq_amd/_fastpath.so), or None with SDNQ_HIP_FAST_PLANS=0 /
+    when the module or the kernel library is not built: host logic only -- every launch it makes is a named entry point of
+    libsdnq_hip.so, and sdnq_amd/linear.py is the complete forward without it."""
+    global _fastpath
+    if _fastpath is None:
+        with _lock:
+            if _fastpath is None:
+                mod = False
+                if USE_FAST_PLANS and os.path.exists(LIB_PATH):
+                    try:
+                        import torch  # noqa: F401  (the module links against torch's libraries: they must be loaded first)
+                        from . import _fastpath as mod
+                        mod.init(LIB_PATH)
+                    except (ImportError, OSError) as e:
+                        import warnings
+                        warnings.warn(f"sdnq_amd._fastpath is unavailable ({e}); eager Linear calls take the Python forward")
+                        mod = False
+                _fastpath = mod
+    return _fastpath or None
 
 
 def check(status: int, what: str = ""):

@@ -43,5 +43,17 @@ BD_HASH=$(sha256sum "$HERE/binding.c" | cut -d' ' -f1)
 ALL="$ALL binding:$BD_HASH"
 PYINC=$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')
 gcc -O2 -Wall -Werror -shared -fPIC -I"$PYINC" "$HERE/binding.c" -o "$(dirname "$OUT")/_binding.so" -ldl
+# host-side fast path of the eager Linear forward (C++ against torch's headers: tensor checks, allocation and the launches of a plain w8a8
+# layer in ONE call, see fastpath.cpp): sdnq_amd/_fastpath.so.  Keyed like the objects; SDNQ_SKIP_FASTPATH=1 leaves it out.
+FP_HASH=$(cat "$HERE/fastpath.cpp" "$HERE/../../include/sdnq_hip.h" | sha256sum | cut -d' ' -f1)
+ALL="$ALL fastpath:$FP_HASH"
+FP_OUT="$(dirname "$OUT")/_fastpath.so"
+if [ "${SDNQ_SKIP_FASTPATH:-0}" != 1 ] && { [ "${FORCE:-0}" = 1 ] || [ ! -f "$FP_OUT" ] || [ "$(cat "$OBJ/fastpath.hash" 2>/dev/null)" != "$FP_HASH" ]; }; then
+  TI=$(python3 -c 'import os, torch; print(os.path.dirname(torch.__file__))')
+  g++ -O2 -std=c++17 -Wall -Wno-unused-function -shared -fPIC -D__HIP_PLATFORM_AMD__=1 -DUSE_ROCM=1 -D_GLIBCXX_USE_CXX11_ABI=1 \
+    -I"$TI/include" -I"$TI/include/torch/csrc/api/include" -I/opt/rocm/include -I"$PYINC" "$HERE/fastpath.cpp" -o "$FP_OUT" \
+    -L"$TI/lib" -lc10 -lc10_hip -ltorch -ltorch_cpu -ltorch_hip -ltorch_python -ldl -Wl,-rpath,"$TI/lib"
+  echo "$FP_HASH" > "$OBJ/fastpath.hash"
+fi
 echo "$ALL" | sha256sum | cut -d' ' -f1 > "$OUT.srchash"
 echo "built $OUT ($(cat "$OUT.srchash" | cut -c1-12))"

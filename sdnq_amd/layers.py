@@ -28,7 +28,7 @@ class SDNQLayer(torch.nn.Module):
 
     # per-object runtime state that must not travel with a copy: the operator handle names THIS module, the projection group and the
     # kernel-ready tensor cache point at the original's siblings / parameters
-    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_hip_plan", "_sdnq_group", "_sdnq_hip_state", "_sdnq_unshared", "_sdnq_compile_groups")
+    _RUNTIME_KEYS = ("_sdnq_hip_handle", "_sdnq_hip_plan", "_sdnq_group", "_sdnq_hip_state", "_sdnq_unshared", "_sdnq_compile_groups", "_sdnq_plan", "_sdnq_plan_declined")
 
     def __deepcopy__(self, memo):
         import copy
@@ -64,6 +64,7 @@ class SDNQLayer(torch.nn.Module):
             self.weight = torch.nn.Parameter(w, requires_grad=True)
             del self.sdnq_dequantizer, self.scale, self.zero_point, self.svd_up, self.svd_down
             self.__dict__.pop("_sdnq_hip_state", None)
+            self.__dict__.pop("_sdnq_plan", None)
             group = self.__dict__.pop("_sdnq_group", None)
             if group is not None:  # linked siblings (attention projections sharing this layer's input) run alone from now on
                 group[0].dissolve()

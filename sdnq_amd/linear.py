@@ -51,6 +51,13 @@ FUSED_ROWQUANT = os.environ.get("SDNQ_HIP_FUSED_ROWQUANT", "1").lower() not in {
 # (sdnq_hip_scaled_mm_w4, csrc/gemm_w4.hip; 0.25 B per weight resident instead of the cached mode's 1.0).  Bit-identical.
 FUSED_LUT4 = os.environ.get("SDNQ_HIP_FUSED_LUT4", "1").lower() not in {"0", "false", "no"}
 CACHE_ACTIVATIONS = int(os.environ.get("SDNQ_HIP_CACHE_ACTIVATIONS", "12"))  # LRU entries; 0 disables
+# Round 6: the C++ fast path of the eager forward (csrc/fastpath.cpp; None: not built / SDNQ_HIP_FAST_PLANS=0).  A layer that has taken
+# one of the three common routes -- a group member picking up its output, the one-launch w8a8 Linear, row quantizer + GEMM on the stream's
+# scratch -- gets a `_sdnq_plan` that carries its later calls through ONE C++ call (state check, allocation, launches); everything else,
+# and every call a plan declines, runs the Python forward below.  Assigning any UPPER-CASE switch of this module makes every plan stale.
+_FP = ops._lib.fastpath()
+FAST_PLANS = _FP is not None
+_PLAN_NAMES = ("weight", "scale", "zero_point", "svd_up", "svd_down", "bias")
 
 
 UNSHARED_FAST_PATH = os.environ.get("SDNQ_HIP_UNSHARED_FAST_PATH", "1").lower() not in {"0", "false", "no"}
@@ -183,6 +190,8 @@ class _PerThreadFlag:
 
     def __setitem__(self, i, v):
         _ts.no_reuse = v
+        if _FP is not None:
+            _FP.set_no_reuse(v)
 
 
 _act_cache = _PerThread(lambda: _ts.act_cache)
@@ -198,9 +207,13 @@ _no_identity_reuse = _PerThreadFlag()
 class identity_reuse_disabled:
     def __enter__(self):
         _ts.no_reuse += 1
+        if _FP is not None:
+            _FP.set_no_reuse(_ts.no_reuse)
 
     def __exit__(self, *exc):
         _ts.no_reuse -= 1
+        if _FP is not None:
+            _FP.set_no_reuse(_ts.no_reuse)
         return False
 _groups = []  # weak references to the live SharedInputGroups (invalidate() reaches their pending outputs); guarded by _groups_lock
 _groups_lock = __import__("threading").Lock()
@@ -257,7 +270,7 @@ class _State:
 class _LaunchUnit:
     """One GEMM launch site of a model step (a layer, or a ProjectionGroup) as the weight prefetch sees it: the weight tensors the
     launch reads (held, so the ranges stay mapped) and a weak link to the unit that launched right after it in the last step."""
-    __slots__ = ("tensors", "ranges", "next", "device", "__weakref__")
+    __slots__ = ("tensors", "ranges", "next", "device", "c", "__weakref__")
 
     def __init__(self, tensors):
         self.tensors = tuple(tensors)
@@ -270,6 +283,8 @@ class _LaunchUnit:
         if sum(b for _, b in self.ranges) > PREFETCH_NEXT_MAX_BYTES or len(self.ranges) > 4:
             self.ranges = ()  # (the model-wide key / value group: 340 MB of weights, more than the cache holds)
         self.next = None
+        # with the C++ fast path the chain itself (who launched after whom, per thread) lives there: plans and this module link ONE chain
+        self.c = None if _FP is None else _FP.Unit(self.ranges, -1 if self.device is None or self.device.index is None else self.device.index)
 
 
 class _PrefetchChain:
@@ -287,6 +302,9 @@ class _PrefetchChain:
         self._tls = threading.local()
 
     def launch(self, unit: _LaunchUnit):
+        if unit.c is not None:
+            unit.c.launch()
+            return
         tls = self._tls
         prev = getattr(tls, "prev", None)
         prev = prev() if prev is not None else None
@@ -311,6 +329,8 @@ class _PrefetchChain:
 
     def reset(self):
         self._tls.prev = None
+        if _FP is not None:
+            _FP.chain_reset()
 
 
 _prefetch_chain = _PrefetchChain()
@@ -335,11 +355,33 @@ def _no_grad(fn):
 
     @functools.wraps(fn)
     def forward(self, input):
+        plan = self.__dict__.get("_sdnq_plan")
+        if plan is not None:  # (csrc/fastpath.cpp) Tensor: done; None: not this call; False: stale
+            y = plan(self, input)
+            if y is not None:
+                if y is not False:
+                    return y
+                del self.__dict__["_sdnq_plan"]
         if grad_on():
             with no_grad():
                 return fn(self, input)
         return fn(self, input)
     return forward
+
+
+def _install_plan(mod, **kw):
+    """A plan for `mod`'s later calls, keyed on the identity / storage / version of its parameters as they are NOW (what _state checks)."""
+    refs = tuple(_attr(mod, name) for name in _PLAN_NAMES)
+    try:
+        mod.__dict__["_sdnq_plan"] = _FP.Plan(_PLAN_NAMES, refs, **kw)
+    except (TypeError, ValueError):  # a parameter form the plan does not take (a non-contiguous bias, ...): the Python forward stays
+        mod.__dict__["_sdnq_plan_declined"] = True
+
+
+def drop_plans(mods):
+    for m in mods:
+        m.__dict__.pop("_sdnq_plan", None)
+        m.__dict__.pop("_sdnq_plan_declined", None)
 
 
 def _attr(mod, name):
@@ -632,18 +674,50 @@ class ProjectionGroup:
         self.float_mode = float_mode  # members run dequantize + F.linear (use_quantized_matmul=False) instead of the quantized matmul
         self.sig = None    # what the unit table was built from: matmul dtype + every member's operand identity / storage / version
         self.gemm = None   # ops.GemmGroup
-        self.last = None   # (input tensor, its key, stream, outputs, indices not handed out yet)
-        self.wasted = 0    # consecutive computes whose outputs were not all claimed
+        # claim state: (input tensor, its key, stream, outputs, indices not handed out yet) + consecutive computes whose outputs were not
+        # all claimed.  With the C++ fast path it lives THERE (the members' plans claim without entering this module); `last` / `wasted`
+        # below show it
+        self._c = None if _FP is None else _FP.Group(len(self.mods))
+        self._last = None
+        self._wasted = 0
         self.fallback = None  # smaller groups (lists of members) to form when THIS grouping turns out wrong (loader.link_projections)
         self.pf = None            # _LaunchUnit of the grouped launch (weight prefetch across layers)
         self.pf_tensors = ()      # the members' weight operands, as the unit table was built from them
         with _groups_lock:
             _groups.append(weakref.ref(self))
 
+    @property
+    def last(self):
+        if self._c is None:
+            return self._last
+        st = self._c.peek()
+        return None if st is None else (st[0], None, None, st[1], st[2])
+
+    @last.setter
+    def last(self, value):
+        if self._c is None:
+            self._last = value
+        elif value is None:
+            self._c.clear()
+        else:
+            self._c.publish(value[0], value[3])
+
+    @property
+    def wasted(self):
+        return self._wasted if self._c is None else self._c.wasted
+
+    @wasted.setter
+    def wasted(self, value):
+        if self._c is None:
+            self._wasted = value
+        else:
+            self._c.wasted = value
+
     def dissolve(self):
         for m in self.mods:
             if m.__dict__.get("_sdnq_group", (None,))[0] is self:
                 m.__dict__.pop("_sdnq_group", None)
+        drop_plans(self.mods)
         self.last = None
         self.gemm = None
 
@@ -731,19 +805,21 @@ class ProjectionGroup:
 
     def _claim(self, idx: int, input: torch.Tensor, key, stream):
         """The stored output of member idx if `input` is the tensor the stored outputs were computed from, else None."""
-        last = self.last
+        if self._c is not None:
+            return self._c.claim(idx, input)  # (key and stream are taken from `input` there)
+        last = self._last
         if last is None or last[0] is not input or last[1] != key or last[2] != stream or idx not in last[4]:
             return None
         y = last[3][idx].view(*input.shape[:-1], -1)
         last[4].discard(idx)
         if not last[4]:
-            self.last = None  # every member has its output: hold on to nothing (the input and the outputs belong to the host again)
-            self.wasted = 0
+            self._last = None  # every member has its output: hold on to nothing (the input and the outputs belong to the host again)
+            self._wasted = 0
         return y
 
     def _begin_compute(self) -> bool:
         """Account for outputs nobody claimed; False once the group has dissolved itself."""
-        if self.last is not None and self.last[4]:
+        if (self._c.pending() if self._c is not None else (self._last is not None and self._last[4])):
             self.wasted += 1
             if self.wasted >= 2:
                 fallback = self.fallback
@@ -771,6 +847,12 @@ class ProjectionGroup:
             _pf_launch(self, self.pf_tensors)
         outs = ops.scaled_mm_grouped(mm, xq, xs, self.gemm, input.dtype)
         self.last = (input, key, stream, outs, set(range(len(self.mods))))
+        if FAST_PLANS and self._c is not None and "_sdnq_plan" not in mod.__dict__:
+            # from now on a member that finds its output waiting takes it without entering this module (csrc/fastpath.cpp: plan_call)
+            for i, m in enumerate(self.mods):
+                if "_sdnq_plan" not in m.__dict__ and m.__dict__.get("_sdnq_group", (None,))[0] is self:
+                    _install_plan(m, mm=mm, n=m.sdnq_dequantizer.out_features, k=m.sdnq_dequantizer.in_features, group=self._c,
+                                  idx=m.__dict__["_sdnq_group"][1])
         return self._claim(idx, input, key, stream)
 
     def forward_float(self, mod, idx: int, input: torch.Tensor):
@@ -836,8 +918,11 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
     had = dq.hadamard_group_size if dq.use_hadamard else 0
     has_svd = st.svd_up is not None
     bias = _attr(self, "bias")
-    if PREFETCH_NEXT and st.mm_weight is wq and input.is_cuda:  # (a cached operand: the per-call mode's scratch copies are not prefetched)
+    pf_on = PREFETCH_NEXT and st.mm_weight is wq and input.is_cuda
+    if pf_on:  # (a cached operand: the per-call mode's scratch copies are not prefetched)
         _pf_launch(st, (wq,))
+    # what a plan may carry later: this layer, called through its own forward on its own input (no conv caller, no group), its matmul operand cached
+    plannable = cache_input and small_batch_branch and group is None and st.mm_weight is wq
     if not has_svd and zp is None and (had == 0 or k <= 5120):
         # plain w8a8 layer: on a cache miss the row quantization and the GEMM go through ONE binding call (an eager model is
         # bound by the host-side cost per layer); the quantized activation still lands in the cache for sibling layers
@@ -852,6 +937,9 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
                 x2 = x2.contiguous()
             if ops.linear_w8a8_fused_supported(mm, x2, n, input.dtype):
                 y = ops.linear_w8a8_fused(mm, x2, wq, ws, bias, input.dtype)
+                if FAST_PLANS and plannable and "_sdnq_plan_declined" not in self.__dict__:
+                    _install_plan(self, mm=mm, n=n, k=k, wq=wq, ws=ws, bias=bias, had=0, allow_fused=True,
+                                  allow_ws=use_cache and UNSHARED_FAST_PATH, unit=st.pf.c if pf_on else None)
                 return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         if (use_cache and UNSHARED_FAST_PATH and self.__dict__.get("_sdnq_unshared", 0) >= UNSHARED_AFTER and input.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
@@ -861,6 +949,9 @@ def _quantized_matmul_forward(self, input: torch.Tensor, mm: int, small_batch_br
             if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
                 x2 = x2.contiguous()
             y = ops.linear_w8a8_ws(mm, x2, wq, ws, bias, input.dtype, had)
+            if FAST_PLANS and plannable and "_sdnq_plan_declined" not in self.__dict__:
+                _install_plan(self, mm=mm, n=n, k=k, wq=wq, ws=ws, bias=bias, had=had, allow_fused=FUSED_ROWQUANT and had == 0, allow_ws=True,
+                              unit=st.pf.c if pf_on else None)
             return y if input.dim() == 2 else y.view(*input.shape[:-1], n)
         params = (mm, had, False, False, False, ops._stream(input) if input.is_cuda else -1)
         key = tensor_key(input) if (use_cache and not _ts.no_reuse) else None  # one key for the look-up and the store
@@ -1067,3 +1158,21 @@ def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Ten
         x2 = x2.contiguous()
     xq, xs = ops.rowquant_f16(x2)
     return ops.scaled_mm_f16(xq, st.mm_weight, xs, st.mm_scale, _attr(self, "bias"), input.dtype).view(*input.shape[:-1], n)
+
+
+class _SwitchModule(__import__("types").ModuleType):
+    """Assigning an UPPER-CASE switch of this module (tests and tuning scripts flip them at run time) makes every fast-path plan stale:
+    a plan restates the route the Python forward took under the switches as they were."""
+
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name.isupper() and _FP is not None:
+            _FP.bump_epoch()
+
+    def __delattr__(self, name):
+        super().__delattr__(name)
+        if name.isupper() and _FP is not None:
+            _FP.bump_epoch()
+
+
+__import__("sys").modules[__name__].__class__ = _SwitchModule

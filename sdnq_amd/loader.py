@@ -164,6 +164,8 @@ def link_layers(mods) -> bool:
     for m in mods:
         _unlink(m)
     group = ProjectionGroup(mods, float_mode=float_mode)
+    from .linear import drop_plans
+    drop_plans(mods)  # (fast-path plans made while the layers ran alone)
     for i, m in enumerate(mods):
         m.__dict__["_sdnq_group"] = (group, i)
     return True

@@ -458,7 +458,20 @@ def linear_w8a8_fused_supported(mm: int, x2d: torch.Tensor, n: int, out_dtype: t
 
 
 _fused_ok = {}
-fused_calls = [0]  # how many Linear calls took the one-launch route (bench.py reports it per step)
+fused_calls = [0]  # how many Linear calls took the one-launch route through THIS module (fused_call_count() adds the fast path's)
+
+
+def fused_call_count() -> int:
+    """Linear calls that took the one-launch route since reset_fused_calls() (bench.py reports it per step)."""
+    fp = _lib.fastpath()
+    return fused_calls[0] + (fp.fused_calls() if fp is not None else 0)
+
+
+def reset_fused_calls():
+    fused_calls[0] = 0
+    fp = _lib.fastpath()
+    if fp is not None:
+        fp.reset_counters()
 
 
 def linear_w8a8_fused(mm: int, x2d: torch.Tensor, b_phys: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype) -> torch.Tensor:

@@ -386,6 +386,7 @@ def test_prefetch_chain_learns_the_launch_order_and_names_two_units_ahead(monkey
             return 0
 
     monkeypatch.setattr(L.ops._lib, "load", lambda: FakeLib())
+    monkeypatch.setattr(L, "_FP", None)  # the Python form of the chain (the C++ form: test_prefetch_chain_in_the_fast_path_module below)
     chain = L._PrefetchChain()
     ws = [torch.zeros(64 * (i + 1), dtype=torch.int8) for i in range(4)]
     units = [L._LaunchUnit((w,)) for w in ws]
@@ -442,6 +443,53 @@ class TinyNet(torch.nn.Module):
         h = torch.nn.functional.silu(self.mid(h))
         h = self.norm(self.proj_out(h))
         return self.head(h)
+
+
+def test_prefetch_chain_in_the_fast_path_module():
+    """The same chain as csrc/fastpath.cpp keeps it (units made with the module present link THERE: the plans and linear.py share one
+    chain per thread): same hand-overs, read back through _fastpath.last_hint()."""
+    import torch
+    from sdnq_amd import linear as L
+    fp = L._FP
+    if fp is None:
+        pytest.skip("sdnq_amd._fastpath is not built")
+    chain = L._PrefetchChain()
+    ws = [torch.zeros(64 * (i + 1), dtype=torch.int8) for i in range(4)]
+    units = [L._LaunchUnit((w,)) for w in ws]
+    assert all(u.c is not None for u in units)
+    rng = lambda i: (ws[i].data_ptr(), ws[i].numel())  # noqa: E731
+    chain.reset()
+    n0 = fp.last_hint()[0]
+    for u in units:
+        chain.launch(u)
+    assert fp.last_hint()[0] == n0  # first step: nothing known yet
+    chain.reset()
+    seen = []
+    for u in units:
+        chain.launch(u)
+        seen.append(fp.last_hint())
+    assert seen[0][1:5] == (*rng(1), *rng(2)) and seen[0][5:] == (0, 0, 0, 0)
+    assert seen[1][1:5] == (*rng(2), *rng(3))
+    assert seen[2][1:3] == rng(3) and seen[2][3:] == (0, 0, 0, 0, 0, 0)
+    assert seen[3] == seen[2] and seen[3][0] == n0 + 3  # the last unit has no successor: no hand-over
+    for _ in range(2):  # another order: re-learned in one step
+        chain.reset()
+        for i in (0, 2, 1, 3):
+            chain.launch(units[i])
+            if i == 0:
+                first = fp.last_hint()
+    assert first[1:5] == (*rng(2), *rng(1))
+    # a dead unit ends the chain; a unit on another device is never named
+    a, b = L._LaunchUnit((ws[0],)), L._LaunchUnit((ws[1],))
+    chain.reset(); chain.launch(a); chain.launch(b)
+    del b
+    n1 = fp.last_hint()[0]
+    chain.reset(); chain.launch(a)
+    assert fp.last_hint()[0] == n1
+    c0, c1 = fp.Unit((rng(0),), 0), fp.Unit((rng(1),), 1)
+    fp.chain_reset(); c0.launch(); c1.launch()
+    fp.chain_reset(); c0.launch()
+    assert fp.last_hint()[0] == n1
 
 
 def test_save_sdnq_model_writes_what_the_reference_wrote(tmp_path):
