@@ -430,6 +430,11 @@ def load_sdnq_model(model_path: str, model_cls=None, file_name: str | None = Non
     if still_meta:
         raise RuntimeError(f"{model_path}: {len(still_meta)} tensor(s) of the model are not in the checkpoint ({', '.join(still_meta[:6])}"
                            f"{' ...' if len(still_meta) > 6 else ''}); unexpected keys: {list(unexpected)[:6]}")
+    if unexpected:
+        # the reference loads strictly (loader.py:215-227: load_state_dict of the rebuilt skeleton): a tensor the skeleton has no slot for -- a
+        # `codebook` of a configuration this build does not construct, a layer the config did not mention -- must not be dropped silently
+        raise RuntimeError(f"{model_path}: {len(unexpected)} tensor(s) of the checkpoint have no place in the rebuilt model "
+                           f"({', '.join(list(unexpected)[:6])}{' ...' if len(unexpected) > 6 else ''})")
     model.quantization_config = quantization_config
     model.quantization_method = QuantizationMethod.SDNQ
     if hasattr(model, "config"):

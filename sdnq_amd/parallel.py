@@ -141,32 +141,50 @@ class PeerArena:
         self.buf = torch.zeros(self.CTRL + self.size, dtype=torch.uint8, device=self.device)  # (the first CTRL bytes stay unused: offsets as before)
         if self.buf.data_ptr() % 256:
             raise _lib.SdnqHipError("PeerArena: allocation is not 256-byte aligned")
-        # ---- control words in signal memory, the status word in host-coherent memory
-        with torch.cuda.device(self.device):
-            pp, granted = ctypes.c_void_p(), ctypes.c_int()
-            _lib.check(lib.sdnq_hip_signal_alloc(self.CTRL_BYTES, 0, ctypes.byref(pp), ctypes.byref(granted)), "signal_alloc")
-            self._ctrl = int(pp.value)
-            self.ctrl_kind = {1: "uncached", 2: "finegrained"}[granted.value]
-            _lib.check(lib.sdnq_hip_signal_alloc(64, 1, ctypes.byref(pp), ctypes.byref(granted)), "signal_alloc(host)")
-            self._status_ptr = int(pp.value)
-            handle = ctypes.create_string_buffer(64)
-            _lib.check(lib.sdnq_hip_ipc_export(self._ctrl, handle), "ipc_export")
-        torch.cuda.synchronize(self.device)  # the zeroed words are in memory before any peer maps them
+        # ---- control words in signal memory, the status word in host-coherent memory.  Every step that can fail on ONE rank (allocation, IPC
+        # export, IPC import) is followed by an agreement step: a rank that raised alone would leave the others blocked in the next collective
+        # until the process-group timeout (advisor, round 5)
+        pp, granted = ctypes.c_void_p(), ctypes.c_int()
+        handle = ctypes.create_string_buffer(64)
+        err = None
+        try:
+            with torch.cuda.device(self.device):
+                _lib.check(lib.sdnq_hip_signal_alloc(self.CTRL_BYTES, 0, ctypes.byref(pp), ctypes.byref(granted)), "signal_alloc")
+                self._ctrl = int(pp.value)
+                self.ctrl_kind = {1: "uncached", 2: "finegrained"}[granted.value]
+                _lib.check(lib.sdnq_hip_signal_alloc(64, 1, ctypes.byref(pp), ctypes.byref(granted)), "signal_alloc(host)")
+                self._status_ptr = int(pp.value)
+                _lib.check(lib.sdnq_hip_ipc_export(self._ctrl, handle), "ipc_export")
+            torch.cuda.synchronize(self.device)  # the zeroed words are in memory before any peer maps them
+        except (_lib.SdnqHipError, RuntimeError, KeyError) as e:
+            err = f"rank {rank}: {e!r}"
         # exchange the IPC handles (plain data: picklable through any backend's all_gather_object)
         fn, args = reduce_tensor(self.buf)
         gathered = [None] * world
-        dist.all_gather_object(gathered, (rank, args, bytes(handle.raw), os.getpid()), group=group)
+        dist.all_gather_object(gathered, (rank, args, bytes(handle.raw), os.getpid(), err), group=group)
+        failed = [g[4] for g in gathered if g[4]]
+        if failed:
+            raise PeerUnavailable("PeerArena: control memory could not be set up on every rank: " + "; ".join(failed))
         self.peers = [None] * world
         ctrl_ptrs = [0] * world
-        for r, a, h, pid in gathered:
-            if r == rank:
-                self.peers[r], ctrl_ptrs[r] = self.buf, self._ctrl
-                continue
-            self.peers[r] = fn(*a)
-            with torch.cuda.device(self.device):
-                _lib.check(lib.sdnq_hip_ipc_import(ctypes.create_string_buffer(h, 64), ctypes.byref(pp)), "ipc_import")
-            ctrl_ptrs[r] = int(pp.value)
-            self._imported.append(ctrl_ptrs[r])
+        err = None
+        try:
+            for r, a, h, pid, _ in gathered:
+                if r == rank:
+                    self.peers[r], ctrl_ptrs[r] = self.buf, self._ctrl
+                    continue
+                self.peers[r] = fn(*a)
+                with torch.cuda.device(self.device):
+                    _lib.check(lib.sdnq_hip_ipc_import(ctypes.create_string_buffer(h, 64), ctypes.byref(pp)), "ipc_import")
+                ctrl_ptrs[r] = int(pp.value)
+                self._imported.append(ctrl_ptrs[r])
+        except (_lib.SdnqHipError, RuntimeError) as e:
+            err = f"rank {rank}: {e!r}"
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, err, group=group)
+        failed = [v for v in verdicts if v]
+        if failed:
+            raise PeerUnavailable("PeerArena: a peer's memory could not be mapped on every rank: " + "; ".join(failed))
         ptrs = [int(t.data_ptr()) for t in self.peers]
         arr = ctypes.c_void_p * world
         self._arena = arr(*[p for p in ptrs])

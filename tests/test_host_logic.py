@@ -576,6 +576,18 @@ def test_load_sdnq_model_rebuilds_the_layers_of_a_reference_checkpoint():
     import pytest
     with pytest.raises(RuntimeError, match="not in the checkpoint"):
         sdnq_amd.load_sdnq_model(path, model_cls=Bigger, device="cpu")
+    # ... and the other direction (the reference loads strictly): a tensor of the checkpoint the rebuilt model has no slot for is an error, not dropped
+    import shutil
+    import tempfile
+    from safetensors.torch import load_file, save_file
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, "ckpt")
+        shutil.copytree(path, dst)
+        tensors = load_file(os.path.join(dst, "model.safetensors"))
+        tensors["mid.codebook"] = torch.zeros(16)
+        save_file(tensors, os.path.join(dst, "model.safetensors"))
+        with pytest.raises(RuntimeError, match="no place in the rebuilt model.*mid.codebook"):
+            sdnq_amd.load_sdnq_model(dst, model_cls=TinyNet, device="cpu")
 
 
 def test_module_lists_match_like_the_reference():
