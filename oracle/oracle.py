@@ -926,10 +926,43 @@ def _forward_uint8_bf16(mod: OracleLinear, x2: np.ndarray, tag: str, conv_form: 
 
 
 # ---- quantized attention forward ---------------------------------------------------------------
-def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True, hadamard_group: int = 0, tag: str = "bf16"):
-    """quantize_attn (kernels/triton_atten.py:443-487) for matmul_dtype="int8": K minus its token mean in fp32 (:457-463),
-    then quantize_int_mm per token (quant_utils.py:265-273).  q [Z,H,QN,D], k [Z,KH,KN,D] float32 values.
-    Returns (q_q int8, q_scale [Z,H,QN], k_q int8, k_scale [Z,KH,KN])."""
+def _mm_key(matmul_dtype):
+    if matmul_dtype in ("auto", "enabled", "uint8", "int8"):  # triton_atten.py:452-455
+        return "int8"
+    if matmul_dtype in ("fp8", "float8_e4m3fn"):
+        return "fp8"
+    if matmul_dtype == "float16":
+        return "float16"
+    raise ValueError(f"attention oracle: matmul dtype {matmul_dtype!r}")
+
+
+def _f32_to_e4m3(x: np.ndarray) -> np.ndarray:
+    flat = _c(x, np.float32).reshape(-1)
+    return np.array([lib().orc_f32_to_e4m3fn(float(v)) for v in flat], dtype=np.uint8).reshape(x.shape)
+
+
+def _rowquant_attn(x2: np.ndarray, key: str):
+    """quantize_int_mm / quantize_fp_mm (quant_utils.py:265-273, 290-299) of float32 rows -> (operand VALUES as float32 [exact for all three
+    formats], scale [M], stored codes: int8 / e4m3 bytes / float16)."""
+    f = np.float32
+    if key in ("int8", "fp8"):
+        q, s, _ = rowquant(x2, key)
+        return (q.astype(f) if key == "int8" else e4m3_decode(q).astype(f)), s, q
+    x = _c(x2, f)
+    s = (np.abs(x).max(-1, keepdims=True).astype(f) / f(65504.0)).astype(f)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = (x / s).astype(f)
+    q = np.clip(np.nan_to_num(q, nan=0.0, posinf=3.4028235e38, neginf=-3.4028235e38), f(-65504.0), f(65504.0)).astype(np.float16)
+    return q.astype(f), s.reshape(-1), q
+
+
+def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True, hadamard_group: int = 0, tag: str = "bf16", matmul_dtype: str = "int8",
+                       v: np.ndarray | None = None, pv_matmul_dtype=None):
+    """quantize_attn (kernels/triton_atten.py:443-487): K minus its token mean in fp32 (:457-463), then quantize_int_mm / quantize_fp_mm per
+    token (quant_utils.py:265-273, 290-299); with pv_matmul_dtype the (rotated) V per token too (:478-483).
+    q [Z,H,QN,D], k / v [Z,KH,KN,D] float32 values.
+    Returns (q_q codes, q_scale [Z,H,QN], k_q codes, k_scale [Z,KH,KN]) -- int8 or e4m3 bytes -- and, when v is given, a dict with the
+    float32 VALUES of the three operands (+ v codes / scales when V is quantized) as fifth element."""
     f = np.float32
     q, k = _c(q, f), _c(k, f)
     if smooth_k:
@@ -938,16 +971,29 @@ def attention_quantize(q: np.ndarray, k: np.ndarray, smooth_k: bool = True, hada
         q = rotate_hadamard(q, hadamard_group, tag)
         k = rotate_hadamard(round_dtype(k, tag), hadamard_group, tag)
     d = q.shape[-1]
-    qq, qs, _ = rowquant(q.reshape(-1, d), "int8")
-    kq, ks, _ = rowquant(k.reshape(-1, d), "int8")
-    return qq.reshape(q.shape), qs.reshape(q.shape[:-1]), kq.reshape(k.shape), ks.reshape(k.shape[:-1])
+    key = _mm_key(matmul_dtype)
+    qv, qs, qq = _rowquant_attn(q.reshape(-1, d), key)
+    kv, ks, kq = _rowquant_attn(k.reshape(-1, d), key)
+    res = (qq.reshape(q.shape), qs.reshape(q.shape[:-1]), kq.reshape(k.shape), ks.reshape(k.shape[:-1]))
+    if v is None:
+        return res
+    vals = dict(q=qv.reshape(q.shape), k=kv.reshape(k.shape), v=_c(v, f), v_scale=None, v_q=None)
+    if pv_matmul_dtype not in (None, "auto", "none", "no", "disabled"):
+        vv = _c(v, f)
+        if hadamard_group:  # rotate_hadamard(v.to(dtype=hadamard.dtype)) (:479-480)
+            vv = rotate_hadamard(round_dtype(vv, tag), hadamard_group, tag)
+        pk = _mm_key("int8" if pv_matmul_dtype in ("enabled", "uint8") else pv_matmul_dtype)
+        vq, vs, vc = _rowquant_attn(vv.reshape(-1, vv.shape[-1]), pk)
+        vals.update(v=vq.reshape(vv.shape), v_scale=vs.reshape(vv.shape[:-1]), v_q=vc.reshape(vv.shape), pv=pk)
+    return res + (vals,)
 
 
 def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: bool = False, scale=None, smooth_k: bool = True,
               block_n: int = 32, out_tag: str | None = None, want_intermediates: bool = False, hadamard_group: int = 0,
-              mask: np.ndarray | None = None):
-    """sdnq_triton_atten (kernels/triton_atten.py:540-618) in its default configuration (int8 Q.K^T, P.V in the value dtype):
-    the online-softmax loop of sdnq_attn_kernel (:143-335) over key blocks of `block_n`, all queries of a head at once.
+              mask: np.ndarray | None = None, matmul_dtype: str = "int8", pv_matmul_dtype=None):
+    """sdnq_triton_atten (kernels/triton_atten.py:540-618): int8 or fp8 (e4m3) Q.K^T, P.V in the value dtype or quantized (int8 / fp8 /
+    float16, :303-323): the online-softmax loop of sdnq_attn_kernel (:143-335) over key blocks of `block_n` -- the quantized P is scaled
+    per (query, key BLOCK), so block_n is part of the result there --, all queries of a head at once.
     q/k/v: float32 VALUES of `tag` tensors [Z,H,N,D]; returns float32 values rounded to out_tag (default tag).
     mask: None, a bool / int8 array (0 = masked out, :290-291) or a float array added to the base-2 logits as is (:292-293),
     broadcastable to [Z,H,QN,KN] after left-padding to 4-D (get_attn_inputs :520-527)."""
@@ -956,7 +1002,9 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
     _, KH, KN, _ = k.shape
     sm_scale = f(D ** -0.5 if scale is None else scale)                       # :512-513
     log2_sm = f(sm_scale * f(1.4426950408889634))                            # :203
-    qq, qs, kq, ks = attention_quantize(q, k, smooth_k, hadamard_group, tag)
+    qq, qs, kq, ks, vals = attention_quantize(q, k, smooth_k, hadamard_group, tag, matmul_dtype, v=v, pv_matmul_dtype=pv_matmul_dtype)
+    pv = vals.get("pv")
+    vop, vsc = vals["v"], vals["v_scale"]
     out = np.empty((Z, QH, QN, D), dtype=f)
     qidx = np.arange(QN)[:, None]
     mask_is_bool = False
@@ -967,7 +1015,8 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
     for z in range(Z):
         for h in range(QH):
             kh = (h * KH) // QH                                              # :212-213
-            S = qq[z, h].astype(np.int32) @ kq[z, kh].astype(np.int32).T     # exact
+            # int8: exact; fp8: every product is exact in float32, the sum of D of them in float64 rounds once (tl.dot accumulates in float32)
+            S = (vals["q"][z, h].astype(np.float64) @ vals["k"][z, kh].astype(np.float64).T).astype(f)
             m = np.full(QN, -np.inf, dtype=f)
             l = np.ones(QN, dtype=f)
             acc = np.zeros((QN, D), dtype=f)
@@ -975,8 +1024,8 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
                 n1 = min(n0 + block_n, KN)
                 if is_causal and QN <= n0:
                     continue
-                s = ((S[:, n0:n1].astype(f) * qs[z, h][:, None]).astype(f) * ks[z, kh][None, n0:n1]).astype(f)
-                s = (s * log2_sm).astype(f)                                  # :278
+                s = ((S[:, n0:n1] * qs[z, h][:, None]).astype(f) * ks[z, kh][None, n0:n1]).astype(f)
+                s = (s * log2_sm).astype(f)                                  # :278 / :283
                 if is_causal:
                     s = np.where(qidx >= np.arange(n0, n1)[None, :], s, f(-np.inf))  # :287-288
                 if mask is not None:
@@ -989,10 +1038,28 @@ def attention(q: np.ndarray, k: np.ndarray, v: np.ndarray, tag: str, is_causal: 
                     p = np.exp2(s - np.where(dead, f(0), m_new)[:, None]).astype(f)
                 l = (l * alpha + p.sum(axis=1, dtype=f)).astype(f)           # :308
                 acc = (acc * alpha[:, None]).astype(f)
-                acc = (acc + round_dtype(p, tag) @ _c(v[z, kh, n0:n1], f)).astype(f)  # p.to(v.dtype); fp32 accumulate (:332-333)
+                vb = _c(vop[z, kh, n0:n1], f)
+                if pv is None:
+                    acc = (acc + round_dtype(p, tag) @ vb).astype(f)         # p.to(v.dtype); fp32 accumulate (:332-333)
+                else:                                                        # :311-327
+                    p = (p * vsc[z, kh][None, n0:n1]).astype(f)
+                    qmax = {"int8": 127.0, "fp8": 448.0, "float16": 65504.0}[pv]
+                    ps = (p.max(axis=1, keepdims=True) * f(1.0 / qmax)).astype(f)
+                    ps = np.where(ps <= f(2e-38), f(1.0), ps).astype(f)
+                    inv = (f(1.0) / ps).astype(f)
+                    if pv == "int8":
+                        pq = np.floor((p.astype(np.float64) * inv.astype(np.float64) + 0.5).astype(f)).astype(f)  # floor(fma(p, 1 / p_scale, 0.5))
+                    elif pv == "fp8":
+                        pq = e4m3_decode(_f32_to_e4m3((p * inv).astype(f))).astype(f)
+                    else:
+                        pq = (p * inv).astype(f).astype(np.float16).astype(f)
+                    dot = (pq.astype(np.float64) @ vb.astype(np.float64)).astype(f)  # int8: exact; fp8 / f16: one rounding of the float32 sum
+                    acc = (dot.astype(np.float64) * ps.astype(np.float64) + acc.astype(np.float64)).astype(f)  # fma(dot, p_scale, acc)
                 m = m_new
             out[z, h] = acc * (f(1.0) / l)[:, None]                          # :336
+    if pv is not None and hadamard_group:  # the output comes back out of the rotated basis (triton_atten.py:609-612), in the OUTPUT dtype
+        out = rotate_hadamard(round_dtype(out, out_tag or tag), hadamard_group, out_tag or tag)
     out = round_dtype(out, out_tag or tag)
     if want_intermediates:
-        return out, dict(q_q=qq, q_scale=qs, k_q=kq, k_scale=ks)
+        return out, dict(q_q=qq, q_scale=qs, k_q=kq, k_scale=ks, v_q=vals["v_q"], v_scale=vals["v_scale"])
     return out

@@ -16,6 +16,10 @@ What this harness has to supply because there is no GPU driver here (nothing of 
     k_q / k_scale of the fixture are the reference's bfloat16 path bit for bit; the KERNEL then runs on those quantized operands with V
     handed over as float32 (the same values: every bfloat16 is a float32), i.e. with P and the output NOT rounded to bfloat16 -- the
     fixture's `out` is float32 and a bfloat16 implementation is compared with it at bfloat16 tolerance (meta: "out_is").
+  * the fp8 P.V cases (round 6): the interpreter's float32 -> float8 cast (`_convert_float`) TRUNCATES the mantissa (its "rtne" branch adds
+    the cut-off bit without carrying into the exponent), where Triton's language semantics -- and every GPU lowering -- round `x.to(tl.float8e4nv)`
+    to nearest even (`fp_downcast_rounding` defaults to "rtne").  For `p.to(v.dtype)` (triton_atten.py:319) the harness substitutes torch's
+    float32 -> float8_e4m3fn conversion (round to nearest even) for that one cast of the interpreter; every other interpreter operation is untouched;
 Fixtures are DATA only (inputs, the reference's quantized operands, outputs).  Run:  python tests/golden/make_golden_attention.py
 """
 import json
@@ -55,6 +59,20 @@ class FixedConfig:
         return launch
 
 
+import triton.runtime.interpreter as _interp  # noqa: E402
+
+_interp_convert_float = _interp._convert_float
+
+
+def _convert_float_rne(input, input_dtype, output_dtype, rounding_mode):
+    if input_dtype == tl.float32 and output_dtype == tl.float8e4nv:  # (see the module docstring)
+        t = torch.from_numpy(np.ascontiguousarray(input).view(np.float32)).to(torch.float8_e4m3fn)
+        return t.view(torch.uint8).numpy().reshape(input.shape)
+    return _interp_convert_float(input, input_dtype, output_dtype, rounding_mode)
+
+
+_interp._convert_float = _convert_float_rne
+
 ta.wrap_triton = lambda k: k
 ta.sdnq_attn_kernel = FixedConfig(ta.sdnq_attn_kernel.fn)
 
@@ -77,6 +95,17 @@ CASES = [
     dict(name="bf16_d128_gqa_causal", dtype="bf16", z=1, qh=4, kh=2, qn=44, kn=44, d=128, kw=dict(is_causal=True)),
     dict(name="bf16_d64_hadamard", dtype="bf16", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(use_hadamard=True)),
     dict(name="bf16_d64_boolmask", dtype="bf16", z=2, qh=2, kh=1, qn=40, kn=80, d=64, kw={}, mask=dict(kind="bool", shape=(2, 1, 40, 80), dead_rows=(5,))),
+    # round 6: fp8 (e4m3) Q.K^T and the quantized P.V variants (triton_atten.py:303-323, 443-487).  The P quantization is per (query, key
+    # BLOCK): the fixtures hold it for BLOCK_SIZE_N = 32 (meta "block_n"), the block the MI355X kernel works in
+    dict(name="f16_d64_fp8qk_tail", z=1, qh=2, kh=2, qn=40, kn=52, d=64, kw=dict(matmul_dtype="fp8")),
+    dict(name="f16_d128_fp8qk_gqa_causal", z=1, qh=4, kh=2, qn=44, kn=44, d=128, kw=dict(matmul_dtype="fp8", is_causal=True)),
+    dict(name="f16_d64_pvint8_tail", z=1, qh=2, kh=2, qn=40, kn=84, d=64, kw=dict(pv_matmul_dtype="int8")),
+    dict(name="f16_d128_pvint8_causal", z=1, qh=2, kh=1, qn=68, kn=68, d=128, kw=dict(pv_matmul_dtype="int8", is_causal=True)),
+    dict(name="f16_d64_fp8qk_pvfp8", z=1, qh=2, kh=2, qn=36, kn=100, d=64, kw=dict(matmul_dtype="fp8", pv_matmul_dtype="fp8")),
+    dict(name="f16_d64_pvfp8_boolmask", z=2, qh=2, kh=2, qn=40, kn=80, d=64, kw=dict(pv_matmul_dtype="fp8"), mask=dict(kind="bool", shape=(2, 1, 40, 80), dead_rows=(3,))),
+    dict(name="bf16_d64_fp8qk_pvint8", dtype="bf16", z=1, qh=2, kh=2, qn=40, kn=52, d=64, kw=dict(matmul_dtype="fp8", pv_matmul_dtype="int8")),
+    dict(name="f16_d64_pvint8_hadamard", z=1, qh=2, kh=2, qn=48, kn=72, d=64, kw=dict(pv_matmul_dtype="int8", use_hadamard=True)),
+    dict(name="f16_d64_pvf16_tail", z=1, qh=2, kh=1, qn=36, kn=52, d=64, kw=dict(pv_matmul_dtype="float16")),
 ]
 
 
@@ -88,6 +117,8 @@ def bits(t):
         return t.view(torch.uint16).numpy().copy(), "bf16"
     if t.dtype == torch.bool:
         return t.view(torch.uint8).numpy().copy(), "bool"
+    if t.dtype == torch.float8_e4m3fn:
+        return t.view(torch.uint8).numpy().copy(), "e4m3"
     return t.numpy().copy(), str(t.dtype).replace("torch.", "")
 
 
@@ -121,7 +152,8 @@ def run(case):
             r = list(real_quantize(q_.to(torch.bfloat16), k_.to(torch.bfloat16), v_.to(torch.bfloat16), smooth_k=smooth_k,
                                    hadamard=None if hadamard is None else hadamard.to(torch.bfloat16), **kw_))
             captured["r"] = tuple(r)
-            r[4] = r[4].float()  # V: the same values as float32, so that the interpreter can run the kernel
+            if r[5] is None:
+                r[4] = r[4].float()  # V: the same values as float32, so that the interpreter can run the kernel
             return tuple(r)
         ta.quantize_attn = on_bf16
         try:
@@ -136,15 +168,17 @@ def run(case):
         ok, hgroup = ta.get_hadamard_group_size(hch, min(case["kw"].get("hadamard_group_size", 256), hch))
         hadamard = ta.get_hadamard(hgroup, dtype=q.dtype, device=q.device) if ok else None
     q_q, q_s, k_q, k_s, v_q, v_s, used_h, used_g = ta.quantize_attn(q, k, v, smooth_k=case["kw"].get("smooth_k", True), hadamard=hadamard,
-                                                                    hadamard_group_size=hgroup or 256)
-    assert v_s is None and v_q.dtype == tdt
+                                                                    hadamard_group_size=hgroup or 256, matmul_dtype=case["kw"].get("matmul_dtype", "int8"),
+                                                                    pv_matmul_dtype=case["kw"].get("pv_matmul_dtype"))
+    assert (v_s is None and v_q.dtype == tdt) or case["kw"].get("pv_matmul_dtype")
     if bf16:  # what the kernel really consumed == what the reference's host code gives on the bfloat16 tensors
         c_ = captured["r"]
         assert torch.equal(c_[0], q_q) and torch.equal(c_[1], q_s) and torch.equal(c_[2], k_q) and torch.equal(c_[3], k_s) and torch.equal(c_[4], v_q)
     arrays, meta = {}, {"name": case["name"], "dtype": case.get("dtype", "f16"), "shape": dict(z=z, qh=qh, kh=kh, qn=qn, kn=kn, d=d), "kwargs": case["kw"],
                         "block_m": BLOCK_M, "block_n": BLOCK_N, "hadamard_group": int(used_g) if used_h else 0, "tensors": {},
                         **({"out_is": "float32: the reference kernel on the bfloat16 path's quantized operands with V as float32 (P and the output unrounded)"} if bf16 else {})}
-    for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s))             + ((("mask", mask),) if mask is not None else ()):
+    for key, t in (("q", q), ("k", k), ("v", v), ("out", out), ("q_q", q_q), ("q_scale", q_s), ("k_q", k_q), ("k_scale", k_s)) \
+            + ((("mask", mask),) if mask is not None else ()) + ((("v_q", v_q), ("v_scale", v_s)) if v_s is not None else ()):
         arrays[key], tag = bits(t)
         meta["tensors"][key] = {"dtype": tag, "shape": list(t.shape)}
     np.savez_compressed(os.path.join(HERE, f"attn_{case['name']}.npz"), **arrays)

@@ -12,12 +12,32 @@ def _quant_agreement(got_q, got_s, ref_q, ref_s, inexact, hadamard=False):
     code may move by one step where x/scale sits on a rounding boundary.  With a Hadamard rotation the rotated value itself is
     rounded to the tensor dtype after a differently ordered fp32 sum (FWHT vs matrix product): one dtype ulp on some elements,
     i.e. a few codes move by one step and a row scale can move by one ulp of the dtype (Hadamard tolerance)."""
+    if got_q.dtype == np.float16:
+        got_q = got_q.view(np.uint16)  # (fixtures hold 16-bit floats as their bit patterns)
     if not inexact and not hadamard:
         assert np.array_equal(got_q, ref_q) and np.array_equal(got_s, ref_s)
         return
     assert np.allclose(got_s, ref_s, rtol=2e-3 if hadamard else 1e-5, atol=0)
+    if got_q.dtype == np.uint8:  # e4m3 codes: sign + magnitude, monotonic in the low 7 bits -> a signed step count
+        step = lambda c: np.where(c & 0x80, -(c & 0x7f).astype(np.int32), (c & 0x7f).astype(np.int32))  # noqa: E731
+        got_q, ref_q = step(got_q), step(ref_q)
+    elif got_q.dtype in (np.float16, np.uint16):  # float16 operand values (pv_matmul_dtype="float16"): steps of the 11-bit mantissa
+        a, b = got_q.view(np.float16).astype(np.float32), ref_q.view(np.float16).astype(np.float32)
+        assert np.all(np.abs(a - b) <= 2.0 ** -10 * np.abs(b) + 1e-30) and np.mean(a != b) < (2e-2 if hadamard else 2e-3)
+        return
     diff = np.abs(got_q.astype(np.int32) - ref_q.astype(np.int32))
     assert diff.max() <= 1 and np.mean(diff != 0) < (2e-2 if hadamard else 2e-3)
+
+
+def _variant(kw):
+    """(matmul_dtype, pv_matmul_dtype) of a fixture + the tolerances its output is compared at.  The default configuration keeps the limits of
+    rounds 3-5.  fp8 Q.K^T: the scores are sums of exact products, equal up to float32 summation order -> the same limits.  A QUANTIZED P (8 bits per
+    (query, 32-key block); 3 mantissa bits for e4m3) turns every exp2 ulp that crosses a rounding boundary into one code step of one
+    probability: |step| / p_scale-range = 1/127 (int8) or 2^-4 (e4m3) of ONE of ~KN terms of a row -> the output limits are those of the
+    format, stated here: int8 4e-3 max / 1.5e-3 L2, e4m3 2e-2 / 6e-3, float16 as the unquantized path."""
+    mm, pv = kw.get("matmul_dtype", "int8"), kw.get("pv_matmul_dtype")
+    lim = {None: None, "int8": (4e-3, 1.5e-3), "fp8": (2e-2, 6e-3), "float16": None}[pv]
+    return mm, pv, lim
 
 
 @pytest.mark.parametrize("name", attn_case_names())
@@ -25,17 +45,22 @@ def test_oracle_attention_vs_reference_kernel(name):
     c = AttnCase(name)
     kw = c.kwargs
     hg = c.meta.get("hadamard_group", 0)
+    mm, pv, vlim = _variant(kw)
     out, inter = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
                              smooth_k=kw.get("smooth_k", True), block_n=c.meta["block_n"], want_intermediates=True, hadamard_group=hg,
-                             mask=c.mask_array())
+                             mask=c.mask_array(), matmul_dtype=mm, pv_matmul_dtype=pv)
     _quant_agreement(inter["q_q"], inter["q_scale"], c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
     _quant_agreement(inter["k_q"], inter["k_scale"], c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True), hadamard=bool(hg))
+    if pv is not None:  # V per token (rotated first under use_hadamard): elementwise, bit-exact without a rotation
+        _quant_agreement(inter["v_q"], inter["v_scale"], c.raw("v_q"), c.raw("v_scale"), False, hadamard=bool(hg))
     ref = c.f32("out")
     assert out.shape == ref.shape
     # same arithmetic as the kernel up to exp2 / reduction-order rounding, then one f16 rounding of the output.  bf16_* fixtures hold the
     # reference kernel's float32 output on the bfloat16 path's quantized operands (P and the output unrounded, make_golden_attention.py):
     # the bfloat16 restatement rounds both to 8 bits of mantissa
-    lim, lim2 = (1.2e-2, 4e-3) if c.tag == "bf16" else (2e-3, 5e-4)
+    lim, lim2 = (1.2e-2, 4e-3) if c.tag == "bf16" else (2e-3, 5e-4)  # (bf16 fixtures hold the float32 output: the restatement rounds it)
+    if vlim is not None:
+        lim, lim2 = max(lim, vlim[0]), max(lim2, vlim[1])
     err = np.abs(out - ref).max() / np.abs(ref).max()
     assert err <= lim, (name, err)
     assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= lim2, name
