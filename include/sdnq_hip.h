@@ -612,6 +612,26 @@ int sdnq_hip_attn_fwd_q16(const void* q, const int64_t* q_strides, const void* k
                           int64_t batch, int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim,
                           sdnq_stream_t stream);
 
+/* The other matmul formats of the reference's attention (round 6; quantize_attn triton_atten.py:443-487 with matmul_dtype / pv_matmul_dtype,
+ * sdnq_attn_kernel :273-284 and :303-323):
+ *   qk_dtype  SDNQ_MM_I8 | SDNQ_MM_FP8: Q.K^T on int8 codes or on e4m3 codes (quantize_fp_mm, quant_utils.py:290-299: scale = amax / 448);
+ *   pv_dtype  -1: P.V in the value dtype | SDNQ_MM_I8 | SDNQ_MM_FP8 | SDNQ_MM_F16: V quantized per token (vs [batch*kv_heads][kv_len
+ *             rounded up to 32], rotated first under hadamard_group: the CALLER rotates the output back, triton_atten.py:609-612), P scaled
+ *             by v_scale and quantized per (query, 32-key block): p_scale = max / qmax (1 where <= 2e-38), int8 floor(fma(p, 1 / p_scale, 0.5)),
+ *             fp8 / float16 round-to-nearest-even; acc = fma(dot(p_q, v_q), p_scale, acc).  The 32-key block is the reference's
+ *             BLOCK_SIZE_N (autotuned there; the fixtures are made with 32).
+ * sdnq_hip_attn_prepare_ex always quantizes Q too (qq / qs required); kq and the 8-bit vt are MFMA-fragment ordered like sdnq_hip_attn_prepare's
+ * (vt: [batch*kv_heads][blocks][head_dim/32][64 lanes][16 bytes], or the 16-bit layout for pv_dtype -1 / SDNQ_MM_F16); kmean: [batch*kv_heads][head_dim
+ * padded to 64 / 128] floats of workspace when smooth_k.  sdnq_hip_attn_fwd_ex: out_dtype any SdnqFloat; v_dtype matters for pv_dtype -1 only. */
+int sdnq_hip_attn_prepare_ex(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads, int64_t kv_heads,
+                             int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, int hadamard_group, const int64_t* q_strides,
+                             const int64_t* k_strides, const int64_t* v_strides, int qk_dtype, int pv_dtype, void* qq, float* qs, void* kq,
+                             float* ks, void* vt, float* vs, float* kmean, sdnq_stream_t stream);
+int sdnq_hip_attn_fwd_ex(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, const float* vs, int v_dtype,
+                         int qk_dtype, int pv_dtype, float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                         int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, const int64_t* out_strides, int64_t batch,
+                         int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, sdnq_stream_t stream);
+
 /* sdnq_hip_attn <- sdnq_triton_atten (triton_atten.py:540-618) as ONE call: quantize_attn + sdnq_atten_fwd with the arguments of the three
  * entry points above (q / k / v of `dtype` = bf16 / f16 with element strides or NULL, smooth_k, hadamard_group, sm_scale, is_causal, mask, out).
  * Route, chosen here:

@@ -27,7 +27,7 @@ EXPORTS = [
     "sdnq_hip_lowrank_down", "sdnq_hip_scaled_mm_lowrank", "sdnq_hip_linear_float", "sdnq_hip_linear_skinny",
     "sdnq_hip_quantize_weight", "sdnq_hip_im2col", "sdnq_hip_im2col_rowquant", "sdnq_hip_scaled_mm_nchw",
     "sdnq_hip_linear_skinny_svd", "sdnq_hip_linear_w8a8", "sdnq_hip_requant_asym",
-    "sdnq_hip_im2col_rowquant_z", "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_attn_fwd_q16", "sdnq_hip_attn", "sdnq_hip_attn_workspace_bytes", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
+    "sdnq_hip_im2col_rowquant_z", "sdnq_hip_attn_prepare", "sdnq_hip_attn_fwd", "sdnq_hip_attn_fwd_q16", "sdnq_hip_attn_prepare_ex", "sdnq_hip_attn_fwd_ex", "sdnq_hip_attn", "sdnq_hip_attn_workspace_bytes", "sdnq_hip_scaled_mm_multi", "sdnq_hip_linear_float_multi",
     "sdnq_hip_scaled_mm_grouped", "sdnq_hip_set_tile_override", "sdnq_hip_linear_w8a16", "sdnq_hip_linear_w8a16_grouped",
     "sdnq_hip_rowquant_lp", "sdnq_hip_rowquant_lp_asym", "sdnq_hip_scaled_mm_lp", "sdnq_hip_scaled_mm_lp_uzp", "sdnq_hip_unshard_columns", "sdnq_hip_requant_ws", "sdnq_hip_linear", "sdnq_hip_linear_workspace_bytes",
     "sdnq_hip_scaled_mm_strided", "sdnq_hip_linear_float_strided", "sdnq_hip_scaled_mm_lp_zp",
@@ -194,6 +194,8 @@ def _declare(lib):
     lib.sdnq_hip_im2col_rowquant_z.argtypes = [vp, i32] + [i32] * 12 + [i32, vp, vp, vp, vp]
     lib.sdnq_hip_attn_prepare.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.sdnq_hip_attn_fwd.argtypes = [vp, vp, vp, vp, vp, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp] + [i64] * 6 + [vp]
+    lib.sdnq_hip_attn_prepare_ex.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [i32, i32, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.sdnq_hip_attn_fwd_ex.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp] + [i64] * 6 + [vp]
     lib.sdnq_hip_attn_fwd_q16.argtypes = [vp, vp, vp, vp, vp, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp] + [i64] * 6 + [vp]
     lib.sdnq_hip_attn.argtypes = [vp, vp, vp, i32] + [i64] * 6 + [vp, vp, vp, i32, i32, c.c_float, i32, vp, i32, i64, i64, i64, vp, i32, vp, vp, i64, vp]
     lib.sdnq_hip_attn_workspace_bytes.argtypes = [i64] * 6 + [i32]

@@ -2,8 +2,10 @@
 
 Host-side mirror of the reference's ``sdnq_triton_atten`` (kernels/triton_atten.py:540-618): same argument names, same
 defaults.  Built: the default configuration -- int8 Q.K^T (``matmul_dtype="int8"``), P.V in the value dtype
-(``pv_matmul_dtype=None``), ``smooth_k``, optional ``use_hadamard``, ``is_causal`` and ``attn_mask`` (bool or additive), grouped-query heads.  Reference-valid options that are not
-built raise ``NotImplementedError`` naming the gap (quantized P.V, fp16 accumulation, the backward outputs).
+(``pv_matmul_dtype=None``), ``smooth_k``, optional ``use_hadamard``, ``is_causal`` and ``attn_mask`` (bool or additive), grouped-query heads -- on its
+tuned kernels, and (round 6) the other matmul formats -- fp8 (e4m3) Q.K^T, P.V on int8 / fp8 / float16 codes with P quantized per (query,
+32-key block) -- on a plain kernel of their own (``sdnq_hip_attn_prepare_ex`` / ``sdnq_hip_attn_fwd_ex``).  Reference-valid options that are not
+built raise ``NotImplementedError`` naming the gap (fp16 accumulation -- an RDNA work-around --, the backward outputs).
 """
 from __future__ import annotations
 
@@ -28,6 +30,86 @@ def _rows16(t: torch.Tensor) -> torch.Tensor:
 
 def _strides(t: torch.Tensor):
     return (ctypes.c_int64 * 3)(*t.stride()[:3])
+
+
+def _mm_name(matmul_dtype, pv: bool = False):
+    """The reference's spellings (triton_atten.py:452-455) -> "int8" | "fp8" | "float16" | None (pv only: P.V in the value dtype)."""
+    if pv and matmul_dtype in _DISABLED | {"auto"}:
+        return None
+    if matmul_dtype in ({"enabled", "uint8", "int8"} if pv else {"auto", "enabled", "uint8", "int8"}):
+        return "int8"
+    if matmul_dtype in {"fp8", "float8_e4m3fn"}:
+        return "fp8"
+    if pv and matmul_dtype == "float16":
+        return "float16"
+    raise NotImplementedError(f"quantized attention with {'pv_' if pv else ''}matmul_dtype={matmul_dtype!r} is not built "
+                              f"(int8 and fp8{', float16' if pv else ''} are)")
+
+
+_MM_CODE = {"int8": _lib.MM_I8, "fp8": _lib.MM_FP8, "float16": _lib.MM_F16, None: -1}
+
+
+def quantize_attn_ex(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True, hadamard_group: int = 0,
+                     matmul_dtype: str = "int8", pv_matmul_dtype: str | None = None):
+    """quantize_attn (triton_atten.py:443-487) for any built (matmul_dtype, pv_matmul_dtype): (q_q, q_scale, k_q, k_scale, v_op, v_scale | None).
+    q_q [Z,H,QN,D] and k_q (fragment order, see ``unpack_k_fragments``) are uint8 tensors holding int8 or e4m3 codes; v_op is the P.V operand:
+    the value-dtype / float16-code tiles of ``unpack_v_fragments`` or, for int8 / fp8, uint8 tiles [Z,KH,B,D/32,64,16] (``unpack_v8_fragments``)."""
+    mm, pv = _mm_name(matmul_dtype), _mm_name(pv_matmul_dtype, pv=True)
+    if not query.is_cuda:
+        raise _lib.SdnqHipError("sdnq_amd attention needs CUDA/HIP tensors (no CPU fallback)")
+    z, qh, qn, d = query.shape
+    _, kh, kn, _ = key.shape
+    query, key, value = _rows16(query), _rows16(key), _rows16(value)
+    dev = query.device
+    knp = (kn + 31) // 32 * 32
+    d_src, d = d, (64 if d <= 64 else 128)
+    v_shape = ((z, kh, knp // 32, d // 32, 64, 16), torch.uint8) if pv in ("int8", "fp8") else \
+        ((z, kh, knp // 32, d // 32, 2, 64, 8), torch.float16 if pv == "float16" else value.dtype)
+    shapes = (((z, qh, qn, d), torch.uint8), ((z, qh, qn), torch.float32), ((z, kh, knp // 32, d // 32, 64, 16), torch.uint8),
+              ((z, kh, knp), torch.float32), v_shape, ((z, kh, knp), torch.float32), ((z, kh, d), torch.float32))
+    sizes = [-(-(math.prod(shp) * dt.itemsize) // 256) * 256 for shp, dt in shapes]
+    pool = torch.empty((sum(sizes),), device=dev, dtype=torch.uint8)
+    parts, off = [], 0
+    for (shp, dt), nbytes in zip(shapes, sizes):
+        parts.append(pool[off:off + math.prod(shp) * dt.itemsize].view(dt).view(shp))
+        off += nbytes
+    qq, qs, kq, ks, vt, vs, kmean = parts
+    ops.check(_lib.load().sdnq_hip_attn_prepare_ex(query.data_ptr(), key.data_ptr(), value.data_ptr(), ops.float_code(query.dtype), z, qh, kh, qn, kn,
+                                                   d_src, 1 if smooth_k else 0, hadamard_group, _strides(query), _strides(key), _strides(value),
+                                                   _MM_CODE[mm], _MM_CODE[pv], qq.data_ptr(), qs.data_ptr(), kq.data_ptr(), ks.data_ptr(),
+                                                   vt.data_ptr(), vs.data_ptr(), kmean.data_ptr(), ops._stream(query)), "attn_prepare_ex")
+    return qq, qs, kq, ks, vt, (vs if pv is not None else None)
+
+
+def unpack_v8_fragments(vf: torch.Tensor) -> torch.Tensor:
+    """8-bit V operand tiles [Z,KH,B,D/32,64,16] -> codes [Z,KH,B*32,D] (lane = g*32 + ql holds, as byte j, key 16 (j >> 3) + 8 g + (j & 7) of
+    channel 32dd + ql)."""
+    z, kh, nb, kk = vf.shape[:4]
+    t = vf.view(z, kh, nb, kk, 2, 32, 2, 8)  # [.., dd, g, ql, c, j8]
+    return t.permute(0, 1, 2, 6, 4, 7, 3, 5).reshape(z, kh, nb * 32, kk * 32)  # key = 16c + 8g + j8, channel = 32dd + ql
+
+
+def atten_fwd_ex(qq, qs, kq, ks, vt, vs, kn: int, sm_scale: float, is_causal: bool, out_dtype: torch.dtype, v_dtype: torch.dtype,
+                 matmul_dtype: str = "int8", pv_matmul_dtype: str | None = None, attn_mask: torch.Tensor | None = None,
+                 token_major: bool = False, head_dim: int | None = None) -> torch.Tensor:
+    """sdnq_atten_fwd (triton_atten.py:338-385) on the operands of ``quantize_attn_ex``."""
+    mm, pv = _mm_name(matmul_dtype), _mm_name(pv_matmul_dtype, pv=True)
+    z, qh, qn, d = qq.shape
+    kh = kq.shape[1]
+    d = head_dim or d
+    if token_major:
+        out = torch.empty((z, qn, qh, d), device=qq.device, dtype=out_dtype).transpose(1, 2)
+    else:
+        out = torch.empty((z, qh, qn, d), device=qq.device, dtype=out_dtype)
+    mptr, mdt, ms = None, 0, (0, 0, 0)
+    if attn_mask is not None:
+        mptr = attn_mask.data_ptr()
+        mdt = -1 if attn_mask.dtype == torch.int8 else ops.float_code(attn_mask.dtype)
+        ms = tuple(attn_mask.stride(i) if attn_mask.shape[i] != 1 else 0 for i in range(3))
+    ops.check(_lib.load().sdnq_hip_attn_fwd_ex(qq.data_ptr(), qs.data_ptr(), kq.data_ptr(), ks.data_ptr(), vt.data_ptr(), None if vs is None else vs.data_ptr(),
+                                               ops.float_code(v_dtype), _MM_CODE[mm], _MM_CODE[pv], float(sm_scale), 1 if is_causal else 0, mptr, mdt, *ms,
+                                               out.data_ptr(), ops.float_code(out_dtype), _strides(out), z, qh, kh, qn, kn, d, ops._stream(qq)), "attn_fwd_ex")
+    return out
 
 
 def quantize_attn(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, smooth_k: bool = True, hadamard_group: int = 0,
@@ -142,12 +224,9 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
         raise NotImplementedError("the backward outputs (lse) of the quantized attention are not built for MI355X")
     if use_fp16_accum:
         raise NotImplementedError("use_fp16_accum is an RDNA work-around; the MI355X kernels accumulate in fp32")
-    if matmul_dtype in {"auto", "enabled", "uint8"}:  # triton_atten.py:452-453
-        matmul_dtype = "int8"
-    if not do_quantize or matmul_dtype in _DISABLED or matmul_dtype != "int8":
-        raise NotImplementedError(f"quantized attention with matmul_dtype={matmul_dtype!r} is not built (int8 Q.K^T is)")
-    if pv_matmul_dtype not in _DISABLED | {"auto"}:
-        raise NotImplementedError("quantized P.V (pv_matmul_dtype) is not built for MI355X; P.V runs in the value dtype")
+    if not do_quantize or matmul_dtype in _DISABLED:
+        raise NotImplementedError("the unquantized attention (do_quantize=False / matmul_dtype disabled) is torch's SDPA, not an SDNQ kernel")
+    mm, pv = _mm_name(matmul_dtype), _mm_name(pv_matmul_dtype, pv=True)  # triton_atten.py:452-455; unknown formats raise
     if query.ndim != 4 or key.ndim != 4 or value.ndim != 4:
         raise ValueError("query / key / value must be [batch, heads, tokens, head_dim]")
     d = query.shape[-1]
@@ -171,6 +250,15 @@ def sdnq_hip_atten(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, 
     # like torch's SDPA, the output takes the memory layout of the query: a [Z,N,H,D]-backed query (the transposed view a
     # diffusers / transformers attention processor passes) gets a [Z,N,H,D]-backed output
     token_major = query.shape[1] > 1 and query.shape[2] > 1 and query.stride(2) > query.stride(1) and query.stride(-1) == 1
+    if mm != "int8" or pv is not None:  # fp8 Q.K^T / quantized P.V (round 6): prepare + forward on the kernels of their own
+        if pv is not None and group and d not in (64, 128):
+            raise NotImplementedError("quantized P.V under a Hadamard rotation is built for head dims 64 and 128 (the output is rotated back over the padded head dim)")
+        qq, qs, kq, ks, vt, vs = quantize_attn_ex(query, key, value, smooth_k=smooth_k, hadamard_group=group, matmul_dtype=mm, pv_matmul_dtype=pv)
+        out = atten_fwd_ex(qq, qs, kq, ks, vt, vs, key.shape[2], sm_scale, is_causal, out_dtype, query.dtype, mm, pv, attn_mask,
+                           token_major=token_major and not (pv is not None and group), head_dim=d)
+        if pv is not None and group:  # V was rotated: the output comes back out of the rotated basis (triton_atten.py:609-612)
+            out = ops.hadamard(out, group)
+        return out
     if not _Q16:  # SDNQ_HIP_ATTN_Q16=0 (A/B aid): the three-step sequence with the separate pass over Q
         qq, qs, kq, ks, vt = quantize_attn(query, key, value, smooth_k=smooth_k, hadamard_group=group)
         return atten_fwd(qq, qs, kq, ks, vt, key.shape[2], sm_scale, is_causal, out_dtype, attn_mask, token_major=token_major, head_dim=d)

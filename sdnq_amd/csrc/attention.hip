@@ -23,6 +23,7 @@
 #include "../../include/sdnq_hip.h"
 #include "sdnq_dev.h"
 #include "hadamard_dev.h"
+#include "quant8_dev.h"
 
 namespace {
 
@@ -1111,4 +1112,511 @@ extern "C" int sdnq_hip_attn(const void* q, const void* k, const void* v, int dt
     return attn_fwd_impl(with_q ? ws + w.qq : nullptr, with_q ? (const float*)(ws + w.qs) : nullptr, with_q ? nullptr : q, q_strides, nullptr, ws + w.kq,
                          (const float*)(ws + w.ks), ws + w.vt, dtype, sm_scale, is_causal, mask, mask_dtype, mask_stride_b, mask_stride_h, mask_stride_q, out,
                          out_dtype, out_strides, batch, q_heads, kv_heads, q_len, kv_len, head_dim, stream);
+}
+
+// =====================================================================================================================================
+// Round 6: the other matmul formats of the reference's attention (triton_atten.py:443-487 quantize_attn, :273-284 Q.K^T, :303-323 P.V):
+//   Q.K^T on fp8 (e4m3) codes, per-token scale amax / 448 (quantize_fp_mm, quant_utils.py:290-299);
+//   P.V with V quantized per token (int8 / fp8 / float16 codes) and P quantized per (query, 32-key block):
+//       p *= v_scale;  p_scale = max_k(p) / qmax  (1 where <= 2e-38);  int8: floor(fma(p, 1 / p_scale, 0.5)),  fp8 / f16: (p * (1 / p_scale)).to(fmt)
+//       acc = fma(dot(p_q, v_q), p_scale, acc)
+//   The key block of the P quantization is the reference's autotuned BLOCK_SIZE_N; this kernel works in blocks of 32 keys (= the fixtures').
+// A separate, plain kernel (one wave = 32 queries, fragments straight from memory, every block on the reference's exact -inf-safe update,
+// causal / mask / output dtype as run-time switches): the default configuration above keeps its tuned kernel untouched.  Same fragment
+// layouts: K codes as attn_kfrag_offset places them (int8 and e4m3 bytes alike -- the fp8 MFMA pairs the same byte of both operands, so
+// any byte order common to K and Q is a valid K order of the dot product); 8-bit V codes in 1-KiB tiles per (32-key block, 32-channel
+// block): lane (g, ql) holds the 16 bytes j = 0..15 <-> key 16 (j >> 3) + 8 g + (j & 7) of channel 32 dd + ql -- the order this lane's 16
+// probabilities come out of the score MFMA in.
+namespace {
+
+enum { PVQ_NONE = 0, PVQ_I8 = 1, PVQ_FP8 = 2, PVQ_F16 = 3 };
+
+struct VarPrepParams {
+    const void *q, *k, *v;
+    uint8_t *qq, *kq;
+    float *qs, *ks, *vs;
+    void* vt;
+    const float* kmean;  // [kheads][d] channel means (smooth_k) or nullptr
+    Strides qst, kst, vst;
+    int64_t qheads, kheads, qn, kn, knp, nqb, nkb, nvb;
+    int d, d_src, log2g, qk_fp8, pvq;
+};
+
+template <int T_ID>
+__global__ __launch_bounds__(256) void attn_var_kmean_kernel(const void* k, const Strides kst, float* kmean, int64_t kn, int d, int d_src) {
+    __shared__ float xw[512];
+    __shared__ float smean[128];
+    attn_head_means<T_ID>(k, kst, blockIdx.x, kn, d, d_src, xw, smean);
+    if ((int)threadIdx.x < d) kmean[(int64_t)blockIdx.x * d + threadIdx.x] = smean[threadIdx.x];
+}
+
+// one token row spread over lpr lanes (8 channels each) -> codes of this lane's 8 channels + the row's scale.  FMT 0: int8 (attn_quant8),
+// 1: e4m3 (quant8<fp8>: x / scale, nan_to_num, clamp, round to nearest even), 2: float16 (same with +-65504)
+template <int FMT>
+__device__ __forceinline__ float attn_quant_row(const float (&v)[8], int lpr, u32 (&o)[4]) {
+    if constexpr (FMT == 0) {
+        u32 o2[2];
+        const float s = attn_quant8(v, lpr, o2);
+        o[0] = o2[0]; o[1] = o2[1]; o[2] = o[3] = 0;
+        return s;
+    } else {
+        float amax = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+        amax = fmaxf(amax, lane_xor(amax, 1));
+        amax = fmaxf(amax, lane_xor(amax, 2));
+        amax = fmaxf(amax, lane_xor(amax, 4));
+        if (lpr == 16) amax = fmaxf(amax, lane_xor(amax, 8));
+        const float scale = amax / (FMT == 1 ? 448.0f : 65504.0f);
+        if constexpr (FMT == 1) {
+            RowDiv rd;
+            rd.set(scale);
+            int isum = 0;
+            const uint2 w = quant8<SDNQ_MM_FP8>(v, rd, isum);
+            o[0] = w.x; o[1] = w.y; o[2] = o[3] = 0;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float qv = v[e] / scale;
+                if (qv != qv) qv = 0.0f;                                   // nan_to_num_
+                qv = fminf(fmaxf(qv, -65504.0f), 65504.0f);               // clamp_ (+-inf fall to it)
+                const u32 h = f32_to_f16_bits(qv);
+                if (e & 1) o[e >> 1] |= h << 16; else o[e >> 1] = h;
+            }
+        }
+        return scale;
+    }
+}
+
+template <int T_ID>
+__global__ __launch_bounds__(256) void attn_var_prepare_kernel(const VarPrepParams p) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[32][128 + 2];
+    const int64_t b = blockIdx.x;
+    const int d = p.d, lpr = d / 8, lsh = d == 64 ? 3 : 4;
+    if (p.pvq == PVQ_NONE && b >= p.nqb + p.nkb) {  // V in the value dtype: the operand layout of the default configuration
+        int64_t vhead, vblk;
+        divmod(b - p.nqb - p.nkb, p.knp >> 5, vhead, vblk);
+        attn_vt_block((const uint16_t*)p.v, p.vst, (uint16_t*)p.vt, p.kn, p.knp, d, vhead, vblk, tile, p.d_src);
+        return;
+    }
+    // ---- token rows: section 0 = Q, 1 = K (minus the channel means, MFMA-fragment order), 2 = V (quantized P.V)
+    int sec = 0;
+    int64_t blk = b;
+    if (b >= p.nqb + p.nkb) { sec = 2; blk = b - p.nqb - p.nkb; }
+    else if (b >= p.nqb) { sec = 1; blk = b - p.nqb; }
+    const void* x = sec == 0 ? p.q : (sec == 1 ? p.k : p.v);
+    const Strides xst = sec == 0 ? p.qst : (sec == 1 ? p.kst : p.vst);
+    const int64_t heads = sec == 0 ? p.qheads : p.kheads, n_src = sec == 0 ? p.qn : p.kn, n_dst = sec == 0 ? p.qn : p.knp;
+    const int64_t t = blk * 256 + threadIdx.x;
+    const int64_t row = t >> lsh;
+    const int c8 = (int)(t & (lpr - 1)) * 8;
+    const bool live = row < heads * n_dst;
+    int64_t head = 0, n = 0;
+    if (live) divmod(row, n_dst, head, n);
+    const bool real = live && n < n_src;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (real && c8 < p.d_src) Vec16<T_ID>::unpack(*(const uint4*)((const uint16_t*)x + xst.at(head, n) + c8), v);
+    const bool smooth = sec == 1 && p.kmean != nullptr;
+    if (smooth && real && c8 < p.d_src) {
+        const float* mean = p.kmean + head * d + c8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] -= mean[e];  // k.to(float32).sub_(mean), triton_atten.py:459-463
+    }
+    if (p.log2g != 0) {  // apply_hadamard(q) / rotate_hadamard(k.to(hadamard.dtype)) / rotate_hadamard(v.to(hadamard.dtype)), :464-467, :479-480
+        if (smooth) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+        }
+        wave_hadamard(v, p.log2g, hadamard_scale(p.log2g, T_ID));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = FT<T_ID>::round(v[e]);
+    }
+    const int fmt = sec == 2 ? (p.pvq == PVQ_I8 ? 0 : (p.pvq == PVQ_FP8 ? 1 : 2)) : (p.qk_fp8 ? 1 : 0);  // workgroup-uniform
+    u32 o[4];
+    float scale;
+    if (fmt == 0) scale = attn_quant_row<0>(v, lpr, o);
+    else if (fmt == 1) scale = attn_quant_row<1>(v, lpr, o);
+    else scale = attn_quant_row<2>(v, lpr, o);
+    if (!live) return;
+    if (sec == 0) {
+        *(uint2*)(p.qq + row * d + c8) = make_uint2(o[0], o[1]);
+        if (c8 == 0) p.qs[row] = scale;
+    } else if (sec == 1) {
+        *(uint2*)(p.kq + head * n_dst * d + attn_kfrag_offset(n, c8, d)) = make_uint2(o[0], o[1]);
+        if (c8 == 0) p.ks[row] = scale;
+    } else {
+        const int nl = (int)(n & 31), vg = (nl >> 3) & 1;
+        const int64_t kb = n >> 5;
+        if (p.pvq == PVQ_F16) {  // 16-bit operand tiles: (kb, dd, c = nl >> 4), lane (g, ql), element nl & 7
+            uint16_t* base = (uint16_t*)p.vt + (head * (n_dst >> 5) + kb) * (int64_t)(d / 32 * 2 * 512) + (nl >> 4) * 512 + (vg * 32) * 8 + (nl & 7);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = c8 + e;
+                base[(ch >> 5) * 1024 + (ch & 31) * 8] = (uint16_t)(o[e >> 1] >> (16 * (e & 1)));
+            }
+        } else {  // 8-bit operand tiles: (kb, dd), lane (g, ql), byte j = 8 (nl >> 4) + (nl & 7)
+            uint8_t* base = (uint8_t*)p.vt + (head * (n_dst >> 5) + kb) * (int64_t)(d / 32 * 1024) + (vg * 32) * 16 + ((nl >> 4) << 3) + (nl & 7);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = c8 + e;
+                base[(ch >> 5) * 1024 + (ch & 31) * 16] = (uint8_t)(o[e >> 2] >> (8 * (e & 3)));
+            }
+        }
+        if (c8 == 0) p.vs[row] = scale;
+    }
+}
+
+struct VarParams {
+    const uint8_t* qq; const float* qs; const uint8_t* kq; const float* ks; const void* vt; const float* vs;
+    void* out;
+    int64_t qh, kh, qn, kn, knp;
+    int qblocks, causal, out_dtype;
+    float log2_sm_scale;
+    Strides ost;
+    int d_out;
+    const void* mask;
+    int mask_dtype;
+    int64_t ms_z, ms_h, ms_q;
+};
+
+template <int QK_FP8, int PVQ, int V_T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
+    constexpr int KK = D / 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ql = lane & 31, g = lane >> 5;
+    const int64_t head_lin = blockIdx.x / p.qblocks;  // z * QH + h
+    const int qblk = blockIdx.x % p.qblocks;
+    const int64_t q0 = ((int64_t)qblk * 4 + wave) * 32;
+    if (q0 >= p.qn) return;
+    int64_t z, h;
+    divmod(head_lin, p.qh, z, h);
+    int64_t kvh, kvr;
+    divmod(h * p.kh, p.qh, kvh, kvr);
+    const int64_t kv_lin = z * p.kh + kvh;  // offset_k of triton_atten.py:212
+    const int64_t qi = q0 + ql, qrow = qi < p.qn ? qi : p.qn - 1;
+    v4i qf[KK];
+    {
+        const uint8_t* qp = p.qq + (head_lin * p.qn + qrow) * D + 16 * g;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[kk] = *(const v4i*)(qp + 32 * kk);
+    }
+    const float qsl = p.qs[head_lin * p.qn + qrow] * p.log2_sm_scale;
+    v16f o[KK];
+#pragma unroll
+    for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dd][r] = 0.0f;
+    float m_i = -__builtin_inff();
+    v2f l2 = {0.0f, 0.0f};
+    const uint8_t* kbase = p.kq + kv_lin * p.knp * D + lane * 16;
+    const float* ksb = p.ks + kv_lin * p.knp + 8 * g;
+    const float* vsb = PVQ != PVQ_NONE ? p.vs + kv_lin * p.knp + 8 * g : nullptr;
+    constexpr int VTILE = (PVQ == PVQ_I8 || PVQ == PVQ_FP8) ? 1024 : 2048;  // bytes of V operand per (key block, 32-channel block)
+    const uint8_t* vbase = (const uint8_t*)p.vt + kv_lin * (p.knp / 32) * (int64_t)(KK * VTILE) + lane * 16;
+    const char* mrow = nullptr;
+    if (p.mask != nullptr)
+        mrow = (const char*)p.mask + (z * p.ms_z + h * p.ms_h + qrow * p.ms_q) * (p.mask_dtype == -1 ? 1 : (p.mask_dtype == SDNQ_F32 ? 4 : 2));
+    int nkb = (int)((p.kn + 31) / 32);
+    if (p.causal) {
+        const int lim = (int)(q0 / 32) + 1;  // blocks past the last query of this wave are fully masked (triton_atten.py:255)
+        nkb = nkb < lim ? nkb : lim;
+    }
+#pragma nounroll
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int64_t key0 = (int64_t)kb * 32;
+        v4i kf[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + ((int64_t)kb * KK + kk) * 1024);
+        v4f ks4[4], vs4[4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            ks4[2 * c] = *(const v4f*)(ksb + key0 + 16 * c);
+            ks4[2 * c + 1] = *(const v4f*)(ksb + key0 + 16 * c + 4);
+            if constexpr (PVQ != PVQ_NONE) {
+                vs4[2 * c] = *(const v4f*)(vsb + key0 + 16 * c);
+                vs4[2 * c + 1] = *(const v4f*)(vsb + key0 + 16 * c + 4);
+            }
+        }
+        // ---- scores: lane holds keys key0 + 16 (r >> 3) + 8 g + (r & 7), r = 0..15, of query q0 + ql
+        float sf[16];
+        if constexpr (!QK_FP8) {
+            v16i s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) s = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kk], qf[kk], s, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sf[r] = (float)s[r];
+        } else {
+            v16f s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const long ka = ((long)(u32)kf[kk][1] << 32) | (u32)kf[kk][0], kb2 = ((long)(u32)kf[kk][3] << 32) | (u32)kf[kk][2];
+                const long qa = ((long)(u32)qf[kk][1] << 32) | (u32)qf[kk][0], qb = ((long)(u32)qf[kk][3] << 32) | (u32)qf[kk][2];
+                s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(ka, qa, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kb2, qb, s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sf[r] = s[r];
+        }
+        float t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float kscale = ks4[r >> 2][r & 3];
+            float tv = sf[r] * kscale * qsl;   // (acc * k_scale) * (q_scale * log2_sm_scale): the factor order of the default kernel
+            const int64_t key = key0 + 16 * (r >> 3) + 8 * g + (r & 7);
+            bool ok = key < p.kn;                      // triton_atten.py:295-296
+            if (p.causal) ok = ok && key <= qi;        // :287-288
+            float add = 0.0f;
+            if (mrow != nullptr && ok) {
+                if (p.mask_dtype == -1) ok = ((const int8_t*)mrow)[key] != 0;   // :290-291
+                else add = ldf_mask(mrow, key, p.mask_dtype);                   // :292-293
+            }
+            t[r] = ok ? tv + add : -__builtin_inff();
+        }
+        float m_blk = t[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m_blk = fmaxf(m_blk, t[r]);
+        {
+            const u32 mb = __float_as_uint(m_blk);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            m_blk = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float m_new = fmaxf(m_i, m_blk);
+        const bool dead = m_new == -__builtin_inff();   // no visible key so far: alpha = 1, p = 0 (:299-301)
+        const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(m_i - m_new);
+        m_i = m_new;
+        const float m_use = dead ? 0.0f : m_new;
+        v2f psum = {0.0f, 0.0f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[r] = __builtin_amdgcn_exp2f(t[r] - m_use);
+            psum[r & 1] += t[r];
+        }
+        l2 = l2 * alpha + psum;  // l_i = fma(l_i, alpha, sum(p)), :308
+#pragma unroll
+        for (int dd = 0; dd < KK; ++dd) o[dd] *= alpha;
+        // ---- P.V
+        if constexpr (PVQ == PVQ_NONE) {
+            v4i pf[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) pf[c][w] = (int)pack2<V_T>(t[8 * c + 2 * w], t[8 * c + 2 * w + 1]);   // p.to(v.dtype), :332
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int dd = 0; dd < KK; ++dd) {
+                    const v4i vf = *(const v4i*)(vbase + (((int64_t)kb * KK + dd) * 2 + c) * 1024);
+                    if constexpr (V_T == SDNQ_BF16)
+                        o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pf[c]), o[dd], 0, 0, 0);
+                    else
+                        o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vf), __builtin_bit_cast(v8h, pf[c]), o[dd], 0, 0, 0);
+                }
+        } else {
+            // p *= v_scale; p_scale = max(p, 1) / qmax, 1 where tiny (:311-319)
+            float pmax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                t[r] *= vs4[r >> 2][r & 3];
+                pmax = fmaxf(pmax, t[r]);
+            }
+            {
+                const u32 mb = __float_as_uint(pmax);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+                pmax = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            float ps = pmax * (PVQ == PVQ_I8 ? (float)(1.0 / 127.0) : (PVQ == PVQ_FP8 ? (float)(1.0 / 448.0) : (float)(1.0 / 65504.0)));
+            if (ps <= 2e-38f) ps = 1.0f;
+            const float inv = 1.0f / ps;  // tl.fdiv(1.0, p_scale)
+            if constexpr (PVQ == PVQ_I8) {
+                v4i pq;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    u32 word = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float qv = __builtin_floorf(__builtin_fmaf(t[4 * w + e], inv, 0.5f));  // <= 127
+                        word |= ((u32)(int)qv & 0xffu) << (8 * e);
+                    }
+                    pq[w] = (int)word;
+                }
+#pragma unroll
+                for (int dd = 0; dd < KK; ++dd) {
+                    const v4i vf = *(const v4i*)(vbase + ((int64_t)kb * KK + dd) * 1024);
+                    v16i acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0;
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf, pq, acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dd][r] = __builtin_fmaf((float)acc[r], ps, o[dd][r]);  // :315
+                }
+            } else if constexpr (PVQ == PVQ_FP8) {
+                float c[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = fminf(t[r] * inv, 448.0f);  // (max * (1 / (max / 448)) can land an ulp above 448)
+                const u32 w0 = pack4_e4m3fn_clamped(c[0], c[1], c[2], c[3]), w1 = pack4_e4m3fn_clamped(c[4], c[5], c[6], c[7]);
+                const u32 w2 = pack4_e4m3fn_clamped(c[8], c[9], c[10], c[11]), w3 = pack4_e4m3fn_clamped(c[12], c[13], c[14], c[15]);
+                const long pa = ((long)w1 << 32) | w0, pb = ((long)w3 << 32) | w2;
+#pragma unroll
+                for (int dd = 0; dd < KK; ++dd) {
+                    const v4i vf = *(const v4i*)(vbase + ((int64_t)kb * KK + dd) * 1024);
+                    const long va = ((long)(u32)vf[1] << 32) | (u32)vf[0], vb = ((long)(u32)vf[3] << 32) | (u32)vf[2];
+                    v16f acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(va, pa, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vb, pb, acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dd][r] = __builtin_fmaf(acc[r], ps, o[dd][r]);  // :323
+                }
+            } else {
+                v4i pf[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        pf[c][w] = (int)((u32)f32_to_f16_bits(t[8 * c + 2 * w] * inv) | ((u32)f32_to_f16_bits(t[8 * c + 2 * w + 1] * inv) << 16));
+#pragma unroll
+                for (int dd = 0; dd < KK; ++dd) {
+                    v16f acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const v4i vf = *(const v4i*)(vbase + (((int64_t)kb * KK + dd) * 2 + c) * 1024);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vf), __builtin_bit_cast(v8h, pf[c]), acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dd][r] = __builtin_fmaf(acc[r], ps, o[dd][r]);
+                }
+            }
+        }
+    }
+    if (qi >= p.qn) return;
+    float l_i = l2[0] + l2[1];
+    l_i += __shfl_xor(l_i, 32);
+    const float inv = l_i > 0.0f ? 1.0f / l_i : 0.0f;  // acc *= fdiv(1.0, l_i), :336; a row with no visible key is 0
+    const int ob = p.out_dtype == SDNQ_F32 ? 4 : 2;
+    char* orow = (char*)p.out + p.ost.at(head_lin, qi) * ob;
+#pragma unroll
+    for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int dcol = 32 * dd + 8 * t4 + 4 * g;  // registers 4t..4t+3 are 4 consecutive channels
+            if (dcol >= p.d_out) continue;
+            float f[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f[u] = o[dd][4 * t4 + u] * inv;
+            if (p.out_dtype == SDNQ_F32) {
+                *(float4*)(orow + dcol * 4) = make_float4(f[0], f[1], f[2], f[3]);
+            } else if (p.out_dtype == SDNQ_BF16) {
+                *(uint2*)(orow + dcol * 2) = make_uint2(pack2<SDNQ_BF16>(f[0], f[1]), pack2<SDNQ_BF16>(f[2], f[3]));
+            } else {
+                *(uint2*)(orow + dcol * 2) = make_uint2(pack2<SDNQ_F16>(f[0], f[1]), pack2<SDNQ_F16>(f[2], f[3]));
+            }
+        }
+}
+
+template <int QK_FP8, int PVQ, int V_T>
+int launch_var(const VarParams& p, int d, int64_t blocks, hipStream_t s) {
+    const dim3 grid((unsigned)blocks), block(256);
+    if (d == 64) hipLaunchKernelGGL((attn_fwd_var_kernel<QK_FP8, PVQ, V_T, 64>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((attn_fwd_var_kernel<QK_FP8, PVQ, V_T, 128>), grid, block, 0, s, p);
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+int pvq_of(int pv_dtype) { return pv_dtype < 0 ? PVQ_NONE : (pv_dtype == SDNQ_MM_I8 ? PVQ_I8 : (pv_dtype == SDNQ_MM_FP8 ? PVQ_FP8 : (pv_dtype == SDNQ_MM_F16 ? PVQ_F16 : -1))); }
+
+}  // namespace
+
+extern "C" int sdnq_hip_attn_prepare_ex(const void* q, const void* k, const void* v, int dtype, int64_t batch, int64_t q_heads, int64_t kv_heads,
+                                        int64_t q_len, int64_t kv_len, int64_t head_dim, int smooth_k, int hadamard_group, const int64_t* q_strides,
+                                        const int64_t* k_strides, const int64_t* v_strides, int qk_dtype, int pv_dtype, void* qq, float* qs, void* kq,
+                                        float* ks, void* vt, float* vs, float* kmean, sdnq_stream_t stream) {
+    const int pvq = pvq_of(pv_dtype);
+    if (!q || !k || !v || !qq || !qs || !kq || !ks || !vt || (smooth_k && !kmean) || (pvq != PVQ_NONE && !vs)) return SDNQ_ERR_NULL;
+    if ((qk_dtype != SDNQ_MM_I8 && qk_dtype != SDNQ_MM_FP8) || pvq < 0) return SDNQ_ERR_DTYPE;
+    if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
+    if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
+    if (dtype != SDNQ_BF16 && dtype != SDNQ_F16) return SDNQ_ERR_UNSUPPORTED;
+    const int64_t head_dim_src = head_dim;
+    head_dim = head_dim <= 64 ? 64 : 128;
+    int log2g = 0;
+    if (hadamard_group != 0) {
+        if (hadamard_group < 4 || hadamard_group > head_dim || (hadamard_group & (hadamard_group - 1)) || head_dim % hadamard_group) return SDNQ_ERR_SHAPE;
+        while ((1 << log2g) < hadamard_group) ++log2g;
+    }
+    if (((uintptr_t)q | (uintptr_t)qq | (uintptr_t)k | (uintptr_t)v | (uintptr_t)kq | (uintptr_t)vt) % 16) return SDNQ_ERR_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int d = (int)head_dim, lpr = d / 8;
+    VarPrepParams p{};
+    p.q = q; p.k = k; p.v = v; p.qq = (uint8_t*)qq; p.kq = (uint8_t*)kq; p.qs = qs; p.ks = ks; p.vs = vs; p.vt = vt;
+    auto strides_of = [&](const int64_t* st, int64_t heads, int64_t len, Strides& out) {
+        out.heads = heads;
+        if (st) { out.b = st[0]; out.h = st[1]; out.n = st[2]; } else { out.b = heads * len * head_dim_src; out.h = len * head_dim_src; out.n = head_dim_src; }
+        return out.b % 8 == 0 && out.h % 8 == 0 && out.n % 8 == 0;  // 16-byte rows
+    };
+    if (!strides_of(q_strides, q_heads, q_len, p.qst) || !strides_of(k_strides, kv_heads, kv_len, p.kst) || !strides_of(v_strides, kv_heads, kv_len, p.vst))
+        return SDNQ_ERR_ALIGN;
+    p.qheads = batch * q_heads; p.kheads = batch * kv_heads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32;
+    p.d = d; p.d_src = (int)head_dim_src; p.log2g = log2g; p.qk_fp8 = qk_dtype == SDNQ_MM_FP8; p.pvq = pvq;
+    p.kmean = smooth_k ? kmean : nullptr;
+    p.nqb = (p.qheads * q_len * lpr + 255) / 256;
+    p.nkb = p.kheads * p.knp * lpr / 256;  // exact: knp * lpr is a multiple of 256
+    p.nvb = pvq == PVQ_NONE ? p.kheads * (p.knp / 32) : p.nkb;
+    if (smooth_k) {
+        if (dtype == SDNQ_BF16) hipLaunchKernelGGL((attn_var_kmean_kernel<SDNQ_BF16>), dim3((unsigned)p.kheads), dim3(256), 0, s, k, p.kst, kmean, kv_len, d, (int)head_dim_src);
+        else hipLaunchKernelGGL((attn_var_kmean_kernel<SDNQ_F16>), dim3((unsigned)p.kheads), dim3(256), 0, s, k, p.kst, kmean, kv_len, d, (int)head_dim_src);
+    }
+    const int64_t blocks = p.nqb + p.nkb + p.nvb;
+    if (dtype == SDNQ_BF16) hipLaunchKernelGGL((attn_var_prepare_kernel<SDNQ_BF16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_var_prepare_kernel<SDNQ_F16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    SDNQ_CHECK_LAUNCH();
+    return SDNQ_OK;
+}
+
+extern "C" int sdnq_hip_attn_fwd_ex(const void* qq, const float* qs, const void* kq, const float* ks, const void* vt, const float* vs, int v_dtype,
+                                    int qk_dtype, int pv_dtype, float sm_scale, int is_causal, const void* mask, int mask_dtype, int64_t mask_stride_b,
+                                    int64_t mask_stride_h, int64_t mask_stride_q, void* out, int out_dtype, const int64_t* out_strides, int64_t batch,
+                                    int64_t q_heads, int64_t kv_heads, int64_t q_len, int64_t kv_len, int64_t head_dim, sdnq_stream_t stream) {
+    const int pvq = pvq_of(pv_dtype);
+    if (!qq || !qs || !kq || !ks || !vt || !out || (pvq != PVQ_NONE && !vs)) return SDNQ_ERR_NULL;
+    if ((qk_dtype != SDNQ_MM_I8 && qk_dtype != SDNQ_MM_FP8) || pvq < 0) return SDNQ_ERR_DTYPE;
+    if (out_dtype != SDNQ_F32 && out_dtype != SDNQ_BF16 && out_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
+    if (pvq == PVQ_NONE && v_dtype != SDNQ_BF16 && v_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
+    if (mask && mask_dtype != -1 && mask_dtype != SDNQ_F32 && mask_dtype != SDNQ_BF16 && mask_dtype != SDNQ_F16) return SDNQ_ERR_DTYPE;
+    if (!shape_ok(batch, q_heads, kv_heads, q_len, kv_len, head_dim)) return SDNQ_ERR_SHAPE;
+    if (head_dim < 8 || head_dim > 128 || head_dim % 8) return SDNQ_ERR_UNSUPPORTED;
+    const int64_t head_dim_src = head_dim;
+    head_dim = head_dim <= 64 ? 64 : 128;
+    if (((uintptr_t)qq | (uintptr_t)kq | (uintptr_t)vt) % 16 || (uintptr_t)out % 8) return SDNQ_ERR_ALIGN;
+    VarParams p{};
+    p.qq = (const uint8_t*)qq; p.qs = qs; p.kq = (const uint8_t*)kq; p.ks = ks; p.vt = vt; p.vs = vs; p.out = out;
+    p.qh = q_heads; p.kh = kv_heads; p.qn = q_len; p.kn = kv_len; p.knp = (kv_len + 31) / 32 * 32;
+    p.qblocks = (int)((q_len + 127) / 128);
+    p.causal = is_causal ? 1 : 0;
+    p.out_dtype = out_dtype;
+    p.log2_sm_scale = sm_scale * 1.4426950408889634f;  // triton_atten.py:203
+    p.ost.heads = q_heads;
+    if (out_strides) { p.ost.b = out_strides[0]; p.ost.h = out_strides[1]; p.ost.n = out_strides[2]; }
+    else { p.ost.b = q_heads * q_len * head_dim_src; p.ost.h = q_len * head_dim_src; p.ost.n = head_dim_src; }
+    p.d_out = (int)head_dim_src;
+    if (p.ost.b % 4 || p.ost.h % 4 || p.ost.n % 4) return SDNQ_ERR_ALIGN;
+    p.mask = mask; p.mask_dtype = mask_dtype; p.ms_z = mask_stride_b; p.ms_h = mask_stride_h; p.ms_q = mask_stride_q;
+    const int64_t blocks = batch * q_heads * p.qblocks;
+    hipStream_t s = (hipStream_t)stream;
+    const int d = (int)head_dim;
+    const bool f8 = qk_dtype == SDNQ_MM_FP8;
+    switch (pvq) {
+        case PVQ_NONE:
+            if (v_dtype == SDNQ_BF16) return f8 ? launch_var<1, PVQ_NONE, SDNQ_BF16>(p, d, blocks, s) : launch_var<0, PVQ_NONE, SDNQ_BF16>(p, d, blocks, s);
+            return f8 ? launch_var<1, PVQ_NONE, SDNQ_F16>(p, d, blocks, s) : launch_var<0, PVQ_NONE, SDNQ_F16>(p, d, blocks, s);
+        case PVQ_I8: return f8 ? launch_var<1, PVQ_I8, SDNQ_F16>(p, d, blocks, s) : launch_var<0, PVQ_I8, SDNQ_F16>(p, d, blocks, s);
+        case PVQ_FP8: return f8 ? launch_var<1, PVQ_FP8, SDNQ_F16>(p, d, blocks, s) : launch_var<0, PVQ_FP8, SDNQ_F16>(p, d, blocks, s);
+        default: return f8 ? launch_var<1, PVQ_F16, SDNQ_F16>(p, d, blocks, s) : launch_var<0, PVQ_F16, SDNQ_F16>(p, d, blocks, s);
+    }
 }

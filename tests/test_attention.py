@@ -73,8 +73,13 @@ def test_oracle_attention_block_size_only_changes_rounding():
     assert np.abs(a - b).max() / np.abs(a).max() <= 2e-3
 
 
+def _is_variant(name):
+    kw = AttnCase(name).kwargs
+    return kw.get("matmul_dtype", "int8") != "int8" or kw.get("pv_matmul_dtype") is not None
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", attn_case_names())
+@pytest.mark.parametrize("name", [n for n in attn_case_names() if not _is_variant(n)])
 def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
     import torch
     from sdnq_amd import attention as A
@@ -101,6 +106,55 @@ def test_hip_attention_vs_reference_kernel_and_oracle(name, gpu_device):
         err = np.abs(got - ref).max() / np.abs(ref).max()
         assert err <= lim, (name, what, err)
         assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= lim2, (name, what)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", [n for n in attn_case_names() if _is_variant(n)])
+def test_hip_attention_variants_vs_reference_kernel_and_oracle(name, gpu_device):
+    """fp8 Q.K^T and the quantized P.V formats (round 6; sdnq_hip_attn_prepare_ex / sdnq_hip_attn_fwd_ex): the quantized operands against the
+    reference's (Q / V codes and scales bit for bit, K up to the summation order of its token mean), the output against the reference kernel's
+    and the oracle's at the limits of `_variant`."""
+    import torch
+    from sdnq_amd import attention as A
+    c = AttnCase(name)
+    kw = c.kwargs
+    mm, pv, vlim = _variant(kw)
+    q, k, v = (c.torch_tensor(t, gpu_device) for t in ("q", "k", "v"))
+    hg = c.meta.get("hadamard_group", 0)
+    qq, qs, kq, ks, vt, vs = A.quantize_attn_ex(q, k, v, smooth_k=kw.get("smooth_k", True), hadamard_group=hg, matmul_dtype=mm, pv_matmul_dtype=pv)
+    d, kn = q.shape[-1], k.shape[2]
+    as_ref = (lambda t: t.cpu().numpy().view(np.int8)) if mm == "int8" else (lambda t: t.cpu().numpy())
+    _quant_agreement(as_ref(qq[..., :d]), qs.cpu().numpy(), c.raw("q_q"), c.raw("q_scale"), False, hadamard=bool(hg))
+    k_rows = A.unpack_k_fragments(kq)
+    _quant_agreement(as_ref(k_rows[:, :, :kn, :d]), ks[..., :kn].cpu().numpy(), c.raw("k_q"), c.raw("k_scale"), kw.get("smooth_k", True), hadamard=bool(hg))
+    assert not k_rows[:, :, kn:].any() and not ks[..., kn:].any()
+    if pv is not None:
+        v_rows = A.unpack_v8_fragments(vt) if pv in ("int8", "fp8") else A.unpack_v_fragments(vt)
+        got_v = v_rows[:, :, :kn, :d].cpu().numpy()
+        got_v = got_v.view(np.int8) if pv == "int8" else (got_v.view(np.uint16) if pv == "float16" else got_v)
+        _quant_agreement(got_v, vs[..., :kn].cpu().numpy(), c.raw("v_q"), c.raw("v_scale"), False, hadamard=bool(hg))
+        assert not v_rows[:, :, kn:].any() and not vs[..., kn:].any()
+    else:
+        assert vs is None and torch.equal(A.unpack_v_fragments(vt)[:, :, :kn, :d], v)
+    out = A.sdnq_hip_atten(q, k, v, attn_mask=c.torch_tensor("mask", gpu_device) if c.has("mask") else None, **kw)
+    assert out.dtype == q.dtype and out.shape == q.shape
+    got = out.float().cpu().numpy()
+    orc = O.attention(c.f32("q"), c.f32("k"), c.f32("v"), c.tag, is_causal=kw.get("is_causal", False), scale=kw.get("scale"),
+                      smooth_k=kw.get("smooth_k", True), hadamard_group=hg, mask=c.mask_array(), matmul_dtype=mm, pv_matmul_dtype=pv)
+    for ref, what in ((c.f32("out"), "reference kernel"), (orc, "oracle")):
+        lim, lim2 = (1.2e-2, 4e-3) if c.tag == "bf16" else (3e-3, 1e-3)
+        if vlim is not None:
+            lim, lim2 = max(lim, vlim[0]), max(lim2, vlim[1])
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        assert err <= lim, (name, what, err)
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= lim2, (name, what)
+    # float32 output and a token-major query view (what an attention processor passes)
+    out32 = A.sdnq_hip_atten(q.transpose(1, 2).contiguous().transpose(1, 2), k, v, attn_mask=c.torch_tensor("mask", gpu_device) if c.has("mask") else None,
+                             out_dtype=torch.float32, **kw)
+    assert out32.dtype == torch.float32
+    lim = max(1.2e-2 if c.tag == "bf16" else 3e-3, vlim[0] if vlim else 0)
+    assert np.abs(out32.cpu().numpy() - got).max() / np.abs(got).max() <= lim
+
 
 
 @pytest.mark.gpu
@@ -294,10 +348,14 @@ def test_attention_rejects_unbuilt_options():
     import torch
     from sdnq_amd import attention as A
     q = torch.zeros(1, 1, 32, 64, dtype=torch.bfloat16)
-    for kw in (dict(pv_matmul_dtype="int8"), dict(use_fp16_accum=True),
-               dict(matmul_dtype="float8_e4m3fn"), dict(return_backward=True)):
+    for kw in (dict(use_fp16_accum=True), dict(return_backward=True), dict(matmul_dtype="float16"), dict(matmul_dtype="int4"),
+               dict(pv_matmul_dtype="float8_e5m2"), dict(do_quantize=False), dict(matmul_dtype="none")):
         with pytest.raises(NotImplementedError):
             A.sdnq_hip_atten(q, q, q, **kw)
     from sdnq_amd._lib import SdnqHipError
-    with pytest.raises(SdnqHipError):
-        A.sdnq_hip_atten(q, q, q)  # CPU tensors: no fallback
+    for kw in ({}, dict(matmul_dtype="float8_e4m3fn"), dict(pv_matmul_dtype="int8"), dict(matmul_dtype="fp8", pv_matmul_dtype="fp8")):
+        with pytest.raises(SdnqHipError):
+            A.sdnq_hip_atten(q, q, q, **kw)  # built formats, CPU tensors: no fallback
+    # the reference's spellings of the formats (triton_atten.py:452-455)
+    assert A._mm_name("auto") == A._mm_name("enabled") == A._mm_name("uint8") == "int8" and A._mm_name("float8_e4m3fn") == "fp8"
+    assert A._mm_name("auto", pv=True) is None and A._mm_name(None, pv=True) is None and A._mm_name("uint8", pv=True) == "int8"
