@@ -1308,11 +1308,33 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
         for (int r = 0; r < 16; ++r) o[dd][r] = 0.0f;
     float m_i = -__builtin_inff();
     v2f l2 = {0.0f, 0.0f};
-    const uint8_t* kbase = p.kq + kv_lin * p.knp * D + lane * 16;
-    const float* ksb = p.ks + kv_lin * p.knp + 8 * g;
-    const float* vsb = PVQ != PVQ_NONE ? p.vs + kv_lin * p.knp + 8 * g : nullptr;
+    // every load of the loop goes through a buffer descriptor (head base in SGPRs, constant per-lane offset, block offset in the scalar
+    // operand; see attn_fwd_kernel), and the fragments of block kb + 1 are requested before the arithmetic of block kb starts
+    auto rsK = SDNQ_MAKE_RSRC(p.kq + kv_lin * p.knp * D);
+    auto rsS = SDNQ_MAKE_RSRC(p.ks + kv_lin * p.knp);
+    auto rsVS = SDNQ_MAKE_RSRC((PVQ != PVQ_NONE ? p.vs : p.ks) + kv_lin * p.knp);
     constexpr int VTILE = (PVQ == PVQ_I8 || PVQ == PVQ_FP8) ? 1024 : 2048;  // bytes of V operand per (key block, 32-channel block)
-    const uint8_t* vbase = (const uint8_t*)p.vt + kv_lin * (p.knp / 32) * (int64_t)(KK * VTILE) + lane * 16;
+    constexpr int NV = VTILE / 1024;
+    auto rsV = SDNQ_MAKE_RSRC((const uint8_t*)p.vt + kv_lin * (p.knp / 32) * (int64_t)(KK * VTILE));
+    const int lofs = lane * 16, sofs = 32 * g;
+    struct Blk { v4i kf[KK]; v4i vf[KK][NV]; v4f ks4[4]; v4f vs4[4]; };
+    auto load_blk = [&](int kb, Blk& b) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) b.kf[kk] = SDNQ_BUF_LOAD16(rsK, lofs, kb * (KK * 1024) + kk * 1024);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            b.ks4[2 * c] = __builtin_bit_cast(v4f, SDNQ_BUF_LOAD16(rsS, sofs, kb * 128 + 64 * c));
+            b.ks4[2 * c + 1] = __builtin_bit_cast(v4f, SDNQ_BUF_LOAD16(rsS, sofs, kb * 128 + 64 * c + 16));
+            if constexpr (PVQ != PVQ_NONE) {
+                b.vs4[2 * c] = __builtin_bit_cast(v4f, SDNQ_BUF_LOAD16(rsVS, sofs, kb * 128 + 64 * c));
+                b.vs4[2 * c + 1] = __builtin_bit_cast(v4f, SDNQ_BUF_LOAD16(rsVS, sofs, kb * 128 + 64 * c + 16));
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < KK; ++dd)
+#pragma unroll
+            for (int c = 0; c < NV; ++c) b.vf[dd][c] = SDNQ_BUF_LOAD16(rsV, lofs, kb * (KK * VTILE) + (dd * NV + c) * 1024);
+    };
     const char* mrow = nullptr;
     if (p.mask != nullptr)
         mrow = (const char*)p.mask + (z * p.ms_z + h * p.ms_h + qrow * p.ms_q) * (p.mask_dtype == -1 ? 1 : (p.mask_dtype == SDNQ_F32 ? 4 : 2));
@@ -1321,22 +1343,13 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
         const int lim = (int)(q0 / 32) + 1;  // blocks past the last query of this wave are fully masked (triton_atten.py:255)
         nkb = nkb < lim ? nkb : lim;
     }
-#pragma nounroll
-    for (int kb = 0; kb < nkb; ++kb) {
+    auto compute = [&](const Blk& b, int kb) {
         const int64_t key0 = (int64_t)kb * 32;
-        v4i kf[KK];
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) kf[kk] = *(const v4i*)(kbase + ((int64_t)kb * KK + kk) * 1024);
-        v4f ks4[4], vs4[4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            ks4[2 * c] = *(const v4f*)(ksb + key0 + 16 * c);
-            ks4[2 * c + 1] = *(const v4f*)(ksb + key0 + 16 * c + 4);
-            if constexpr (PVQ != PVQ_NONE) {
-                vs4[2 * c] = *(const v4f*)(vsb + key0 + 16 * c);
-                vs4[2 * c + 1] = *(const v4f*)(vsb + key0 + 16 * c + 4);
-            }
-        }
+        const v4i (&kf)[KK] = b.kf;
+        const v4f (&ks4)[4] = b.ks4;
+        const v4f (&vs4)[4] = b.vs4;
+        // wave-uniform: does this block need any of the three masks?
+        const bool need_mask = key0 + 32 > p.kn || (p.causal && key0 + 31 > q0) || mrow != nullptr;
         // ---- scores: lane holds keys key0 + 16 (r >> 3) + 8 g + (r & 7), r = 0..15, of query q0 + ql
         float sf[16];
         if constexpr (!QK_FP8) {
@@ -1367,12 +1380,15 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
             const float kscale = ks4[r >> 2][r & 3];
             float tv = sf[r] * kscale * qsl;   // (acc * k_scale) * (q_scale * log2_sm_scale): the factor order of the default kernel
             const int64_t key = key0 + 16 * (r >> 3) + 8 * g + (r & 7);
-            bool ok = key < p.kn;                      // triton_atten.py:295-296
-            if (p.causal) ok = ok && key <= qi;        // :287-288
+            bool ok = true;
             float add = 0.0f;
-            if (mrow != nullptr && ok) {
-                if (p.mask_dtype == -1) ok = ((const int8_t*)mrow)[key] != 0;   // :290-291
-                else add = ldf_mask(mrow, key, p.mask_dtype);                   // :292-293
+            if (need_mask) {
+                ok = key < p.kn;                           // triton_atten.py:295-296
+                if (p.causal) ok = ok && key <= qi;        // :287-288
+                if (mrow != nullptr && ok) {
+                    if (p.mask_dtype == -1) ok = ((const int8_t*)mrow)[key] != 0;   // :290-291
+                    else add = ldf_mask(mrow, key, p.mask_dtype);                   // :292-293
+                }
             }
             t[r] = ok ? tv + add : -__builtin_inff();
         }
@@ -1409,7 +1425,7 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int dd = 0; dd < KK; ++dd) {
-                    const v4i vf = *(const v4i*)(vbase + (((int64_t)kb * KK + dd) * 2 + c) * 1024);
+                    const v4i vf = b.vf[dd][c];
                     if constexpr (V_T == SDNQ_BF16)
                         o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(v8bf, vf), __builtin_bit_cast(v8bf, pf[c]), o[dd], 0, 0, 0);
                     else
@@ -1445,7 +1461,7 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
                 }
 #pragma unroll
                 for (int dd = 0; dd < KK; ++dd) {
-                    const v4i vf = *(const v4i*)(vbase + ((int64_t)kb * KK + dd) * 1024);
+                    const v4i vf = b.vf[dd][0];
                     v16i acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0;
@@ -1462,7 +1478,7 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
                 const long pa = ((long)w1 << 32) | w0, pb = ((long)w3 << 32) | w2;
 #pragma unroll
                 for (int dd = 0; dd < KK; ++dd) {
-                    const v4i vf = *(const v4i*)(vbase + ((int64_t)kb * KK + dd) * 1024);
+                    const v4i vf = b.vf[dd][0];
                     const long va = ((long)(u32)vf[1] << 32) | (u32)vf[0], vb = ((long)(u32)vf[3] << 32) | (u32)vf[2];
                     v16f acc;
 #pragma unroll
@@ -1486,13 +1502,34 @@ __global__ __launch_bounds__(256) void attn_fwd_var_kernel(const VarParams p) {
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const v4i vf = *(const v4i*)(vbase + (((int64_t)kb * KK + dd) * 2 + c) * 1024);
+                        const v4i vf = b.vf[dd][c];
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, vf), __builtin_bit_cast(v8h, pf[c]), acc, 0, 0, 0);
                     }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dd][r] = __builtin_fmaf(acc[r], ps, o[dd][r]);
                 }
             }
+        }
+    };
+    if constexpr (D == 128) {
+        // (measured, tools/attn_variants_lab.py: with two register sets of 128-channel fragments the quantized-P.V kernels lose occupancy --
+        //  24 x 4608^2 x 128 int8 / int8 907 us against 721 without the prefetch; at head_dim 64 the prefetch wins, 292 -> 259 us)
+#pragma nounroll
+        for (int kb = 0; kb < nkb; ++kb) {
+            Blk b;
+            load_blk(kb, b);
+            compute(b, kb);
+        }
+    } else if (nkb > 0) {
+        Blk bA, bB;
+        load_blk(0, bA);
+#pragma nounroll
+        for (int kb = 0; kb < nkb; kb += 2) {  // two blocks per trip: the register sets swap roles without moves
+            if (kb + 1 < nkb) load_blk(kb + 1, bB);
+            compute(bA, kb);
+            if (kb + 1 >= nkb) break;
+            if (kb + 2 < nkb) load_blk(kb + 2, bA);
+            compute(bB, kb + 1);
         }
     }
     if (qi >= p.qn) return;
