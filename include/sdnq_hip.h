@@ -162,10 +162,12 @@ int sdnq_hip_scaled_mm_tile(int mm_dtype, int out_dtype, int has_bias, int64_t m
  * sdnq_hip_rowquant_f16: per row, in float32, xs[m] = amax|x| / 65504, xq[m][k] = float16(clamp(nan_to_num(x / xs[m]), +-65504)).
  * sdnq_hip_scaled_mm_f16: out[m][n] = cast(fma(f32(sum_k a[m][k] * b[n][k]) * sa[m], sb[n], bias[n])), a [M][K], b [N][K] float16,
  * fp32 accumulation on the f16 matrix cores (the reference's CPU route instead pre-scales both operands by 1 / sqrt(65536 K) and rounds
- * them to float16 again, kernel_wrappers.py:115-129: results agree to the float16 rounding of the operands).  K % 8 == 0, N % 8 == 0. */
+ * them to float16 again, kernel_wrappers.py:115-129: results agree to the float16 rounding of the operands).  K % 8 == 0, N % 8 == 0.
+ * bias: NULL (bias_ndim 0), [N] (1) or [M][ld_bias] (2: the low-rank term of a layer with SVD factors, addmm(bias, x . svd_down, svd_up) of
+ * linear_fp16.py:38-43, computed by the caller in the factors' dtype), of bias_dtype. */
 int sdnq_hip_rowquant_f16(const void* x, int x_dtype, int64_t m, int64_t k, int64_t ldx, void* xq, float* xs, sdnq_stream_t stream);
-int sdnq_hip_scaled_mm_f16(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, void* out,
-                           int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
+int sdnq_hip_scaled_mm_f16(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, int bias_ndim,
+                           int64_t ld_bias, void* out, int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream);
 
 /* ---- N1: the re-quantization of 4-bit weights fused into the matmul (round 6) -----------------------------------------------
  * replaces, as ONE launch per call, what sdnq_hip_requant + sdnq_hip_scaled_mm compute for 4-bit packed weights

@@ -397,6 +397,16 @@ class OracleLinear:
         """re_quantize_matmul (dequantizer.py:204-239): fp32 dequant (no SVD, Hadamard not undone) -> per-row quant.
         Returns (wq [N,K] int8 | e4m3 codes uint8, ws [N])."""
         W = self.dequant_f32_nk()
+        if self.deq["quantized_matmul_dtype"] == "float16":
+            # re_quantize_fp_mm (dequantizer.py:190-200) -> quantize_fp_mm with matmul_dtype "float16" (quant_utils.py:290-299): scale = amax / 65504,
+            # codes = float16(clamp(nan_to_num(w / scale), +-65504)); returns (float16 [N,K], scale [N])
+            assert self.scale_tag == "f32", "float16 matmul: float32 scales"
+            W = _c(W, np.float32)
+            with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+                sc = (np.abs(W).max(axis=1, keepdims=True).astype(np.float32) / np.float32(65504.0)).astype(np.float32)
+                wq = (W / sc).astype(np.float32)
+                wq = np.nan_to_num(wq, nan=0.0, posinf=np.finfo(np.float32).max, neginf=np.finfo(np.float32).min)
+            return np.clip(wq, np.float32(-65504.0), np.float32(65504.0)).astype(np.float16), sc.reshape(-1)
         if self.scale_tag != "f32":  # dequantize_weight(..., dtype=scale.dtype) then quantize_*_mm in that dtype (dequantizer.py:219-239)
             if self.deq["quantized_matmul_dtype"] == "uint8":  # re_quantize_uint_mm on the scale-dtype dequantization (dequantizer.py:178-187, 219-239)
                 if self.scale_tag != "bf16":
@@ -788,10 +798,22 @@ def _forward_fp16(mod: OracleLinear, x2: np.ndarray, tag: str, inter: dict) -> n
     The float16 GEMM's summation order is the library's: the float32-accumulated dot product rounded once to float16 stands in for it."""
     d = mod.deq
     K, N = mod.K, mod.N
-    assert not d["re_quantize_for_matmul"] and mod.svd_up is None and not d["use_hadamard"], "fp16 matmul oracle: row-wise float weights only"
-    vals, sc, zpv, group = mod._nk_values_scale()
-    assert group == K and zpv is None
-    w16 = _c(vals, np.float32).astype(np.float16)
+    assert mod.scale_tag == "f32", "fp16 matmul oracle: float32 scales"
+    if d["re_quantize_for_matmul"]:
+        w16, sc = mod.re_quantize_matmul()  # float32 dequantization (no SVD term, rotation not undone) -> float16 codes per output row
+    else:
+        vals, sc, zpv, group = mod._nk_values_scale()
+        assert group == K and zpv is None
+        w16 = _c(vals, np.float32).astype(np.float16)
+    if d["use_hadamard"]:
+        x2 = rotate_hadamard(x2, d["hadamard_group_size"], tag)  # linear_fp16.py:35-36
+        inter["xrot"] = x2
+    bias2d = None
+    if mod.svd_up is not None:  # linear_fp16.py:37-43: addmm(bias.to(svd dtype), mm(input.to(svd dtype), svd_down), svd_up)
+        up, down = mod.svd_nr_rk()
+        t = linear_float(round_dtype(x2, mod.svd_tag), down, None, mod.svd_tag)
+        b1 = None if mod.bias is None else round_dtype(mod.bias, mod.svd_tag)
+        bias2d = lowrank_bias(t, up, b1, mod.svd_tag)
     x = _c(x2, np.float32)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         amax = np.abs(x).max(axis=1, keepdims=True).astype(np.float32)
@@ -808,7 +830,9 @@ def _forward_fp16(mod: OracleLinear, x2: np.ndarray, tag: str, inter: dict) -> n
     acc = (mm.astype(np.float32) * fp16_scale).astype(np.float32)
     vv = (acc * xs).astype(np.float32)
     sb = _c(sc, np.float32).reshape(1, -1)
-    if mod.bias is not None:  # addcmul: the product and the sum round once (float64 holds the float32 product exactly)
+    if bias2d is not None:
+        y = (vv.astype(np.float64) * sb.astype(np.float64) + _c(bias2d, np.float32).astype(np.float64)).astype(np.float32)
+    elif mod.bias is not None:  # addcmul: the product and the sum round once (float64 holds the float32 product exactly)
         y = (vv.astype(np.float64) * sb.astype(np.float64) + _c(mod.bias, np.float32).astype(np.float64).reshape(1, -1)).astype(np.float32)
     else:
         y = (vv * sb).astype(np.float32)

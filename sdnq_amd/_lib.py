@@ -204,7 +204,7 @@ def _declare(lib):
     lib.sdnq_hip_scaled_mm_w4.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, i64, vp]
     lib.sdnq_hip_scaled_mm_w4_supported.argtypes = [i32, i32, i64, i64, i64]
     lib.sdnq_hip_rowquant_f16.argtypes = [vp, i32, i64, i64, i64, vp, vp, vp]
-    lib.sdnq_hip_scaled_mm_f16.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, i64, i64, i64, vp]
+    lib.sdnq_hip_scaled_mm_f16.argtypes = [vp, vp, vp, vp, vp, i32, i32, i64, vp, i32, i64, i64, i64, vp]
     for name in EXPORTS:
         if name not in ("sdnq_hip_strerror", "sdnq_hip_set_tile_override"):
             getattr(lib, name).restype = c.c_int

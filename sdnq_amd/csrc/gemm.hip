@@ -2351,6 +2351,10 @@ extern "C" int sdnq_hip_scaled_mm_lp(int mm_dtype, const void* a, const void* b,
 template <int OUT_T, int EPI>
 int launch_f16s(const GemmParams& p, hipStream_t s) {
     auto tiles = [&](int bm, int bn) { return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+    if constexpr (EPI == EPI_BIAS2D) {  // (the [M][N] bias of a layer with SVD factors: never on the 256-row tiles, see launch_tiles)
+        if (p.M > 128) return launch_one<MM_F16S, OUT_T, EPI, 64, 128, 32, 32, 3, LD_DMA>(p, s);
+        return launch_one<MM_F16S, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
+    } else
     if (p.M > 128 && tiles(256, 256) >= 160 && p.K >= 2048) {
         if (ht_ok(p)) return launch_one<MM_F16S, OUT_T, EPI, 256, 256, 128, 64, 2, LD_HT, 128>(p, s);
         return launch_one<MM_F16S, OUT_T, EPI, 256, 256, 128, 64, 4, LD_PIPE, 64>(p, s);
@@ -2360,20 +2364,24 @@ int launch_f16s(const GemmParams& p, hipStream_t s) {
     return launch_one<MM_F16S, OUT_T, EPI, 64, 64, 32, 32, 4, LD_PIPE>(p, s);
 }
 
-extern "C" int sdnq_hip_scaled_mm_f16(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, void* out,
-                                      int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
+extern "C" int sdnq_hip_scaled_mm_f16(const void* a, const void* b, const float* sa, const float* sb, const void* bias, int bias_dtype, int bias_ndim,
+                                      int64_t ld_bias, void* out, int out_dtype, int64_t m, int64_t n, int64_t k, sdnq_stream_t stream) {
     if (!a || !b || !sa || !sb || !out) return SDNQ_ERR_NULL;
+    if (bias_ndim < 0 || bias_ndim > 2 || (bias_ndim != 0 && !bias) || (bias_ndim == 2 && ld_bias < n)) return SDNQ_ERR_SHAPE;
+    if (bias_ndim == 0) bias = nullptr;
     if (out_dtype < 0 || out_dtype > 2) return SDNQ_ERR_DTYPE;
     if (bias && (bias_dtype < 0 || bias_dtype > 2)) return SDNQ_ERR_DTYPE;
     if (m <= 0 || n <= 0 || k <= 0 || (k % 8) != 0 || (n % 8) != 0) return SDNQ_ERR_SHAPE;
     if (((uintptr_t)a % 16) || ((uintptr_t)b % 16) || ((uintptr_t)out % 16)) return SDNQ_ERR_ALIGN;
     GemmParams p{};
     p.a = (const uint8_t*)a; p.b = (const uint8_t*)b; p.sa = sa; p.sb = sb; p.bias = bias; p.out = out;
-    p.M = m; p.N = n; p.K = k * 2; p.bias_ndim = bias ? 1 : 0; p.bias_dtype = bias ? bias_dtype : out_dtype;
+    p.M = m; p.N = n; p.K = k * 2; p.bias_ndim = bias ? bias_ndim : 0; p.ld_bias = ld_bias; p.bias_dtype = bias ? bias_dtype : out_dtype;
     hipStream_t s = (hipStream_t)stream;
-    if (out_dtype == SDNQ_BF16) return bias ? launch_f16s<SDNQ_BF16, EPI_BIAS1D>(p, s) : launch_f16s<SDNQ_BF16, EPI_NONE>(p, s);
-    if (out_dtype == SDNQ_F16) return bias ? launch_f16s<SDNQ_F16, EPI_BIAS1D>(p, s) : launch_f16s<SDNQ_F16, EPI_NONE>(p, s);
-    return bias ? launch_f16s<SDNQ_F32, EPI_BIAS1D>(p, s) : launch_f16s<SDNQ_F32, EPI_NONE>(p, s);
+#define F16S_EPI(OT) (p.bias_ndim == 2 ? launch_f16s<OT, EPI_BIAS2D>(p, s) : (bias ? launch_f16s<OT, EPI_BIAS1D>(p, s) : launch_f16s<OT, EPI_NONE>(p, s)))
+    if (out_dtype == SDNQ_BF16) return F16S_EPI(SDNQ_BF16);
+    if (out_dtype == SDNQ_F16) return F16S_EPI(SDNQ_F16);
+    return F16S_EPI(SDNQ_F32);
+#undef F16S_EPI
 }
 
 // internal (used by sdnq_hip_linear_float in dequant.hip): out[M][N] = cast(x[M][K] . w[N][K]^T + bias), all of `dtype`

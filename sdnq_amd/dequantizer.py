@@ -120,6 +120,11 @@ class SDNQDequantizer:
         if self.quantized_matmul_dtype == "uint8":
             wq, ws, wzp = ops.requant_asym(qw)
             return wq.t(), ws.view(1, -1), wzp.view(1, -1)
+        if self.quantized_matmul_dtype == "float16":  # re_quantize_fp_mm (dequantizer.py:190-200): float16 codes per output row, scale = amax / 65504
+            if scale.dtype != torch.float32:
+                raise NotImplementedError("re-quantization to float16 codes with 16-bit scales is not built")
+            w16, ws = ops.rowquant_f16(ops.dequant(qw, torch.float32, 0))
+            return w16.t(), ws.view(1, -1)
         wq, ws = ops.requant(qw, ops.mm_code(self.quantized_matmul_dtype))
         if scale.dtype in (torch.bfloat16, torch.float16):  # 16-bit scales: the row scale was computed in that dtype (exact cast)
             ws = ws.to(scale.dtype)

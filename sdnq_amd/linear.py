@@ -1140,8 +1140,10 @@ def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Te
 @_no_grad
 def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Tensor:
     """quantized_matmul_dtype = "float16" (layers/linear/linear_fp16.py:16-110; round 6): float16 operands on the f16 matrix cores with
-    the scaled epilogue.  Built for row-wise float weights whose codes ARE the operand (native fp8, packed eXmY floats: linear_fp16.py:27-31),
-    no SVD, no Hadamard; `support.unsupported_reason` names the rest.  A compatibility mode: plain launches, the operand cached per module."""
+    the scaled epilogue.  The weight operand, cached per module: the stored float codes `.to(float16)` (native fp8, packed eXmY floats,
+    linear_fp16.py:27-31) or, where the layer re-quantizes (integer / group-wise weights), the float32 dequantization quantized per output
+    row to float16 codes (re_quantize_fp_mm, dequantizer.py:190-200); the input is rotated first on Hadamard layers (:35-36) and layers with
+    SVD factors add addmm(bias, x . svd_down, svd_up) as a 2-D bias (:37-43).  A compatibility mode: plain launches."""
     dq = self.sdnq_dequantizer
     st = _state(self)
     k, n = dq.in_features, dq.out_features
@@ -1152,12 +1154,24 @@ def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Ten
         raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
     key = ("f16", False)
     if st.mm != key or st.mm_weight is None:
-        st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, ops.unpack_mm_f16(st.qw), st.qw.keep[1], None, None
+        if dq.re_quantize_for_matmul:
+            # dequantize_weight(..., dtype=scale.dtype) WITHOUT the SVD term and without undoing the rotation (linear_fp16.py:81-82), then
+            # quantize_fp_mm per output row: scale = amax / 65504, codes = float16(clamp(w / scale))
+            w16, ws = ops.rowquant_f16(ops.dequant(st.qw, torch.float32, 0, use_svd=False).reshape(n, -1))
+        else:
+            w16, ws = ops.unpack_mm_f16(st.qw), st.qw.keep[1]
+        st.mm, st.mm_weight, st.mm_scale, st.mm_zp, st.mm_wcs = key, w16, ws.reshape(-1), None, None
     x2 = input.reshape(-1, k)
     if x2.stride(-1) != 1 or (x2.stride(0) * x2.element_size()) % 16:
         x2 = x2.contiguous()
+    if dq.use_hadamard:
+        x2 = ops.hadamard(x2, dq.hadamard_group_size)  # rotate_hadamard(input) in the tensor dtype
+    bias = _attr(self, "bias")
+    if st.svd_up is not None:
+        t = ops.lowrank_down(x2, st.svd_down)                                    # mm(input.to(svd dtype), svd_down)
+        bias = ops.linear_float(t, st.svd_up.contiguous(), None if bias is None else bias.to(st.svd_up.dtype))  # addmm(bias, t, svd_up): [M, N]
     xq, xs = ops.rowquant_f16(x2)
-    return ops.scaled_mm_f16(xq, st.mm_weight, xs, st.mm_scale, _attr(self, "bias"), input.dtype).view(*input.shape[:-1], n)
+    return ops.scaled_mm_f16(xq, st.mm_weight, xs, st.mm_scale, bias, input.dtype).view(*input.shape[:-1], n)
 
 
 class _SwitchModule(__import__("types").ModuleType):

@@ -668,15 +668,26 @@ def unpack_mm_f16(qw: QuantWeight) -> torch.Tensor:
 
 
 def scaled_mm_f16(a: torch.Tensor, b_phys: torch.Tensor, sa: torch.Tensor, sb: torch.Tensor, bias, out_dtype: torch.dtype) -> torch.Tensor:
-    """fp_scaled_mm_func on float16 operands (kernel_wrappers.py:207-211): a [M, K] f16, b_phys [N, K] f16 -> [M, N]."""
+    """fp_scaled_mm_func on float16 operands (kernel_wrappers.py:207-211): a [M, K] f16, b_phys [N, K] f16 -> [M, N]; bias None, [N] or the
+    [M, N] low-rank term of a layer with SVD factors (linear_fp16.py:38-43)."""
     _require_cuda(a, b_phys, sa, sb, bias)
     m, k = a.shape
     n = b_phys.shape[0]
     if a.dtype != torch.float16 or b_phys.dtype != torch.float16 or not a.is_contiguous() or not b_phys.is_contiguous() or b_phys.shape[1] != k:
         raise _lib.SdnqHipError("scaled_mm_f16: contiguous float16 operands a [M, K], b [N, K]")
+    nd, ldb = 0, 0
+    if bias is not None:
+        bias = bias.contiguous()
+        nd = bias.dim()
+        if nd == 2:
+            if tuple(bias.shape) != (m, n):
+                raise _lib.SdnqHipError("scaled_mm_f16: a 2-D bias must be [M, N]")
+            ldb = bias.stride(0)
+        elif nd != 1 or bias.numel() != n:
+            raise _lib.SdnqHipError("scaled_mm_f16: bias must be [N] or [M, N]")
     out = torch.empty((m, n), device=a.device, dtype=out_dtype)
     check(_lib.load().sdnq_hip_scaled_mm_f16(a.data_ptr(), b_phys.data_ptr(), sa.data_ptr(), sb.data_ptr(), _ptr(bias), 0 if bias is None else float_code(bias.dtype),
-                                             out.data_ptr(), float_code(out_dtype), m, n, k, _stream(a)), "scaled_mm_f16")
+                                             nd, ldb, out.data_ptr(), float_code(out_dtype), m, n, k, _stream(a)), "scaled_mm_f16")
     return out
 
 

@@ -43,13 +43,10 @@ def unsupported_reason(module) -> str | None:
         return (f"scale dtype {sdt} differs from the layer's result dtype {dq.result_dtype}: 16-bit scales are built for the layout "
                 "apply_sdnq_options_to_model(dequantize_fp32=False) produces")
     if qmm and not mm["is_integer"] and mm["num_bits"] != 8:
-        # the float16 matmul (linear_fp16.py; round 6) is built for Linear layers whose stored float codes are the operand
+        # the float16 matmul (linear_fp16.py; round 6) is built for Linear layers: stored float codes or weights re-quantized to float16 codes,
+        # with Hadamard rotation and SVD factors
         if dq.quantized_matmul_dtype != "float16" or cls not in linear_types:
             return f"quantized_matmul_dtype='{dq.quantized_matmul_dtype}' on {cls} is outside the MI355X hot path (SURVEY 8a note)"
-        if dtype_dict[dq.weights_dtype]["is_integer"] or dq.re_quantize_for_matmul:
-            return "the float16 matmul is built for row-wise float weights only (re-quantization to float16, dequantizer.py:190-200, is not built)"
-        if getattr(module, "svd_up", None) is not None or getattr(dq, "use_hadamard", False):
-            return "the float16 matmul with SVD factors or Hadamard rotation is not built"
         if lp:
             return "the float16 matmul with 16-bit scales (dequantize_fp32=False) is not built"
     w = dtype_dict[dq.weights_dtype]

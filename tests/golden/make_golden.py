@@ -257,6 +257,13 @@ CASES = [
          cfg=dict(weights_dtype="fp8", quantized_matmul_dtype="float16", group_size=-1, use_quantized_matmul=True)),
     dict(name="float6_e3m2_f16mm_f16_nobias", K=256, N=80, Ms=[40, 136], dtype="f16", bias=False,
          cfg=dict(weights_dtype="float6_e3m2fn", quantized_matmul_dtype="float16", group_size=-1, use_quantized_matmul=True)),
+    # ... weights re-quantized to float16 codes (dequantizer.py:190-200), Hadamard rotation, SVD factors
+    dict(name="int8_f16mm_bf16", K=256, N=128, Ms=[4, 40, 200], dtype="bf16",
+         cfg=dict(weights_dtype="int8", quantized_matmul_dtype="float16", group_size=-1, use_quantized_matmul=True)),
+    dict(name="uint4_group32_f16mm_hadamard_f16", K=256, N=96, Ms=[48], dtype="f16",
+         cfg=dict(weights_dtype="uint4", quantized_matmul_dtype="float16", group_size=32, use_quantized_matmul=True, use_hadamard=True, hadamard_group_size=64)),
+    dict(name="int8_svd_f16mm_bf16", K=192, N=128, Ms=[40, 130], dtype="bf16",
+         cfg=dict(weights_dtype="int8", quantized_matmul_dtype="float16", group_size=-1, use_quantized_matmul=True, use_svd=True, svd_rank=16, svd_steps=2)),
 ]
 
 # Every packed storage dtype gets a dequant-only golden (small).

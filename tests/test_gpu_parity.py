@@ -71,7 +71,7 @@ def test_module_forward_vs_golden_and_oracle(name, gpu_device):
             assert_close_float(got, orc, c.tag, (name, M, "oracle"), hadamard=d["use_hadamard"], f16mm=f16mm)
 
 
-@pytest.mark.parametrize("name", ["fp8_f16mm_bf16", "float6_e3m2_f16mm_f16_nobias"])
+@pytest.mark.parametrize("name", ["fp8_f16mm_bf16", "float6_e3m2_f16mm_f16_nobias", "int8_f16mm_bf16", "uint4_group32_f16mm_hadamard_f16", "int8_svd_f16mm_bf16"])
 def test_float16_matmul_operators_vs_oracle(name, gpu_device):
     """The three pieces of the float16 matmul forward (round 6; linear_fp16.py): the activation quantizer and the weight operand are
     elementwise and must equal the oracle (= the reference's) bit for bit; the scaled matmul is checked against a float64 evaluation of
@@ -80,18 +80,23 @@ def test_float16_matmul_operators_vs_oracle(name, gpu_device):
     c = Case(name)
     mod = module_from_case(c, gpu_device)
     omod = c.oracle_module()
+    d = c.deq
+    mod(c.torch_tensor(f"x_{max(c.ms())}", device=gpu_device))  # builds the cached weight operand: stored codes, or re-quantized to float16 codes
     st = L._state(mod)
-    w16 = ops.unpack_mm_f16(st.qw)
+    w16, wsc = st.mm_weight, st.mm_scale
     for M in [m for m in c.ms() if m >= 32]:
         x = c.torch_tensor(f"x_{M}", device=gpu_device)
         x2 = x.reshape(-1, c.K)
         _, inter = O.forward(omod, c.f32(f"x_{M}"), c.tag, want_intermediates=True)
+        assert np.array_equal(w16.cpu().numpy().view(np.uint16), inter["wq"].view(np.uint16)), (name, "weight operand")
+        assert np.array_equal(wsc.cpu().numpy().reshape(-1), np.asarray(inter["ws"], dtype=np.float32).reshape(-1)), (name, "weight scales")
+        if d["use_hadamard"] or c.has("svd_up"):
+            continue  # (the rotated input differs by the dtype's rounding of another summation order: covered by the forward test)
         xq, xs = ops.rowquant_f16(x2)
         assert np.array_equal(xq.cpu().numpy().view(np.uint16), inter["xq"].view(np.uint16)), (name, M, "float16 codes")
         assert np.array_equal(xs.cpu().numpy(), inter["xs"]), (name, M, "row scales")
-        assert np.array_equal(w16.cpu().numpy().view(np.uint16), inter["wq"].view(np.uint16)), (name, "weight operand")
         for out_dtype, tag in ((torch.float32, "f32"), (x.dtype, c.tag)):
-            y = ops.scaled_mm_f16(xq, w16, xs, st.qw.keep[1], mod.bias, out_dtype)
+            y = ops.scaled_mm_f16(xq, w16, xs, wsc, mod.bias, out_dtype)
             acc = inter["xq"].astype(np.float64) @ inter["wq"].astype(np.float64).T
             want = acc * inter["xs"].astype(np.float64)[:, None] * inter["ws"].astype(np.float64).reshape(1, -1)
             if mod.bias is not None:
@@ -191,7 +196,7 @@ def test_dequant_and_requant_vs_golden(name, gpu_device):
         wq, ws, *wzp = dq.re_quantize_matmul(mod.weight, mod.scale, zero_point=mod.zero_point)
         assert tuple(wq.shape) == (c.K, c.N) and wq.stride() == (1, c.K)
         rw = c.raw("requant_weight").reshape(c.K, c.N)
-        assert np.array_equal(bits_of(wq.contiguous()), rw.view(np.uint8)), name
+        assert np.array_equal(bits_of(wq.contiguous()).view(np.uint8), rw.view(np.uint8)), name  # (int8 / e4m3 bytes, or float16 bit patterns)
         assert np.array_equal(ws.float().cpu().numpy().reshape(-1), c.f32("requant_scale").reshape(-1)), name
         assert len(wzp) == int(c.has("requant_zero_point")), name
         if wzp:  # asymmetric re-quantizer of the uint8 matmul (dequantizer.py:178-187)

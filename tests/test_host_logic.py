@@ -302,8 +302,8 @@ def test_support_predicate_on_the_uint8_matmul_with_16_bit_scales():
 
 
 def test_float16_matmul_support_rules():
-    """The float16 matmul forward (linear_fp16.py; round 6): built for Linear layers with row-wise float weights, float32 scales, no SVD /
-    Hadamard; integer weights (re-quantized to float16 by the reference), conv layers and 16-bit scales keep a reason."""
+    """The float16 matmul forward (linear_fp16.py; round 6): built for Linear layers with float32 scales -- stored float codes or weights
+    re-quantized to float16 codes, Hadamard rotation, SVD factors; conv layers and 16-bit scales keep a reason."""
     import sdnq_amd
     from sdnq_amd import support
     import pytest
@@ -320,12 +320,13 @@ def test_float16_matmul_support_rules():
     q = layer()
     assert support.unsupported_reason(q) is None and q.forward_func is quantized_linear_forward_fp16_matmul
     assert support.unsupported_reason(layer(weights_dtype="float6_e3m2fn")) is None
-    assert "row-wise float" in support.unsupported_reason(layer(weights_dtype="int8"))
-    assert "row-wise float" in support.unsupported_reason(layer(weights_dtype="int4", group_size=32))
+    assert support.unsupported_reason(layer(weights_dtype="int8")) is None
+    assert support.unsupported_reason(layer(weights_dtype="int4", group_size=32)) is None
+    assert support.unsupported_reason(layer(weights_dtype="uint4", group_size=32, use_hadamard=True, hadamard_group_size=32)) is None
     with pytest.raises(NotImplementedError, match="float16"):  # the conv forwards in float16 are not built: loud at quantize time
         layer(conv=True)
     assert "16-bit scales" in support.unsupported_reason(layer(dequantize_fp32=False))
-    assert "SVD" in support.unsupported_reason(layer(use_svd=True, svd_rank=8))
+    assert support.unsupported_reason(layer(use_svd=True, svd_rank=8)) is None
 
 
 def test_support_predicate_on_grouped_convs_with_16_bit_scales():

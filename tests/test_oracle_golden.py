@@ -124,7 +124,10 @@ def test_case_dequant_and_requant(name):
         assert len(wzp) == int(c.has("requant_zero_point"))
         if wzp:  # re_quantize_uint_mm (dequantizer.py:178-187)
             assert np.array_equal(wzp[0], c.f32("requant_zero_point").reshape(-1)), name  # (values: bf16 bits under 16-bit scales)
-        assert np.array_equal(wq.view(np.uint8), rw.view(np.uint8)), name
+        if wq.dtype == np.float16:  # the float16 matmul's operand (fixtures hold 16-bit floats as their bit patterns)
+            assert np.array_equal(wq.view(np.uint16), rw.view(np.uint16)), name
+        else:
+            assert np.array_equal(wq.view(np.uint8), rw.view(np.uint8)), name
 
 
 @pytest.mark.parametrize("name", case_names())
