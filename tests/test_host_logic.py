@@ -207,8 +207,10 @@ def test_accelerate_never_breaks_a_working_model():
     model[1] = sdnq_amd.sdnq_quantize_layer(model[1], sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
     model[2] = sdnq_amd.sdnq_quantize_layer(model[2], sdnq_amd.SDNQConfig(weights_dtype="int8", quant_conv=True, use_quantized_matmul_conv=True,
                                                                           use_svd=True, svd_rank=8))[0]
-    # layer 1: the reference's 16-bit float matmul (linear_fp16.py) -- not built here; layer 2: a grouped conv with SVD factors -- not built
+    # layer 1: the reference's 16-bit float matmul (linear_fp16.py) with 16-bit scales -- not built here (with float32 scales it is, since
+    # round 6); layer 2: a grouped conv with SVD factors -- not built
     model[1].sdnq_dequantizer.quantized_matmul_dtype = "float16"
+    model[1].scale = torch.nn.Parameter(model[1].scale.data.to(torch.bfloat16), requires_grad=False)
     for i in (0, 1, 2):
         model[i].forward_func = ref_forward
     assert support.unsupported_reason(model[0]) is None
@@ -256,7 +258,8 @@ def test_accelerate_reads_foreign_records_of_grouped_convs_and_options_leave_for
     q.forward_func = ref_forward
     assert support.unsupported_reason(q) is None  # (raised AttributeError before)
     lin = sdnq_amd.sdnq_quantize_layer(torch.nn.Linear(64, 64).to(torch.bfloat16), sdnq_amd.SDNQConfig(weights_dtype="int8", use_quantized_matmul=True))[0]
-    lin.sdnq_dequantizer.quantized_matmul_dtype = "float16"  # the 16-bit float matmul: not built -> stays on its own forward
+    lin.sdnq_dequantizer.quantized_matmul_dtype = "float16"  # the 16-bit float matmul on 16-bit scales: not built -> stays on its own forward
+    lin.scale = torch.nn.Parameter(lin.scale.data.to(torch.bfloat16), requires_grad=False)
     lin.forward_func = ref_forward
     model = torch.nn.Sequential(q, lin)
     with warnings.catch_warnings(record=True):
