@@ -1110,8 +1110,9 @@ def main():
         linked = link_shared_input_layers(layers)
     ops_per_step = sum(2 * m * k * n + (m * n if b else 0) for (_, _, _, m, k, n, b) in layers)
 
-    # eager warm-up (builds the per-module weight caches), then capture the whole step
-    for _ in range(2):
+    # eager warm-up (builds the per-module weight caches; in eager mode also: the layers learn which of them share their input and get
+    # their fast-path plans, sdnq_amd/linear.py UNSHARED_AFTER), then capture the whole step
+    for _ in range(5 if args.launch == "eager" or args.no_graph else 2):
         run_step(layers)
     torch.cuda.synchronize()
     graph = None
