@@ -20,6 +20,8 @@ def get_forward_func(layer_class_name: str, quantized_matmul_dtype: str, use_qua
                 return conv.quantized_conv_forward_uint8_matmul if ent["is_unsigned"] else conv.quantized_conv_forward_int8_matmul
             if not ent["is_integer"] and ent["num_bits"] == 8:
                 return conv.quantized_conv_forward_fp8_matmul
+            # (float16: the reference's own conv_fp16 forward fails on the layers its quantizer builds -- `result_shape` is None for them,
+            #  layers/conv/conv_fp16.py:98 -> forward.py:39 -- so there is nothing to be in parity with; Linear layers have it)
             raise NotImplementedError(f"conv matmul in {quantized_matmul_dtype} is not built (int8, uint8 and fp8 are)")
         return conv.quantized_conv_forward
     from . import linear

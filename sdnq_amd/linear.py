@@ -1137,9 +1137,8 @@ def quantized_linear_forward_uint8_matmul(self, input: torch.Tensor) -> torch.Te
     return _uint8_matmul_forward(self, input)
 
 
-@_no_grad
-def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Tensor:
-    """quantized_matmul_dtype = "float16" (layers/linear/linear_fp16.py:16-110; round 6): float16 operands on the f16 matrix cores with
+def _fp16_matmul_forward(self, input: torch.Tensor, small_batch_branch: bool = True) -> torch.Tensor:
+    """quantized_matmul_dtype = "float16" (layers/linear/linear_fp16.py:16-110, layers/conv/conv_fp16.py:18-60 on the unfolded input; round 6): float16 operands on the f16 matrix cores with
     the scaled epilogue.  The weight operand, cached per module: the stored float codes `.to(float16)` (native fp8, packed eXmY floats,
     linear_fp16.py:27-31) or, where the layer re-quantizes (integer / group-wise weights), the float32 dequantization quantized per output
     row to float16 codes (re_quantize_fp_mm, dequantizer.py:190-200); the input is rotated first on Hadamard layers (:35-36) and layers with
@@ -1148,7 +1147,7 @@ def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Ten
     st = _state(self)
     k, n = dq.in_features, dq.out_features
     m = input.numel() // input.shape[-1]
-    if m < 32:  # linear_fp16.py:79-80
+    if small_batch_branch and m < 32:  # linear_fp16.py:79-80 (the conv forward applies its own criterion to the image)
         return _float_forward(self, input, st)
     if not input.is_cuda:
         raise ops._lib.SdnqHipError("sdnq_amd forwards need CUDA/HIP tensors (no CPU fallback)")
@@ -1172,6 +1171,11 @@ def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Ten
         bias = ops.linear_float(t, st.svd_up.contiguous(), None if bias is None else bias.to(st.svd_up.dtype))  # addmm(bias, t, svd_up): [M, N]
     xq, xs = ops.rowquant_f16(x2)
     return ops.scaled_mm_f16(xq, st.mm_weight, xs, st.mm_scale, bias, input.dtype).view(*input.shape[:-1], n)
+
+
+@_no_grad
+def quantized_linear_forward_fp16_matmul(self, input: torch.Tensor) -> torch.Tensor:
+    return _fp16_matmul_forward(self, input)
 
 
 class _SwitchModule(__import__("types").ModuleType):
