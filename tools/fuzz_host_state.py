@@ -82,7 +82,9 @@ def run(seed: int = 0, steps: int = 300, verbose: bool = True) -> list:
             sdnq_amd.invalidate(None)
     torch.cuda.synchronize()
     if verbose:
-        print(f"host-state fuzz done: {len(bad)} mismatches in {steps} operations", flush=True)
+        fp = L._FP
+        print(f"host-state fuzz done: {len(bad)} mismatches in {steps} operations"
+              + (f" ({fp.plan_calls()} layer calls carried by fast-path plans)" if fp is not None else ""), flush=True)
     return bad
 
 
