@@ -567,6 +567,8 @@ void plan_dealloc(PlanObj* p) {
     delete p->fused_no;
     Py_TYPE(p)->tp_free((PyObject*)p);
 }
+PyMemberDef plan_members[] = {{"mm", T_INT, offsetof(PlanObj, mm), READONLY, "matmul dtype code of the forward this plan restates"},
+                              {nullptr, 0, 0, 0, nullptr}};
 PyTypeObject PlanType = {PyVarObject_HEAD_INIT(nullptr, 0)};
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -651,6 +653,7 @@ PyMODINIT_FUNC PyInit__fastpath(void) {
     PlanType.tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_HAVE_VECTORCALL;
     PlanType.tp_new = plan_new;
     PlanType.tp_dealloc = (destructor)plan_dealloc;
+    PlanType.tp_members = plan_members;
     PlanType.tp_call = PyVectorcall_Call;
     PlanType.tp_vectorcall_offset = offsetof(PlanObj, vc);
 

@@ -19,6 +19,7 @@ inputs never change.  ``SDNQ_HIP_CACHE_WEIGHTS=0`` restores the per-call behavio
 """
 from __future__ import annotations
 
+import functools
 import os
 
 import torch
@@ -347,20 +348,25 @@ def _pf_launch(holder, tensors):
 _STATE_FIELDS = ("weight", "scale", "zero_point", "svd_up", "svd_down")
 
 
-def _no_grad(fn):
+def _no_grad(fn, plan_mm=None):
     """@torch.no_grad() for the layer forwards, minus its cost when gradients are already off -- the state every inference pipeline
-    runs in: the context-manager decorator is ~3 us per call, a sixth of an eager layer's host time (tools/eager_call_cost.py)."""
+    runs in: the context-manager decorator is ~3 us per call, a sixth of an eager layer's host time (tools/eager_call_cost.py).
+    plan_mm: the matmul dtype code of the two forwards whose calls a fast-path plan may carry (csrc/fastpath.cpp); a plan made for another
+    forward of the layer -- `apply_sdnq_options_to_model(use_quantized_matmul=...)` re-points forward_func -- is dropped, never called."""
     import functools
     grad_on, no_grad = torch.is_grad_enabled, torch.no_grad
 
     @functools.wraps(fn)
     def forward(self, input):
         plan = self.__dict__.get("_sdnq_plan")
-        if plan is not None:  # (csrc/fastpath.cpp) Tensor: done; None: not this call; False: stale
-            y = plan(self, input)
-            if y is not None:
-                if y is not False:
-                    return y
+        if plan is not None:
+            if plan.mm == plan_mm:  # Tensor: done; None: not this call; False: stale
+                y = plan(self, input)
+                if y is not None:
+                    if y is not False:
+                        return y
+                    del self.__dict__["_sdnq_plan"]
+            else:
                 del self.__dict__["_sdnq_plan"]
         if grad_on():
             with no_grad():
@@ -1054,12 +1060,12 @@ def _lp_matmul_forward(self, input: torch.Tensor, st: _State, mm: int) -> torch.
     return y.view(*input.shape[:-1], n)
 
 
-@_no_grad
+@functools.partial(_no_grad, plan_mm=ops.MM_I8)
 def quantized_linear_forward_int8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _quantized_matmul_forward(self, input, ops.MM_I8)
 
 
-@_no_grad
+@functools.partial(_no_grad, plan_mm=ops.MM_FP8)
 def quantized_linear_forward_fp8_matmul(self, input: torch.Tensor) -> torch.Tensor:
     return _quantized_matmul_forward(self, input, ops.MM_FP8)
 

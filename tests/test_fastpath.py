@@ -144,6 +144,20 @@ def test_plan_goes_stale_with_its_parameters(gpu_device):
         assert fp.plan_calls() == 0 and "_sdnq_plan" in mod.__dict__
         mod(x)
         assert fp.plan_calls() == 1
+        # the layer is re-pointed at another forward (apply_sdnq_options_to_model): the int8 plan must not carry the float forward's calls
+        import sdnq_amd
+        model = torch.nn.Sequential(mod)
+        sdnq_amd.apply_sdnq_options_to_model(model, use_quantized_matmul=False)
+        assert not mod.sdnq_dequantizer.use_quantized_matmul
+        fp.reset_counters()
+        y_float = model(x)
+        assert fp.plan_calls() == 0 and "_sdnq_plan" not in mod.__dict__
+        want = torch.nn.functional.linear(x.float(), mod.sdnq_dequantizer(mod.weight, mod.scale, skip_quantized_matmul=True).float(), mod.bias.float())
+        assert float((y_float.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())   # bf16 activations x dequantized weight: not the int8 matmul
+        sdnq_amd.apply_sdnq_options_to_model(model, use_quantized_matmul=True)
+        for _ in range(4):
+            L.clear_activation_cache(); y_back = model(x)
+        assert np.array_equal(_bits(y_back), _bits(ref(x)))
 
 
 @pytest.mark.gpu
