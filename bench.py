@@ -1339,6 +1339,21 @@ def main():
                                   "peak_measured": peak_meas, "frac_of_measured_peak": round(ach / peak_meas, 4) if peak_meas else None,
                                   "peak_measured_source": peak_meas_src,
                                   "traffic_over_algorithmic": round(traffic / (gk["bytes"] / gk["launches"]), 3) if traffic else None}
+        if world == 1 and graph is not None and not is_conv:
+            # beside the headline (outside its timed region): the same step launched EAGERLY from Python, layer call by layer call -- what
+            # `accelerate(model)` gives a pipeline that does not capture anything (round 6: the per-layer plans of csrc/fastpath.cpp)
+            try:
+                for _ in range(8):
+                    run_step(layers)
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()
+                for _ in range(20):
+                    run_step(layers)
+                torch.cuda.synchronize()
+                result["config"]["eager_ms_per_step"] = round((time.perf_counter() - t_e) / 20 * 1e3, 4)
+                result["config"]["eager_fast_path"] = L._FP is not None
+            except Exception as e:  # noqa: BLE001
+                result["config"]["eager_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline and not is_conv:
             try:
                 port = cpu_baseline(shape_list, mm_name, args.cpu_seconds / 2)
