@@ -193,6 +193,7 @@ def _worker_flux_geometry(rank, world, port, q):
     import sdnq_amd
     from sdnq_amd.parallel import column_shard_module, shard_bounds
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)  # eight ranks on a few host cores: one thread each instead of 8 x all cores fighting over them
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ok = True
