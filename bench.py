@@ -1298,7 +1298,8 @@ def main():
             gk, result["roofline_error"] = None, repr(e)
         traffic, traffic_src, traffic_meta, traffic_stale = None, None, None, None
         # the PMC profile of the SAME launch set (tools/pmc_step.sh <tag> <set>): one tracked file per workload, newest round first
-        pmc_set = {"sdxl_int8": "sdxl", "sdxl_fp8": "sdxl_fp8", "flux_int4_had": "flux", "flux_int8_svd": "flux_svd"}.get(args.workload)
+        pmc_set = {"sdxl_int8": "sdxl", "sdxl_fp8": "sdxl_fp8", "flux_int4_had": "flux", "flux_int8_svd": "flux_svd", "sdxl_int8_dequant": "sdxl_dequant",
+                   "linear_int8": "linear"}.get(args.workload)
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
         cands = ([f"r06_pmc_gemm_traffic_{pmc_set}.json"] if pmc_set else []) + (["r05_pmc_gemm_traffic_linked.json"] if args.workload == "sdxl_int8" and linked else []) \
             + (["r01_pmc_gemm_traffic.json"] if args.workload == "sdxl_int8" and not linked else [])

@@ -6,7 +6,7 @@ D=gpurun_out/${1:-r6/final}
 mkdir -p $D
 timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $D/pytest_gpu_serial.txt
 cat $D/pytest_gpu_serial.txt
-for set in sdxl sdxl_fp8 flux flux_svd; do
+for set in sdxl sdxl_fp8 sdxl_dequant linear flux flux_svd; do
   bash tools/pmc_step.sh ${1:-r6/final}_pmc_$set $set > $D/pmc_$set.log 2>&1
   cp gpurun_out/${1:-r6/final}_pmc_$set/pmc_gemm_traffic.json profiles/r06_pmc_gemm_traffic_$set.json
   cp gpurun_out/${1:-r6/final}_pmc_$set/pmc_gemm_traffic.json $D/r06_pmc_gemm_traffic_$set.json

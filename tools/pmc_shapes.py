@@ -2,7 +2,9 @@
 """One pass of a workload's M>=32 layers through the raw ops (rowquant + scaled_mm), with distinct weights per layer and
 the model's activation sharing -- the smallest process that launches exactly the step's hot kernels, for rocprofv3
 counter collection (--pmc serialises dispatches at ~50 ms each, so bench.py's layer construction is far too slow there).
-usage: pmc_shapes.py [sdxl|sdxl_fp8|flux|flux_svd] [passes] [linked]   (sdxl_fp8: e4m3 operands on the fp8 MFMA; flux: the int8 GEMMs of
+usage: pmc_shapes.py [sdxl|sdxl_fp8|sdxl_dequant|linear|flux|flux_svd] [passes] [linked]   (sdxl_dequant: the default float mode -- bf16 activations,
+int8 weight bytes dequantized inside the GEMM, sdnq_hip_linear_w8a16(_grouped); linear: the reference's micro-benchmark layer 16384 x 4096 -> 8192,
+eight layers with weights of their own; sdxl_fp8: e4m3 operands on the fp8 MFMA; flux: the int8 GEMMs of
 FLUX.1-dev -- what flux_int4_had runs after its weights were re-quantized; flux_svd: the same with the rank-32 low-rank epilogue of
 flux_int8_svd; linked: attention projections that share their input run as ONE grouped launch
 -- sdnq_hip_scaled_mm_grouped over the layers' own weights -- exactly as sdnq_amd.accelerate / bench.py do by default: q/k/v of a
@@ -15,8 +17,11 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "sdxl"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 linked = len(sys.argv) > 3 and sys.argv[3] == "linked"
 seq = shapes.sdxl_unet_layer_sequence() if wl.startswith("sdxl") else shapes.flux_dev_layer_sequence()
+if wl == "linear":
+    seq = [(f"layer{i}", 16384, 4096, 8192, True, f"x{i}") for i in range(8)]
 MM = ops.MM_FP8 if wl == "sdxl_fp8" else ops.MM_I8
 SVD = wl == "flux_svd"
+FLOAT = wl == "sdxl_dequant"
 dev = torch.device("cuda:0")
 layers, inputs = [], {}
 for (name, m, k, n, has_bias, key) in seq:
@@ -57,6 +62,12 @@ for _ in range(passes):
     quant = {}
     for (kind, i, g) in plan:
         name, x, w, key, n, has_bias = layers[i]
+        if FLOAT:  # (no activation quantization in this mode)
+            if kind == "single":
+                ops.linear_w8a16(x, w, sb[:n], None, bias[:n] if has_bias else None)
+            else:
+                ops.linear_w8a16_grouped(x, g)
+            continue
         if key not in quant:
             quant[key] = ops.rowquant(x, MM)
         q = quant[key]
